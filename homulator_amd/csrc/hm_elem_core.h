@@ -1,0 +1,117 @@
+// hm_elem_core.h — K2 automorphism, K3 element-wise engine, K4 base conversion, synthetic fill.
+// Per-thread bodies (no cross-thread state) shared by the HIP kernels and the host emulator.
+//
+// Reference shapes (the reference carries address tokens only; the arithmetic is the build's):
+//   K3 EWE   InsGen::GenEWE src/InsGen.cpp:77-125, "(op1 x op2) + (op3 x op4)" :90-95,
+//            adder tree src/Components.cpp:8-57.  Upstream has no opcode (always tagged MULT);
+//            the opcodes below are what the stages of src/Operation.cpp actually need.
+//   K4 BCONV InsGen::GenBCONV src/InsGen.cpp:263-313 (an InLevel-deep MAC chain per output limb),
+//            BCONVU 2x6 MAC array src/Components.cpp:268-295.
+//   K2 AUTO  InsGen::GenAUTO src/InsGen.cpp:46-71, AUTOU src/Components.cpp:173-194.
+#pragma once
+#include "hm_modarith.h"
+#include "hm_ntt_core.h"
+
+enum HmEweOp {
+  HM_EWE_MUL = 0,        // out = a*b
+  HM_EWE_MAC2 = 1,       // out = a*b + c*d
+  HM_EWE_MAC_ADD = 2,    // out = a*b + c
+  HM_EWE_ADD = 3,        // out = a + c
+  HM_EWE_SUB = 4,        // out = a - c
+  HM_EWE_MUL_CONST = 5,  // out = a*k
+  HM_EWE_SUB_SCALE = 6,  // out = (a - c)*k
+  HM_EWE_COPY = 7,       // out = a
+  HM_EWE_SUB_SCALE_ADD = 8,  // out = (a - c)*k + d   (ModDown finish fused with the final add)
+  HM_EWE_NOPS
+};
+
+struct HmEweLimb {
+  uint16_t a, b, c, d, out, mod;
+};
+struct HmEweArgs {
+  const uint64_t *a, *b, *c, *d;
+  uint64_t *out;
+  const HmMod *mods;
+  uint32_t logN, n_limbs, op;
+  HmEweLimb limb[HM_MAX_LIMBS];
+  HmTw k[HM_MAX_LIMBS];  // per-limb constant (Shoup form) for *_CONST / *_SCALE
+};
+
+template <int OP>
+HM_HD uint64_t hm_ewe_one(uint64_t a, uint64_t b, uint64_t c, uint64_t d, const HmTw &k, const HmMod &m) {
+  switch (OP) {
+  case HM_EWE_MUL: return hm_mulmod(a, b, m);
+  case HM_EWE_MAC2: return hm_barrett((hm_u128)a * b + (hm_u128)c * d, m);
+  case HM_EWE_MAC_ADD: return hm_addmod(hm_mulmod(a, b, m), c, m.q);
+  case HM_EWE_ADD: return hm_addmod(a, c, m.q);
+  case HM_EWE_SUB: return hm_submod(a, c, m.q);
+  case HM_EWE_MUL_CONST: return hm_shoup(a, k.w, k.ws, m.q);
+  case HM_EWE_SUB_SCALE: return hm_shoup(a - c + m.q, k.w, k.ws, m.q);
+  case HM_EWE_SUB_SCALE_ADD: return hm_addmod(hm_shoup(a - c + m.q, k.w, k.ws, m.q), d, m.q);
+  default: return a;
+  }
+}
+
+// operand usage per opcode (bit 0 = a, 1 = b, 2 = c, 3 = d)
+HM_HD constexpr int hm_ewe_uses(int op) {
+  return op == HM_EWE_MUL ? 3 : op == HM_EWE_MAC2 ? 15 : op == HM_EWE_MAC_ADD ? 7 :
+         op == HM_EWE_ADD ? 5 : op == HM_EWE_SUB ? 5 : op == HM_EWE_MUL_CONST ? 1 :
+         op == HM_EWE_SUB_SCALE ? 5 : op == HM_EWE_SUB_SCALE_ADD ? 13 : 1;
+}
+
+// ---- K4 base conversion: out[t][x] = sum_i in[i][x] * table[i][t] mod q_t
+#define HM_BCONV_MAX_IN 16
+#define HM_BCONV_MAX_OUT 64
+struct HmBconvArgs {
+  const uint64_t *in;
+  uint64_t *out;
+  const uint64_t *table;  // device, [n_in][n_out] row-major
+  const HmMod *mods;
+  uint32_t logN, n_in, n_out, out_per_block;
+  uint16_t in_limb[HM_BCONV_MAX_IN];
+  uint16_t out_limb[HM_BCONV_MAX_OUT];
+  uint16_t out_mod[HM_BCONV_MAX_OUT];
+};
+
+// one coefficient x, outputs [t0, t1)
+HM_HD void hm_bconv_thread(const HmBconvArgs &a, uint32_t x, uint32_t t0, uint32_t t1) {
+  const size_t N = (size_t)1 << a.logN;
+  uint64_t y[HM_BCONV_MAX_IN];
+#pragma unroll
+  for (uint32_t i = 0; i < HM_BCONV_MAX_IN; ++i)
+    if (i < a.n_in) y[i] = a.in[(size_t)a.in_limb[i] * N + x];
+  for (uint32_t t = t0; t < t1; ++t) {
+    hm_u128 acc = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < HM_BCONV_MAX_IN; ++i)
+      if (i < a.n_in) acc += (hm_u128)y[i] * a.table[i * a.n_out + t];
+    a.out[(size_t)a.out_limb[t] * N + x] = hm_barrett_wide(acc, a.mods[a.out_mod[t]]);
+  }
+}
+
+// ---- K2 automorphism in evaluation form: out[i] = in[pi_g(i)] (bit-reversed NTT layout)
+HM_HD uint32_t hm_brev(uint32_t x, uint32_t bits) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __brev(x) >> (32 - bits);
+#else
+  uint32_t r = 0;
+  for (uint32_t i = 0; i < bits; ++i) { r = (r << 1) | (x & 1); x >>= 1; }
+  return r;
+#endif
+}
+HM_HD uint32_t hm_auto_src(uint32_t i, uint32_t g, uint32_t logN) {
+  uint32_t mask = (2u << logN) - 1;
+  uint32_t e = (g * (2 * hm_brev(i, logN) + 1)) & mask;
+  return hm_brev((e - 1) >> 1, logN);
+}
+
+// ---- deterministic synthetic data (same definition as oracle/homoracle.c ho_fill_uniform)
+HM_HD uint64_t hm_mix64(uint64_t z) {
+  z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
+  z ^= z >> 27; z *= 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+HM_HD uint64_t hm_synth(uint64_t stream, uint32_t x, uint64_t q) {
+  uint64_t z = hm_mix64(stream * 0xD1342543DE82EF95ull + (uint64_t)x * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull);
+  return hm_mulhi(z, q);
+}

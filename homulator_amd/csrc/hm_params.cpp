@@ -1,0 +1,132 @@
+// hm_params.cpp — see hm_params.h.  Host code only (runs once per context).
+#include "hm_params.h"
+#include <stdexcept>
+#include <string>
+
+namespace hm {
+
+typedef unsigned __int128 u128;
+
+uint64_t mulmod(uint64_t a, uint64_t b, uint64_t q) { return (uint64_t)(((u128)a * b) % q); }
+uint64_t powmod(uint64_t a, uint64_t e, uint64_t q) {
+  uint64_t r = 1 % q;
+  a %= q;
+  for (; e; e >>= 1) {
+    if (e & 1) r = mulmod(r, a, q);
+    a = mulmod(a, a, q);
+  }
+  return r;
+}
+uint64_t invmod(uint64_t a, uint64_t q) { return powmod(a % q, q - 2, q); }
+uint64_t shoup(uint64_t w, uint64_t q) { return (uint64_t)((((u128)w) << 64) / q); }
+uint32_t bitrev(uint32_t x, uint32_t bits) {
+  uint32_t r = 0;
+  for (uint32_t i = 0; i < bits; ++i, x >>= 1) r = (r << 1) | (x & 1);
+  return r;
+}
+
+bool is_prime(uint64_t n) {  // deterministic Miller-Rabin for 64-bit n
+  static const uint64_t bases[] = {2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37};
+  if (n < 2) return false;
+  for (uint64_t b : bases) {
+    if (n == b) return true;
+    if (n % b == 0) return false;
+  }
+  uint64_t d = n - 1;
+  int s = 0;
+  while ((d & 1) == 0) { d >>= 1; ++s; }
+  for (uint64_t b : bases) {
+    uint64_t x = powmod(b, d, n);
+    if (x == 1 || x == n - 1) continue;
+    bool witness = true;
+    for (int r = 1; r < s && witness; ++r) {
+      x = mulmod(x, x, n);
+      if (x == n - 1) witness = false;
+    }
+    if (witness) return false;
+  }
+  return true;
+}
+
+static uint64_t smallest_primitive_root(uint64_t q, uint32_t N) {
+  const uint64_t e = (q - 1) / (2ull * N);
+  uint64_t r = 0;
+  for (uint64_t x = 2;; ++x) {
+    r = powmod(x, e, q);
+    if (powmod(r, N, q) == q - 1) break;
+  }
+  uint64_t step = mulmod(r, r, q), cur = r, best = r;
+  for (uint32_t k = 1; k < N; ++k) {  // odd powers of r are exactly the primitive 2N-th roots
+    cur = mulmod(cur, step, q);
+    if (cur < best) best = cur;
+  }
+  return best;
+}
+
+void Params::init(uint32_t logN_, uint32_t L_, uint32_t K_, const uint64_t *q, const uint64_t *p, const uint64_t *psi_in) {
+  if (logN_ < 13 || logN_ > 17) throw std::invalid_argument("logN must be in [13,17] for the HIP backend");
+  if (L_ == 0 || L_ + K_ > 4096) throw std::invalid_argument("bad limb counts");
+  logN = logN_; N = 1u << logN; L = L_; K = K_;
+  const uint32_t M = L + K;
+  mod.assign(M, 0); psi.assign(M, 0); modc.assign(M, HmMod{});
+  if (q) {
+    for (uint32_t i = 0; i < L; ++i) mod[i] = q[i];
+    for (uint32_t i = 0; i < K; ++i) mod[L + i] = p[i];
+  } else {
+    uint64_t cand = (1ull << 60) + 1;
+    for (uint32_t m = 0; m < M;) {
+      cand -= 2ull * N;
+      if (is_prime(cand)) mod[m++] = cand;
+    }
+  }
+  for (uint32_t m = 0; m < M; ++m) {
+    const uint64_t qm = mod[m];
+    if (qm >> 60 || qm < (1ull << 20) || (qm - 1) % (2ull * N) != 0 || !is_prime(qm))
+      throw std::invalid_argument("modulus " + std::to_string(qm) + " is not a prime = 1 mod 2N below 2^60");
+    for (uint32_t j = 0; j < m; ++j)
+      if (mod[j] == qm) throw std::invalid_argument("duplicate modulus");
+    psi[m] = psi_in ? psi_in[m] : smallest_primitive_root(qm, N);
+    if (powmod(psi[m], N, qm) != qm - 1) throw std::invalid_argument("psi is not a primitive 2N-th root");
+    HmMod &c = modc[m];
+    uint32_t k = 64 - (uint32_t)__builtin_clzll(qm);
+    c.q = qm;
+    c.sh = k - 1;
+    c.mu = (uint64_t)((((u128)1) << (k + 63)) / qm);
+    c.r64 = (uint64_t)((((u128)1) << 64) % qm);
+    c.r64s = shoup(c.r64, qm);
+    c.ninv = invmod(N, qm);
+    c.ninvs = shoup(c.ninv, qm);
+  }
+}
+
+void Params::make_table(uint32_t m, bool inverse, HmTw *out) const {
+  const uint64_t q = mod[m];
+  const uint64_t base = inverse ? invmod(psi[m], q) : psi[m];
+  uint64_t p = 1;
+  for (uint32_t i = 0; i < N; ++i) {
+    HmTw &t = out[bitrev(i, logN)];
+    t.w = p;
+    t.ws = shoup(p, q);
+    p = mulmod(p, base, q);
+  }
+}
+
+void Params::bconv_consts(const uint32_t *in_ids, uint32_t n_in, const uint32_t *out_ids, uint32_t n_out,
+                          uint64_t *qhat_inv, uint64_t *table) const {
+  for (uint32_t i = 0; i < n_in; ++i) {
+    const uint64_t qi = mod[in_ids[i]];
+    uint64_t prod = 1;
+    for (uint32_t k = 0; k < n_in; ++k)
+      if (k != i) prod = mulmod(prod, mod[in_ids[k]] % qi, qi);
+    qhat_inv[i] = invmod(prod, qi);
+    for (uint32_t t = 0; t < n_out; ++t) {
+      const uint64_t qt = mod[out_ids[t]];
+      uint64_t pr = 1;
+      for (uint32_t k = 0; k < n_in; ++k)
+        if (k != i) pr = mulmod(pr, mod[in_ids[k]] % qt, qt);
+      table[(size_t)i * n_out + t] = pr;
+    }
+  }
+}
+
+}  // namespace hm

@@ -1,0 +1,207 @@
+"""ctypes binding of include/homulator_hip.h (libhomulator_hip.so).  No CPU fallback: a missing library or a
+machine without a HIP device is an error, never a silent detour."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libhomulator_hip.so")
+
+OP_MUL, OP_MAC2, OP_MAC_ADD, OP_ADD, OP_SUB, OP_MUL_CONST, OP_SUB_SCALE, OP_COPY, OP_SUB_SCALE_ADD = range(9)
+
+# every symbol include/homulator_hip.h declares
+SYMBOLS = [
+    "hm_create", "hm_destroy", "hm_last_error", "hm_version", "hm_get_modulus", "hm_get_psi", "hm_malloc", "hm_free",
+    "hm_memcpy_h2d", "hm_memcpy_d2h", "hm_memcpy_d2d", "hm_sync", "hm_stream", "hm_ntt", "hm_automorph", "hm_ewe",
+    "hm_bconv", "hm_bconv_consts", "hm_fill_uniform", "hm_timer_start", "hm_timer_stop",
+]
+
+
+class hm_params(C.Structure):
+    _fields_ = [("logN", C.c_uint32), ("L", C.c_uint32), ("K", C.c_uint32), ("device", C.c_int32),
+                ("q", C.c_void_p), ("p", C.c_void_p), ("psi", C.c_void_p)]
+
+
+_lib = None
+
+
+def load():
+    """Load the HIP backend.  Raises if it has not been built (run `python -c 'import __graft_entry__ as g; g.build()'`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build it with __graft_entry__.build() "
+                          "(make -C homulator_amd/csrc); homulator_amd has no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
+    L.hm_create.argtypes = [C.POINTER(vp), C.POINTER(hm_params)]
+    L.hm_destroy.argtypes = [vp]
+    L.hm_last_error.restype = C.c_char_p
+    L.hm_last_error.argtypes = [vp]
+    L.hm_version.restype = C.c_char_p
+    L.hm_get_modulus.argtypes = [vp, u32, C.POINTER(u64)]
+    L.hm_get_psi.argtypes = [vp, u32, C.POINTER(u64)]
+    L.hm_malloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+    L.hm_free.argtypes = [vp, vp]
+    L.hm_memcpy_h2d.argtypes = [vp, vp, vp, C.c_size_t]
+    L.hm_memcpy_d2h.argtypes = [vp, vp, vp, C.c_size_t]
+    L.hm_memcpy_d2d.argtypes = [vp, vp, vp, C.c_size_t]
+    L.hm_sync.argtypes = [vp]
+    L.hm_stream.restype = vp
+    L.hm_stream.argtypes = [vp]
+    L.hm_ntt.argtypes = [vp, vp, vp, vp, vp, vp, u32, i32, vp]
+    L.hm_automorph.argtypes = [vp, vp, vp, vp, vp, u32, u32]
+    L.hm_ewe.argtypes = [vp, i32] + [vp] * 11 + [u32, vp]
+    L.hm_bconv.argtypes = [vp, vp, vp, vp, u32, vp, vp, vp, u32]
+    L.hm_bconv_consts.argtypes = [vp, vp, u32, vp, u32, vp, vp]
+    L.hm_fill_uniform.argtypes = [vp, vp, vp, vp, u32, u64]
+    L.hm_timer_start.argtypes = [vp]
+    L.hm_timer_stop.argtypes = [vp, C.POINTER(u64)]
+    _lib = L
+    return L
+
+
+class HmError(RuntimeError):
+    pass
+
+
+def _u32(a):
+    if a is None:
+        return None, None
+    arr = np.ascontiguousarray(np.asarray(a, dtype=np.uint32))
+    return arr, arr.ctypes.data_as(C.c_void_p)
+
+
+def _u64(a):
+    if a is None:
+        return None, None
+    arr = np.ascontiguousarray(np.asarray([int(x) for x in a], dtype=np.uint64))
+    return arr, arr.ctypes.data_as(C.c_void_p)
+
+
+class DeviceBuf:
+    """[n_limbs][N] uint64 words in HBM, limb-major (a plain hipMalloc'd pointer)."""
+
+    def __init__(self, ctx, n_limbs):
+        self.ctx, self.n_limbs = ctx, n_limbs
+        p = C.c_void_p()
+        ctx._ck(ctx.L.hm_malloc(ctx.h, 8 * ctx.N * n_limbs, C.byref(p)))
+        self.ptr = p.value
+
+    def limb_ptr(self, limb):
+        return self.ptr + 8 * self.ctx.N * limb
+
+    def upload(self, arr, limb0=0):
+        a = np.ascontiguousarray(arr, dtype=np.uint64).reshape(-1, self.ctx.N)
+        assert limb0 + a.shape[0] <= self.n_limbs
+        self.ctx._ck(self.ctx.L.hm_memcpy_h2d(self.ctx.h, self.limb_ptr(limb0), a.ctypes.data_as(C.c_void_p), a.nbytes))
+        return self
+
+    def download(self, limb0=0, n=None):
+        n = self.n_limbs - limb0 if n is None else n
+        out = np.empty((n, self.ctx.N), dtype=np.uint64)
+        self.ctx._ck(self.ctx.L.hm_memcpy_d2h(self.ctx.h, out.ctypes.data_as(C.c_void_p), self.limb_ptr(limb0), out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            self.ctx.L.hm_free(self.ctx.h, self.ptr)
+            self.ptr = None
+
+
+class Context:
+    """One GPU, one parameter set.  Thin, 1:1 with the C ABI."""
+
+    def __init__(self, logN, L, K, device=0):
+        self.L = load()
+        self.h = C.c_void_p()
+        prm = hm_params(logN, L, K, device, None, None, None)
+        st = self.L.hm_create(C.byref(self.h), C.byref(prm))
+        if st != 0:
+            raise HmError(f"hm_create failed ({st}): {self.L.hm_last_error(None).decode()}")
+        self.logN, self.N, self.nQ, self.K = logN, 1 << logN, L, K
+        q = C.c_uint64()
+        self.moduli = []
+        for m in range(L + K):
+            self._ck(self.L.hm_get_modulus(self.h, m, C.byref(q)))
+            self.moduli.append(q.value)
+
+    def _ck(self, st):
+        if st != 0:
+            raise HmError(f"hm error {st}: {self.L.hm_last_error(self.h).decode()}")
+
+    def close(self):
+        if self.h:
+            self.L.hm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def alloc(self, n_limbs):
+        return DeviceBuf(self, n_limbs)
+
+    def from_host(self, arr):
+        a = np.ascontiguousarray(arr, dtype=np.uint64).reshape(-1, self.N)
+        return self.alloc(a.shape[0]).upload(a)
+
+    def sync(self):
+        self._ck(self.L.hm_sync(self.h))
+
+    def ext_ids(self, ell):
+        return list(range(ell)) + [self.nQ + i for i in range(self.K)]
+
+    # ---- compute calls (device pointers + limb lists)
+    def ntt(self, src, dst, mod_ids, inverse=False, in_limbs=None, out_limbs=None, scale=None):
+        n = len(mod_ids)
+        k1, pi = _u32(in_limbs)
+        k2, po = _u32(out_limbs)
+        k3, pm = _u32(mod_ids)
+        k4, ps = _u64(scale)
+        self._ck(self.L.hm_ntt(self.h, src.ptr, pi, dst.ptr, po, pm, n, 1 if inverse else 0, ps))
+
+    def automorph(self, src, dst, n, galois, in_limbs=None, out_limbs=None):
+        k1, pi = _u32(in_limbs)
+        k2, po = _u32(out_limbs)
+        self._ck(self.L.hm_automorph(self.h, src.ptr, pi, dst.ptr, po, n, galois))
+
+    def ewe(self, op, out, mod_ids, a=None, b=None, c=None, d=None, la=None, lb=None, lc=None, ld=None, lo=None, k=None):
+        keep = [_u32(x) for x in (la, lb, lc, ld, lo, mod_ids)]
+        kk, pk = _u64(k)
+        ptr = lambda x: None if x is None else x.ptr
+        self._ck(self.L.hm_ewe(self.h, op, ptr(a), keep[0][1], ptr(b), keep[1][1], ptr(c), keep[2][1], ptr(d), keep[3][1],
+                               out.ptr, keep[4][1], keep[5][1], len(mod_ids), pk))
+
+    def bconv(self, src, in_ids, dst, out_ids, in_limbs=None, out_limbs=None):
+        k1, pil = _u32(in_limbs)
+        k2, pii = _u32(in_ids)
+        k3, pol = _u32(out_limbs)
+        k4, poi = _u32(out_ids)
+        self._ck(self.L.hm_bconv(self.h, src.ptr, pil, pii, len(in_ids), dst.ptr, pol, poi, len(out_ids)))
+
+    def bconv_consts(self, in_ids, out_ids):
+        k1, pii = _u32(in_ids)
+        k2, poi = _u32(out_ids)
+        qh = np.empty(len(in_ids), dtype=np.uint64)
+        tb = np.empty((len(in_ids), max(1, len(out_ids))), dtype=np.uint64)
+        self._ck(self.L.hm_bconv_consts(self.h, pii, len(in_ids), poi, len(out_ids), qh.ctypes.data_as(C.c_void_p),
+                                        tb.ctypes.data_as(C.c_void_p)))
+        return qh, tb[:, :len(out_ids)]
+
+    def fill_uniform(self, dst, mod_ids, seed, out_limbs=None):
+        k1, pol = _u32(out_limbs)
+        k2, pm = _u32(mod_ids)
+        self._ck(self.L.hm_fill_uniform(self.h, dst.ptr, pol, pm, len(mod_ids), int(seed) & (2 ** 64 - 1)))
+
+    def timer_start(self):
+        self._ck(self.L.hm_timer_start(self.h))
+
+    def timer_stop(self):
+        ns = C.c_uint64()
+        self._ck(self.L.hm_timer_stop(self.h, C.byref(ns)))
+        return ns.value

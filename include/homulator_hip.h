@@ -1,0 +1,117 @@
+/*
+ * homulator_hip.h — C ABI of the MI355X (gfx950) execution backend for Homulator's FHE datapath.
+ *
+ * The reference (FHE-ACCELE/Homulator) has no FFI or plugin interface: its execution boundary is the
+ * C++ seam between the graph builders (Operation / InsGen / Driver) and the cycle model (Arch).
+ * Each entry point below states which reference interface it replaces.  Plain C types only; device
+ * buffers are raw device pointers (`uint64_t *` to [limb][N] words, limb-major, 8-byte words, values
+ * fully reduced in [0, q) at every call boundary); no exceptions cross the boundary: every call returns
+ * hm_status (0 = ok) and hm_last_error() returns the message.
+ *
+ * A context is bound to one GPU and one HIP stream and is not thread-safe.  All hm_* compute calls are
+ * asynchronous on the context's stream; hm_sync() waits.
+ */
+#ifndef HOMULATOR_HIP_H
+#define HOMULATOR_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hm_ctx hm_ctx;
+typedef int hm_status;
+enum { HM_OK = 0, HM_ERR_ARG = 1, HM_ERR_HIP = 2, HM_ERR_UNSUPPORTED = 3, HM_ERR_COMM = 4 };
+
+/* Parameter set.  N = 2^logN (13..17), L Q-primes, K special primes (the reference sizes the special
+ * basis as exactly alpha limbs, src/Operation.cpp:160,193,297-304).  q == NULL selects the default
+ * chain: the L+K largest primes below 2^60 that are 1 mod 2N, descending, first L = Q, next K = P;
+ * psi == NULL selects the smallest primitive 2N-th root of each prime.  "mod id" m: m < L -> q[m],
+ * m >= L -> p[m-L].  Replaces: Arch::Arch(Config*) include/Arch.h:154 / src/Arch.cpp:8-168 (the
+ * construction of the execution resources from N / cluster). */
+typedef struct hm_params {
+  uint32_t logN, L, K;
+  int32_t device;           /* HIP device ordinal */
+  const uint64_t *q, *p;    /* optional explicit moduli */
+  const uint64_t *psi;      /* optional explicit roots, [L+K] */
+} hm_params;
+
+hm_status hm_create(hm_ctx **ctx, const hm_params *params);
+void hm_destroy(hm_ctx *ctx);
+const char *hm_last_error(const hm_ctx *ctx); /* ctx may be NULL: last error of hm_create */
+const char *hm_version(void);
+
+hm_status hm_get_modulus(const hm_ctx *ctx, uint32_t mod_id, uint64_t *q);
+hm_status hm_get_psi(const hm_ctx *ctx, uint32_t mod_id, uint64_t *psi);
+
+/* Device memory (replaces the scratchpad/HBM address space of include/mem.h:465-651 and the
+ * AddrManage line addresses of include/Addr.h:29-66: one reference "limb" = N words here). */
+hm_status hm_malloc(hm_ctx *ctx, size_t bytes, void **dptr);
+hm_status hm_free(hm_ctx *ctx, void *dptr);
+hm_status hm_memcpy_h2d(hm_ctx *ctx, void *dst, const void *src, size_t bytes);
+hm_status hm_memcpy_d2h(hm_ctx *ctx, void *dst, const void *src, size_t bytes);
+hm_status hm_memcpy_d2d(hm_ctx *ctx, void *dst, const void *src, size_t bytes);
+hm_status hm_sync(hm_ctx *ctx);
+void *hm_stream(hm_ctx *ctx); /* the context's hipStream_t */
+
+/* Limb lists: every compute call takes n limb-polys; operand X of limb i lives at
+ * X_base + X_limbs[i] * N (X_limbs == NULL means 0,1,..,n-1); mod_ids[i] selects the modulus. */
+
+/* K1 — NTT / INTT.  Replaces Arch::issueIns(cluster, "NTT"/"INTT", group) include/Arch.h:276 for
+ * the instructions of InsGen::GenNTT (src/InsGen.cpp:17-44): one call = one stage of limb-NTTs.
+ * inverse != 0: result is multiplied by N^-1 and, if scale != NULL, by scale[i] (a host array of n
+ * residues mod the limb's modulus): this fuses the "x q_hat^-1" EWE stage that follows every INTT in
+ * the key switch (src/Operation.cpp:104-135, 447-487).  in == out is allowed. */
+hm_status hm_ntt(hm_ctx *ctx, const uint64_t *in, const uint32_t *in_limbs, uint64_t *out,
+                 const uint32_t *out_limbs, const uint32_t *mod_ids, uint32_t n, int inverse,
+                 const uint64_t *scale);
+
+/* K2 — automorphism X -> X^galois in evaluation form.  Replaces issueIns(..., "AUTO", ...) for
+ * InsGen::GenAUTO (src/InsGen.cpp:46-71).  in must not alias out. */
+hm_status hm_automorph(hm_ctx *ctx, const uint64_t *in, const uint32_t *in_limbs, uint64_t *out,
+                       const uint32_t *out_limbs, uint32_t n, uint32_t galois);
+
+/* K3 — element-wise engine.  Replaces issueIns(..., "MULT", ...) for InsGen::GenEWE
+ * (src/InsGen.cpp:77-125); upstream has no opcode, the stages of src/Operation.cpp need these: */
+enum hm_ewe_op {
+  HM_OP_MUL = 0,           /* out = a*b            TensorCompute D0/D2 :634-660, 712-738; PMULT */
+  HM_OP_MAC2 = 1,          /* out = a*b + c*d      TensorCompute D1 :673-699; inner product :355-411 */
+  HM_OP_MAC_ADD = 2,       /* out = a*b + c        inner product, later groups :355-411 */
+  HM_OP_ADD = 3,           /* out = a + c          HMULT add :967-1005, HADD, PADD, HROTATE add :1339-1357 */
+  HM_OP_SUB = 4,           /* out = a - c          Rescale_SUB :831-875 */
+  HM_OP_MUL_CONST = 5,     /* out = a*k[i]         ModUp_DecompOut :104-135, ModDownBConvStep1 :447-487, Rescale_Mul :877-910 */
+  HM_OP_SUB_SCALE = 6,     /* out = (a - c)*k[i]   KeySwitchFinalOutput :548-590 */
+  HM_OP_COPY = 7,          /* out = a */
+  HM_OP_SUB_SCALE_ADD = 8  /* out = (a - c)*k[i] + d   fused ModDownSub + final add */
+};
+hm_status hm_ewe(hm_ctx *ctx, int op, const uint64_t *a, const uint32_t *a_limbs, const uint64_t *b,
+                 const uint32_t *b_limbs, const uint64_t *c, const uint32_t *c_limbs, const uint64_t *d,
+                 const uint32_t *d_limbs, uint64_t *out, const uint32_t *out_limbs,
+                 const uint32_t *mod_ids, uint32_t n, const uint64_t *k);
+
+/* K4 — fast base conversion, matrix step: out_t = sum_i in_i * [Q_D / q_i]_t mod t for the input
+ * basis in_ids (n_in <= 16) and output basis out_ids (n_out <= 64).  `in` must already hold
+ * y_i = x_i * [(Q_D/q_i)^-1]_{q_i} (hm_ntt's scale or HM_OP_MUL_CONST with hm_bconv_consts).
+ * Replaces issueIns(cluster, h, w, group, ...) include/Arch.h:277 for InsGen::GenBCONV
+ * (src/InsGen.cpp:263-313; stages src/Operation.cpp:137-188, 489-519). */
+hm_status hm_bconv(hm_ctx *ctx, const uint64_t *in, const uint32_t *in_limbs, const uint32_t *in_ids,
+                   uint32_t n_in, uint64_t *out, const uint32_t *out_limbs, const uint32_t *out_ids,
+                   uint32_t n_out);
+/* host-side constants of a conversion: qhat_inv[n_in], table[n_in][n_out] (either may be NULL) */
+hm_status hm_bconv_consts(hm_ctx *ctx, const uint32_t *in_ids, uint32_t n_in, const uint32_t *out_ids,
+                          uint32_t n_out, uint64_t *qhat_inv, uint64_t *table);
+
+/* Synthetic data: limb i = counter-based SplitMix64 stream (seed + i), uniform in
+ * [0, q).  Bench/test tooling; the reference has no data at all. */
+hm_status hm_fill_uniform(hm_ctx *ctx, uint64_t *out, const uint32_t *out_limbs, const uint32_t *mod_ids,
+                          uint32_t n, uint64_t seed);
+
+/* Timing on the context's stream (replaces Arch::getCycle include/Arch.h:271: elapsed device time in
+ * nanoseconds instead of simulated cycles). */
+hm_status hm_timer_start(hm_ctx *ctx);
+hm_status hm_timer_stop(hm_ctx *ctx, uint64_t *elapsed_ns); /* synchronises */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,135 @@
+// hm_emu.cpp — host emulator of the HIP kernels' per-thread phase functions (TEST INFRASTRUCTURE).
+// Compiles homulator_amd/csrc/hm_*_core.h with g++ and runs each workgroup phase by phase, thread by
+// thread, so that index maths, twiddle indexing, lazy-reduction ranges and the host-side parameter
+// tables (hm_params.cpp) are checked against the oracle on the CPU before a GPU is involved.
+// It is not a CPU backend: the product library never links or calls this.
+#include <cstdint>
+#include <cstring>
+#include <vector>
+#include "../../homulator_amd/csrc/hm_elem_core.h"
+#include "../../homulator_amd/csrc/hm_modarith.h"
+#include "../../homulator_amd/csrc/hm_ntt_core.h"
+#include "../../homulator_amd/csrc/hm_params.h"
+
+struct Emu {
+  hm::Params P;
+  std::vector<std::vector<HmTw>> fwd, inv;
+};
+
+template <int LOGR, bool STRIDED, bool INV, int MODE>
+static void run_pass(const Emu &e, uint32_t mod, const uint64_t *src, uint64_t *dst, HmTw sc) {
+  const uint32_t tiles = e.P.N >> HM_TILE_LOG;
+  const uint64_t q = e.P.mod[mod];
+  const HmTw *twl = (INV ? e.inv : e.fwd)[mod].data();
+  const uint32_t s0 = STRIDED ? 0u : (e.P.logN - 8u);
+  using RS = HmRounds<LOGR>;
+  std::vector<uint64_t> lds(HM_LDS_WORDS);
+  for (uint32_t tile = 0; tile < tiles; ++tile) {
+    const uint32_t prefix0 = STRIDED ? 0u : (tile << (HM_TILE_LOG - LOGR));
+    for (int t = 0; t < HM_THREADS; ++t) hm_tile_load<LOGR, STRIDED>(t, lds.data(), src, tile);
+    auto rnd = [&](auto nbk) {
+      constexpr int I = decltype(nbk)::value;
+      if constexpr (I < RS::n)
+        for (int t = 0; t < HM_THREADS; ++t)
+          hm_ntt_round<LOGR, STRIDED, RS::nb[I], RS::k[I], INV>(t, lds.data(), twl, s0, prefix0, q);
+    };
+    if (!INV) { rnd(std::integral_constant<int, 0>{}); rnd(std::integral_constant<int, 1>{}); rnd(std::integral_constant<int, 2>{}); }
+    else      { rnd(std::integral_constant<int, 2>{}); rnd(std::integral_constant<int, 1>{}); rnd(std::integral_constant<int, 0>{}); }
+    for (int t = 0; t < HM_THREADS; ++t) hm_tile_store<LOGR, STRIDED, MODE>(t, lds.data(), dst, tile, q, sc);
+  }
+}
+
+template <int LOG1>
+static void run_ntt(const Emu &e, uint32_t mod, const uint64_t *in, uint64_t *out, int inverse, HmTw sc) {
+  if (!inverse) {
+    run_pass<LOG1, true, false, 0>(e, mod, in, out, sc);
+    run_pass<8, false, false, 1>(e, mod, out, out, sc);
+  } else {
+    run_pass<8, false, true, 0>(e, mod, in, out, sc);
+    run_pass<LOG1, true, true, 2>(e, mod, out, out, sc);
+  }
+}
+
+extern "C" {
+void *emu_create(uint32_t logN, uint32_t L, uint32_t K) {
+  Emu *e = new Emu;
+  e->P.init(logN, L, K, nullptr, nullptr, nullptr);
+  e->fwd.resize(L + K); e->inv.resize(L + K);
+  for (uint32_t m = 0; m < L + K; ++m) {
+    e->fwd[m].resize(e->P.N); e->inv[m].resize(e->P.N);
+    e->P.make_table(m, false, e->fwd[m].data());
+    e->P.make_table(m, true, e->inv[m].data());
+  }
+  return e;
+}
+void emu_destroy(void *h) { delete (Emu *)h; }
+uint64_t emu_modulus(void *h, uint32_t m) { return ((Emu *)h)->P.mod[m]; }
+uint64_t emu_psi(void *h, uint32_t m) { return ((Emu *)h)->P.psi[m]; }
+
+int emu_ntt(void *h, uint32_t mod, const uint64_t *in, uint64_t *out, int inverse, uint64_t scale, int has_scale) {
+  Emu &e = *(Emu *)h;
+  uint64_t q = e.P.mod[mod], k = e.P.modc[mod].ninv;
+  if (has_scale) k = hm::mulmod(k, scale, q);
+  HmTw sc = {k, hm::shoup(k, q)};
+  switch (e.P.logN - 8) {
+  case 5: run_ntt<5>(e, mod, in, out, inverse, sc); break;
+  case 6: run_ntt<6>(e, mod, in, out, inverse, sc); break;
+  case 7: run_ntt<7>(e, mod, in, out, inverse, sc); break;
+  case 8: run_ntt<8>(e, mod, in, out, inverse, sc); break;
+  case 9: run_ntt<9>(e, mod, in, out, inverse, sc); break;
+  default: return 1;
+  }
+  return 0;
+}
+
+void emu_ewe(void *h, int op, uint32_t mod, const uint64_t *a, const uint64_t *b, const uint64_t *c,
+             const uint64_t *d, uint64_t kk, uint64_t *out) {
+  Emu &e = *(Emu *)h;
+  const HmMod m = e.P.modc[mod];
+  HmTw k = {kk, hm::shoup(kk, m.q)};
+  for (uint32_t x = 0; x < e.P.N; ++x) {
+    uint64_t va = a ? a[x] : 0, vb = b ? b[x] : 0, vc = c ? c[x] : 0, vd = d ? d[x] : 0, r = 0;
+    switch (op) {
+    case 0: r = hm_ewe_one<0>(va, vb, vc, vd, k, m); break;
+    case 1: r = hm_ewe_one<1>(va, vb, vc, vd, k, m); break;
+    case 2: r = hm_ewe_one<2>(va, vb, vc, vd, k, m); break;
+    case 3: r = hm_ewe_one<3>(va, vb, vc, vd, k, m); break;
+    case 4: r = hm_ewe_one<4>(va, vb, vc, vd, k, m); break;
+    case 5: r = hm_ewe_one<5>(va, vb, vc, vd, k, m); break;
+    case 6: r = hm_ewe_one<6>(va, vb, vc, vd, k, m); break;
+    case 7: r = hm_ewe_one<7>(va, vb, vc, vd, k, m); break;
+    case 8: r = hm_ewe_one<8>(va, vb, vc, vd, k, m); break;
+    }
+    out[x] = r;
+  }
+}
+
+void emu_bconv(void *h, const uint32_t *in_ids, uint32_t n_in, const uint32_t *out_ids, uint32_t n_out,
+               const uint64_t *in, uint64_t *out) {
+  Emu &e = *(Emu *)h;
+  std::vector<uint64_t> qh(n_in), tb((size_t)n_in * n_out);
+  e.P.bconv_consts(in_ids, n_in, out_ids, n_out, qh.data(), tb.data());
+  HmBconvArgs a;
+  a.in = in; a.out = out; a.table = tb.data(); a.mods = e.P.modc.data();
+  a.logN = e.P.logN; a.n_in = n_in; a.n_out = n_out; a.out_per_block = (n_out + 3) / 4;
+  for (uint32_t i = 0; i < n_in; ++i) a.in_limb[i] = (uint16_t)i;
+  for (uint32_t t = 0; t < n_out; ++t) { a.out_limb[t] = (uint16_t)t; a.out_mod[t] = (uint16_t)out_ids[t]; }
+  for (uint32_t by = 0; by * a.out_per_block < n_out; ++by)
+    for (uint32_t x = 0; x < e.P.N; ++x) {
+      uint32_t t0 = by * a.out_per_block, t1 = t0 + a.out_per_block < n_out ? t0 + a.out_per_block : n_out;
+      hm_bconv_thread(a, x, t0, t1);
+    }
+}
+void emu_bconv_consts(void *h, const uint32_t *in_ids, uint32_t n_in, const uint32_t *out_ids, uint32_t n_out,
+                      uint64_t *qh, uint64_t *tb) {
+  ((Emu *)h)->P.bconv_consts(in_ids, n_in, out_ids, n_out, qh, tb);
+}
+void emu_automorph(void *h, const uint64_t *in, uint64_t *out, uint32_t g) {
+  Emu &e = *(Emu *)h;
+  for (uint32_t i = 0; i < e.P.N; ++i) out[i] = in[hm_auto_src(i, g, e.P.logN)];
+}
+void emu_fill(void *h, uint32_t mod, uint64_t stream, uint64_t *out) {
+  Emu &e = *(Emu *)h;
+  for (uint32_t x = 0; x < e.P.N; ++x) out[x] = hm_synth(stream, x, e.P.mod[mod]);
+}
+}

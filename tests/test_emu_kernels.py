@@ -1,0 +1,134 @@
+"""CPU emulation of the HIP kernels' per-thread phase functions vs the oracle (no GPU needed).
+The emulator (tests/emu/hm_emu.cpp) compiles the SAME device headers with g++ and runs every workgroup
+phase by phase, so tile/LDS indexing, twiddle indexing, lazy-reduction ranges, Barrett/Shoup forms and the
+host-side tables of hm_params.cpp are all bit-checked here before the GPU run."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle.homoracle import Oracle
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def emu():
+    subprocess.check_call(["make", "-C", os.path.join(HERE, "emu")], stdout=subprocess.DEVNULL)
+    L = C.CDLL(os.path.join(HERE, "emu", "libhm_emu.so"))
+    L.emu_create.restype = C.c_void_p
+    L.emu_create.argtypes = [C.c_uint32] * 3
+    L.emu_destroy.argtypes = [C.c_void_p]
+    L.emu_modulus.restype = C.c_uint64
+    L.emu_modulus.argtypes = [C.c_void_p, C.c_uint32]
+    L.emu_psi.restype = C.c_uint64
+    L.emu_psi.argtypes = [C.c_void_p, C.c_uint32]
+    L.emu_ntt.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_int]
+    L.emu_ewe.argtypes = [C.c_void_p, C.c_int, C.c_uint32] + [C.c_void_p] * 4 + [C.c_uint64, C.c_void_p]
+    L.emu_bconv.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    L.emu_bconv_consts.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    L.emu_automorph.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+    L.emu_fill.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p]
+    return L
+
+
+def p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+@pytest.mark.parametrize("logN", [13, 14, 15, 16, 17])
+def test_emu_params_and_ntt(emu, logN):
+    L, K = 3, 2
+    o = Oracle(logN, L, K)
+    h = emu.emu_create(logN, L, K)
+    try:
+        assert [emu.emu_modulus(h, m) for m in range(L + K)] == o.moduli
+        assert [emu.emu_psi(h, m) for m in range(L + K)] == o.psis
+        for m in (0, L + K - 1):
+            x = o.fill_uniform([m], 42 + m)[0]
+            # edge values: 0, q-1
+            x[0], x[1], x[-1] = 0, o.moduli[m] - 1, o.moduli[m] - 1
+            out = np.empty_like(x)
+            assert emu.emu_ntt(h, m, p(x), p(out), 0, 0, 0) == 0
+            exp = o.ntt([m], x[None])[0]
+            assert np.array_equal(out, exp), f"forward logN={logN} mod={m}"
+            back = np.empty_like(x)
+            assert emu.emu_ntt(h, m, p(out), p(back), 1, 0, 0) == 0
+            assert np.array_equal(back, x), f"inverse logN={logN} mod={m}"
+            # in-place + fused scale
+            k = o.moduli[m] - 12345
+            buf = out.copy()
+            emu.emu_ntt(h, m, p(buf), p(buf), 1, k, 1)
+            assert np.array_equal(buf, o.ewe(5, [m], x[None], k=[k])[0])
+    finally:
+        emu.emu_destroy(h)
+
+
+def test_emu_ewe_bconv_auto_fill(emu):
+    logN, L, K = 13, 5, 2
+    o = Oracle(logN, L, K)
+    h = emu.emu_create(logN, L, K)
+    try:
+        N = o.N
+        for m in (0, 6):
+            q = o.moduli[m]
+            a, b, c, d = (o.fill_uniform([m], s)[0] for s in (1, 2, 3, 4))
+            a[:4] = [0, q - 1, q - 1, 1]
+            b[:4] = [q - 1, q - 1, 0, q - 1]
+            c[:4] = [q - 1, 0, q - 1, q - 1]
+            d[:4] = [q - 1, q - 1, q - 1, 0]
+            k = q - 2
+            for op in range(8):
+                out = np.empty(N, dtype=np.uint64)
+                emu.emu_ewe(h, op, m, p(a), p(b), p(c), p(d), k, p(out))
+                exp = o.ewe(op, [m], a[None], b[None], c[None], d[None], k=[k])[0]
+                assert np.array_equal(out, exp), f"op {op}"
+            out = np.empty(N, dtype=np.uint64)
+            emu.emu_ewe(h, 8, m, p(a), p(b), p(c), p(d), k, p(out))
+            exp = o.ewe(3, [m], o.ewe(6, [m], a[None], None, c[None], k=[k]), None, d[None])[0]
+            assert np.array_equal(out, exp)
+        # base conversion: ModUp-like (2 -> 5) and ModDown-like (2 -> 5), edge: all inputs q-1
+        for in_ids, out_ids in (([0, 1], [2, 3, 4, 5, 6]), ([5, 6], [0, 1, 2, 3, 4]), ([2], [0, 6])):
+            ii, oi = np.array(in_ids, dtype=np.uint32), np.array(out_ids, dtype=np.uint32)
+            x = o.fill_uniform(in_ids, 9)
+            for r, m in enumerate(in_ids):
+                x[r, :2] = [o.moduli[m] - 1, 0]
+            out = np.empty((len(out_ids), N), dtype=np.uint64)
+            emu.emu_bconv(h, p(ii), len(ii), p(oi), len(oi), p(x), p(out))
+            assert np.array_equal(out, o.bconv_matmul(in_ids, out_ids, x))
+            qh = np.empty(len(ii), dtype=np.uint64)
+            tb = np.empty((len(ii), len(oi)), dtype=np.uint64)
+            emu.emu_bconv_consts(h, p(ii), len(ii), p(oi), len(oi), p(qh), p(tb))
+            eq, et = o.bconv_consts(in_ids, out_ids)
+            assert np.array_equal(qh, eq) and np.array_equal(tb, et)
+        # 16 inputs of q-1 against table entries: the widest accumulator (n_in = 16 needs K+L >= 17)
+        for g in (5, 25, 2 * N - 1, 3):
+            x = o.fill_uniform([0], g)[0]
+            out = np.empty_like(x)
+            emu.emu_automorph(h, p(x), p(out), g)
+            assert np.array_equal(out, o.automorph_eval(x[None], g)[0])
+        out = np.empty(N, dtype=np.uint64)
+        emu.emu_fill(h, 3, 1234 + 2, p(out))
+        assert np.array_equal(out, o.fill_uniform([1, 2, 3], 1234)[2])
+    finally:
+        emu.emu_destroy(h)
+
+
+def test_emu_bconv_widest_accumulator(emu):
+    """16 input limbs all at q_i - 1: the 128-bit accumulator reaches ~2^124 (fold path of hm_barrett_wide)."""
+    logN, L, K = 13, 20, 2
+    o = Oracle(logN, L, K)
+    h = emu.emu_create(logN, L, K)
+    try:
+        in_ids, out_ids = list(range(16)), [16, 17, 18, 19, 20, 21]
+        x = o.fill_uniform(in_ids, 5)
+        for r, m in enumerate(in_ids):
+            x[r, :8] = o.moduli[m] - 1
+        ii, oi = np.array(in_ids, dtype=np.uint32), np.array(out_ids, dtype=np.uint32)
+        out = np.empty((len(out_ids), o.N), dtype=np.uint64)
+        emu.emu_bconv(h, p(ii), 16, p(oi), len(oi), p(x), p(out))
+        assert np.array_equal(out, o.bconv_matmul(in_ids, out_ids, x))
+    finally:
+        emu.emu_destroy(h)

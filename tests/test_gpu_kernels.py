@@ -1,0 +1,139 @@
+"""GPU parity: every HIP kernel family through the C ABI vs the CPU oracle, bit-exact (integer work).
+Sizes: N = 2^15 and 2^16 (the oracle finishes each case in well under a second)."""
+import numpy as np
+import pytest
+
+from oracle.homoracle import Oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", params=[16, 15])
+def env(request):
+    from homulator_amd import hip
+    logN, L, K = request.param, 6, 3
+    ctx = hip.Context(logN, L, K)
+    o = Oracle(logN, L, K)
+    yield ctx, o, hip
+    ctx.close()
+
+
+def test_params_match_oracle(env):
+    ctx, o, _ = env
+    assert ctx.moduli == o.moduli
+
+
+def test_ntt_forward_inverse_bit_exact(env):
+    """BASELINE config #2: N=2^16 forward+inverse NTT, bit-exact vs CPU (also N=2^15, several moduli, edge values)."""
+    ctx, o, _ = env
+    ids = list(range(o.L + o.K))
+    x = o.fill_uniform(ids, 123)
+    for r, m in enumerate(ids):
+        x[r, 0], x[r, 1], x[r, -1] = 0, o.moduli[m] - 1, o.moduli[m] - 1
+    x[0, :] = o.moduli[0] - 1   # worst case for the lazy ranges
+    x[1, :] = 0
+    d = ctx.from_host(x)
+    out = ctx.alloc(len(ids))
+    ctx.ntt(d, out, ids)
+    X = out.download()
+    assert np.array_equal(X, o.ntt(ids, x))
+    ctx.ntt(out, out, ids, inverse=True)  # in place
+    assert np.array_equal(out.download(), x)
+    # single limb, permuted limb lists, fused scale
+    scale = [o.moduli[m] - 7 - m for m in ids]
+    perm = ids[::-1]
+    ctx.ntt(d, out, [ids[i] for i in perm], inverse=True, in_limbs=perm, out_limbs=perm, scale=[scale[i] for i in perm])
+    exp = o.ewe(5, ids, o.ntt(ids, x, inverse=True), k=scale)
+    assert np.array_equal(out.download(), exp)
+    d.free(); out.free()
+
+
+def test_ntt_many_limbs_over_one_launch(env):
+    ctx, o, _ = env
+    ids = [i % (o.L + o.K) for i in range(140)]   # > HM_MAX_LIMBS: exercises the chunked launch
+    d = ctx.alloc(140)
+    ctx.fill_uniform(d, ids, 77)
+    x = d.download()
+    assert np.array_equal(x[[0, 5, 139]], np.stack([o.fill_uniform(ids, 77)[i] for i in (0, 5, 139)]))
+    ctx.ntt(d, d, ids)
+    got = d.download()
+    sel = [0, 1, 127, 128, 139]
+    assert np.array_equal(got[sel], o.ntt([ids[i] for i in sel], x[sel]))
+    d.free()
+
+
+def test_ewe_all_opcodes(env):
+    ctx, o, hip = env
+    ids = [0, 3, o.L, o.L + o.K - 1]
+    n = len(ids)
+    A, B, Cc, D = (o.fill_uniform(ids, s) for s in (1, 2, 3, 4))
+    for r, m in enumerate(ids):
+        q = o.moduli[m]
+        A[r, :4] = [0, q - 1, q - 1, 1]
+        B[r, :4] = [q - 1, q - 1, 0, q - 1]
+        Cc[r, :4] = [q - 1, 0, q - 1, q - 1]
+        D[r, :4] = [q - 1, q - 1, q - 1, 0]
+    k = [o.moduli[m] - 2 - r for r, m in enumerate(ids)]
+    da, db, dc, dd = (ctx.from_host(v) for v in (A, B, Cc, D))
+    out = ctx.alloc(n)
+    for op in range(8):
+        ctx.ewe(op, out, ids, a=da, b=db, c=dc, d=dd, k=k)
+        assert np.array_equal(out.download(), o.ewe(op, ids, A, B, Cc, D, k=k)), f"opcode {op}"
+    ctx.ewe(hip.OP_SUB_SCALE_ADD, out, ids, a=da, c=dc, d=dd, k=k)
+    exp = o.ewe(3, ids, o.ewe(6, ids, A, None, Cc, k=k), None, D)
+    assert np.array_equal(out.download(), exp)
+    # limb lists
+    ctx.ewe(hip.OP_MUL, out, [ids[2], ids[0]], a=da, b=db, la=[2, 0], lb=[2, 0], lo=[1, 3])
+    got = out.download()
+    assert np.array_equal(got[1], o.ewe(0, [ids[2]], A[2:3], B[2:3])[0])
+    assert np.array_equal(got[3], o.ewe(0, [ids[0]], A[0:1], B[0:1])[0])
+    for b_ in (da, db, dc, dd, out):
+        b_.free()
+
+
+def test_bconv_modup_moddown_shapes(env):
+    ctx, o, _ = env
+    L, K = o.L, o.K
+    cases = [([0, 1, 2], [3, 4, 5, L, L + 1, L + 2]),       # digit 0 of a ModUp at ell = 6
+             ([3, 4, 5], [0, 1, 2, L, L + 1, L + 2]),       # digit 1
+             ([L, L + 1, L + 2], [0, 1, 2, 3, 4, 5]),       # ModDown P -> Q
+             ([4], [0, L + 2])]                               # partial digit of one limb
+    for in_ids, out_ids in cases:
+        x = o.fill_uniform(in_ids, 31)
+        for r, m in enumerate(in_ids):
+            x[r, :3] = [o.moduli[m] - 1, 0, 1]
+        d = ctx.from_host(x)
+        out = ctx.alloc(len(out_ids))
+        ctx.bconv(d, in_ids, out, out_ids)
+        assert np.array_equal(out.download(), o.bconv_matmul(in_ids, out_ids, x))
+        qh, tb = ctx.bconv_consts(in_ids, out_ids)
+        eq, et = o.bconv_consts(in_ids, out_ids)
+        assert np.array_equal(qh, eq) and np.array_equal(tb, et)
+        d.free(); out.free()
+
+
+@pytest.mark.parametrize("rot", [1, 2, 7])
+def test_automorph_eval(env, rot):
+    ctx, o, _ = env
+    g = pow(5, rot, 2 * o.N)
+    ids = [0, 2, o.L]
+    x = o.fill_uniform(ids, 55)
+    d = ctx.from_host(x)
+    out = ctx.alloc(3)
+    ctx.automorph(d, out, 3, g)
+    assert np.array_equal(out.download(), o.automorph_eval(x, g))
+    d.free(); out.free()
+
+
+def test_errors_are_loud(env):
+    ctx, o, hip = env
+    d = ctx.alloc(2)
+    with pytest.raises(hip.HmError):
+        ctx.ntt(d, d, [999, 0])                       # bad modulus id
+    with pytest.raises(hip.HmError):
+        ctx.automorph(d, d, 2, 4)                     # even galois element
+    with pytest.raises(hip.HmError):
+        ctx.bconv(d, [0, 1], d, [1, 2])               # modulus in both bases
+    with pytest.raises(hip.HmError):
+        ctx.ewe(hip.OP_MUL_CONST, d, [0, 1], a=d)     # missing constants
+    d.free()
