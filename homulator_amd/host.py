@@ -1,0 +1,117 @@
+"""ctypes binding of host/include/homulator_host.h (libhomulator_host.so): build one FHE operation with the
+C++ Operation / InsGen / Driver layer and run it on the HIP backend (or the no-GPU `count` backend that only
+accounts instructions)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(ROOT, "host", "lib", "libhomulator_host.so")
+CONFIG_DIR = os.path.join(ROOT, "config")
+BACKEND_HIP, BACKEND_COUNT = 0, 1
+SEED = 0x484F4D55
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: run __graft_entry__.build() (make -C host)")
+        L = C.CDLL(LIB_PATH)
+        vp, u32, u64p = C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64)
+        L.hh_op_create.argtypes = [C.POINTER(vp), C.c_char_p, C.c_char_p, u32, u32, u32, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int]
+        L.hh_op_destroy.argtypes = [vp]
+        L.hh_last_error.restype = C.c_char_p
+        L.hh_op_simulate.argtypes = [vp]
+        L.hh_op_execute.argtypes = [vp, u32, C.POINTER(C.c_double)]
+        L.hh_op_enqueue.argtypes = [vp, u32]
+        L.hh_op_sync.argtypes = [vp]
+        L.hh_op_total_instructions.argtypes = [vp, u64p]
+        L.hh_op_launch_count.argtypes = [vp, u64p]
+        L.hh_op_stage_bytes.argtypes = [vp, u64p]
+        L.hh_op_buffer_limbs.argtypes = [vp, C.c_char_p, C.POINTER(u32)]
+        L.hh_op_read_buffer.argtypes = [vp, C.c_char_p, vp]
+        L.hh_op_buffer_names.argtypes = [vp, C.c_char_p, u32]
+        L.hh_op_N.restype = u32
+        L.hh_op_N.argtypes = [vp]
+        _lib = L
+    return _lib
+
+
+class HostError(RuntimeError):
+    pass
+
+
+class Op:
+    """One operation instance: `Op("config_4.cfg", "hmult", 45, 35, 15)` = `./Homulator.run config_4.cfg hmult 45 35 15`."""
+
+    def __init__(self, cfg, op, max_level, cur_level, alpha, backend=BACKEND_HIP, fuse=True, device=0, overrides=None, quiet=True):
+        self.L = load()
+        if not os.path.isabs(cfg) and not os.path.exists(cfg):
+            cfg = os.path.join(CONFIG_DIR, cfg)
+        self.h = C.c_void_p()
+        ov = None if not overrides else ";".join(f"{k}={v}" for k, v in overrides.items()).encode()
+        st = self.L.hh_op_create(C.byref(self.h), cfg.encode(), op.encode(), max_level, cur_level, alpha, backend, 1 if fuse else 0,
+                                 device, ov, 1 if quiet else 0)
+        if st:
+            raise HostError(self.L.hh_last_error().decode())
+        self.N = self.L.hh_op_N(self.h)
+
+    def _ck(self, st):
+        if st:
+            raise HostError(self.L.hh_last_error().decode())
+
+    def close(self):
+        if self.h:
+            self.L.hh_op_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def simulate(self):
+        self._ck(self.L.hh_op_simulate(self.h))
+
+    def execute(self, iters=1):
+        """runs the whole op `iters` times; returns device ns per iteration"""
+        ns = C.c_double()
+        self._ck(self.L.hh_op_execute(self.h, iters, C.byref(ns)))
+        return ns.value
+
+    def enqueue(self, iters=1):
+        self._ck(self.L.hh_op_enqueue(self.h, iters))
+
+    def sync(self):
+        self._ck(self.L.hh_op_sync(self.h))
+
+    def _u64(self, fn):
+        v = C.c_uint64()
+        self._ck(fn(self.h, C.byref(v)))
+        return v.value
+
+    def total_instructions(self):
+        return self._u64(self.L.hh_op_total_instructions)
+
+    def launch_count(self):
+        return self._u64(self.L.hh_op_launch_count)
+
+    def stage_bytes(self):
+        return self._u64(self.L.hh_op_stage_bytes)
+
+    def buffer_names(self):
+        buf = C.create_string_buffer(1 << 16)
+        self._ck(self.L.hh_op_buffer_names(self.h, buf, len(buf)))
+        return [s for s in buf.value.decode().split("\n") if s]
+
+    def read(self, name):
+        n = C.c_uint32()
+        self._ck(self.L.hh_op_buffer_limbs(self.h, name.encode(), C.byref(n)))
+        out = np.empty((n.value, self.N), dtype=np.uint64)
+        self._ck(self.L.hh_op_read_buffer(self.h, name.encode(), out.ctypes.data_as(C.c_void_p)))
+        return out

@@ -1,0 +1,92 @@
+// Arch.h — the execution backend behind the reference's Arch surface.
+// Upstream, Arch (include/Arch.h:154-299, src/Arch.cpp) is the cycle model: per-cluster fetch / decode /
+// issue / commit front ends that advance a cycle counter.  Here the same public method set drives REAL
+// execution through the C ABI of include/homulator_hip.h: issueIns() queues a stage, update() launches the
+// next stage on the GPU, simulateComplete() says whether everything was launched, getCycle() returns
+// elapsed DEVICE NANOSECONDS (not cycles), shownStat() prints measured counters in the upstream format.
+// backend = "count" executes nothing (no GPU needed): it only accounts instructions, for the structural
+// parity tests against the compiled reference (tests/golden/structural.json).
+#ifndef HOMULATOR_ARCH_H
+#define HOMULATOR_ARCH_H
+#include "Basic.h"
+#include "Config.h"
+#include "Instruction.h"
+#include "Statistic.h"
+
+struct hm_ctx;
+
+// one dispatched stage: all limb-level instructions of one stage key, in limb order
+struct Stage {
+  std::string name;  // stage key, e.g. "ModUp_INTT"
+  ins_ops kind;
+  std::vector<Instruction *> ins;
+  uint32_t cluster0 = 0;  // placement of limb 0 (limb l runs on (cluster0 + l) % cluster upstream)
+};
+
+// a fill of input limbs with the deterministic synthetic stream
+struct InputFill {
+  std::vector<AddrType> addrs;
+  std::vector<uint32_t> mods;
+  uint64_t seed;
+};
+
+class Arch {
+public:
+  enum Backend { BACKEND_HIP = 0, BACKEND_COUNT = 1 };
+
+  explicit Arch(Config *cfg);
+  ~Arch();
+
+  // ---- build-specific setup (called by the Operation constructors)
+  void bindParams(uint32_t maxLevel, uint32_t alpha);  // creates the HIP context (N from the config)
+  void registerLimbs(const std::vector<AddrType> &limbStarts);  // gives every limb-poly a place in HBM
+  void addInputFill(const InputFill &f) { fills.push_back(f); }
+  uint64_t modulus(uint32_t modId) const;
+  // constants of a base conversion (host side): qhat_inv[n_in]
+  std::vector<uint64_t> bconvScale(const std::vector<uint32_t> &inMods);
+  Backend backend() const { return backendKind; }
+  hm_ctx *context() { return ctx; }
+
+  // ---- the reference's execution surface
+  void issueIns(uint32_t cluster, const std::string &unit, const Stage &stage);  // include/Arch.h:276-277
+  void update();                // launch the next queued stage (src/Arch.cpp:912-929 advanced one cycle)
+  bool simulateComplete();      // include/Arch.h:246-269
+  unsigned long long getCycle();         // elapsed device time in ns
+  unsigned long long getcompletedIns();  // upstream instructions retired so far
+  void state();
+  void shownStat();  // src/Arch.cpp:1019-1022
+
+  // ---- whole-plan execution (bench / tests): prepare once, run many times
+  void prepare();                       // allocate HBM, fill inputs, fuse and coalesce stages into launches
+  void run();                           // enqueue every launch once (asynchronous)
+  void sync();
+  double timedRun(uint32_t iters);      // ns per iteration, device time
+  bool readLimbs(const std::vector<AddrType> &addrs, uint64_t *host);  // download limbs (N words each)
+  size_t launchCount() const { return launches.size(); }
+  unsigned long long algorithmicBytes() const { return algBytes; }
+  Statistic *stats() { return stat; }
+  uint32_t N() const { return n; }
+
+private:
+  struct Launch;
+  Config *config;
+  Backend backendKind;
+  bool fuse;
+  uint32_t n = 0, logN = 0, clusterCount = 1;
+  hm_ctx *ctx = nullptr;
+  uint64_t *pool = nullptr;  // all limb-polys, [limb][N]
+  std::map<AddrType, uint32_t> limbIndex;
+  std::vector<Stage> stages;
+  std::vector<InputFill> fills;
+  std::vector<Launch *> launches;
+  size_t nextLaunch = 0;
+  bool prepared = false;
+  unsigned long long completedIns = 0, elapsedNs = 0, algBytes = 0;
+  Statistic *stat;
+
+  uint32_t limbOf(AddrType a) const;
+  void buildLaunches();
+  void fusePasses(std::vector<Stage> &st);
+  void enqueue(Launch &l);
+};
+#endif

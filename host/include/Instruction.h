@@ -1,0 +1,44 @@
+// Instruction.h — one LIMB-level operation of a stage.
+// The reference's Instruction (include/Instruction.h:26-188) is one 256-coefficient batch of one limb and
+// carries only address tokens and an op kind; a GPU launch covers a whole stage, so this build's record is
+// per limb, stands for `refInstructions` upstream instructions (batchCount of them; x InLevel for BCONV),
+// and carries what the timing model lacks: modulus id, EWE opcode, constants, Galois element, input basis.
+#ifndef HOMULATOR_INSTRUCTION_H
+#define HOMULATOR_INSTRUCTION_H
+#include "Basic.h"
+
+enum ins_ops { NTT, INTT, MULT, MADD, MSUB, BCONV_STEP1, BCONV_STEP2, AUTO, DS, PRNG, IP, FETCH_RF, STORE_RF };
+extern std::vector<std::string> ins_ops_name;
+
+// the arithmetic of an EWE ("MULT"-tagged) instruction; numbering = include/homulator_hip.h hm_ewe_op
+enum ewe_opcode {
+  EWE_MUL = 0, EWE_MAC2 = 1, EWE_MAC_ADD = 2, EWE_ADD = 3, EWE_SUB = 4,
+  EWE_MUL_CONST = 5, EWE_SUB_SCALE = 6, EWE_COPY = 7, EWE_SUB_SCALE_ADD = 8
+};
+
+class Instruction {
+public:
+  ins_ops ops;
+  std::string Name;
+  uint32_t level_id = 0;   // limb index inside its buffer (reference: level_id)
+  uint32_t mod_id = 0;     // modulus id (q_i: i, p_j: maxLevel + j)
+  std::vector<AddrType> operandList;  // up to 4 operands (0 = "fake operand", src/mem.cpp:30); BCONV: the inputs
+  AddrType OutputOperand = 0;
+  ewe_opcode opcode = EWE_MUL;
+  bool hasConstant = false;
+  uint64_t constant = 0;   // per-limb constant of MUL_CONST / SUB_SCALE, or the INTT epilogue scale
+  uint32_t galois = 0;
+  bool passthrough = false;  // an NTT-kind instruction whose input is already in evaluation form (copy)
+  std::vector<uint32_t> inMods;  // BCONV: modulus ids of the inputs
+  unsigned long long refInstructions = 0;  // upstream instructions this record stands for
+  std::vector<Instruction *> depsInsList;
+
+  Instruction(std::string name, ins_ops op, uint32_t level) : ops(op), Name(std::move(name)), level_id(level) {}
+  const std::string &GetOpName() const { return ins_ops_name[ops]; }
+  const std::string &GetName() const { return Name; }
+  uint32_t getinputCount() const { return (uint32_t)operandList.size(); }
+  AddrType getOperand(uint32_t i) const { return operandList[i]; }
+};
+
+typedef std::vector<Instruction *> INSGROUP;
+#endif

@@ -1,0 +1,37 @@
+/*
+ * homulator_host.h — C entry points of the host layer (libhomulator_host.so): build one FHE operation with
+ * the Operation / InsGen / Driver classes and execute it on the backend.  Used by bench.py and the parity
+ * tests through ctypes; the CLI (host/bench_test/bench_micro24.cpp) uses the C++ classes directly.
+ * Mirrors the reference's only caller, main() of bench_test/bench_micro24.cpp:5-52.
+ */
+#ifndef HOMULATOR_HOST_H
+#define HOMULATOR_HOST_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+typedef struct hh_op hh_op;
+
+/* op in {hmult, hrotate, hadd, pmult, padd}; backend: 0 = hip, 1 = count (no GPU); fuse: 0/1;
+ * extra "key=value" config overrides separated by ';' (may be NULL), e.g. "galois=25;seed=7".
+ * quiet != 0 suppresses the constructors' stdout (config echo, Malloc lines). */
+int hh_op_create(hh_op **op, const char *cfg_path, const char *op_name, uint32_t max_level, uint32_t cur_level,
+                 uint32_t alpha, int backend, int fuse, int device, const char *overrides, int quiet);
+void hh_op_destroy(hh_op *op);
+const char *hh_last_error(void);
+
+int hh_op_simulate(hh_op *op);                              /* upstream entry: prints banner + stat block */
+int hh_op_execute(hh_op *op, uint32_t iters, double *ns_per_iter); /* whole op, device time */
+int hh_op_enqueue(hh_op *op, uint32_t iters);               /* asynchronous: no timing, no sync */
+int hh_op_sync(hh_op *op);
+int hh_op_total_instructions(hh_op *op, uint64_t *total);
+int hh_op_launch_count(hh_op *op, uint64_t *n);
+int hh_op_stage_bytes(hh_op *op, uint64_t *bytes);          /* sum over launches of operand bytes */
+int hh_op_buffer_limbs(hh_op *op, const char *name, uint32_t *n_limbs);
+int hh_op_read_buffer(hh_op *op, const char *name, uint64_t *host); /* [n_limbs][N] */
+int hh_op_buffer_names(hh_op *op, char *out, uint32_t cap); /* '\n'-separated */
+uint32_t hh_op_N(hh_op *op);
+#ifdef __cplusplus
+}
+#endif
+#endif

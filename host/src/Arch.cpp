@@ -1,0 +1,374 @@
+// Arch.cpp — execution backend: turns queued stages into GPU launches through the C ABI.
+#include "Arch.h"
+
+#include <chrono>
+#include <cstring>
+#include <set>
+
+#include "../../homulator_amd/csrc/hm_params.h"
+#include "../../include/homulator_hip.h"
+
+// one C-ABI call, with its argument arrays prebuilt so that run() is a tight loop of calls
+struct Arch::Launch {
+  enum Kind { L_NTT, L_INTT, L_EWE, L_BCONV, L_AUTO } kind;
+  std::string name;
+  std::string statKey;
+  int opcode = 0;
+  uint32_t galois = 0;
+  std::vector<uint32_t> a, b, c, d, out, mods, inMods;
+  std::vector<uint64_t> k;
+  bool hasK = false;
+  unsigned long long refInstructions = 0;
+  unsigned long long bytes = 0;  // operand limb-polys read + written x N x 8
+};
+
+struct ArchHost {
+  hm::Params P;
+};
+static std::map<const Arch *, ArchHost *> g_host;  // host-side parameter set per Arch (kept out of the header)
+
+Arch::Arch(Config *cfg) : config(cfg) {
+  n = cfg->getValue("N");
+  logN = 0;
+  while ((1u << logN) < n) ++logN;
+  clusterCount = cfg->getValueOr("cluster", 1);
+  uint32_t b = cfg->getValueOr("backend", BACKEND_HIP);
+  if (const char *e = getenv("HOMULATOR_BACKEND")) b = (std::string(e) == "count") ? BACKEND_COUNT : BACKEND_HIP;
+  backendKind = b == BACKEND_COUNT ? BACKEND_COUNT : BACKEND_HIP;
+  fuse = cfg->getValueOr("fuse", 1) != 0;
+  if (const char *e = getenv("HOMULATOR_FUSE")) fuse = std::string(e) != "0";
+  stat = new Statistic();
+}
+
+Arch::~Arch() {
+  for (Launch *l : launches) delete l;
+  if (ctx) {
+    if (pool) hm_free(ctx, pool);
+    hm_destroy(ctx);
+  }
+  auto it = g_host.find(this);
+  if (it != g_host.end()) {
+    delete it->second;
+    g_host.erase(it);
+  }
+  delete stat;
+}
+
+void Arch::bindParams(uint32_t maxLevel, uint32_t alpha) {
+  if (g_host.count(this)) return;
+  ArchHost *h = new ArchHost;
+  h->P.init(logN, maxLevel, alpha, nullptr, nullptr, nullptr);
+  g_host[this] = h;
+  if (backendKind == BACKEND_HIP) {
+    hm_params p = {logN, maxLevel, alpha, (int32_t)config->getValueOr("device", 0), nullptr, nullptr, nullptr};
+    if (const char *e = getenv("HOMULATOR_DEVICE")) p.device = atoi(e);
+    if (hm_create(&ctx, &p) != HM_OK)
+      throw std::runtime_error(std::string("HIP backend unavailable: ") + hm_last_error(nullptr));
+  }
+}
+
+uint64_t Arch::modulus(uint32_t modId) const { return g_host.at(this)->P.mod.at(modId); }
+
+std::vector<uint64_t> Arch::bconvScale(const std::vector<uint32_t> &inMods) {
+  std::vector<uint64_t> qh(inMods.size()), tb(inMods.size());
+  g_host.at(this)->P.bconv_consts(inMods.data(), (uint32_t)inMods.size(), nullptr, 0, qh.data(), tb.data());
+  return qh;
+}
+
+void Arch::registerLimbs(const std::vector<AddrType> &limbStarts) {
+  for (AddrType a : limbStarts)
+    if (!limbIndex.count(a)) {
+      uint32_t idx = (uint32_t)limbIndex.size();
+      limbIndex[a] = idx;
+    }
+}
+
+uint32_t Arch::limbOf(AddrType a) const {
+  auto it = limbIndex.find(a);
+  if (it == limbIndex.end()) throw std::runtime_error("address " + std::to_string(a) + " is not a registered limb");
+  return it->second;
+}
+
+void Arch::issueIns(uint32_t, const std::string &, const Stage &stage) {
+  if (prepared) throw std::runtime_error("issueIns after prepare()");
+  stages.push_back(stage);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// fusion passes on the stage list (fuse = 1).  All of them preserve every value that a later stage or the
+// caller can observe except the intermediates they eliminate (listed in DESIGN.md §5).
+// ---------------------------------------------------------------------------------------------------
+void Arch::fusePasses(std::vector<Stage> &st) {
+  // consumers of every address
+  std::map<AddrType, int> uses;
+  auto operands = [](Instruction *i) {
+    std::vector<AddrType> v;
+    if (i->ops == BCONV_STEP2) v.assign(i->operandList.begin(), i->operandList.end() - 1);
+    else if (i->ops == MULT) {
+      const int m[9] = {3, 15, 7, 5, 5, 1, 5, 1, 13};
+      for (int b = 0; b < 4; ++b)
+        if (m[i->opcode] & (1 << b)) v.push_back(i->operandList[b]);
+    } else v.push_back(i->operandList[0]);
+    return v;
+  };
+  std::map<AddrType, Instruction *> producer;
+  for (auto &s : st)
+    for (Instruction *i : s.ins) {
+      for (AddrType a : operands(i)) uses[a]++;
+      producer[i->OutputOperand] = i;
+    }
+  std::set<Instruction *> dead;
+  // (1) pass-through NTT records: consumers read the source directly
+  std::map<AddrType, AddrType> alias;
+  for (auto &s : st)
+    for (Instruction *i : s.ins)
+      if ((i->ops == NTT) && i->passthrough) {
+        alias[i->OutputOperand] = i->operandList[0];
+        dead.insert(i);
+      }
+  for (auto &s : st)
+    for (Instruction *i : s.ins) {
+      if (dead.count(i)) continue;
+      for (AddrType &a : i->operandList) {
+        auto al = alias.find(a);
+        if (al != alias.end()) a = al->second;
+      }
+    }
+  // (2) INTT followed by a single MUL_CONST consumer: the constant goes into the INTT epilogue
+  for (auto &s : st)
+    for (Instruction *i : s.ins) {
+      if (i->ops != MULT || i->opcode != EWE_MUL_CONST || dead.count(i)) continue;
+      auto p = producer.find(i->operandList[0]);
+      if (p == producer.end() || p->second->ops != INTT || uses[i->operandList[0]] != 1 || p->second->hasConstant) continue;
+      p->second->hasConstant = true;
+      p->second->constant = i->constant;
+      p->second->OutputOperand = i->OutputOperand;
+      p->second->refInstructions += i->refInstructions;
+      producer[i->OutputOperand] = p->second;
+      dead.insert(i);
+    }
+  // (3) EWE chains: SUB then MUL_CONST -> SUB_SCALE ; SUB_SCALE then ADD -> SUB_SCALE_ADD
+  for (auto &s : st)
+    for (Instruction *i : s.ins) {
+      if (i->ops != MULT || dead.count(i)) continue;
+      if (i->opcode == EWE_MUL_CONST) {
+        auto p = producer.find(i->operandList[0]);
+        if (p == producer.end() || p->second->ops != MULT || p->second->opcode != EWE_SUB || dead.count(p->second) ||
+            uses[i->operandList[0]] != 1)
+          continue;
+        Instruction *sub = p->second;
+        i->opcode = EWE_SUB_SCALE;
+        i->operandList[0] = sub->operandList[0];
+        i->operandList[2] = sub->operandList[2];
+        i->refInstructions += sub->refInstructions;
+        dead.insert(sub);
+      } else if (i->opcode == EWE_ADD) {
+        for (int side = 0; side < 2; ++side) {
+          const int me = side ? 2 : 0, other = side ? 0 : 2;
+          auto p = producer.find(i->operandList[me]);
+          if (p == producer.end() || p->second->ops != MULT || p->second->opcode != EWE_SUB_SCALE || dead.count(p->second) ||
+              uses[i->operandList[me]] != 1)
+            continue;
+          Instruction *ss = p->second;
+          const AddrType addend = i->operandList[other];
+          i->opcode = EWE_SUB_SCALE_ADD;
+          i->operandList[0] = ss->operandList[0];
+          i->operandList[2] = ss->operandList[2];
+          i->operandList[3] = addend;
+          i->hasConstant = true;
+          i->constant = ss->constant;
+          i->refInstructions += ss->refInstructions;
+          dead.insert(ss);
+          break;
+        }
+      }
+    }
+  // drop dead instructions and empty stages; upstream instructions of eliminated pass-through records are
+  // accounted on the first surviving instruction so that the retired total still matches getTotalIns()
+  unsigned long long orphan = 0;
+  std::vector<Stage> keep;
+  for (auto &s : st) {
+    Stage t = s;
+    t.ins.clear();
+    for (Instruction *i : s.ins) {
+      if (!dead.count(i)) t.ins.push_back(i);
+      else if (i->passthrough) orphan += i->refInstructions;
+    }
+    if (!t.ins.empty()) keep.push_back(t);
+  }
+  if (!keep.empty()) keep[0].ins[0]->refInstructions += orphan;
+  st.swap(keep);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// stage -> launch
+// ---------------------------------------------------------------------------------------------------
+void Arch::buildLaunches() {
+  std::vector<Stage> st = stages;
+  if (fuse) fusePasses(st);
+  const unsigned long long LP = (unsigned long long)n * 8;
+  // upstream issues every BCONV group to all MAC ports (include/Driver.h:307-320): same accounting here
+  const unsigned long long bconvPorts = (unsigned long long)config->getValueOr("bconv_num_high", 1) * config->getValueOr("bconv_num_width", 1);
+  for (const Stage &s : st) {
+    // split a stage by what one C-ABI call can express: same kind (+ opcode / direction / pass-through)
+    std::vector<std::vector<Instruction *>> parts;
+    std::vector<int> partKey;
+    for (Instruction *i : s.ins) {
+      int key = i->ops == MULT ? 100 + i->opcode : (i->ops == NTT && i->passthrough) ? 99 : (int)i->ops;
+      size_t p = 0;
+      for (; p < partKey.size(); ++p)
+        if (partKey[p] == key) break;
+      if (p == partKey.size()) { partKey.push_back(key); parts.emplace_back(); }
+      parts[p].push_back(i);
+    }
+    for (size_t p = 0; p < parts.size(); ++p) {
+      Launch *L = new Launch;
+      L->name = s.name;
+      Instruction *f = parts[p][0];
+      for (Instruction *i : parts[p]) L->refInstructions += i->refInstructions * (i->ops == BCONV_STEP2 ? bconvPorts : 1ull);
+      if (f->ops == NTT && f->passthrough) {  // unfused mode: materialise the copy
+        L->kind = Launch::L_EWE; L->opcode = EWE_COPY; L->statKey = "EWE";
+        for (Instruction *i : parts[p]) { L->a.push_back(limbOf(i->operandList[0])); L->out.push_back(limbOf(i->OutputOperand)); L->mods.push_back(i->mod_id); }
+        L->bytes = 2 * LP * parts[p].size();
+      } else if (f->ops == NTT || f->ops == INTT) {
+        L->kind = f->ops == NTT ? Launch::L_NTT : Launch::L_INTT; L->statKey = "NTT";
+        for (Instruction *i : parts[p]) {
+          L->a.push_back(limbOf(i->operandList[0])); L->out.push_back(limbOf(i->OutputOperand)); L->mods.push_back(i->mod_id);
+          L->k.push_back(i->hasConstant ? i->constant : 1);
+          L->hasK |= i->hasConstant;
+        }
+        L->bytes = 2 * LP * parts[p].size();
+      } else if (f->ops == AUTO) {
+        L->kind = Launch::L_AUTO; L->statKey = "AUTO"; L->galois = f->galois;
+        for (Instruction *i : parts[p]) { L->a.push_back(limbOf(i->operandList[0])); L->out.push_back(limbOf(i->OutputOperand)); }
+        L->bytes = 2 * LP * parts[p].size();
+      } else if (f->ops == MULT) {
+        L->kind = Launch::L_EWE; L->opcode = f->opcode; L->statKey = "EWE";
+        const int m[9] = {3, 15, 7, 5, 5, 1, 5, 1, 13};
+        int nops = 1;
+        for (int b = 0; b < 4; ++b) nops += (m[f->opcode] >> b) & 1;
+        for (Instruction *i : parts[p]) {
+          auto get = [&](int b) { return (m[f->opcode] & (1 << b)) ? limbOf(i->operandList[b]) : 0u; };
+          L->a.push_back(get(0)); L->b.push_back(get(1)); L->c.push_back(get(2)); L->d.push_back(get(3));
+          L->out.push_back(limbOf(i->OutputOperand)); L->mods.push_back(i->mod_id);
+          L->k.push_back(i->hasConstant ? i->constant : 0);
+          L->hasK |= i->hasConstant;
+        }
+        L->bytes = (unsigned long long)nops * LP * parts[p].size();
+      } else if (f->ops == BCONV_STEP2) {
+        L->kind = Launch::L_BCONV; L->statKey = "BCONV";
+        L->inMods = f->inMods;
+        for (size_t x = 0; x + 1 < f->operandList.size(); ++x) L->a.push_back(limbOf(f->operandList[x]));
+        for (Instruction *i : parts[p]) {
+          if (i->inMods != f->inMods) throw std::runtime_error("BCONV stage mixes input bases");
+          L->out.push_back(limbOf(i->OutputOperand)); L->mods.push_back(i->mod_id);
+        }
+        L->bytes = LP * (L->a.size() + L->out.size());
+      } else {
+        delete L;
+        throw std::runtime_error("no unit executes op " + f->GetOpName());
+      }
+      algBytes += L->bytes;
+      launches.push_back(L);
+    }
+  }
+}
+
+void Arch::prepare() {
+  if (prepared) return;
+  prepared = true;
+  buildLaunches();
+  stat->setStat("Launches", launches.size());
+  stat->setStat("LimbPolys_resident", limbIndex.size());
+  stat->setStat("HBM_stage_bytes", algBytes);
+  if (backendKind != BACKEND_HIP) return;
+  const size_t bytes = (size_t)limbIndex.size() * n * 8;
+  void *p = nullptr;
+  if (hm_malloc(ctx, bytes, &p) != HM_OK) throw std::runtime_error(std::string("hm_malloc: ") + hm_last_error(ctx));
+  pool = static_cast<uint64_t *>(p);
+  for (const InputFill &f : fills) {
+    std::vector<uint32_t> limbs;
+    for (AddrType a : f.addrs) limbs.push_back(limbOf(a));
+    if (hm_fill_uniform(ctx, pool, limbs.data(), f.mods.data(), (uint32_t)limbs.size(), f.seed) != HM_OK)
+      throw std::runtime_error(std::string("hm_fill_uniform: ") + hm_last_error(ctx));
+  }
+  hm_sync(ctx);
+}
+
+void Arch::enqueue(Launch &l) {
+  hm_status st = HM_OK;
+  const uint32_t cnt = (uint32_t)l.out.size();
+  switch (l.kind) {
+  case Launch::L_NTT:
+    st = hm_ntt(ctx, pool, l.a.data(), pool, l.out.data(), l.mods.data(), cnt, 0, nullptr);
+    break;
+  case Launch::L_INTT:
+    st = hm_ntt(ctx, pool, l.a.data(), pool, l.out.data(), l.mods.data(), cnt, 1, l.hasK ? l.k.data() : nullptr);
+    break;
+  case Launch::L_AUTO:
+    st = hm_automorph(ctx, pool, l.a.data(), pool, l.out.data(), cnt, l.galois);
+    break;
+  case Launch::L_EWE:
+    st = hm_ewe(ctx, l.opcode, pool, l.a.data(), pool, l.b.empty() ? nullptr : l.b.data(), pool, l.c.empty() ? nullptr : l.c.data(), pool,
+                l.d.empty() ? nullptr : l.d.data(), pool, l.out.data(), l.mods.data(), cnt, l.hasK ? l.k.data() : nullptr);
+    break;
+  case Launch::L_BCONV:
+    st = hm_bconv(ctx, pool, l.a.data(), l.inMods.data(), (uint32_t)l.inMods.size(), pool, l.out.data(), l.mods.data(), cnt);
+    break;
+  }
+  if (st != HM_OK) throw std::runtime_error("stage " + l.name + ": " + hm_last_error(ctx));
+}
+
+void Arch::update() {
+  if (!prepared) prepare();
+  if (nextLaunch >= launches.size()) return;
+  Launch &l = *launches[nextLaunch++];
+  if (backendKind == BACKEND_HIP) {
+    hm_timer_start(ctx);
+    enqueue(l);
+    uint64_t ns = 0;
+    hm_timer_stop(ctx, &ns);
+    elapsedNs += ns;
+    stat->increaseStat(l.statKey + "_(0)", ns);  // per-unit busy time, ns (upstream: busy cycles per cluster)
+  }
+  stat->increaseStat(l.statKey + "_launches");
+  completedIns += l.refInstructions;
+}
+
+bool Arch::simulateComplete() { return prepared && nextLaunch >= launches.size(); }
+unsigned long long Arch::getCycle() { return elapsedNs; }
+unsigned long long Arch::getcompletedIns() { return completedIns; }
+
+void Arch::state() {
+  std::cout << "launched " << nextLaunch << " of " << launches.size() << " stages\n";
+  if (nextLaunch < launches.size()) std::cout << "next: " << launches[nextLaunch]->name << "\n";
+}
+
+void Arch::shownStat() {
+  stat->setStat("Total_ns", elapsedNs);
+  stat->showStat();
+}
+
+void Arch::run() {
+  if (backendKind != BACKEND_HIP) return;
+  for (Launch *l : launches) enqueue(*l);
+}
+void Arch::sync() {
+  if (ctx) hm_sync(ctx);
+}
+double Arch::timedRun(uint32_t iters) {
+  if (!prepared) prepare();
+  if (backendKind != BACKEND_HIP) return 0.0;
+  hm_timer_start(ctx);
+  for (uint32_t i = 0; i < iters; ++i) run();
+  uint64_t ns = 0;
+  hm_timer_stop(ctx, &ns);
+  return (double)ns / iters;
+}
+
+bool Arch::readLimbs(const std::vector<AddrType> &addrs, uint64_t *host) {
+  if (backendKind != BACKEND_HIP || !pool) return false;
+  for (size_t i = 0; i < addrs.size(); ++i)
+    if (hm_memcpy_d2h(ctx, host + i * n, pool + (size_t)limbOf(addrs[i]) * n, (size_t)n * 8) != HM_OK) return false;
+  return true;
+}

@@ -1,0 +1,87 @@
+// capi.cpp — C entry points of the host layer (see homulator_host.h).
+#include "../include/homulator_host.h"
+
+#include <cstring>
+#include <sstream>
+
+#include "Operation.h"
+
+struct hh_op {
+  Config *cfg = nullptr;
+  Arch *arch = nullptr;
+  OperationBase *op = nullptr;
+};
+static thread_local std::string g_err;
+const char *hh_last_error(void) { return g_err.c_str(); }
+
+struct QuietScope {  // swallow std::cout while constructing (the reference prints its config and Malloc plan)
+  std::streambuf *old = nullptr;
+  std::ostringstream sink;
+  explicit QuietScope(bool on) { if (on) old = std::cout.rdbuf(sink.rdbuf()); }
+  ~QuietScope() { if (old) std::cout.rdbuf(old); }
+};
+
+#define HH_TRY(body)                      \
+  try { body; return 0; }                 \
+  catch (const std::exception &e) { g_err = e.what(); return 1; }
+
+int hh_op_create(hh_op **out, const char *cfg_path, const char *op_name, uint32_t maxLevel, uint32_t curLevel, uint32_t alpha,
+                 int backend, int fuse, int device, const char *overrides, int quiet) {
+  if (!out || !cfg_path || !op_name) { g_err = "null argument"; return 1; }
+  *out = nullptr;
+  hh_op *h = new hh_op;
+  try {
+    QuietScope qs(quiet != 0);
+    h->cfg = new Config(cfg_path);
+    h->cfg->getValue("N");  // a missing file leaves the map empty: fail here like upstream would at first use
+    h->cfg->setValue("backend", (uint32_t)backend);
+    h->cfg->setValue("fuse", (uint32_t)fuse);
+    h->cfg->setValue("device", (uint32_t)device);
+    if (overrides) {
+      std::stringstream ss(overrides);
+      std::string kv;
+      while (std::getline(ss, kv, ';')) {
+        size_t eq = kv.find('=');
+        if (eq != std::string::npos) h->cfg->setValue(kv.substr(0, eq), (uint32_t)std::stoul(kv.substr(eq + 1)));
+      }
+    }
+    if (curLevel == 0 || curLevel > maxLevel || alpha == 0) throw std::runtime_error("need 0 < curLevel <= maxLevel and alpha > 0");
+    h->arch = new Arch(h->cfg);
+    const std::string o = op_name;
+    if (o == "hmult") h->op = new HMULT("test_hmult", maxLevel, curLevel, alpha, h->cfg, h->arch);
+    else if (o == "hrotate") h->op = new HROTATE("test_hrotate", maxLevel, curLevel, alpha, h->cfg, h->arch);
+    else if (o == "hadd") h->op = new HADD("test_hadd", maxLevel, curLevel, alpha, h->cfg, h->arch);
+    else if (o == "pmult") h->op = new PMULT("test_pmult", maxLevel, curLevel, alpha, h->cfg, h->arch);
+    else if (o == "padd") h->op = new PADD("test_ADD", maxLevel, curLevel, alpha, h->cfg, h->arch);
+    else throw std::runtime_error("Error operation requirement, please double confirm!");
+  } catch (const std::exception &e) {
+    g_err = e.what();
+    hh_op_destroy(h);
+    return 1;
+  }
+  *out = h;
+  return 0;
+}
+void hh_op_destroy(hh_op *h) {
+  if (!h) return;
+  delete h->op;
+  delete h->arch;
+  delete h->cfg;
+  delete h;
+}
+int hh_op_simulate(hh_op *h) { HH_TRY(h->op->simulate()) }
+int hh_op_execute(hh_op *h, uint32_t iters, double *ns) { HH_TRY(double t = h->op->execute(iters); if (ns) *ns = t) }
+int hh_op_enqueue(hh_op *h, uint32_t iters) { HH_TRY(h->op->prepare(); for (uint32_t i = 0; i < iters; ++i) h->arch->run()) }
+int hh_op_sync(hh_op *h) { HH_TRY(h->arch->sync()) }
+int hh_op_total_instructions(hh_op *h, uint64_t *t) { HH_TRY(*t = h->op->totalInstructions()) }
+int hh_op_launch_count(hh_op *h, uint64_t *n) { HH_TRY(h->op->prepare(); *n = h->arch->launchCount()) }
+int hh_op_stage_bytes(hh_op *h, uint64_t *b) { HH_TRY(h->op->prepare(); *b = h->arch->algorithmicBytes()) }
+int hh_op_buffer_limbs(hh_op *h, const char *name, uint32_t *n) { HH_TRY(*n = (uint32_t)h->op->bufferAddrs(name).size()) }
+int hh_op_read_buffer(hh_op *h, const char *name, uint64_t *host) {
+  HH_TRY(if (!h->op->readBuffer(name, host)) throw std::runtime_error("buffer not readable (count backend or not prepared)"))
+}
+int hh_op_buffer_names(hh_op *h, char *out, uint32_t cap) {
+  HH_TRY(std::string s; for (auto &n : h->op->bufferNames()) s += n + "\n"; if (s.size() + 1 > cap) throw std::runtime_error("buffer too small");
+         memcpy(out, s.c_str(), s.size() + 1))
+}
+uint32_t hh_op_N(hh_op *h) { return h->arch->N(); }

@@ -1,0 +1,135 @@
+"""GPU parity of whole operations through the C++ host layer (Operation -> Driver -> Arch -> C ABI -> HIP
+kernels) against the CPU oracle on the same seeded synthetic inputs, bit-exact.
+ * unfused (fuse=0): every named stage buffer of the reference's buffer plan is compared;
+ * fused (fuse=1, the bench path): the operation outputs and every buffer that still exists.
+Covers BASELINE configs #1 (N=2^15, 16/10/4), #3 hmult and #4 hrotate (N=2^16, 45/35/15), beta = 1, uneven
+last digits, and hadd / pmult / padd."""
+import numpy as np
+import pytest
+
+from oracle.homoracle import Oracle
+
+pytestmark = pytest.mark.gpu
+SEED = 0x484F4D55
+_oracles = {}
+
+
+def oracle(logN, L, K):
+    key = (logN, L, K)
+    if key not in _oracles:
+        _oracles[key] = Oracle(logN, L, K)
+        _oracles[key].set_threads(8)
+    return _oracles[key]
+
+
+def inputs(o, ell):
+    return o.synth_ct(ell, SEED), o.synth_ct(ell, SEED + 2000), o.synth_evk(ell, SEED + 10000)
+
+
+def check_keyswitch_buffers(op, dd, ell, K, beta, fused):
+    E = ell + K
+    if not fused:
+        assert np.array_equal(op.read("ModUpINTTOut"), dd["modup_intt"])
+        for k in range(2):
+            assert np.array_equal(op.read(f"INTTOut_ModDown_Key({k})"), dd["moddown_intt"][k])
+    assert np.array_equal(op.read("ModUpDecompOut"), dd["modup_decomp"])
+    for j in range(beta):
+        got = op.read(f"NTTOut_beta({j})")
+        lo, hi = j * K, min(ell, (j + 1) * K)
+        sel = [t for t in range(E) if fused is False or not (lo <= t < hi)]   # fused: the digit's own limbs are aliased away
+        assert np.array_equal(got[sel], dd["ext"][j][sel]), f"NTTOut_beta({j})"
+    for k in range(2):
+        assert np.array_equal(op.read(f"InnerProduceOut_Key{k}"), dd["ip"][k]), f"InnerProduceOut_Key{k}"
+        assert np.array_equal(op.read(f"ModdownBConvOut_Key{k}"), dd["moddown_bconv"][k])
+        assert np.array_equal(op.read(f"NTTOut_ModDown_Key({k})"), dd["moddown_ntt"][k])
+
+
+CASES = [("config_4_N15.cfg", 15, 16, 10, 4), ("config_4_N15.cfg", 15, 8, 8, 8), ("config_4_N15.cfg", 15, 6, 5, 2),
+         ("config_4.cfg", 16, 45, 35, 15)]
+
+
+@pytest.mark.parametrize("cfg,logN,L,ell,alpha", CASES)
+@pytest.mark.parametrize("fuse", [False, True])
+def test_hmult_bit_exact(cfg, logN, L, ell, alpha, fuse):
+    from homulator_amd import host
+    o = oracle(logN, L, alpha)
+    ct1, ct2, evk = inputs(o, ell)
+    ids = list(range(ell))
+    op = host.Op(cfg, "hmult", L, ell, alpha, fuse=fuse)
+    op.execute(1)
+    assert np.array_equal(op.read("ct1.c0"), ct1[0]) and np.array_equal(op.read("ct2.c1"), ct2[1])
+    d0 = o.ewe(0, ids, ct1[0], ct2[0])
+    d1 = o.ewe(1, ids, ct1[0], ct2[1], ct1[1], ct2[0])
+    d2 = o.ewe(0, ids, ct1[1], ct2[1])
+    assert np.array_equal(op.read("TensorD0Out"), d0)
+    assert np.array_equal(op.read("TensorD1Out"), d1)
+    assert np.array_equal(op.read("TensorD2Out"), d2)
+    k0, k1, dd = o.keyswitch(ell, d2, evk, dump=True)
+    check_keyswitch_buffers(op, dd, ell, alpha, o.beta(ell), fuse)
+    if not fuse:
+        assert np.array_equal(op.read("KeySwitchFinalOutput_Key(0)"), k0)
+        assert np.array_equal(op.read("KeySwitchFinalOutput_Key(1)"), k1)
+    assert np.array_equal(op.read("HMULTHaddOutput(0)"), o.ewe(3, ids, k0, None, d0))
+    assert np.array_equal(op.read("HMULTHaddOutput(1)"), o.ewe(3, ids, k1, None, d1))
+    exp = o.hmult(ell, ct1, ct2, evk, rescale=True)
+    assert np.array_equal(op.read("out.c0"), exp[0])
+    assert np.array_equal(op.read("out.c1"), exp[1])
+    # idempotence: a second execution of the same plan reproduces the outputs (no stage clobbers an input)
+    op.execute(2)
+    assert np.array_equal(op.read("out.c0"), exp[0]) and np.array_equal(op.read("out.c1"), exp[1])
+    op.close()
+
+
+@pytest.mark.parametrize("cfg,logN,L,ell,alpha", CASES)
+@pytest.mark.parametrize("fuse", [False, True])
+def test_hrotate_bit_exact(cfg, logN, L, ell, alpha, fuse):
+    from homulator_amd import host
+    o = oracle(logN, L, alpha)
+    ct1, _, evk = inputs(o, ell)
+    op = host.Op(cfg, "hrotate", L, ell, alpha, fuse=fuse)
+    op.execute(1)
+    r0, r1 = o.automorph_eval(ct1[0], 5), o.automorph_eval(ct1[1], 5)
+    assert np.array_equal(op.read("AUTOOutput(0)"), r0) and np.array_equal(op.read("AUTOOutput(1)"), r1)
+    k0, k1, dd = o.keyswitch(ell, r1, evk, dump=True)
+    check_keyswitch_buffers(op, dd, ell, alpha, o.beta(ell), fuse)
+    exp = o.hrotate(ell, ct1, 5, evk)
+    assert np.array_equal(op.read("out.c0"), exp[0])
+    assert np.array_equal(op.read("out.c1"), exp[1])
+    op.close()
+
+
+def test_hrotate_other_galois_element():
+    from homulator_amd import host
+    o = oracle(15, 6, 2)
+    ct1, _, evk = inputs(o, 5)
+    g = pow(5, 3, 2 * o.N)
+    op = host.Op("config_4_N15.cfg", "hrotate", 6, 5, 2, overrides={"galois": g})
+    op.execute(1)
+    exp = o.hrotate(5, ct1, g, evk)
+    assert np.array_equal(op.read("out.c0"), exp[0]) and np.array_equal(op.read("out.c1"), exp[1])
+    op.close()
+
+
+@pytest.mark.parametrize("cfg,logN,L,ell,alpha", [("config_4_N15.cfg", 15, 16, 10, 4), ("config_4.cfg", 16, 45, 35, 15)])
+def test_hadd_pmult_padd_bit_exact(cfg, logN, L, ell, alpha):
+    from homulator_amd import host
+    o = oracle(logN, L, alpha)
+    ct1, ct2, _ = inputs(o, ell)
+    pt = o.fill_uniform(list(range(ell)), SEED + 4000)
+    for name, exp in (("hadd", o.hadd(ell, ct1, ct2)), ("pmult", o.pmult(ell, ct1, pt)), ("padd", o.padd(ell, ct1, pt))):
+        op = host.Op(cfg, name, L, ell, alpha)
+        op.execute(1)
+        assert np.array_equal(op.read("out.c0"), exp[0]), name
+        assert np.array_equal(op.read("out.c1"), exp[1]), name
+        op.close()
+
+
+def test_cli_runs_on_gpu_and_prints_upstream_format():
+    import os, subprocess
+    from homulator_amd import host
+    cli = os.path.join(host.ROOT, "host", "Homulator.run")
+    r = subprocess.run([cli, os.path.join(host.CONFIG_DIR, "config_4_N15.cfg"), "hmult", "16", "10", "4"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "Welcome! Start simulating HMULT!" in r.stdout and "Remaining 0 instructions!" in r.stdout
+    stat = r.stdout.split("Start outPut statistic informations:")[1]
+    assert "NTT_(0) :\t" in stat and "BCONV_(0) :\t" in stat and "EWE_(0) :\t" in stat
