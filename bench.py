@@ -1,0 +1,140 @@
+#!/usr/bin/env python3
+"""bench.py — hmult + key-switch throughput on MI355X (BASELINE.json metric), one JSON line on stdout.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+
+A "step" is one full hmult (tensor -> hybrid key switch -> add -> rescale) at config_4.cfg, L=45, l=35,
+alpha=15 (BASELINE configs[2]) over synthetic limbs already resident in HBM.  The op runs through the same path
+as the CLI: C++ Operation/Driver -> C ABI -> HIP kernels.  `roofline` is measured live with HIP events on the
+backend's own stream; `cpu_baseline` times the CPU oracle ("port": the reference has no arithmetic to time,
+SURVEY.md §0) on a bounded sample, rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CFG, OP, L, ELL, ALPHA = "config_4.cfg", "hmult", 45, 35, 15
+LOGN = 16
+LP = (1 << LOGN) * 8                       # one limb-poly, bytes
+HMULT_ALG_BYTES = 1_102_577_664            # 2 103 LP
+NTT_ALG_BYTES = 2 * LP                     # per limb-NTT
+HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md
+
+
+def measure_ntt_sweep(n_limbs, iters=50):
+    """forward NTT sweep over the extended basis (l + alpha limbs): device time per sweep, HIP events on the
+    backend stream.  One sweep = one hm_ntt call = the two pass kernels k_ntt_pass<COL> + k_ntt_pass<ROW>."""
+    from homulator_amd import hip
+    ctx = hip.Context(LOGN, L, ALPHA)
+    ids = ctx.ext_ids(ELL)[:n_limbs]
+    a, b = ctx.alloc(n_limbs), ctx.alloc(n_limbs)
+    ctx.fill_uniform(a, ids, 1)
+    for _ in range(5):
+        ctx.ntt(a, b, ids)
+    ctx.sync()
+    ctx.timer_start()
+    for _ in range(iters):
+        ctx.ntt(a, b, ids)
+    ns = ctx.timer_stop() / iters
+    a.free(); b.free(); ctx.close()
+    return ns
+
+
+def cpu_baseline(sample_ops=3):
+    from oracle.homoracle import Oracle
+    from homulator_amd import host
+    cores = min(16, os.cpu_count() or 1)
+    o = Oracle(LOGN, L, ALPHA)
+    o.set_threads(cores)
+    ct1, ct2, evk = o.synth_ct(ELL, host.SEED), o.synth_ct(ELL, host.SEED + 2000), o.synth_evk(ELL, host.SEED + 10000)
+    o.hmult(ELL, ct1, ct2, evk)  # warm
+    t0 = time.time()
+    for _ in range(sample_ops):
+        o.hmult(ELL, ct1, ct2, evk)
+    dt = (time.time() - t0) / sample_ops
+    return {"value": 1.0 / dt, "unit": "ops/s", "cores": cores, "kind": "port",
+            "sample": f"{sample_ops} full hmult ops (N=2^16, l=35, alpha=15) on the CPU oracle, OpenMP over limbs"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP backend has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from homulator_amd import host
+    op = host.Op(CFG, OP, L, ELL, ALPHA, device=local_rank)
+    op.enqueue(args.warmup)
+    op.sync()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    op.enqueue(args.steps)
+    op.sync()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    out = None
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        # every rank runs the same op on its own GPU until the limb-sharded path lands: replicas, weak scaling
+        value = world * args.steps / dt
+        sweep_limbs = ELL + ALPHA
+        ntt_ns = measure_ntt_sweep(sweep_limbs)
+        achieved = NTT_ALG_BYTES * sweep_limbs / ntt_ns  # B/ns = GB/s
+        out = {
+            "metric": "hmult+key-switch ops/sec", "value": value, "unit": "ops/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+            "scaling": "weak" if world > 1 else "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": f"{CFG} {OP} L={L} l={ELL} alpha={ALPHA} (N=2^16, beta=3, full hybrid key switch + rescale)",
+                       "parallelism": "single GPU" if world == 1 else f"{world} independent replicas (limb-sharded path not in this round)",
+                       "launches_per_op": op.launch_count()},
+            "hmult_hbm_gbs_algorithmic": HMULT_ALG_BYTES / (ms * 1e-3) / 1e9,
+            "hmult_frac_of_hbm_peak": HMULT_ALG_BYTES / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "forward NTT sweep, 50 limbs = k_ntt_pass<COL> + k_ntt_pass<ROW>",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "us_per_launch": ntt_ns * 1e-3,
+                         "algorithmic_bytes_per_launch": NTT_ALG_BYTES * sweep_limbs},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+    op.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if out is not None:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

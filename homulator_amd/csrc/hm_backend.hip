@@ -20,23 +20,30 @@
 // kernels
 // ------------------------------------------------------------------------------------------------
 
-// XCD-aware block -> (limb entry, tile) map.  Blocks are dealt round-robin over the 8 XCDs, so blocks
-// b and b+8 share an L2; all tiles of one limb-poly get the same b % 8, and both passes of a
-// transform use the same map, so the second pass finds the first pass's output in that XCD's L2.
-__device__ __forceinline__ bool hm_block_map(uint32_t tiles_per_limb, uint32_t n_limbs, uint32_t &entry, uint32_t &tile) {
-  uint32_t b = blockIdx.x, xcd = b & 7u, slot = b >> 3;
-  entry = (slot / tiles_per_limb) * 8u + xcd;
-  tile = slot % tiles_per_limb;
-  return entry < n_limbs;
+// XCD-aware block -> (limb entry, tile) map.  Blocks are dealt round-robin over the 8 XCDs, so blocks b and
+// b+8 share an L2.  All tiles of one limb-poly get the same b % 8, and both passes of a transform use the
+// same map, so the second pass finds the first pass's output in that XCD's L2.  Entries come in PAIRS
+// (e, e+8 inside a group of 16) that the host fills with two limb-polys of the SAME modulus whenever the
+// launch has them (the two keys of a ModDown, two digits of a ModUp, c0/c1 of a rescale): the pair's blocks
+// for one tile sit in adjacent dispatch slots of one XCD, so the second one finds the row twiddles (1 MiB per
+// limb-NTT, as much as the data) in L2 instead of fetching them from HBM again.
+#define HM_NTT_INVALID 0xFFFFu
+__device__ __forceinline__ bool hm_block_map(uint32_t tiles_per_limb, uint32_t n_entries, uint32_t &entry, uint32_t &tile) {
+  const uint32_t b = blockIdx.x, xcd = b & 7u, slot = b >> 3;
+  const uint32_t pair = slot / (2u * tiles_per_limb), within = slot % (2u * tiles_per_limb);
+  tile = within >> 1;
+  entry = pair * 16u + (within & 1u) * 8u + xcd;
+  return entry < n_entries;
 }
 
 template <int LOGR, bool STRIDED, bool INV, int MODE>
-__device__ __forceinline__ void hm_ntt_pass_body(const HmNttArgs &a, const HmTw *scale) {
+__device__ __forceinline__ void hm_ntt_pass_body(const HmNttArgs &a, const HmTw *scale, const HmSubScale *ss = nullptr) {
   __shared__ __attribute__((aligned(16))) uint64_t lds[HM_LDS_WORDS];
   uint32_t entry, tile;
   if (!hm_block_map(1u << (a.logN - HM_TILE_LOG), a.n_limbs, entry, tile)) return;
   const int tid = threadIdx.x;
   const HmLimb lb = a.limb[entry];
+  if (lb.mod == HM_NTT_INVALID) return;
   const size_t N = (size_t)1 << a.logN;
   const uint64_t q = a.mods[lb.mod].q;
   const HmTw *twl = a.tw + (size_t)lb.mod * N;
@@ -47,31 +54,23 @@ __device__ __forceinline__ void hm_ntt_pass_body(const HmNttArgs &a, const HmTw 
   const uint64_t *src = FIRST ? a.in + (size_t)lb.in * N : a.out + (size_t)lb.out * N;
   uint64_t *dst = a.out + (size_t)lb.out * N;
 
-  hm_tile_load<LOGR, STRIDED>(tid, lds, src, tile);
-  __syncthreads();
-  using RS = HmRounds<LOGR>;
-  if constexpr (!INV) {
-    hm_ntt_round<LOGR, STRIDED, RS::nb[0], RS::k[0], false>(tid, lds, twl, s0, prefix0, q);
-    __syncthreads();
-    hm_ntt_round<LOGR, STRIDED, RS::nb[1], RS::k[1], false>(tid, lds, twl, s0, prefix0, q);
-    __syncthreads();
-    if constexpr (RS::n > 2) {
-      hm_ntt_round<LOGR, STRIDED, RS::nb[2], RS::k[2], false>(tid, lds, twl, s0, prefix0, q);
-      __syncthreads();
-    }
-  } else {
-    if constexpr (RS::n > 2) {
-      hm_ntt_round<LOGR, STRIDED, RS::nb[2], RS::k[2], true>(tid, lds, twl, s0, prefix0, q);
-      __syncthreads();
-    }
-    hm_ntt_round<LOGR, STRIDED, RS::nb[1], RS::k[1], true>(tid, lds, twl, s0, prefix0, q);
-    __syncthreads();
-    hm_ntt_round<LOGR, STRIDED, RS::nb[0], RS::k[0], true>(tid, lds, twl, s0, prefix0, q);
-    __syncthreads();
-  }
   HmTw sc = {0, 0};
+  HmEpi ep = {nullptr, nullptr};
   if constexpr (MODE == 2) sc = scale[entry];
-  hm_tile_store<LOGR, STRIDED, MODE>(tid, lds, dst, tile, q, sc);
+  if constexpr (MODE == 3) {
+    sc = ss->k[entry];
+    ep.a = ss->minuend + (size_t)ss->mlimb[entry] * N;
+    ep.d = ss->addend ? ss->addend + (size_t)ss->alimb[entry] * N : nullptr;
+  }
+  HmNttState st;
+  hm_ntt_phase<LOGR, STRIDED, INV, MODE, 0>(st, tid, lds, src, dst, tile, twl, s0, prefix0, q, sc, ep);
+  hm_ntt_phase<LOGR, STRIDED, INV, MODE, 1>(st, tid, lds, src, dst, tile, twl, s0, prefix0, q, sc, ep);
+  __syncthreads();
+  hm_ntt_phase<LOGR, STRIDED, INV, MODE, 2>(st, tid, lds, src, dst, tile, twl, s0, prefix0, q, sc, ep);
+  if constexpr (HmRounds<LOGR>::n == 3) {
+    __syncthreads();
+    hm_ntt_phase<LOGR, STRIDED, INV, MODE, 3>(st, tid, lds, src, dst, tile, twl, s0, prefix0, q, sc, ep);
+  }
 }
 
 template <int LOGR, bool STRIDED, bool INV, int MODE>
@@ -81,6 +80,31 @@ __global__ void __launch_bounds__(HM_THREADS) k_ntt_pass(HmNttArgs a) {
 template <int LOGR>
 __global__ void __launch_bounds__(HM_THREADS) k_intt_final(HmNttArgs a, HmScale s) {
   hm_ntt_pass_body<LOGR, true, true, 2>(a, s.c);
+}
+// forward ROW pass fused with out = (minuend - NTT) * k [+ addend]
+__global__ void __launch_bounds__(HM_THREADS) k_ntt_row_subscale(HmNttArgs a, HmSubScale s) {
+  hm_ntt_pass_body<8, false, false, 3>(a, nullptr, &s);
+}
+
+__global__ void __launch_bounds__(256) k_tensor(HmTensorArgs a) {
+  const uint32_t N = 1u << a.logN;
+  const uint32_t per_limb = N / 512;
+  const uint32_t entry = blockIdx.x / per_limb, chunk = blockIdx.x % per_limb;
+  if (entry >= a.n_limbs) return;
+  const HmTensorLimb lb = a.limb[entry];
+  const HmMod m = a.mods[lb.mod];
+  const size_t x = (size_t)chunk * 512 + 2 * threadIdx.x;
+  const ulonglong2 va = *reinterpret_cast<const ulonglong2 *>(a.a + (size_t)lb.a * N + x);
+  const ulonglong2 vb = *reinterpret_cast<const ulonglong2 *>(a.b + (size_t)lb.b * N + x);
+  const ulonglong2 vc = *reinterpret_cast<const ulonglong2 *>(a.c + (size_t)lb.c * N + x);
+  const ulonglong2 vd = *reinterpret_cast<const ulonglong2 *>(a.d + (size_t)lb.d * N + x);
+  uint64_t x0, x1, x2, y0, y1, y2;
+  hm_tensor_one(va.x, vb.x, vc.x, vd.x, m, x0, x1, x2);
+  hm_tensor_one(va.y, vb.y, vc.y, vd.y, m, y0, y1, y2);
+  const ulonglong2 r0 = {x0, y0}, r1 = {x1, y1}, r2 = {x2, y2};
+  *reinterpret_cast<ulonglong2 *>(a.o0 + (size_t)lb.o0 * N + x) = r0;
+  *reinterpret_cast<ulonglong2 *>(a.o1 + (size_t)lb.o1 * N + x) = r1;
+  *reinterpret_cast<ulonglong2 *>(a.o2 + (size_t)lb.o2 * N + x) = r2;
 }
 
 template <int OP>
@@ -105,11 +129,28 @@ __global__ void __launch_bounds__(256) k_ewe(HmEweArgs a) {
   *reinterpret_cast<ulonglong2 *>(a.out + (size_t)lb.out * N + x) = r;
 }
 
-__global__ void __launch_bounds__(128) k_bconv(HmBconvArgs a) {
-  uint32_t x = blockIdx.x * 128 + threadIdx.x;
-  uint32_t t0 = blockIdx.y * a.out_per_block;
-  uint32_t t1 = min(t0 + a.out_per_block, a.n_out);
-  hm_bconv_thread(a, x, t0, t1);
+template <int N_IN>
+__device__ __forceinline__ void hm_bconv_block(const HmBconvArgs &a, const HmBconvProb &p, uint64_t *tab) {
+  const uint32_t t0 = blockIdx.y * HM_BCONV_CHUNK;
+  if (t0 >= p.n_out) return;
+  const uint32_t t1 = min(t0 + HM_BCONV_CHUNK, p.n_out);
+  for (uint32_t e = threadIdx.x; e < N_IN * HM_BCONV_CHUNK; e += HM_BCONV_THREADS) {
+    const uint32_t i = e / HM_BCONV_CHUNK, t = t0 + e % HM_BCONV_CHUNK;
+    tab[e] = t < t1 ? p.table[i * p.n_out + t] : 0;
+  }
+  __syncthreads();
+  hm_bconv_thread<N_IN>(p, a.mods, a.logN, tab, blockIdx.x * HM_BCONV_THREADS + threadIdx.x, t0, t1);
+}
+
+__global__ void __launch_bounds__(HM_BCONV_THREADS) k_bconv(HmBconvArgs a) {
+  __shared__ uint64_t tab[HM_BCONV_MAX_IN * HM_BCONV_CHUNK];
+  const HmBconvProb &p = a.prob[blockIdx.z];
+  switch (p.n_in) {  // wave-uniform: every block of one problem takes the same case
+#define HM_CASE(n) case n: hm_bconv_block<n>(a, p, tab); break;
+    HM_CASE(1) HM_CASE(2) HM_CASE(3) HM_CASE(4) HM_CASE(5) HM_CASE(6) HM_CASE(7) HM_CASE(8)
+    HM_CASE(9) HM_CASE(10) HM_CASE(11) HM_CASE(12) HM_CASE(13) HM_CASE(14) HM_CASE(15) HM_CASE(16)
+#undef HM_CASE
+  }
 }
 
 struct HmAutoArgs {
@@ -308,16 +349,89 @@ static hm_status check_mods(hm_ctx *c, const char *what, const uint32_t *m, uint
 }
 
 template <int LOG1>
-static void launch_ntt(hm_ctx *c, const HmNttArgs &a, const HmScale *sc, bool inverse) {
+static void launch_ntt(hm_ctx *c, const HmNttArgs &a, const HmScale *sc, const HmSubScale *ss, bool inverse) {
   const uint32_t tiles = c->P.N >> HM_TILE_LOG;
-  dim3 grid(((a.n_limbs + 7) / 8) * 8 * tiles), block(HM_THREADS);
+  dim3 grid(a.n_limbs * tiles), block(HM_THREADS);  // n_limbs = entries, a multiple of 16 (pairs x 8 XCDs)
   if (!inverse) {
     hipLaunchKernelGGL((k_ntt_pass<LOG1, true, false, 0>), grid, block, 0, c->stream, a);
-    hipLaunchKernelGGL((k_ntt_pass<8, false, false, 1>), grid, block, 0, c->stream, a);
+    if (ss) hipLaunchKernelGGL(k_ntt_row_subscale, grid, block, 0, c->stream, a, *ss);
+    else hipLaunchKernelGGL((k_ntt_pass<8, false, false, 1>), grid, block, 0, c->stream, a);
   } else {
     hipLaunchKernelGGL((k_ntt_pass<8, false, true, 0>), grid, block, 0, c->stream, a);
     hipLaunchKernelGGL((k_intt_final<LOG1>), grid, block, 0, c->stream, a, *sc);
   }
+}
+
+// common body of hm_ntt / hm_ntt_sub_scale.  `k`: inverse -> optional extra scale; fused forward -> the
+// mandatory per-limb constant of out = (minuend - NTT(in)) * k [+ addend]
+static hm_status ntt_common(hm_ctx *c, const char *what, const uint64_t *in, const uint32_t *in_limbs, uint64_t *out,
+                            const uint32_t *out_limbs, const uint32_t *mod_ids, uint32_t n, int inverse, const uint64_t *k,
+                            const uint64_t *minuend, const uint32_t *minuend_limbs, const uint64_t *addend,
+                            const uint32_t *addend_limbs) {
+  const bool fused = minuend != nullptr;
+  hm_status st;
+  if ((st = check_limbs(c, what, in_limbs, n)) || (st = check_limbs(c, what, out_limbs, n)) ||
+      (st = check_limbs(c, what, minuend_limbs, n)) || (st = check_limbs(c, what, addend_limbs, n)) ||
+      (st = check_mods(c, what, mod_ids, n)))
+    return st;
+  HM_HIP(c, hipSetDevice(c->device));
+  // pair up limb-polys that share a modulus (see hm_block_map), then the leftovers with each other
+  std::vector<std::pair<int, int>> pairs;  // indices into the caller's lists, -1 = empty
+  {
+    std::map<uint32_t, std::vector<int>> byMod;
+    for (uint32_t i = 0; i < n; ++i) byMod[mod_ids[i]].push_back((int)i);
+    std::vector<int> singles;
+    for (auto &kv : byMod) {
+      auto &v = kv.second;
+      size_t i = 0;
+      for (; i + 1 < v.size(); i += 2) pairs.emplace_back(v[i], v[i + 1]);
+      if (i < v.size()) singles.push_back(v[i]);
+    }
+    for (size_t i = 0; i < singles.size(); i += 2) pairs.emplace_back(singles[i], i + 1 < singles.size() ? singles[i + 1] : -1);
+  }
+  const uint32_t PAIRS_PER_LAUNCH = HM_MAX_LIMBS / 2;
+  for (uint32_t base = 0; base < pairs.size(); base += PAIRS_PER_LAUNCH) {
+    const uint32_t np = std::min<uint32_t>(PAIRS_PER_LAUNCH, (uint32_t)pairs.size() - base);
+    const uint32_t cnt = ((np + 7) / 8) * 16;  // entries: groups of 8 pairs = 16 entries
+    HmNttArgs a;
+    a.in = in; a.out = out;
+    a.tw = inverse ? c->d_tw_inv : c->d_tw_fwd;
+    a.mods = c->d_mods;
+    a.logN = c->P.logN; a.n_limbs = cnt;
+    HmScale sc;
+    HmSubScale ss;
+    ss.minuend = minuend; ss.addend = addend;
+    for (uint32_t e = 0; e < cnt; ++e) a.limb[e] = HmLimb{0, 0, (uint16_t)HM_NTT_INVALID, 0};
+    for (uint32_t kk = 0; kk < np; ++kk) {
+      for (int which = 0; which < 2; ++which) {
+        const int gi = which ? pairs[base + kk].second : pairs[base + kk].first;
+        if (gi < 0) continue;
+        const uint32_t g = (uint32_t)gi, e = (kk / 8) * 16 + which * 8 + (kk % 8), m = mod_ids[g];
+        const uint64_t q = c->P.mod[m];
+        a.limb[e] = HmLimb{(uint16_t)limb_at(in_limbs, g), (uint16_t)limb_at(out_limbs, g), (uint16_t)m, 0};
+        if (k && k[g] >= q) return fail(c, HM_ERR_ARG, "%s: constant [%u] is not reduced", what, g);
+        if (inverse) {
+          uint64_t v = c->P.modc[m].ninv;
+          if (k) v = hm::mulmod(v, k[g], q);
+          sc.c[e] = HmTw{v, hm::shoup(v, q)};
+        } else if (fused) {
+          ss.k[e] = HmTw{k[g], hm::shoup(k[g], q)};
+          ss.mlimb[e] = (uint16_t)limb_at(minuend_limbs, g);
+          ss.alimb[e] = (uint16_t)limb_at(addend_limbs, g);
+        }
+      }
+    }
+    switch (c->P.logN - 8) {
+    case 5: launch_ntt<5>(c, a, &sc, fused ? &ss : nullptr, inverse); break;
+    case 6: launch_ntt<6>(c, a, &sc, fused ? &ss : nullptr, inverse); break;
+    case 7: launch_ntt<7>(c, a, &sc, fused ? &ss : nullptr, inverse); break;
+    case 8: launch_ntt<8>(c, a, &sc, fused ? &ss : nullptr, inverse); break;
+    case 9: launch_ntt<9>(c, a, &sc, fused ? &ss : nullptr, inverse); break;
+    default: return fail(c, HM_ERR_UNSUPPORTED, "%s: logN %u", what, c->P.logN);
+    }
+    HM_HIP(c, hipGetLastError());
+  }
+  return HM_OK;
 }
 
 extern "C" hm_status hm_ntt(hm_ctx *c, const uint64_t *in, const uint32_t *in_limbs, uint64_t *out,
@@ -326,40 +440,41 @@ extern "C" hm_status hm_ntt(hm_ctx *c, const uint64_t *in, const uint32_t *in_li
   if (!c) return HM_ERR_ARG;
   if (!in || !out) return fail(c, HM_ERR_ARG, "hm_ntt: null buffer");
   if (scale && !inverse) return fail(c, HM_ERR_ARG, "hm_ntt: scale is only defined for the inverse transform");
+  return ntt_common(c, "hm_ntt", in, in_limbs, out, out_limbs, mod_ids, n, inverse, scale, nullptr, nullptr, nullptr, nullptr);
+}
+
+extern "C" hm_status hm_ntt_sub_scale(hm_ctx *c, const uint64_t *in, const uint32_t *in_limbs, const uint64_t *minuend,
+                                      const uint32_t *minuend_limbs, const uint64_t *addend, const uint32_t *addend_limbs,
+                                      uint64_t *out, const uint32_t *out_limbs, const uint32_t *mod_ids, uint32_t n,
+                                      const uint64_t *k) {
+  if (!c) return HM_ERR_ARG;
+  if (!in || !out || !minuend || !k) return fail(c, HM_ERR_ARG, "hm_ntt_sub_scale: null argument");
+  return ntt_common(c, "hm_ntt_sub_scale", in, in_limbs, out, out_limbs, mod_ids, n, 0, k, minuend, minuend_limbs, addend, addend_limbs);
+}
+
+extern "C" hm_status hm_tensor(hm_ctx *c, const uint64_t *pa, const uint32_t *la, const uint64_t *pb, const uint32_t *lb,
+                               const uint64_t *pc, const uint32_t *lc, const uint64_t *pd, const uint32_t *ld, uint64_t *o0,
+                               const uint32_t *l0, uint64_t *o1, const uint32_t *l1, uint64_t *o2, const uint32_t *l2,
+                               const uint32_t *mod_ids, uint32_t n) {
+  if (!c) return HM_ERR_ARG;
+  if (!pa || !pb || !pc || !pd || !o0 || !o1 || !o2) return fail(c, HM_ERR_ARG, "hm_tensor: null buffer");
   hm_status st;
-  if ((st = check_limbs(c, "hm_ntt", in_limbs, n)) || (st = check_limbs(c, "hm_ntt", out_limbs, n)) ||
-      (st = check_mods(c, "hm_ntt", mod_ids, n)))
-    return st;
+  const uint32_t *lists[7] = {la, lb, lc, ld, l0, l1, l2};
+  for (auto l : lists)
+    if ((st = check_limbs(c, "hm_tensor", l, n))) return st;
+  if ((st = check_mods(c, "hm_tensor", mod_ids, n))) return st;
   HM_HIP(c, hipSetDevice(c->device));
   for (uint32_t base = 0; base < n; base += HM_MAX_LIMBS) {
     const uint32_t cnt = std::min<uint32_t>(HM_MAX_LIMBS, n - base);
-    HmNttArgs a;
-    a.in = in; a.out = out;
-    a.tw = inverse ? c->d_tw_inv : c->d_tw_fwd;
-    a.mods = c->d_mods;
-    a.logN = c->P.logN; a.n_limbs = cnt;
-    HmScale sc;
+    HmTensorArgs a;
+    a.a = pa; a.b = pb; a.c = pc; a.d = pd; a.o0 = o0; a.o1 = o1; a.o2 = o2;
+    a.mods = c->d_mods; a.logN = c->P.logN; a.n_limbs = cnt;
     for (uint32_t i = 0; i < cnt; ++i) {
-      const uint32_t g = base + i, m = mod_ids[g];
-      a.limb[i] = HmLimb{(uint16_t)limb_at(in_limbs, g), (uint16_t)limb_at(out_limbs, g), (uint16_t)m, 0};
-      if (inverse) {
-        const uint64_t q = c->P.mod[m];
-        uint64_t k = c->P.modc[m].ninv;
-        if (scale) {
-          if (scale[g] >= q) return fail(c, HM_ERR_ARG, "hm_ntt: scale[%u] is not reduced", g);
-          k = hm::mulmod(k, scale[g], q);
-        }
-        sc.c[i] = HmTw{k, hm::shoup(k, q)};
-      }
+      const uint32_t g = base + i;
+      a.limb[i] = HmTensorLimb{(uint16_t)limb_at(la, g), (uint16_t)limb_at(lb, g), (uint16_t)limb_at(lc, g), (uint16_t)limb_at(ld, g),
+                               (uint16_t)limb_at(l0, g), (uint16_t)limb_at(l1, g), (uint16_t)limb_at(l2, g), (uint16_t)mod_ids[g]};
     }
-    switch (c->P.logN - 8) {
-    case 5: launch_ntt<5>(c, a, &sc, inverse); break;
-    case 6: launch_ntt<6>(c, a, &sc, inverse); break;
-    case 7: launch_ntt<7>(c, a, &sc, inverse); break;
-    case 8: launch_ntt<8>(c, a, &sc, inverse); break;
-    case 9: launch_ntt<9>(c, a, &sc, inverse); break;
-    default: return fail(c, HM_ERR_UNSUPPORTED, "hm_ntt: logN %u", c->P.logN);
-    }
+    hipLaunchKernelGGL(k_tensor, dim3(cnt * (c->P.N / 512)), dim3(256), 0, c->stream, a);
     HM_HIP(c, hipGetLastError());
   }
   return HM_OK;
@@ -452,48 +567,63 @@ extern "C" hm_status hm_bconv_consts(hm_ctx *c, const uint32_t *in_ids, uint32_t
   return HM_OK;
 }
 
+extern "C" hm_status hm_bconv_batch(hm_ctx *c, const hm_bconv_desc *descs, uint32_t n_desc) {
+  if (!c) return HM_ERR_ARG;
+  if (!descs || n_desc == 0) return fail(c, HM_ERR_ARG, "hm_bconv_batch: no problems");
+  HM_HIP(c, hipSetDevice(c->device));
+  for (uint32_t base = 0; base < n_desc; base += HM_BCONV_MAX_PROB) {
+    const uint32_t cnt = std::min<uint32_t>(HM_BCONV_MAX_PROB, n_desc - base);
+    HmBconvArgs a;
+    a.mods = c->d_mods; a.logN = c->P.logN; a.n_prob = cnt;
+    uint32_t max_out = 0;
+    for (uint32_t pi = 0; pi < cnt; ++pi) {
+      const hm_bconv_desc &d = descs[base + pi];
+      if (!d.in || !d.out) return fail(c, HM_ERR_ARG, "hm_bconv: null buffer");
+      if (d.n_in == 0 || d.n_in > HM_BCONV_MAX_IN) return fail(c, HM_ERR_ARG, "hm_bconv: n_in %u not in [1,%d]", d.n_in, HM_BCONV_MAX_IN);
+      if (d.n_out == 0 || d.n_out > HM_BCONV_MAX_OUT) return fail(c, HM_ERR_ARG, "hm_bconv: n_out %u not in [1,%d]", d.n_out, HM_BCONV_MAX_OUT);
+      hm_status st;
+      if ((st = check_limbs(c, "hm_bconv", d.in_limbs, d.n_in)) || (st = check_limbs(c, "hm_bconv", d.out_limbs, d.n_out)) ||
+          (st = check_mods(c, "hm_bconv", d.in_ids, d.n_in)) || (st = check_mods(c, "hm_bconv", d.out_ids, d.n_out)))
+        return st;
+      for (uint32_t i = 0; i < d.n_in; ++i)
+        for (uint32_t t = 0; t < d.n_out; ++t)
+          if (d.in_ids[i] == d.out_ids[t]) return fail(c, HM_ERR_ARG, "hm_bconv: modulus %u is in both bases", d.in_ids[i]);
+      // conversion tables are cached per (input basis, output basis); built and uploaded on first use
+      std::vector<uint32_t> key;
+      key.push_back(d.n_in);
+      key.insert(key.end(), d.in_ids, d.in_ids + d.n_in);
+      key.insert(key.end(), d.out_ids, d.out_ids + d.n_out);
+      auto it = c->bconv_tables.find(key);
+      if (it == c->bconv_tables.end()) {
+        std::vector<uint64_t> qh(d.n_in), tb((size_t)d.n_in * d.n_out);
+        c->P.bconv_consts(d.in_ids, d.n_in, d.out_ids, d.n_out, qh.data(), tb.data());
+        for (uint64_t &w : tb) w = hm_bconv_pack(w);  // split-30 device format
+        uint64_t *dev = nullptr;
+        HM_HIP(c, hipMalloc(&dev, 8ull * d.n_in * d.n_out));
+        HM_HIP(c, hipMemcpy(dev, tb.data(), 8ull * d.n_in * d.n_out, hipMemcpyHostToDevice));
+        it = c->bconv_tables.emplace(key, dev).first;
+      }
+      HmBconvProb &p = a.prob[pi];
+      p.in = d.in; p.out = d.out; p.table = it->second; p.n_in = d.n_in; p.n_out = d.n_out;
+      for (uint32_t i = 0; i < d.n_in; ++i) p.in_limb[i] = (uint16_t)limb_at(d.in_limbs, i);
+      for (uint32_t t = 0; t < d.n_out; ++t) {
+        p.out_limb[t] = (uint16_t)limb_at(d.out_limbs, t);
+        p.out_mod[t] = (uint16_t)d.out_ids[t];
+      }
+      max_out = std::max(max_out, d.n_out);
+    }
+    dim3 grid(c->P.N / HM_BCONV_THREADS, (max_out + HM_BCONV_CHUNK - 1) / HM_BCONV_CHUNK, cnt);
+    hipLaunchKernelGGL(k_bconv, grid, dim3(HM_BCONV_THREADS), 0, c->stream, a);
+    HM_HIP(c, hipGetLastError());
+  }
+  return HM_OK;
+}
+
 extern "C" hm_status hm_bconv(hm_ctx *c, const uint64_t *in, const uint32_t *in_limbs, const uint32_t *in_ids,
                               uint32_t n_in, uint64_t *out, const uint32_t *out_limbs, const uint32_t *out_ids,
                               uint32_t n_out) {
-  if (!c) return HM_ERR_ARG;
-  if (!in || !out) return fail(c, HM_ERR_ARG, "hm_bconv: null buffer");
-  if (n_in == 0 || n_in > HM_BCONV_MAX_IN) return fail(c, HM_ERR_ARG, "hm_bconv: n_in %u not in [1,%d]", n_in, HM_BCONV_MAX_IN);
-  if (n_out == 0 || n_out > HM_BCONV_MAX_OUT) return fail(c, HM_ERR_ARG, "hm_bconv: n_out %u not in [1,%d]", n_out, HM_BCONV_MAX_OUT);
-  hm_status st;
-  if ((st = check_limbs(c, "hm_bconv", in_limbs, n_in)) || (st = check_limbs(c, "hm_bconv", out_limbs, n_out)) ||
-      (st = check_mods(c, "hm_bconv", in_ids, n_in)) || (st = check_mods(c, "hm_bconv", out_ids, n_out)))
-    return st;
-  for (uint32_t i = 0; i < n_in; ++i)
-    for (uint32_t t = 0; t < n_out; ++t)
-      if (in_ids[i] == out_ids[t]) return fail(c, HM_ERR_ARG, "hm_bconv: modulus %u is in both bases", in_ids[i]);
-  HM_HIP(c, hipSetDevice(c->device));
-  // conversion tables are cached per (input basis, output basis); built and uploaded on first use
-  std::vector<uint32_t> key;
-  key.push_back(n_in);
-  key.insert(key.end(), in_ids, in_ids + n_in);
-  key.insert(key.end(), out_ids, out_ids + n_out);
-  auto it = c->bconv_tables.find(key);
-  if (it == c->bconv_tables.end()) {
-    std::vector<uint64_t> qh(n_in), tb((size_t)n_in * n_out);
-    c->P.bconv_consts(in_ids, n_in, out_ids, n_out, qh.data(), tb.data());
-    uint64_t *d = nullptr;
-    HM_HIP(c, hipMalloc(&d, 8ull * n_in * n_out));
-    HM_HIP(c, hipMemcpy(d, tb.data(), 8ull * n_in * n_out, hipMemcpyHostToDevice));
-    it = c->bconv_tables.emplace(key, d).first;
-  }
-  HmBconvArgs a;
-  a.in = in; a.out = out; a.table = it->second; a.mods = c->d_mods;
-  a.logN = c->P.logN; a.n_in = n_in; a.n_out = n_out;
-  a.out_per_block = n_out <= 8 ? n_out : (n_out + 3) / 4;
-  for (uint32_t i = 0; i < n_in; ++i) a.in_limb[i] = (uint16_t)limb_at(in_limbs, i);
-  for (uint32_t t = 0; t < n_out; ++t) {
-    a.out_limb[t] = (uint16_t)limb_at(out_limbs, t);
-    a.out_mod[t] = (uint16_t)out_ids[t];
-  }
-  dim3 grid(c->P.N / 128, (n_out + a.out_per_block - 1) / a.out_per_block);
-  hipLaunchKernelGGL(k_bconv, grid, dim3(128), 0, c->stream, a);
-  HM_HIP(c, hipGetLastError());
-  return HM_OK;
+  hm_bconv_desc d = {in, in_limbs, in_ids, n_in, out, out_limbs, out_ids, n_out};
+  return hm_bconv_batch(c, &d, 1);
 }
 
 extern "C" hm_status hm_fill_uniform(hm_ctx *c, uint64_t *out, const uint32_t *out_limbs, const uint32_t *mod_ids,

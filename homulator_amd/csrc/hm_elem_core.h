@@ -59,33 +59,80 @@ HM_HD constexpr int hm_ewe_uses(int op) {
          op == HM_EWE_SUB_SCALE ? 5 : op == HM_EWE_SUB_SCALE_ADD ? 13 : 1;
 }
 
+// tensor product of two ciphertexts in one pass over the four inputs (TensorCompute::computeD0/D1/D2,
+// src/Operation.cpp:624-739): d0 = a*b, d1 = a*d + c*b, d2 = c*d with a = c00, b = c10, c = c01, d = c11
+struct HmTensorLimb {
+  uint16_t a, b, c, d, o0, o1, o2, mod;
+};
+struct HmTensorArgs {
+  const uint64_t *a, *b, *c, *d;
+  uint64_t *o0, *o1, *o2;
+  const HmMod *mods;
+  uint32_t logN, n_limbs;
+  HmTensorLimb limb[HM_MAX_LIMBS];
+};
+HM_HD void hm_tensor_one(uint64_t a, uint64_t b, uint64_t c, uint64_t d, const HmMod &m, uint64_t &d0, uint64_t &d1, uint64_t &d2) {
+  d0 = hm_mulmod(a, b, m);
+  d1 = hm_barrett((hm_u128)a * d + (hm_u128)c * b, m);
+  d2 = hm_mulmod(c, d, m);
+}
+
 // ---- K4 base conversion: out[t][x] = sum_i in[i][x] * table[i][t] mod q_t
+// One launch carries up to HM_BCONV_MAX_PROB independent conversions (the beta digits of a ModUp, the two
+// keys of a ModDown): grid = (N / HM_BCONV_THREADS, output chunks, problems); one coefficient per thread.
 #define HM_BCONV_MAX_IN 16
 #define HM_BCONV_MAX_OUT 64
-struct HmBconvArgs {
+#define HM_BCONV_MAX_PROB 4
+#define HM_BCONV_CHUNK 8    // output limbs per block (table slice staged in LDS)
+#define HM_BCONV_THREADS 256
+struct HmBconvProb {
   const uint64_t *in;
   uint64_t *out;
   const uint64_t *table;  // device, [n_in][n_out] row-major
-  const HmMod *mods;
-  uint32_t logN, n_in, n_out, out_per_block;
+  uint32_t n_in, n_out;
   uint16_t in_limb[HM_BCONV_MAX_IN];
   uint16_t out_limb[HM_BCONV_MAX_OUT];
   uint16_t out_mod[HM_BCONV_MAX_OUT];
 };
+struct HmBconvArgs {
+  const HmMod *mods;
+  uint32_t logN, n_prob;
+  HmBconvProb prob[HM_BCONV_MAX_PROB];
+};
 
-// one coefficient x, outputs [t0, t1)
-HM_HD void hm_bconv_thread(const HmBconvArgs &a, uint32_t x, uint32_t t0, uint32_t t1) {
-  const size_t N = (size_t)1 << a.logN;
-  uint64_t y[HM_BCONV_MAX_IN];
+// Split-30 MAC: operands are below 2^60, so y = y1 2^30 + y0 and w = w1 2^30 + w0 with 30-bit halves; each
+// of the four partial-product columns y_a w_b stays below 2^64 over 16 terms, so a MAC is four
+// v_mad_u64_u32 into plain 64-bit accumulators with no carry chain; the columns are recombined once per
+// output.  Device table entries are pre-split: low word = w0, high word = w1 (hm_bconv_pack).
+HM_HD uint64_t hm_bconv_pack(uint64_t w) { return (w & 0x3FFFFFFFull) | ((w >> 30) << 32); }
+
+// coefficient x for outputs [t0, t1); tab = packed table slice [N_IN][HM_BCONV_CHUNK]
+template <int N_IN>
+HM_HD void hm_bconv_thread(const HmBconvProb &p, const HmMod *mods, uint32_t logN, const uint64_t *tab, uint32_t x,
+                           uint32_t t0, uint32_t t1) {
+  const size_t N = (size_t)1 << logN;
+  uint32_t yl[N_IN], yh[N_IN];
 #pragma unroll
-  for (uint32_t i = 0; i < HM_BCONV_MAX_IN; ++i)
-    if (i < a.n_in) y[i] = a.in[(size_t)a.in_limb[i] * N + x];
+  for (int i = 0; i < N_IN; ++i) {
+    const uint64_t v = p.in[(size_t)p.in_limb[i] * N + x];
+    yl[i] = (uint32_t)v & 0x3FFFFFFFu;
+    yh[i] = (uint32_t)(v >> 30);
+  }
   for (uint32_t t = t0; t < t1; ++t) {
-    hm_u128 acc = 0;
+    uint64_t w[N_IN];
 #pragma unroll
-    for (uint32_t i = 0; i < HM_BCONV_MAX_IN; ++i)
-      if (i < a.n_in) acc += (hm_u128)y[i] * a.table[i * a.n_out + t];
-    a.out[(size_t)a.out_limb[t] * N + x] = hm_barrett_wide(acc, a.mods[a.out_mod[t]]);
+    for (int i = 0; i < N_IN; ++i) w[i] = tab[i * HM_BCONV_CHUNK + (t - t0)];
+    uint64_t s00 = 0, s01 = 0, s10 = 0, s11 = 0;
+#pragma unroll
+    for (int i = 0; i < N_IN; ++i) {
+      const uint32_t wl = (uint32_t)w[i], wh = (uint32_t)(w[i] >> 32);
+      s00 += (uint64_t)yl[i] * wl;
+      s01 += (uint64_t)yl[i] * wh;
+      s10 += (uint64_t)yh[i] * wl;
+      s11 += (uint64_t)yh[i] * wh;
+    }
+    const hm_u128 acc = (hm_u128)s00 + (((hm_u128)s01 + s10) << 30) + ((hm_u128)s11 << 60);
+    p.out[(size_t)p.out_limb[t] * N + x] = hm_barrett_wide(acc, mods[p.out_mod[t]]);
   }
 }
 

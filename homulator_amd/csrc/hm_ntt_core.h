@@ -19,7 +19,9 @@
 
 #define HM_TILE 4096
 #define HM_TILE_LOG 12
-#define HM_THREADS 256
+#ifndef HM_THREADS
+#define HM_THREADS 512
+#endif
 #define HM_MAX_LIMBS 128
 
 struct HmLimb {  // one limb-poly of a launch: limb indices into the in/out bases, modulus id
@@ -37,6 +39,15 @@ struct HmNttArgs {
 };
 struct HmScale {  // per-limb epilogue constant of the inverse transform: c = N^-1 * extra, Shoup form
   HmTw c[HM_MAX_LIMBS];
+};
+// fused forward epilogue (MODE 3): out = (minuend - NTT(in)) * k [+ addend]   (ModDown finish, rescale)
+struct HmSubScale {
+  const uint64_t *minuend, *addend;  // addend may be null
+  uint16_t mlimb[HM_MAX_LIMBS], alimb[HM_MAX_LIMBS];
+  HmTw k[HM_MAX_LIMBS];
+};
+struct HmEpi {  // the epilogue operands of one limb-poly, resolved by the kernel
+  const uint64_t *a, *d;
 };
 
 // LDS image of a tile.  STRIDED: [x][c] with the C columns contiguous (a plain copy of C-element
@@ -66,87 +77,23 @@ HM_HD int hm_tile_lidx(uint32_t lin) {
   return (int)(lin + ((lin >> 5) << 2));
 }
 
-// ---- phase: global -> LDS, 16 B per lane
-template <int LOGR, bool STRIDED>
-HM_HD void hm_tile_load(int tid, uint64_t *lds, const uint64_t *g, uint32_t tile) {
-#pragma unroll
-  for (int it = 0; it < HM_TILE / 2 / HM_THREADS; ++it) {
-    uint32_t lin = 2u * (uint32_t)(it * HM_THREADS + tid);
-    uint32_t gi = hm_tile_gidx<LOGR, STRIDED>(tile, lin);
-    int li = hm_tile_lidx<LOGR, STRIDED>(lin);
-    uint64_t a = g[gi], b = g[gi + 1];
-    lds[li] = a;
-    lds[li + 1] = b;
-  }
-}
+// ---------------------------------------------------------------------------------------------------
+// Per-thread phases.  A round = NB butterfly stages on local bits [K, K+NB) of x, done in registers by the
+// thread that owns the 2^NB elements of a group.  The first round of a pass reads its elements straight
+// from global memory and the last one writes straight back; only the exchanges between rounds go through
+// LDS (one barrier each).  Twiddles of round r+1 are requested before round r is computed, so that their
+// HBM latency overlaps the butterflies.  HmNttState is the per-thread register state (the host emulator
+// keeps one per thread).
+// ---------------------------------------------------------------------------------------------------
+#define HM_MAX_GPT 2  // groups per thread in one round (HM_TILE >> NB) / HM_THREADS
+struct HmNttState {
+  uint64_t v[HM_MAX_GPT][8];
+  HmTw tw[3][HM_MAX_GPT][7];
+  uint64_t ea[HM_MAX_GPT][8], ed[HM_MAX_GPT][8];  // MODE 3 only: epilogue operands, requested before the last round
+};
 
-// ---- phase: LDS -> global with the pass epilogue
-// MODE 0: store as is (lazy values, internal hand-off between the two passes)
-// MODE 1: forward final: reduce [0,4q) -> [0,q)
-// MODE 2: inverse final: multiply by the per-limb constant, reduce to [0,q)
-template <int LOGR, bool STRIDED, int MODE>
-HM_HD void hm_tile_store(int tid, const uint64_t *lds, uint64_t *g, uint32_t tile, uint64_t q, HmTw sc) {
-#pragma unroll
-  for (int it = 0; it < HM_TILE / 2 / HM_THREADS; ++it) {
-    uint32_t lin = 2u * (uint32_t)(it * HM_THREADS + tid);
-    uint32_t gi = hm_tile_gidx<LOGR, STRIDED>(tile, lin);
-    int li = hm_tile_lidx<LOGR, STRIDED>(lin);
-    uint64_t a = lds[li], b = lds[li + 1];
-    if (MODE == 1) {
-      a = hm_csub(hm_csub(a, 2 * q), q);
-      b = hm_csub(hm_csub(b, 2 * q), q);
-    } else if (MODE == 2) {
-      a = hm_shoup(a, sc.w, sc.ws, q);
-      b = hm_shoup(b, sc.w, sc.ws, q);
-    }
-    g[gi] = a;
-    g[gi + 1] = b;
-  }
-}
-
-// ---- phase: one round = NB butterfly stages on local bits [K, K+NB) of x, in registers.
-// twl = twiddle table of this limb; s0 = first global stage of the pass (0 for COL, LOG1 for ROW);
-// prefix0 = global row index of tile column 0 (ROW pass) or 0 (COL pass: twiddles do not depend on c).
-template <int LOGR, bool STRIDED, int NB, int K, bool INV>
-HM_HD void hm_ntt_round(int tid, uint64_t *lds, const HmTw *twl, uint32_t s0, uint32_t prefix0, uint64_t q) {
-  constexpr int R = 1 << LOGR, LOGC = HM_TILE_LOG - LOGR, C = 1 << LOGC;
-  constexpr int E = 1 << NB;
-  constexpr int GROUPS = HM_TILE >> NB;
-  constexpr int XR = R >> NB;  // groups per sub-transform
-  const uint64_t q2 = 2 * q;
-#pragma unroll
-  for (int u = 0; u < GROUPS / HM_THREADS; ++u) {
-    int gid = tid + HM_THREADS * u;
-    int c, xr;
-    if (STRIDED) { c = gid & (C - 1); xr = gid >> LOGC; }
-    else         { xr = gid & (XR - 1); c = gid / XR; }
-    int lo = xr & ((1 << K) - 1), hi = xr >> K;
-    int xb = (hi << (K + NB)) | lo;
-    uint64_t v[E];
-#pragma unroll
-    for (int e = 0; e < E; ++e) v[e] = lds[hm_lds_idx<LOGR, STRIDED>(xb | (e << K), c)];
-    uint32_t prefix = STRIDED ? 0u : (prefix0 + (uint32_t)c);
-#pragma unroll
-    for (int jj = 0; jj < NB; ++jj) {
-      const int j = INV ? (NB - 1 - jj) : jj;   // sub-stage: combines e-bit (NB-1-j)
-      const int sigma = LOGR - K - NB + j;      // local stage index
-      const uint32_t twbase = (1u << (s0 + sigma)) + (prefix << sigma) + ((uint32_t)hi << j);
-      const int pb = NB - 1 - j;
-#pragma unroll
-      for (int e = 0; e < E; ++e) {
-        if (e & (1 << pb)) continue;
-        HmTw t = twl[twbase + (uint32_t)(e >> (NB - j))];
-        if (INV) hm_bfly_inv(v[e], v[e | (1 << pb)], t, q, q2);
-        else     hm_bfly_fwd(v[e], v[e | (1 << pb)], t, q, q2);
-      }
-    }
-#pragma unroll
-    for (int e = 0; e < E; ++e) lds[hm_lds_idx<LOGR, STRIDED>(xb | (e << K), c)] = v[e];
-  }
-}
-
-// Round schedule per sub-transform length: bits are consumed from the top for the forward
-// transform (K descending) and from the bottom for the inverse.  {NB, K} lists, forward order.
+// Round schedule per sub-transform length: bits are consumed from the top for the forward transform
+// (K descending) and from the bottom for the inverse.  {NB, K} lists, forward order.
 template <int LOGR> struct HmRounds;
 template <> struct HmRounds<5> { static constexpr int n = 2; static constexpr int nb[3] = {3, 2, 0}; static constexpr int k[3] = {2, 0, 0}; };
 template <> struct HmRounds<6> { static constexpr int n = 2; static constexpr int nb[3] = {3, 3, 0}; static constexpr int k[3] = {3, 0, 0}; };
@@ -154,8 +101,180 @@ template <> struct HmRounds<7> { static constexpr int n = 3; static constexpr in
 template <> struct HmRounds<8> { static constexpr int n = 3; static constexpr int nb[3] = {3, 3, 2}; static constexpr int k[3] = {5, 2, 0}; };
 template <> struct HmRounds<9> { static constexpr int n = 3; static constexpr int nb[3] = {3, 3, 3}; static constexpr int k[3] = {6, 3, 0}; };
 
-#if defined(__HIPCC__)
-#define HM_SYNC() __syncthreads()
-#else
-#define HM_SYNC()
-#endif
+// geometry of round R of a pass
+template <int LOGR, bool STRIDED, int R>
+struct HmRound {
+  static constexpr int NB = HmRounds<LOGR>::nb[R], K = HmRounds<LOGR>::k[R];
+  static constexpr int E = 1 << NB;
+  static constexpr int LOGC = HM_TILE_LOG - LOGR, C = 1 << LOGC;
+  static constexpr int GPT = (HM_TILE >> NB) / HM_THREADS;
+  static constexpr int XR = (1 << LOGR) >> NB;  // groups per sub-transform
+  static_assert(GPT >= 1 && GPT <= HM_MAX_GPT, "tile / thread geometry");
+  // group u of thread tid: column c, high/low parts of the group index
+  static HM_HD void coords(int tid, int u, int &c, int &hi, int &xb) {
+    const int gid = tid + HM_THREADS * u;
+    int xr;
+    if (STRIDED) { c = gid & (C - 1); xr = gid >> LOGC; }
+    else         { xr = gid & (XR - 1); c = gid / XR; }
+    const int lo = xr & ((1 << K) - 1);
+    hi = xr >> K;
+    xb = (hi << (K + NB)) | lo;
+  }
+  static HM_HD uint32_t gidx(uint32_t tile, int x, int c) {
+    if (STRIDED) return ((uint32_t)x << 8) + (tile << LOGC) + (uint32_t)c;
+    return (tile << HM_TILE_LOG) + ((uint32_t)c << LOGR) + (uint32_t)x;
+  }
+};
+
+// request the twiddles of round R: sub-stage j needs 2^j of them, indexed by the top j bits of e
+template <int LOGR, bool STRIDED, int R>
+HM_HD void hm_ph_load_tw(HmNttState &st, int tid, const HmTw *twl, uint32_t s0, uint32_t prefix0) {
+  using G = HmRound<LOGR, STRIDED, R>;
+#pragma unroll
+  for (int u = 0; u < G::GPT; ++u) {
+    int c, hi, xb;
+    G::coords(tid, u, c, hi, xb);
+    const uint32_t prefix = STRIDED ? 0u : (prefix0 + (uint32_t)c);
+#pragma unroll
+    for (int j = 0; j < G::NB; ++j) {
+      const int sigma = LOGR - G::K - G::NB + j;  // local stage index
+      const uint32_t twbase = (1u << (s0 + sigma)) + (prefix << sigma) + ((uint32_t)hi << j);
+#pragma unroll
+      for (int t = 0; t < (1 << j); ++t) st.tw[R][u][(1 << j) - 1 + t] = twl[twbase + (uint32_t)t];
+    }
+  }
+}
+
+template <int LOGR, bool STRIDED, int R>
+HM_HD void hm_ph_load_global(HmNttState &st, int tid, const uint64_t *g, uint32_t tile) {
+  using G = HmRound<LOGR, STRIDED, R>;
+#pragma unroll
+  for (int u = 0; u < G::GPT; ++u) {
+    int c, hi, xb;
+    G::coords(tid, u, c, hi, xb);
+#pragma unroll
+    for (int e = 0; e < G::E; ++e) st.v[u][e] = g[G::gidx(tile, xb | (e << G::K), c)];
+  }
+}
+
+// MODE 3: request the epilogue operands of the elements this thread will store (same coordinates as the store)
+template <int LOGR, bool STRIDED, int R>
+HM_HD void hm_ph_load_epi(HmNttState &st, int tid, uint32_t tile, HmEpi ep) {
+  using G = HmRound<LOGR, STRIDED, R>;
+#pragma unroll
+  for (int u = 0; u < G::GPT; ++u) {
+    int c, hi, xb;
+    G::coords(tid, u, c, hi, xb);
+#pragma unroll
+    for (int e = 0; e < G::E; ++e) {
+      const uint32_t gi = G::gidx(tile, xb | (e << G::K), c);
+      st.ea[u][e] = ep.a[gi];
+      st.ed[u][e] = ep.d ? ep.d[gi] : 0;
+    }
+  }
+}
+
+// MODE 0: store as is (lazy values, hand-off between the two passes); 1: forward final, reduce [0,8q) ->
+// [0,q); 2: inverse final, multiply by the per-limb constant and reduce to [0,q); 3: forward final fused with
+// out = (minuend - x) * k [+ addend]
+template <int LOGR, bool STRIDED, int R, int MODE>
+HM_HD void hm_ph_store_global(const HmNttState &st, int tid, uint64_t *g, uint32_t tile, uint64_t q, HmTw sc, HmEpi ep) {
+  using G = HmRound<LOGR, STRIDED, R>;
+#pragma unroll
+  for (int u = 0; u < G::GPT; ++u) {
+    int c, hi, xb;
+    G::coords(tid, u, c, hi, xb);
+#pragma unroll
+    for (int e = 0; e < G::E; ++e) {
+      uint64_t a = st.v[u][e];
+      if (MODE == 1) a = hm_reduce8(a, q);
+      else if (MODE == 2) a = hm_shoup(a, sc.w, sc.ws, q);
+      const uint32_t gi = G::gidx(tile, xb | (e << G::K), c);
+      if (MODE == 3) {  // a in [0, 8q): minuend - a + 8q stays positive and below 2^64; the product reduces it
+        a = hm_shoup(st.ea[u][e] + 8 * q - a, sc.w, sc.ws, q);
+        if (ep.d) a = hm_addmod(a, st.ed[u][e], q);
+      }
+      g[gi] = a;
+    }
+  }
+}
+
+template <int LOGR, bool STRIDED, int R>
+HM_HD void hm_ph_load_lds(HmNttState &st, int tid, const uint64_t *lds) {
+  using G = HmRound<LOGR, STRIDED, R>;
+#pragma unroll
+  for (int u = 0; u < G::GPT; ++u) {
+    int c, hi, xb;
+    G::coords(tid, u, c, hi, xb);
+#pragma unroll
+    for (int e = 0; e < G::E; ++e) st.v[u][e] = lds[hm_lds_idx<LOGR, STRIDED>(xb | (e << G::K), c)];
+  }
+}
+template <int LOGR, bool STRIDED, int R>
+HM_HD void hm_ph_store_lds(const HmNttState &st, int tid, uint64_t *lds) {
+  using G = HmRound<LOGR, STRIDED, R>;
+#pragma unroll
+  for (int u = 0; u < G::GPT; ++u) {
+    int c, hi, xb;
+    G::coords(tid, u, c, hi, xb);
+#pragma unroll
+    for (int e = 0; e < G::E; ++e) lds[hm_lds_idx<LOGR, STRIDED>(xb | (e << G::K), c)] = st.v[u][e];
+  }
+}
+
+template <int LOGR, bool STRIDED, int R, bool INV>
+HM_HD void hm_ph_compute(HmNttState &st, uint64_t q) {
+  using G = HmRound<LOGR, STRIDED, R>;
+  const uint64_t q2 = 4 * q;  // lazy ranges: forward [0, 8q), inverse [0, 4q)
+#pragma unroll
+  for (int u = 0; u < G::GPT; ++u) {
+#pragma unroll
+    for (int jj = 0; jj < G::NB; ++jj) {
+      const int j = INV ? (G::NB - 1 - jj) : jj;  // sub-stage j combines e-bit (NB-1-j)
+      const int pb = G::NB - 1 - j;
+#pragma unroll
+      for (int e = 0; e < G::E; ++e) {
+        if (e & (1 << pb)) continue;
+        const HmTw t = st.tw[R][u][(1 << j) - 1 + (e >> (G::NB - j))];
+        if (INV) hm_bfly_inv(st.v[u][e], st.v[u][e | (1 << pb)], t, q, q2);
+        else     hm_bfly_fwd(st.v[u][e], st.v[u][e | (1 << pb)], t, q, q2);
+      }
+    }
+  }
+}
+
+// The whole pass of one thread, phase by phase.  `sync` is __syncthreads() on the GPU; the emulator calls the
+// phases itself (see tests/emu/hm_emu.cpp) in the same order, one phase for all threads at a time.
+// Phase list (forward; the inverse walks the rounds from the last to the first):
+//   P0: tw[r0], global -> v, tw[r1]          P1: compute r0, v -> LDS            | barrier
+//   P2: tw[r2] (3 rounds), LDS -> v, compute r1, then  (2 rounds) v -> global    or  v -> LDS | barrier
+//   P3: LDS -> v, compute r2, v -> global
+template <int LOGR, bool STRIDED, bool INV, int MODE, int PHASE>
+HM_HD void hm_ntt_phase(HmNttState &st, int tid, uint64_t *lds, const uint64_t *src, uint64_t *dst, uint32_t tile,
+                        const HmTw *twl, uint32_t s0, uint32_t prefix0, uint64_t q, HmTw sc, HmEpi ep) {
+  using RS = HmRounds<LOGR>;
+  constexpr int n = RS::n;
+  constexpr int r0 = INV ? n - 1 : 0, r1 = INV ? n - 2 : 1, r2 = INV ? 0 : 2;  // r2 only when n == 3
+  if (PHASE == 0) {
+    hm_ph_load_tw<LOGR, STRIDED, r0>(st, tid, twl, s0, prefix0);
+    hm_ph_load_global<LOGR, STRIDED, r0>(st, tid, src, tile);
+    hm_ph_load_tw<LOGR, STRIDED, r1>(st, tid, twl, s0, prefix0);
+  } else if (PHASE == 1) {
+    hm_ph_compute<LOGR, STRIDED, r0, INV>(st, q);
+    hm_ph_store_lds<LOGR, STRIDED, r0>(st, tid, lds);
+  } else if (PHASE == 2) {
+    if (n == 3) hm_ph_load_tw<LOGR, STRIDED, (n == 3 ? r2 : r1)>(st, tid, twl, s0, prefix0);
+    if (n == 2 && MODE == 3) hm_ph_load_epi<LOGR, STRIDED, r1>(st, tid, tile, ep);
+    hm_ph_load_lds<LOGR, STRIDED, r1>(st, tid, lds);
+    hm_ph_compute<LOGR, STRIDED, r1, INV>(st, q);
+    if (n == 3) hm_ph_store_lds<LOGR, STRIDED, r1>(st, tid, lds);
+    else hm_ph_store_global<LOGR, STRIDED, r1, MODE>(st, tid, dst, tile, q, sc, ep);
+  } else if (PHASE == 3) {
+    if (n == 3) {
+      if (MODE == 3) hm_ph_load_epi<LOGR, STRIDED, (n == 3 ? r2 : r1)>(st, tid, tile, ep);
+      hm_ph_load_lds<LOGR, STRIDED, (n == 3 ? r2 : r1)>(st, tid, lds);
+      hm_ph_compute<LOGR, STRIDED, (n == 3 ? r2 : r1), INV>(st, q);
+      hm_ph_store_global<LOGR, STRIDED, (n == 3 ? r2 : r1), MODE>(st, tid, dst, tile, q, sc, ep);
+    }
+  }
+}

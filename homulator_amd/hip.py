@@ -13,8 +13,8 @@ OP_MUL, OP_MAC2, OP_MAC_ADD, OP_ADD, OP_SUB, OP_MUL_CONST, OP_SUB_SCALE, OP_COPY
 # every symbol include/homulator_hip.h declares
 SYMBOLS = [
     "hm_create", "hm_destroy", "hm_last_error", "hm_version", "hm_get_modulus", "hm_get_psi", "hm_malloc", "hm_free",
-    "hm_memcpy_h2d", "hm_memcpy_d2h", "hm_memcpy_d2d", "hm_sync", "hm_stream", "hm_ntt", "hm_automorph", "hm_ewe",
-    "hm_bconv", "hm_bconv_consts", "hm_fill_uniform", "hm_timer_start", "hm_timer_stop",
+    "hm_memcpy_h2d", "hm_memcpy_d2h", "hm_memcpy_d2d", "hm_sync", "hm_stream", "hm_ntt", "hm_ntt_sub_scale", "hm_tensor", "hm_automorph", "hm_ewe",
+    "hm_bconv", "hm_bconv_batch", "hm_bconv_consts", "hm_fill_uniform", "hm_timer_start", "hm_timer_stop",
 ]
 
 
@@ -52,6 +52,8 @@ def load():
     L.hm_stream.restype = vp
     L.hm_stream.argtypes = [vp]
     L.hm_ntt.argtypes = [vp, vp, vp, vp, vp, vp, u32, i32, vp]
+    L.hm_ntt_sub_scale.argtypes = [vp] + [vp] * 9 + [u32, vp]
+    L.hm_tensor.argtypes = [vp] + [vp] * 15 + [u32]
     L.hm_automorph.argtypes = [vp, vp, vp, vp, vp, u32, u32]
     L.hm_ewe.argtypes = [vp, i32] + [vp] * 11 + [u32, vp]
     L.hm_bconv.argtypes = [vp, vp, vp, vp, u32, vp, vp, vp, u32]
@@ -164,6 +166,19 @@ class Context:
         k3, pm = _u32(mod_ids)
         k4, ps = _u64(scale)
         self._ck(self.L.hm_ntt(self.h, src.ptr, pi, dst.ptr, po, pm, n, 1 if inverse else 0, ps))
+
+    def ntt_sub_scale(self, src, minuend, out, mod_ids, k, addend=None, in_limbs=None, minuend_limbs=None, addend_limbs=None,
+                      out_limbs=None):
+        keep = [_u32(x) for x in (in_limbs, minuend_limbs, addend_limbs, out_limbs, mod_ids)]
+        kk, pk = _u64(k)
+        self._ck(self.L.hm_ntt_sub_scale(self.h, src.ptr, keep[0][1], minuend.ptr, keep[1][1], None if addend is None else addend.ptr,
+                                         keep[2][1], out.ptr, keep[3][1], keep[4][1], len(mod_ids), pk))
+
+    def tensor(self, a, b, c, d, o0, o1, o2, mod_ids, limbs=None):
+        ls = limbs or [None] * 7
+        keep = [_u32(x) for x in ls] + [_u32(mod_ids)]
+        self._ck(self.L.hm_tensor(self.h, a.ptr, keep[0][1], b.ptr, keep[1][1], c.ptr, keep[2][1], d.ptr, keep[3][1], o0.ptr, keep[4][1],
+                                  o1.ptr, keep[5][1], o2.ptr, keep[6][1], keep[7][1], len(mod_ids)))
 
     def automorph(self, src, dst, n, galois, in_limbs=None, out_limbs=None):
         k1, pi = _u32(in_limbs)

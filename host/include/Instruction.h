@@ -31,6 +31,11 @@ public:
   bool passthrough = false;  // an NTT-kind instruction whose input is already in evaluation form (copy)
   std::vector<uint32_t> inMods;  // BCONV: modulus ids of the inputs
   unsigned long long refInstructions = 0;  // upstream instructions this record stands for
+  // set by the backend's fusion passes (Arch::fusePasses), never by the generators:
+  bool fusedSubScale = false;          // forward NTT whose epilogue is out = (minuend - NTT(in)) * constant [+ addend]
+  AddrType fMinuend = 0, fAddend = 0;  // fAddend == 0: no addend
+  bool fusedTensor = false;            // MAC2 record that also produces d0 -> extraOutputs[0] and d2 -> extraOutputs[1]
+  std::vector<AddrType> extraOutputs;
   std::vector<Instruction *> depsInsList;
 
   Instruction(std::string name, ins_ops op, uint32_t level) : ops(op), Name(std::move(name)), level_id(level) {}

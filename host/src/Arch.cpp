@@ -10,12 +10,14 @@
 
 // one C-ABI call, with its argument arrays prebuilt so that run() is a tight loop of calls
 struct Arch::Launch {
-  enum Kind { L_NTT, L_INTT, L_EWE, L_BCONV, L_AUTO } kind;
+  enum Kind { L_NTT, L_INTT, L_EWE, L_BCONV, L_AUTO, L_NTT_SUBSCALE, L_TENSOR } kind;
   std::string name;
   std::string statKey;
   int opcode = 0;
   uint32_t galois = 0;
-  std::vector<uint32_t> a, b, c, d, out, mods, inMods;
+  std::vector<uint32_t> a, b, c, d, out, out1, out2, mods, inMods;
+  struct Prob { std::vector<uint32_t> in, inMods, out, outMods; };
+  std::vector<Prob> probs;  // BCONV: independent conversions batched into one launch
   std::vector<uint64_t> k;
   bool hasK = false;
   unsigned long long refInstructions = 0;
@@ -183,6 +185,48 @@ void Arch::fusePasses(std::vector<Stage> &st) {
         }
       }
     }
+  // (4) forward NTT whose only consumer is (minuend - x) * k [+ addend]: the epilogue moves into the transform's
+  //     last pass (ModDowNTT + ModDownSub + final add; Rescale_NTT + Rescale_SUB + Rescale_Mul)
+  for (auto &s : st)
+    for (Instruction *i : s.ins) {
+      if (i->ops != MULT || dead.count(i) || (i->opcode != EWE_SUB_SCALE && i->opcode != EWE_SUB_SCALE_ADD)) continue;
+      auto p = producer.find(i->operandList[2]);
+      if (p == producer.end() || p->second->ops != NTT || p->second->passthrough || dead.count(p->second) ||
+          p->second->fusedSubScale || uses[i->operandList[2]] != 1)
+        continue;
+      Instruction *t = p->second;
+      const AddrType minuend = i->operandList[0], addend = i->opcode == EWE_SUB_SCALE_ADD ? i->operandList[3] : 0;
+      const AddrType out = i->OutputOperand;
+      if (out == t->operandList[0] || out == minuend || out == addend) continue;  // out doubles as first-pass scratch
+      t->fusedSubScale = true;
+      t->fMinuend = minuend;
+      t->fAddend = addend;
+      t->hasConstant = true;
+      t->constant = i->constant;
+      t->OutputOperand = out;
+      t->refInstructions += i->refInstructions;
+      producer[out] = t;
+      dead.insert(i);
+    }
+  // (5) tensor product: d1 = p*s + r*t (MAC2) with d0 = p*t and d2 = r*s (MUL) of the same limb -> one pass
+  {
+    std::map<std::pair<AddrType, AddrType>, Instruction *> muls;
+    for (auto &s : st)
+      for (Instruction *i : s.ins)
+        if (i->ops == MULT && i->opcode == EWE_MUL && !dead.count(i)) muls[{i->operandList[0], i->operandList[1]}] = i;
+    for (auto &s : st)
+      for (Instruction *i : s.ins) {
+        if (i->ops != MULT || i->opcode != EWE_MAC2 || dead.count(i)) continue;
+        const AddrType P = i->operandList[0], S = i->operandList[1], R = i->operandList[2], T = i->operandList[3];
+        auto u = muls.find({P, T}), v = muls.find({R, S});
+        if (u == muls.end() || v == muls.end() || u->second->mod_id != i->mod_id || v->second->mod_id != i->mod_id) continue;
+        i->fusedTensor = true;
+        i->extraOutputs = {u->second->OutputOperand, v->second->OutputOperand};
+        i->refInstructions += u->second->refInstructions + v->second->refInstructions;
+        dead.insert(u->second);
+        dead.insert(v->second);
+      }
+  }
   // drop dead instructions and empty stages; upstream instructions of eliminated pass-through records are
   // accounted on the first surviving instruction so that the retired total still matches getTotalIns()
   unsigned long long orphan = 0;
@@ -209,61 +253,148 @@ void Arch::buildLaunches() {
   const unsigned long long LP = (unsigned long long)n * 8;
   // upstream issues every BCONV group to all MAC ports (include/Driver.h:307-320): same accounting here
   const unsigned long long bconvPorts = (unsigned long long)config->getValueOr("bconv_num_high", 1) * config->getValueOr("bconv_num_width", 1);
+  const int useMask[9] = {3, 15, 7, 5, 5, 1, 5, 1, 13};
+
+  // ---- 1. split every stage into parts one C-ABI call can express (same kind / opcode / direction)
+  struct Part { std::string name; int key; std::vector<Instruction *> ins; int depth = 0; };
+  std::vector<Part> parts;
   for (const Stage &s : st) {
-    // split a stage by what one C-ABI call can express: same kind (+ opcode / direction / pass-through)
-    std::vector<std::vector<Instruction *>> parts;
-    std::vector<int> partKey;
+    size_t first = parts.size();
     for (Instruction *i : s.ins) {
-      int key = i->ops == MULT ? 100 + i->opcode : (i->ops == NTT && i->passthrough) ? 99 : (int)i->ops;
-      size_t p = 0;
-      for (; p < partKey.size(); ++p)
-        if (partKey[p] == key) break;
-      if (p == partKey.size()) { partKey.push_back(key); parts.emplace_back(); }
-      parts[p].push_back(i);
+      int key = i->fusedTensor ? 200 : i->fusedSubScale ? (i->fAddend ? 201 : 202) : i->ops == MULT ? 100 + i->opcode : (i->ops == NTT && i->passthrough) ? 100 + EWE_COPY : i->ops == AUTO ? 1000 + (int)i->galois : (int)i->ops;
+      size_t p = first;
+      for (; p < parts.size(); ++p)
+        if (parts[p].key == key) break;
+      if (p == parts.size()) parts.push_back(Part{s.name, key, {}, 0});
+      parts[p].ins.push_back(i);
     }
-    for (size_t p = 0; p < parts.size(); ++p) {
+  }
+  // ---- 2. dependency depth of every part (RAW, WAR and WAW through limb addresses).  With fuse = 1 parts
+  // of equal depth and kind are coalesced into one launch: the two keys of a ModDown, the beta digits of a
+  // ModUp, D0/D2 of the tensor product ...  The reference dispatches stage by stage (Operation.cpp:947-964);
+  // the stage ORDER it fixes is only a topological order of this graph.
+  auto reads = [&](Instruction *i) {
+    std::vector<AddrType> v;
+    if (i->ops == BCONV_STEP2) v.assign(i->operandList.begin(), i->operandList.end() - 1);
+    else if (i->ops == MULT) { for (int b = 0; b < 4; ++b) if (useMask[i->opcode] & (1 << b)) v.push_back(i->operandList[b]); }
+    else v.push_back(i->operandList[0]);
+    if (i->fusedSubScale) { v.push_back(i->fMinuend); if (i->fAddend) v.push_back(i->fAddend); }
+    return v;
+  };
+  auto writes = [&](Instruction *i) {
+    std::vector<AddrType> v = {i->OutputOperand};
+    v.insert(v.end(), i->extraOutputs.begin(), i->extraOutputs.end());
+    return v;
+  };
+  std::map<AddrType, int> writerDepth, readerDepth;
+  int serial = 0;
+  for (Part &p : parts) {
+    int d = 0;
+    for (Instruction *i : p.ins) {
+      for (AddrType a : reads(i)) { auto w = writerDepth.find(a); if (w != writerDepth.end()) d = std::max(d, w->second + 1); }
+      for (AddrType o : writes(i)) {
+        auto w = writerDepth.find(o); if (w != writerDepth.end()) d = std::max(d, w->second + 1);
+        auto r = readerDepth.find(o); if (r != readerDepth.end()) d = std::max(d, r->second + 1);
+      }
+    }
+    if (!fuse) d = serial++;  // unfused: one launch per stage part, upstream's order
+    p.depth = d;
+    for (Instruction *i : p.ins) {
+      for (AddrType a : reads(i)) { int &r = readerDepth[a]; r = std::max(r, d); }
+      for (AddrType o : writes(i)) writerDepth[o] = d;
+    }
+  }
+  // ---- 3. coalesce and emit, level by level
+  int maxDepth = 0;
+  for (const Part &p : parts) maxDepth = std::max(maxDepth, p.depth);
+  for (int d = 0; d <= maxDepth; ++d) {
+    std::vector<int> keysDone;
+    for (size_t pi = 0; pi < parts.size(); ++pi) {
+      if (parts[pi].depth != d) continue;
+      const int key = parts[pi].key;
+      if (std::find(keysDone.begin(), keysDone.end(), key) != keysDone.end()) continue;
+      keysDone.push_back(key);
+      std::vector<const Part *> group;
+      for (size_t pj = pi; pj < parts.size(); ++pj)
+        if (parts[pj].depth == d && parts[pj].key == key) group.push_back(&parts[pj]);
       Launch *L = new Launch;
-      L->name = s.name;
-      Instruction *f = parts[p][0];
-      for (Instruction *i : parts[p]) L->refInstructions += i->refInstructions * (i->ops == BCONV_STEP2 ? bconvPorts : 1ull);
-      if (f->ops == NTT && f->passthrough) {  // unfused mode: materialise the copy
+      for (const Part *g : group) L->name += (L->name.empty() ? "" : "+") + g->name;
+      Instruction *f = group[0]->ins[0];
+      size_t count = 0;
+      for (const Part *g : group)
+        for (Instruction *i : g->ins) { L->refInstructions += i->refInstructions * (i->ops == BCONV_STEP2 ? bconvPorts : 1ull); ++count; }
+      if (f->fusedTensor) {
+        L->kind = Launch::L_TENSOR; L->statKey = "EWE";
+        for (const Part *g : group)
+          for (Instruction *i : g->ins) {  // a = c00 (P), b = c10 (T), c = c01 (R), d = c11 (S)
+            L->a.push_back(limbOf(i->operandList[0])); L->b.push_back(limbOf(i->operandList[3]));
+            L->c.push_back(limbOf(i->operandList[2])); L->d.push_back(limbOf(i->operandList[1]));
+            L->out.push_back(limbOf(i->extraOutputs[0])); L->out1.push_back(limbOf(i->OutputOperand)); L->out2.push_back(limbOf(i->extraOutputs[1]));
+            L->mods.push_back(i->mod_id);
+          }
+        L->bytes = 7 * LP * count;
+      } else if (f->fusedSubScale) {
+        L->kind = Launch::L_NTT_SUBSCALE; L->statKey = "NTT";
+        bool anyAddend = false, allAddend = true;
+        for (const Part *g : group)
+          for (Instruction *i : g->ins) { anyAddend |= i->fAddend != 0; allAddend &= i->fAddend != 0; }
+        if (anyAddend != allAddend) throw std::runtime_error("fused NTT stage mixes epilogues with and without addend");
+        for (const Part *g : group)
+          for (Instruction *i : g->ins) {
+            L->a.push_back(limbOf(i->operandList[0])); L->b.push_back(limbOf(i->fMinuend));
+            if (anyAddend) L->c.push_back(limbOf(i->fAddend));
+            L->out.push_back(limbOf(i->OutputOperand)); L->mods.push_back(i->mod_id); L->k.push_back(i->constant);
+          }
+        L->hasK = true;
+        L->bytes = (anyAddend ? 4 : 3) * LP * count;
+      } else if (f->ops == NTT && f->passthrough) {  // unfused mode: materialise the copy
         L->kind = Launch::L_EWE; L->opcode = EWE_COPY; L->statKey = "EWE";
-        for (Instruction *i : parts[p]) { L->a.push_back(limbOf(i->operandList[0])); L->out.push_back(limbOf(i->OutputOperand)); L->mods.push_back(i->mod_id); }
-        L->bytes = 2 * LP * parts[p].size();
+        for (const Part *g : group)
+          for (Instruction *i : g->ins) { L->a.push_back(limbOf(i->operandList[0])); L->out.push_back(limbOf(i->OutputOperand)); L->mods.push_back(i->mod_id); }
+        L->bytes = 2 * LP * count;
       } else if (f->ops == NTT || f->ops == INTT) {
         L->kind = f->ops == NTT ? Launch::L_NTT : Launch::L_INTT; L->statKey = "NTT";
-        for (Instruction *i : parts[p]) {
-          L->a.push_back(limbOf(i->operandList[0])); L->out.push_back(limbOf(i->OutputOperand)); L->mods.push_back(i->mod_id);
-          L->k.push_back(i->hasConstant ? i->constant : 1);
-          L->hasK |= i->hasConstant;
-        }
-        L->bytes = 2 * LP * parts[p].size();
+        for (const Part *g : group)
+          for (Instruction *i : g->ins) {
+            L->a.push_back(limbOf(i->operandList[0])); L->out.push_back(limbOf(i->OutputOperand)); L->mods.push_back(i->mod_id);
+            L->k.push_back(i->hasConstant ? i->constant : 1);
+            L->hasK |= i->hasConstant;
+          }
+        L->bytes = 2 * LP * count;
       } else if (f->ops == AUTO) {
         L->kind = Launch::L_AUTO; L->statKey = "AUTO"; L->galois = f->galois;
-        for (Instruction *i : parts[p]) { L->a.push_back(limbOf(i->operandList[0])); L->out.push_back(limbOf(i->OutputOperand)); }
-        L->bytes = 2 * LP * parts[p].size();
+        for (const Part *g : group)
+          for (Instruction *i : g->ins) { L->a.push_back(limbOf(i->operandList[0])); L->out.push_back(limbOf(i->OutputOperand)); }
+        L->bytes = 2 * LP * count;
       } else if (f->ops == MULT) {
         L->kind = Launch::L_EWE; L->opcode = f->opcode; L->statKey = "EWE";
-        const int m[9] = {3, 15, 7, 5, 5, 1, 5, 1, 13};
+        const int m = useMask[f->opcode];
         int nops = 1;
-        for (int b = 0; b < 4; ++b) nops += (m[f->opcode] >> b) & 1;
-        for (Instruction *i : parts[p]) {
-          auto get = [&](int b) { return (m[f->opcode] & (1 << b)) ? limbOf(i->operandList[b]) : 0u; };
-          L->a.push_back(get(0)); L->b.push_back(get(1)); L->c.push_back(get(2)); L->d.push_back(get(3));
-          L->out.push_back(limbOf(i->OutputOperand)); L->mods.push_back(i->mod_id);
-          L->k.push_back(i->hasConstant ? i->constant : 0);
-          L->hasK |= i->hasConstant;
-        }
-        L->bytes = (unsigned long long)nops * LP * parts[p].size();
+        for (int b = 0; b < 4; ++b) nops += (m >> b) & 1;
+        for (const Part *g : group)
+          for (Instruction *i : g->ins) {
+            auto get = [&](int b) { return (m & (1 << b)) ? limbOf(i->operandList[b]) : 0u; };
+            L->a.push_back(get(0)); L->b.push_back(get(1)); L->c.push_back(get(2)); L->d.push_back(get(3));
+            L->out.push_back(limbOf(i->OutputOperand)); L->mods.push_back(i->mod_id);
+            L->k.push_back(i->hasConstant ? i->constant : 0);
+            L->hasK |= i->hasConstant;
+          }
+        L->bytes = (unsigned long long)nops * LP * count;
       } else if (f->ops == BCONV_STEP2) {
         L->kind = Launch::L_BCONV; L->statKey = "BCONV";
-        L->inMods = f->inMods;
-        for (size_t x = 0; x + 1 < f->operandList.size(); ++x) L->a.push_back(limbOf(f->operandList[x]));
-        for (Instruction *i : parts[p]) {
-          if (i->inMods != f->inMods) throw std::runtime_error("BCONV stage mixes input bases");
-          L->out.push_back(limbOf(i->OutputOperand)); L->mods.push_back(i->mod_id);
+        for (const Part *g : group) {
+          // one conversion per distinct (input limbs) inside the part
+          for (Instruction *i : g->ins) {
+            std::vector<uint32_t> in;
+            for (size_t x = 0; x + 1 < i->operandList.size(); ++x) in.push_back(limbOf(i->operandList[x]));
+            Launch::Prob *pr = nullptr;
+            for (auto &q : L->probs) if (q.in == in && q.inMods == i->inMods) pr = &q;
+            if (!pr) { L->probs.push_back(Launch::Prob{in, i->inMods, {}, {}}); pr = &L->probs.back(); }
+            pr->out.push_back(limbOf(i->OutputOperand));
+            pr->outMods.push_back(i->mod_id);
+          }
         }
-        L->bytes = LP * (L->a.size() + L->out.size());
+        for (auto &q : L->probs) L->bytes += LP * (q.in.size() + q.out.size());
       } else {
         delete L;
         throw std::runtime_error("no unit executes op " + f->GetOpName());
@@ -298,12 +429,21 @@ void Arch::prepare() {
 void Arch::enqueue(Launch &l) {
   hm_status st = HM_OK;
   const uint32_t cnt = (uint32_t)l.out.size();
+  std::vector<hm_bconv_desc> descs;
   switch (l.kind) {
   case Launch::L_NTT:
     st = hm_ntt(ctx, pool, l.a.data(), pool, l.out.data(), l.mods.data(), cnt, 0, nullptr);
     break;
   case Launch::L_INTT:
     st = hm_ntt(ctx, pool, l.a.data(), pool, l.out.data(), l.mods.data(), cnt, 1, l.hasK ? l.k.data() : nullptr);
+    break;
+  case Launch::L_NTT_SUBSCALE:
+    st = hm_ntt_sub_scale(ctx, pool, l.a.data(), pool, l.b.data(), l.c.empty() ? nullptr : pool, l.c.empty() ? nullptr : l.c.data(), pool,
+                          l.out.data(), l.mods.data(), cnt, l.k.data());
+    break;
+  case Launch::L_TENSOR:
+    st = hm_tensor(ctx, pool, l.a.data(), pool, l.b.data(), pool, l.c.data(), pool, l.d.data(), pool, l.out.data(), pool, l.out1.data(), pool,
+                   l.out2.data(), l.mods.data(), cnt);
     break;
   case Launch::L_AUTO:
     st = hm_automorph(ctx, pool, l.a.data(), pool, l.out.data(), cnt, l.galois);
@@ -313,7 +453,10 @@ void Arch::enqueue(Launch &l) {
                 l.d.empty() ? nullptr : l.d.data(), pool, l.out.data(), l.mods.data(), cnt, l.hasK ? l.k.data() : nullptr);
     break;
   case Launch::L_BCONV:
-    st = hm_bconv(ctx, pool, l.a.data(), l.inMods.data(), (uint32_t)l.inMods.size(), pool, l.out.data(), l.mods.data(), cnt);
+    for (auto &q : l.probs)
+      descs.push_back(hm_bconv_desc{pool, q.in.data(), q.inMods.data(), (uint32_t)q.in.size(), pool, q.out.data(), q.outMods.data(),
+                                    (uint32_t)q.out.size()});
+    st = hm_bconv_batch(ctx, descs.data(), (uint32_t)descs.size());
     break;
   }
   if (st != HM_OK) throw std::runtime_error("stage " + l.name + ": " + hm_last_error(ctx));

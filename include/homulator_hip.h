@@ -66,6 +66,15 @@ hm_status hm_ntt(hm_ctx *ctx, const uint64_t *in, const uint32_t *in_limbs, uint
                  const uint32_t *out_limbs, const uint32_t *mod_ids, uint32_t n, int inverse,
                  const uint64_t *scale);
 
+/* K1 fused with the element-wise stage that consumes it: out_i = (minuend_i - NTT(in_i)) * k[i] (+ addend_i).
+ * One call = ModDowNTT + ModDownSub (+ the final add), src/Operation.cpp:521-590, 967-1005, or Rescale_NTT +
+ * Rescale_SUB + Rescale_Mul, :806-910: the transformed limbs never travel to HBM.  `out` also serves as the
+ * scratch of the first pass, so it must not alias `in`, `minuend` or `addend`. */
+hm_status hm_ntt_sub_scale(hm_ctx *ctx, const uint64_t *in, const uint32_t *in_limbs, const uint64_t *minuend,
+                           const uint32_t *minuend_limbs, const uint64_t *addend, const uint32_t *addend_limbs,
+                           uint64_t *out, const uint32_t *out_limbs, const uint32_t *mod_ids, uint32_t n,
+                           const uint64_t *k);
+
 /* K2 — automorphism X -> X^galois in evaluation form.  Replaces issueIns(..., "AUTO", ...) for
  * InsGen::GenAUTO (src/InsGen.cpp:46-71).  in must not alias out. */
 hm_status hm_automorph(hm_ctx *ctx, const uint64_t *in, const uint32_t *in_limbs, uint64_t *out,
@@ -89,6 +98,13 @@ hm_status hm_ewe(hm_ctx *ctx, int op, const uint64_t *a, const uint32_t *a_limbs
                  const uint32_t *d_limbs, uint64_t *out, const uint32_t *out_limbs,
                  const uint32_t *mod_ids, uint32_t n, const uint64_t *k);
 
+/* K3, tensor product in one pass over the four input polynomials: o0 = a*b, o1 = a*d + c*b, o2 = c*d
+ * (TensorCompute::computeD0/D1/D2, src/Operation.cpp:624-739 with a = c00, b = c10, c = c01, d = c11). */
+hm_status hm_tensor(hm_ctx *ctx, const uint64_t *a, const uint32_t *a_limbs, const uint64_t *b, const uint32_t *b_limbs,
+                    const uint64_t *c, const uint32_t *c_limbs, const uint64_t *d, const uint32_t *d_limbs,
+                    uint64_t *o0, const uint32_t *o0_limbs, uint64_t *o1, const uint32_t *o1_limbs, uint64_t *o2,
+                    const uint32_t *o2_limbs, const uint32_t *mod_ids, uint32_t n);
+
 /* K4 — fast base conversion, matrix step: out_t = sum_i in_i * [Q_D / q_i]_t mod t for the input
  * basis in_ids (n_in <= 16) and output basis out_ids (n_out <= 64).  `in` must already hold
  * y_i = x_i * [(Q_D/q_i)^-1]_{q_i} (hm_ntt's scale or HM_OP_MUL_CONST with hm_bconv_consts).
@@ -97,6 +113,13 @@ hm_status hm_ewe(hm_ctx *ctx, int op, const uint64_t *a, const uint32_t *a_limbs
 hm_status hm_bconv(hm_ctx *ctx, const uint64_t *in, const uint32_t *in_limbs, const uint32_t *in_ids,
                    uint32_t n_in, uint64_t *out, const uint32_t *out_limbs, const uint32_t *out_ids,
                    uint32_t n_out);
+/* several independent conversions in ONE launch (the beta digits of a ModUp, the two keys of a ModDown:
+ * src/Operation.cpp:31-35 loops over the digits, :489-519 over the keys) */
+typedef struct hm_bconv_desc {
+  const uint64_t *in; const uint32_t *in_limbs; const uint32_t *in_ids; uint32_t n_in;
+  uint64_t *out; const uint32_t *out_limbs; const uint32_t *out_ids; uint32_t n_out;
+} hm_bconv_desc;
+hm_status hm_bconv_batch(hm_ctx *ctx, const hm_bconv_desc *descs, uint32_t n_desc);
 /* host-side constants of a conversion: qhat_inv[n_in], table[n_in][n_out] (either may be NULL) */
 hm_status hm_bconv_consts(hm_ctx *ctx, const uint32_t *in_ids, uint32_t n_in, const uint32_t *out_ids,
                           uint32_t n_out, uint64_t *qhat_inv, uint64_t *table);

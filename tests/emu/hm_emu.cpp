@@ -17,25 +17,21 @@ struct Emu {
 };
 
 template <int LOGR, bool STRIDED, bool INV, int MODE>
-static void run_pass(const Emu &e, uint32_t mod, const uint64_t *src, uint64_t *dst, HmTw sc) {
+static void run_pass(const Emu &e, uint32_t mod, const uint64_t *src, uint64_t *dst, HmTw sc, HmEpi ep = HmEpi{nullptr, nullptr}) {
   const uint32_t tiles = e.P.N >> HM_TILE_LOG;
   const uint64_t q = e.P.mod[mod];
   const HmTw *twl = (INV ? e.inv : e.fwd)[mod].data();
   const uint32_t s0 = STRIDED ? 0u : (e.P.logN - 8u);
-  using RS = HmRounds<LOGR>;
   std::vector<uint64_t> lds(HM_LDS_WORDS);
+  std::vector<HmNttState> st(HM_THREADS);
+  // a pass may run in place (src == dst): every thread reads its elements before any thread writes its own
   for (uint32_t tile = 0; tile < tiles; ++tile) {
     const uint32_t prefix0 = STRIDED ? 0u : (tile << (HM_TILE_LOG - LOGR));
-    for (int t = 0; t < HM_THREADS; ++t) hm_tile_load<LOGR, STRIDED>(t, lds.data(), src, tile);
-    auto rnd = [&](auto nbk) {
-      constexpr int I = decltype(nbk)::value;
-      if constexpr (I < RS::n)
-        for (int t = 0; t < HM_THREADS; ++t)
-          hm_ntt_round<LOGR, STRIDED, RS::nb[I], RS::k[I], INV>(t, lds.data(), twl, s0, prefix0, q);
-    };
-    if (!INV) { rnd(std::integral_constant<int, 0>{}); rnd(std::integral_constant<int, 1>{}); rnd(std::integral_constant<int, 2>{}); }
-    else      { rnd(std::integral_constant<int, 2>{}); rnd(std::integral_constant<int, 1>{}); rnd(std::integral_constant<int, 0>{}); }
-    for (int t = 0; t < HM_THREADS; ++t) hm_tile_store<LOGR, STRIDED, MODE>(t, lds.data(), dst, tile, q, sc);
+    for (int t = 0; t < HM_THREADS; ++t) hm_ntt_phase<LOGR, STRIDED, INV, MODE, 0>(st[t], t, lds.data(), src, dst, tile, twl, s0, prefix0, q, sc, ep);
+    for (int t = 0; t < HM_THREADS; ++t) hm_ntt_phase<LOGR, STRIDED, INV, MODE, 1>(st[t], t, lds.data(), src, dst, tile, twl, s0, prefix0, q, sc, ep);
+    for (int t = 0; t < HM_THREADS; ++t) hm_ntt_phase<LOGR, STRIDED, INV, MODE, 2>(st[t], t, lds.data(), src, dst, tile, twl, s0, prefix0, q, sc, ep);
+    if (HmRounds<LOGR>::n == 3)
+      for (int t = 0; t < HM_THREADS; ++t) hm_ntt_phase<LOGR, STRIDED, INV, MODE, 3>(st[t], t, lds.data(), src, dst, tile, twl, s0, prefix0, q, sc, ep);
   }
 }
 
@@ -47,6 +43,19 @@ static void run_ntt(const Emu &e, uint32_t mod, const uint64_t *in, uint64_t *ou
   } else {
     run_pass<8, false, true, 0>(e, mod, in, out, sc);
     run_pass<LOG1, true, true, 2>(e, mod, out, out, sc);
+  }
+}
+
+template <int N_IN>
+static void emu_bconv_n(Emu &e, HmBconvProb &p, const std::vector<uint64_t> &tb) {
+  std::vector<uint64_t> tab(HM_BCONV_MAX_IN * HM_BCONV_CHUNK);
+  for (uint32_t t0 = 0; t0 < p.n_out; t0 += HM_BCONV_CHUNK) {
+    uint32_t t1 = t0 + HM_BCONV_CHUNK < p.n_out ? t0 + HM_BCONV_CHUNK : p.n_out;
+    for (uint32_t el = 0; el < N_IN * HM_BCONV_CHUNK; ++el) {
+      uint32_t i = el / HM_BCONV_CHUNK, t = t0 + el % HM_BCONV_CHUNK;
+      tab[el] = t < t1 ? hm_bconv_pack(tb[i * p.n_out + t]) : 0;
+    }
+    for (uint32_t x = 0; x < e.P.N; ++x) hm_bconv_thread<N_IN>(p, e.P.modc.data(), e.P.logN, tab.data(), x, t0, t1);
   }
 }
 
@@ -82,6 +91,30 @@ int emu_ntt(void *h, uint32_t mod, const uint64_t *in, uint64_t *out, int invers
   return 0;
 }
 
+// fused forward transform: out = (minuend - NTT(in)) * k [+ addend]
+int emu_ntt_sub_scale(void *h, uint32_t mod, const uint64_t *in, const uint64_t *minuend, const uint64_t *addend, uint64_t *out,
+                      uint64_t k) {
+  Emu &e = *(Emu *)h;
+  const uint64_t q = e.P.mod[mod];
+  HmTw sc = {k, hm::shoup(k, q)};
+  HmEpi ep = {minuend, addend};
+  switch (e.P.logN - 8) {
+  case 5: run_pass<5, true, false, 0>(e, mod, in, out, sc); break;
+  case 6: run_pass<6, true, false, 0>(e, mod, in, out, sc); break;
+  case 7: run_pass<7, true, false, 0>(e, mod, in, out, sc); break;
+  case 8: run_pass<8, true, false, 0>(e, mod, in, out, sc); break;
+  case 9: run_pass<9, true, false, 0>(e, mod, in, out, sc); break;
+  default: return 1;
+  }
+  run_pass<8, false, false, 3>(e, mod, out, out, sc, ep);
+  return 0;
+}
+void emu_tensor(void *h, uint32_t mod, const uint64_t *a, const uint64_t *b, const uint64_t *c, const uint64_t *d, uint64_t *o0,
+                uint64_t *o1, uint64_t *o2) {
+  Emu &e = *(Emu *)h;
+  for (uint32_t x = 0; x < e.P.N; ++x) hm_tensor_one(a[x], b[x], c[x], d[x], e.P.modc[mod], o0[x], o1[x], o2[x]);
+}
+
 void emu_ewe(void *h, int op, uint32_t mod, const uint64_t *a, const uint64_t *b, const uint64_t *c,
              const uint64_t *d, uint64_t kk, uint64_t *out) {
   Emu &e = *(Emu *)h;
@@ -109,16 +142,16 @@ void emu_bconv(void *h, const uint32_t *in_ids, uint32_t n_in, const uint32_t *o
   Emu &e = *(Emu *)h;
   std::vector<uint64_t> qh(n_in), tb((size_t)n_in * n_out);
   e.P.bconv_consts(in_ids, n_in, out_ids, n_out, qh.data(), tb.data());
-  HmBconvArgs a;
-  a.in = in; a.out = out; a.table = tb.data(); a.mods = e.P.modc.data();
-  a.logN = e.P.logN; a.n_in = n_in; a.n_out = n_out; a.out_per_block = (n_out + 3) / 4;
-  for (uint32_t i = 0; i < n_in; ++i) a.in_limb[i] = (uint16_t)i;
-  for (uint32_t t = 0; t < n_out; ++t) { a.out_limb[t] = (uint16_t)t; a.out_mod[t] = (uint16_t)out_ids[t]; }
-  for (uint32_t by = 0; by * a.out_per_block < n_out; ++by)
-    for (uint32_t x = 0; x < e.P.N; ++x) {
-      uint32_t t0 = by * a.out_per_block, t1 = t0 + a.out_per_block < n_out ? t0 + a.out_per_block : n_out;
-      hm_bconv_thread(a, x, t0, t1);
-    }
+  HmBconvProb p;
+  p.in = in; p.out = out; p.table = tb.data(); p.n_in = n_in; p.n_out = n_out;
+  for (uint32_t i = 0; i < n_in; ++i) p.in_limb[i] = (uint16_t)i;
+  for (uint32_t t = 0; t < n_out; ++t) { p.out_limb[t] = (uint16_t)t; p.out_mod[t] = (uint16_t)out_ids[t]; }
+  switch (n_in) {
+#define HM_CASE(n) case n: emu_bconv_n<n>(e, p, tb); break;
+    HM_CASE(1) HM_CASE(2) HM_CASE(3) HM_CASE(4) HM_CASE(5) HM_CASE(6) HM_CASE(7) HM_CASE(8)
+    HM_CASE(9) HM_CASE(10) HM_CASE(11) HM_CASE(12) HM_CASE(13) HM_CASE(14) HM_CASE(15) HM_CASE(16)
+#undef HM_CASE
+  }
 }
 void emu_bconv_consts(void *h, const uint32_t *in_ids, uint32_t n_in, const uint32_t *out_ids, uint32_t n_out,
                       uint64_t *qh, uint64_t *tb) {

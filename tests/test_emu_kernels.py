@@ -26,6 +26,8 @@ def emu():
     L.emu_psi.restype = C.c_uint64
     L.emu_psi.argtypes = [C.c_void_p, C.c_uint32]
     L.emu_ntt.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_int]
+    L.emu_ntt_sub_scale.argtypes = [C.c_void_p, C.c_uint32] + [C.c_void_p] * 4 + [C.c_uint64]
+    L.emu_tensor.argtypes = [C.c_void_p, C.c_uint32] + [C.c_void_p] * 7
     L.emu_ewe.argtypes = [C.c_void_p, C.c_int, C.c_uint32] + [C.c_void_p] * 4 + [C.c_uint64, C.c_void_p]
     L.emu_bconv.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
     L.emu_bconv_consts.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
@@ -62,6 +64,35 @@ def test_emu_params_and_ntt(emu, logN):
             buf = out.copy()
             emu.emu_ntt(h, m, p(buf), p(buf), 1, k, 1)
             assert np.array_equal(buf, o.ewe(5, [m], x[None], k=[k])[0])
+    finally:
+        emu.emu_destroy(h)
+
+
+@pytest.mark.parametrize("logN", [13, 15, 16])
+def test_emu_fused_ntt_sub_scale_and_tensor(emu, logN):
+    L, K = 3, 1
+    o = Oracle(logN, L, K)
+    h = emu.emu_create(logN, L, K)
+    try:
+        for m in (0, L):
+            q = o.moduli[m]
+            x, mn, ad, d = (o.fill_uniform([m], s)[0] for s in (1, 2, 3, 4))
+            x[:3] = [q - 1, 0, q - 1]
+            mn[:3] = [0, q - 1, q - 1]
+            ad[:3] = [q - 1, q - 1, 0]
+            k = q - 5
+            ntt = o.ntt([m], x[None])
+            exp = o.ewe(6, [m], mn[None], None, ntt, k=[k])
+            out = np.empty_like(x)
+            assert emu.emu_ntt_sub_scale(h, m, p(x), p(mn), None, p(out), k) == 0
+            assert np.array_equal(out, exp[0])
+            assert emu.emu_ntt_sub_scale(h, m, p(x), p(mn), p(ad), p(out), k) == 0
+            assert np.array_equal(out, o.ewe(3, [m], exp, None, ad[None])[0])
+            o0, o1, o2 = (np.empty_like(x) for _ in range(3))
+            emu.emu_tensor(h, m, p(x), p(mn), p(ad), p(d), p(o0), p(o1), p(o2))
+            assert np.array_equal(o0, o.ewe(0, [m], x[None], mn[None])[0])
+            assert np.array_equal(o1, o.ewe(1, [m], x[None], d[None], ad[None], mn[None])[0])
+            assert np.array_equal(o2, o.ewe(0, [m], ad[None], d[None])[0])
     finally:
         emu.emu_destroy(h)
 

@@ -137,3 +137,31 @@ def test_errors_are_loud(env):
     with pytest.raises(hip.HmError):
         ctx.ewe(hip.OP_MUL_CONST, d, [0, 1], a=d)     # missing constants
     d.free()
+
+
+def test_fused_ntt_sub_scale_and_tensor(env):
+    """fused forward NTT epilogue out = (minuend - NTT(in)) * k [+ addend] and the one-pass tensor product"""
+    ctx, o, _ = env
+    ids = [0, 0, 3, o.L, o.L, 5, 2]            # pairs of equal moduli + singles: exercises the XCD pairing
+    n = len(ids)
+    x, mn, ad, dd = (o.fill_uniform(ids, s) for s in (1, 2, 3, 4))
+    for r, m in enumerate(ids):
+        q = o.moduli[m]
+        x[r, :3] = [q - 1, 0, q - 1]
+        mn[r, :3] = [0, q - 1, q - 1]
+        ad[r, :3] = [q - 1, q - 1, 0]
+    k = [o.moduli[m] - 3 - r for r, m in enumerate(ids)]
+    dx, dmn, dad, ddd = (ctx.from_host(v) for v in (x, mn, ad, dd))
+    out = ctx.alloc(n)
+    exp = o.ewe(6, ids, mn, None, o.ntt(ids, x), k=k)
+    ctx.ntt_sub_scale(dx, dmn, out, ids, k)
+    assert np.array_equal(out.download(), exp)
+    ctx.ntt_sub_scale(dx, dmn, out, ids, k, addend=dad)
+    assert np.array_equal(out.download(), o.ewe(3, ids, exp, None, ad))
+    o0, o1, o2 = ctx.alloc(n), ctx.alloc(n), ctx.alloc(n)
+    ctx.tensor(dx, dmn, dad, ddd, o0, o1, o2, ids)
+    assert np.array_equal(o0.download(), o.ewe(0, ids, x, mn))
+    assert np.array_equal(o1.download(), o.ewe(1, ids, x, dd, ad, mn))
+    assert np.array_equal(o2.download(), o.ewe(0, ids, ad, dd))
+    for b_ in (dx, dmn, dad, ddd, out, o0, o1, o2):
+        b_.free()

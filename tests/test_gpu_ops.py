@@ -41,7 +41,8 @@ def check_keyswitch_buffers(op, dd, ell, K, beta, fused):
     for k in range(2):
         assert np.array_equal(op.read(f"InnerProduceOut_Key{k}"), dd["ip"][k]), f"InnerProduceOut_Key{k}"
         assert np.array_equal(op.read(f"ModdownBConvOut_Key{k}"), dd["moddown_bconv"][k])
-        assert np.array_equal(op.read(f"NTTOut_ModDown_Key({k})"), dd["moddown_ntt"][k])
+        if not fused:   # fused: the ModDown NTT output only exists inside the fused transform's epilogue
+            assert np.array_equal(op.read(f"NTTOut_ModDown_Key({k})"), dd["moddown_ntt"][k])
 
 
 CASES = [("config_4_N15.cfg", 15, 16, 10, 4), ("config_4_N15.cfg", 15, 8, 8, 8), ("config_4_N15.cfg", 15, 6, 5, 2),
