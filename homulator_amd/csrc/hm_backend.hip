@@ -1,6 +1,8 @@
 // hm_backend.hip — HIP kernels (gfx950) + context + the C ABI of include/homulator_hip.h.
 // There is no CPU fallback in this library: every compute entry point launches a HIP kernel.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -153,6 +155,23 @@ __global__ void __launch_bounds__(HM_BCONV_THREADS) k_bconv(HmBconvArgs a) {
   }
 }
 
+// strided chunk copy used to pack / unpack the exchange buffers: chunk c copies `len` words
+#define HM_MAX_CHUNKS 512
+struct HmChunkArgs {
+  const uint64_t *src;
+  uint64_t *dst;
+  uint32_t len, n_chunks;
+  uint32_t src_off[HM_MAX_CHUNKS / 2], dst_off[HM_MAX_CHUNKS / 2];  // in units of `len` words... see launch
+};
+__global__ void __launch_bounds__(256) k_chunk_copy(HmChunkArgs a) {
+  const uint32_t per = a.len / 512;  // blocks per chunk (256 threads x 2 words)
+  const uint32_t chunk = blockIdx.x / per, part = blockIdx.x % per;
+  if (chunk >= a.n_chunks) return;
+  const size_t x = (size_t)part * 512 + 2 * threadIdx.x;
+  const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(a.src + (size_t)a.src_off[chunk] * a.len + x);
+  *reinterpret_cast<ulonglong2 *>(a.dst + (size_t)a.dst_off[chunk] * a.len + x) = v;
+}
+
 struct HmAutoArgs {
   const uint64_t *in;
   uint64_t *out;
@@ -196,7 +215,41 @@ struct hm_ctx {
   HmMod *d_mods = nullptr;
   std::map<std::vector<uint32_t>, uint64_t *> bconv_tables;  // key: n_in, in_ids..., out_ids...
   std::string err;
+  // multi-GPU
+  int rank = 0, world = 1;
+  ncclComm_t comm = nullptr;
+  hm_exchange_fn ext_fn = nullptr;
+  void *ext_user = nullptr;
+  uint64_t *stage_send = nullptr, *stage_recv = nullptr;
+  size_t stage_words = 0;
 };
+
+// RCCL is loaded lazily so that the library itself never depends on it being present
+struct RcclApi {
+  void *h = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+static RcclApi g_rccl;
+static const char *rccl_load() {
+  if (g_rccl.h) return nullptr;
+  void *h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) return "librccl.so not found";
+#define HM_SYM(field, name) g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(h, name)); if (!g_rccl.field) return "RCCL symbol missing: " name;
+  HM_SYM(GetUniqueId, "ncclGetUniqueId") HM_SYM(CommInitRank, "ncclCommInitRank") HM_SYM(CommDestroy, "ncclCommDestroy")
+  HM_SYM(Send, "ncclSend") HM_SYM(Recv, "ncclRecv") HM_SYM(GroupStart, "ncclGroupStart") HM_SYM(GroupEnd, "ncclGroupEnd")
+  HM_SYM(GetErrorString, "ncclGetErrorString")
+#undef HM_SYM
+  g_rccl.h = h;
+  return nullptr;
+}
 
 static thread_local std::string g_create_err;
 
@@ -260,6 +313,9 @@ extern "C" void hm_destroy(hm_ctx *c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   for (auto &kv : c->bconv_tables) (void)hipFree(kv.second);
+  if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
+  (void)hipFree(c->stage_send);
+  (void)hipFree(c->stage_recv);
   (void)hipFree(c->d_tw_fwd);
   (void)hipFree(c->d_tw_inv);
   (void)hipFree(c->d_mods);
@@ -574,11 +630,14 @@ extern "C" hm_status hm_bconv_batch(hm_ctx *c, const hm_bconv_desc *descs, uint3
   for (uint32_t base = 0; base < n_desc; base += HM_BCONV_MAX_PROB) {
     const uint32_t cnt = std::min<uint32_t>(HM_BCONV_MAX_PROB, n_desc - base);
     HmBconvArgs a;
-    a.mods = c->d_mods; a.logN = c->P.logN; a.n_prob = cnt;
+    a.mods = c->d_mods; a.n_prob = cnt;
+    a.logN = descs[base].log_len ? descs[base].log_len : c->P.logN;
+    if (a.logN < 8 || a.logN > c->P.logN) return fail(c, HM_ERR_ARG, "hm_bconv: log_len %u", a.logN);
     uint32_t max_out = 0;
     for (uint32_t pi = 0; pi < cnt; ++pi) {
       const hm_bconv_desc &d = descs[base + pi];
       if (!d.in || !d.out) return fail(c, HM_ERR_ARG, "hm_bconv: null buffer");
+      if ((d.log_len ? d.log_len : c->P.logN) != a.logN) return fail(c, HM_ERR_ARG, "hm_bconv_batch: mixed log_len");
       if (d.n_in == 0 || d.n_in > HM_BCONV_MAX_IN) return fail(c, HM_ERR_ARG, "hm_bconv: n_in %u not in [1,%d]", d.n_in, HM_BCONV_MAX_IN);
       if (d.n_out == 0 || d.n_out > HM_BCONV_MAX_OUT) return fail(c, HM_ERR_ARG, "hm_bconv: n_out %u not in [1,%d]", d.n_out, HM_BCONV_MAX_OUT);
       hm_status st;
@@ -612,7 +671,7 @@ extern "C" hm_status hm_bconv_batch(hm_ctx *c, const hm_bconv_desc *descs, uint3
       }
       max_out = std::max(max_out, d.n_out);
     }
-    dim3 grid(c->P.N / HM_BCONV_THREADS, (max_out + HM_BCONV_CHUNK - 1) / HM_BCONV_CHUNK, cnt);
+    dim3 grid((1u << a.logN) / HM_BCONV_THREADS, (max_out + HM_BCONV_CHUNK - 1) / HM_BCONV_CHUNK, cnt);
     hipLaunchKernelGGL(k_bconv, grid, dim3(HM_BCONV_THREADS), 0, c->stream, a);
     HM_HIP(c, hipGetLastError());
   }
@@ -622,8 +681,222 @@ extern "C" hm_status hm_bconv_batch(hm_ctx *c, const hm_bconv_desc *descs, uint3
 extern "C" hm_status hm_bconv(hm_ctx *c, const uint64_t *in, const uint32_t *in_limbs, const uint32_t *in_ids,
                               uint32_t n_in, uint64_t *out, const uint32_t *out_limbs, const uint32_t *out_ids,
                               uint32_t n_out) {
-  hm_bconv_desc d = {in, in_limbs, in_ids, n_in, out, out_limbs, out_ids, n_out};
+  hm_bconv_desc d = {in, in_limbs, in_ids, n_in, out, out_limbs, out_ids, n_out, 0};
   return hm_bconv_batch(c, &d, 1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// multi-GPU exchange
+// ------------------------------------------------------------------------------------------------
+extern "C" hm_status hm_comm_unique_id(void *out128) {
+  if (!out128) return HM_ERR_ARG;
+  if (const char *e = rccl_load()) return fail(nullptr, HM_ERR_COMM, "hm_comm_unique_id: %s", e);
+  ncclUniqueId id;
+  ncclResult_t r = g_rccl.GetUniqueId(&id);
+  if (r != ncclSuccess) return fail(nullptr, HM_ERR_COMM, "ncclGetUniqueId: %s", g_rccl.GetErrorString(r));
+  memcpy(out128, &id, sizeof id);
+  return HM_OK;
+}
+extern "C" hm_status hm_comm_init_rccl(hm_ctx *c, int rank, int world, const void *id128) {
+  if (!c || !id128 || world < 1 || rank < 0 || rank >= world) return HM_ERR_ARG;
+  if (c->P.N % ((uint32_t)world * 512u)) return fail(c, HM_ERR_ARG, "hm_comm_init: world %d does not divide N / 512", world);
+  if (const char *e = rccl_load()) return fail(c, HM_ERR_COMM, "hm_comm_init_rccl: %s", e);
+  HM_HIP(c, hipSetDevice(c->device));
+  ncclUniqueId id;
+  memcpy(&id, id128, sizeof id);
+  ncclResult_t r = g_rccl.CommInitRank(&c->comm, world, id, rank);
+  if (r != ncclSuccess) return fail(c, HM_ERR_COMM, "ncclCommInitRank: %s", g_rccl.GetErrorString(r));
+  c->rank = rank; c->world = world; c->ext_fn = nullptr;
+  return HM_OK;
+}
+extern "C" hm_status hm_comm_init_external(hm_ctx *c, int rank, int world, hm_exchange_fn fn, void *user) {
+  if (!c || !fn || world < 1 || rank < 0 || rank >= world) return HM_ERR_ARG;
+  if (c->P.N % ((uint32_t)world * 512u)) return fail(c, HM_ERR_ARG, "hm_comm_init: world %d does not divide N / 512", world);
+  c->rank = rank; c->world = world; c->ext_fn = fn; c->ext_user = user;
+  return HM_OK;
+}
+extern "C" hm_status hm_comm_info(const hm_ctx *c, int *rank, int *world) {
+  if (!c) return HM_ERR_ARG;
+  if (rank) *rank = c->rank;
+  if (world) *world = c->world;
+  return HM_OK;
+}
+extern "C" hm_status hm_slice_rows(const uint32_t *owners, uint32_t n, uint32_t world, uint32_t *rows) {
+  if (!owners || !rows || world == 0) return HM_ERR_ARG;
+  std::vector<uint32_t> count(world + 1, 0);
+  for (uint32_t i = 0; i < n; ++i) {
+    if (owners[i] >= world) return HM_ERR_ARG;
+    count[owners[i] + 1]++;
+  }
+  for (uint32_t r = 0; r < world; ++r) count[r + 1] += count[r];  // first row of each owner
+  std::vector<uint32_t> next(count.begin(), count.end() - 1);
+  for (uint32_t i = 0; i < n; ++i) rows[i] = next[owners[i]]++;
+  return HM_OK;
+}
+
+static hm_status ensure_stage(hm_ctx *c, size_t words) {
+  if (c->stage_words >= words) return HM_OK;
+  HM_HIP(c, hipStreamSynchronize(c->stream));
+  (void)hipFree(c->stage_send);
+  (void)hipFree(c->stage_recv);
+  c->stage_send = c->stage_recv = nullptr;
+  HM_HIP(c, hipMalloc(&c->stage_send, words * 8));
+  HM_HIP(c, hipMalloc(&c->stage_recv, words * 8));
+  c->stage_words = words;
+  return HM_OK;
+}
+static hm_status chunk_copy(hm_ctx *c, const uint64_t *src, uint64_t *dst, uint32_t len, const std::vector<uint32_t> &so,
+                            const std::vector<uint32_t> &dof) {
+  for (size_t base = 0; base < so.size(); base += HM_MAX_CHUNKS / 2) {
+    const uint32_t cnt = (uint32_t)std::min<size_t>(HM_MAX_CHUNKS / 2, so.size() - base);
+    HmChunkArgs a;
+    a.src = src; a.dst = dst; a.len = len; a.n_chunks = cnt;
+    for (uint32_t i = 0; i < cnt; ++i) { a.src_off[i] = so[base + i]; a.dst_off[i] = dof[base + i]; }
+    hipLaunchKernelGGL(k_chunk_copy, dim3(cnt * (len / 512)), dim3(256), 0, c->stream, a);
+    HM_HIP(c, hipGetLastError());
+  }
+  return HM_OK;
+}
+// the exchange itself: per peer p, send_bytes[p] bytes at send + send_off[p] go to rank p and recv_bytes[p] bytes
+// from rank p land at recv + recv_off[p].  Nothing is sent to self (callers place their own part directly).
+static hm_status all_to_all(hm_ctx *c, const uint64_t *send, std::vector<size_t> send_off, std::vector<size_t> send_bytes,
+                            uint64_t *recv, std::vector<size_t> recv_off, std::vector<size_t> recv_bytes) {
+  if (c->world == 1) return HM_OK;
+  send_bytes[c->rank] = recv_bytes[c->rank] = 0;
+  if (c->ext_fn) {
+    HM_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->ext_fn(c->ext_user, send, send_off.data(), send_bytes.data(), recv, recv_off.data(), recv_bytes.data()))
+      return fail(c, HM_ERR_COMM, "external exchange failed");
+    return HM_OK;
+  }
+  if (!c->comm) return fail(c, HM_ERR_COMM, "no communicator: call hm_comm_init_rccl first");
+  ncclResult_t r = g_rccl.GroupStart();
+  for (int p = 0; p < c->world && r == ncclSuccess; ++p) {
+    if (send_bytes[p]) r = g_rccl.Send((const char *)send + send_off[p], send_bytes[p] / 8, ncclUint64, p, c->comm, c->stream);
+    if (recv_bytes[p] && r == ncclSuccess) r = g_rccl.Recv((char *)recv + recv_off[p], recv_bytes[p] / 8, ncclUint64, p, c->comm, c->stream);
+  }
+  ncclResult_t e = g_rccl.GroupEnd();
+  if (r == ncclSuccess) r = e;
+  if (r != ncclSuccess) return fail(c, HM_ERR_COMM, "RCCL exchange: %s", g_rccl.GetErrorString(r));
+  return HM_OK;
+}
+
+extern "C" hm_status hm_limbs_to_slices(hm_ctx *c, const uint64_t *buf, const uint32_t *limbs, const uint32_t *owners,
+                                        uint32_t n, uint64_t *slices) {
+  if (!c) return HM_ERR_ARG;
+  if (!buf || !limbs || !owners || !slices) return fail(c, HM_ERR_ARG, "hm_limbs_to_slices: null argument");
+  const uint32_t W = (uint32_t)c->world, me = (uint32_t)c->rank, len = c->P.N / W;
+  std::vector<uint32_t> rows(n);
+  if (hm_slice_rows(owners, n, W, rows.data())) return fail(c, HM_ERR_ARG, "hm_limbs_to_slices: owner out of range");
+  HM_HIP(c, hipSetDevice(c->device));
+  std::vector<uint32_t> cnt(W, 0);
+  for (uint32_t i = 0; i < n; ++i) cnt[owners[i]]++;
+  const uint32_t mine = cnt[me];
+  // send block for rank p: my limbs' slice p, in list order -> [mine][len]; laid out rank after rank (self skipped)
+  hm_status st = ensure_stage(c, (size_t)std::max<uint32_t>(mine, 1) * W * len);
+  if (st) return st;
+  std::vector<size_t> send_off(W, 0), send_bytes(W, 0), recv_off(W, 0), recv_bytes(W, 0);
+  size_t so_acc = 0;
+  for (uint32_t p = 0; p < W; ++p) {
+    send_off[p] = so_acc;
+    send_bytes[p] = p == me ? 0 : (size_t)mine * len * 8;
+    so_acc += send_bytes[p];
+  }
+  // receive straight into the slice rows of each source (rows of one owner are contiguous)
+  uint32_t first = 0;
+  for (uint32_t p = 0; p < W; ++p) { recv_off[p] = (size_t)first * len * 8; recv_bytes[p] = (size_t)cnt[p] * len * 8; first += cnt[p]; }
+  std::vector<uint32_t> so, dof, so_self, do_self;
+  // chunk units are `len` words: limb l slice p starts at (l * W + p) chunks of buf
+  for (uint32_t p = 0; p < W; ++p) {
+    uint32_t j = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+      if (owners[i] != me) continue;
+      if (p == me) { so_self.push_back(limbs[i] * W + p); do_self.push_back(rows[i]); }
+      else { so.push_back(limbs[i] * W + p); dof.push_back((uint32_t)(send_off[p] / 8 / len) + j); }
+      ++j;
+    }
+  }
+  if ((st = chunk_copy(c, buf, slices, len, so_self, do_self))) return st;
+  if ((st = chunk_copy(c, buf, c->stage_send, len, so, dof))) return st;
+  // a rank's own rows must not be overwritten by the receive: recv_off[me] block is skipped by all_to_all
+  return all_to_all(c, c->stage_send, send_off, send_bytes, slices, recv_off, recv_bytes);
+}
+
+extern "C" hm_status hm_slices_to_limbs(hm_ctx *c, const uint64_t *slices, uint64_t *buf, const uint32_t *limbs,
+                                        const uint32_t *owners, uint32_t n) {
+  if (!c) return HM_ERR_ARG;
+  if (!buf || !limbs || !owners || !slices) return fail(c, HM_ERR_ARG, "hm_slices_to_limbs: null argument");
+  const uint32_t W = (uint32_t)c->world, me = (uint32_t)c->rank, len = c->P.N / W;
+  std::vector<uint32_t> rows(n);
+  if (hm_slice_rows(owners, n, W, rows.data())) return fail(c, HM_ERR_ARG, "hm_slices_to_limbs: owner out of range");
+  HM_HIP(c, hipSetDevice(c->device));
+  std::vector<uint32_t> cnt(W, 0);
+  for (uint32_t i = 0; i < n; ++i) cnt[owners[i]]++;
+  const uint32_t mine = cnt[me];
+  hm_status st = ensure_stage(c, (size_t)std::max<uint32_t>(mine, 1) * W * len);
+  if (st) return st;
+  // send: the rows of owner p (contiguous in `slices`) go to rank p as they are
+  std::vector<size_t> send_off(W, 0), send_bytes(W, 0), recv_off(W, 0), recv_bytes(W, 0);
+  uint32_t first = 0;
+  for (uint32_t p = 0; p < W; ++p) { send_off[p] = (size_t)first * len * 8; send_bytes[p] = (size_t)cnt[p] * len * 8; first += cnt[p]; }
+  // receive: from rank s the slice s of each of my limbs, [mine][len], into the staging buffer
+  size_t ro_acc = 0;
+  for (uint32_t p = 0; p < W; ++p) {
+    recv_off[p] = ro_acc;
+    recv_bytes[p] = p == me ? 0 : (size_t)mine * len * 8;
+    ro_acc += recv_bytes[p];
+  }
+  if ((st = all_to_all(c, slices, send_off, send_bytes, c->stage_recv, recv_off, recv_bytes))) return st;
+  std::vector<uint32_t> so, dof, so_self, do_self;
+  for (uint32_t p = 0; p < W; ++p) {
+    uint32_t j = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+      if (owners[i] != me) continue;
+      if (p == me) { so_self.push_back(rows[i]); do_self.push_back(limbs[i] * W + p); }
+      else { so.push_back((uint32_t)(recv_off[p] / 8 / len) + j); dof.push_back(limbs[i] * W + p); }
+      ++j;
+    }
+  }
+  if ((st = chunk_copy(c, slices, buf, len, so_self, do_self))) return st;
+  return chunk_copy(c, c->stage_recv, buf, len, so, dof);
+}
+
+extern "C" hm_status hm_replicate_limbs(hm_ctx *c, uint64_t *buf, const uint32_t *limbs, const uint32_t *owners, uint32_t n) {
+  if (!c) return HM_ERR_ARG;
+  if (!buf || !limbs || !owners) return fail(c, HM_ERR_ARG, "hm_replicate_limbs: null argument");
+  const uint32_t W = (uint32_t)c->world, me = (uint32_t)c->rank, N = c->P.N;
+  if (W == 1) return HM_OK;
+  HM_HIP(c, hipSetDevice(c->device));
+  std::vector<uint32_t> cnt(W, 0);
+  for (uint32_t i = 0; i < n; ++i) {
+    if (owners[i] >= W) return fail(c, HM_ERR_ARG, "hm_replicate_limbs: owner out of range");
+    cnt[owners[i]]++;
+  }
+  hm_status st = ensure_stage(c, (size_t)std::max<uint32_t>(n, 1) * N);
+  if (st) return st;
+  // send: my limbs packed [mine][N] (the same block to every peer); receive: block of source s = its limbs, list order
+  std::vector<size_t> send_off(W, 0), send_bytes(W, 0), recv_off(W, 0), recv_bytes(W, 0);
+  size_t acc = 0;
+  for (uint32_t p = 0; p < W; ++p) {
+    send_bytes[p] = p == me ? 0 : (size_t)cnt[me] * N * 8;
+    recv_off[p] = acc;
+    recv_bytes[p] = p == me ? 0 : (size_t)cnt[p] * N * 8;
+    acc += recv_bytes[p];
+  }
+  std::vector<uint32_t> so, dof;
+  uint32_t j = 0;
+  for (uint32_t i = 0; i < n; ++i)
+    if (owners[i] == me) { so.push_back(limbs[i]); dof.push_back(j++); }
+  if ((st = chunk_copy(c, buf, c->stage_send, N, so, dof))) return st;
+  if ((st = all_to_all(c, c->stage_send, send_off, send_bytes, c->stage_recv, recv_off, recv_bytes))) return st;
+  so.clear(); dof.clear();
+  for (uint32_t p = 0; p < W; ++p) {
+    if (p == me) continue;
+    uint32_t k = 0;
+    for (uint32_t i = 0; i < n; ++i)
+      if (owners[i] == p) { so.push_back((uint32_t)(recv_off[p] / 8 / N) + k++); dof.push_back(limbs[i]); }
+  }
+  return chunk_copy(c, c->stage_recv, buf, N, so, dof);
 }
 
 extern "C" hm_status hm_fill_uniform(hm_ctx *c, uint64_t *out, const uint32_t *out_limbs, const uint32_t *mod_ids,

@@ -1,0 +1,86 @@
+"""Multi-GPU plumbing: one process per GPU, torch.distributed for rendezvous.
+
+ * RCCL over xGMI (the product path): rank 0 draws the 128-byte RCCL unique id, torch.distributed broadcasts it, and
+   every rank hands it to the HIP library, which then issues the ncclSend/ncclRecv groups itself on its own stream.
+ * GlooTransport (tests): the same exchange carried by torch.distributed P2P ops on host copies, so that several
+   ranks can share ONE GPU (RCCL refuses two ranks per device) or run without any GPU (memcpy injected).
+"""
+import ctypes as C
+
+import torch
+import torch.distributed as dist
+
+from . import host
+
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.c_void_p,
+                          C.POINTER(C.c_size_t), C.POINTER(C.c_size_t))
+
+
+def init_rccl(op, group=None):
+    """collective over `group`: distribute rank 0's RCCL unique id and create the communicator inside the HIP library"""
+    obj = [host.rccl_unique_id() if dist.get_rank(group) == 0 else None]
+    dist.broadcast_object_list(obj, src=0, group=group)
+    op.comm_init_rccl(obj[0])
+
+
+def _hip_memcpy():
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipMemcpy.restype = C.c_int
+
+    def d2h(dst_host, src_dev, n):
+        if hip.hipMemcpy(dst_host, src_dev, n, 2):
+            raise RuntimeError("hipMemcpy D2H failed")
+
+    def h2d(dst_dev, src_host, n):
+        if hip.hipMemcpy(dst_dev, src_host, n, 1):
+            raise RuntimeError("hipMemcpy H2D failed")
+    return d2h, h2d
+
+
+def host_memcpy():
+    """for CPU-only tests: 'device' pointers are host pointers"""
+    def cp(dst, src, n):
+        C.memmove(dst, src, n)
+    return cp, cp
+
+
+class GlooTransport:
+    """hm_exchange_fn implemented with torch.distributed P2P ops on host staging tensors."""
+
+    def __init__(self, group=None, memcpy=None):
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.d2h, self.h2d = memcpy if memcpy is not None else _hip_memcpy()
+        self.calls = 0
+        self.bytes_sent = 0
+        self.cfunc = EXCHANGE_FN(self._exchange)
+
+    def _exchange(self, user, send_dev, send_off, send_bytes, recv_dev, recv_off, recv_bytes):
+        try:
+            ops, recvs = [], []
+            for p in range(self.world):
+                if p == self.rank:
+                    continue
+                nb = send_bytes[p]
+                if nb:
+                    t = torch.empty(nb, dtype=torch.uint8)
+                    self.d2h(t.data_ptr(), send_dev + send_off[p], nb)
+                    ops.append(dist.P2POp(dist.isend, t, p, self.group))
+                    self.bytes_sent += nb
+                nb = recv_bytes[p]
+                if nb:
+                    r = torch.empty(nb, dtype=torch.uint8)
+                    ops.append(dist.P2POp(dist.irecv, r, p, self.group))
+                    recvs.append((r, recv_off[p], nb))
+            if ops:
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+            for r, off, nb in recvs:
+                self.h2d(recv_dev + off, r.data_ptr(), nb)
+            self.calls += 1
+            return 0
+        except Exception as e:  # never let an exception cross the C boundary
+            print("GlooTransport failed:", repr(e), flush=True)
+            return 1

@@ -14,7 +14,8 @@ OP_MUL, OP_MAC2, OP_MAC_ADD, OP_ADD, OP_SUB, OP_MUL_CONST, OP_SUB_SCALE, OP_COPY
 SYMBOLS = [
     "hm_create", "hm_destroy", "hm_last_error", "hm_version", "hm_get_modulus", "hm_get_psi", "hm_malloc", "hm_free",
     "hm_memcpy_h2d", "hm_memcpy_d2h", "hm_memcpy_d2d", "hm_sync", "hm_stream", "hm_ntt", "hm_ntt_sub_scale", "hm_tensor", "hm_automorph", "hm_ewe",
-    "hm_bconv", "hm_bconv_batch", "hm_bconv_consts", "hm_fill_uniform", "hm_timer_start", "hm_timer_stop",
+    "hm_bconv", "hm_bconv_batch", "hm_bconv_consts", "hm_fill_uniform", "hm_timer_start", "hm_timer_stop", "hm_comm_unique_id", "hm_comm_init_rccl", "hm_comm_init_external",
+    "hm_comm_info", "hm_slice_rows", "hm_limbs_to_slices", "hm_slices_to_limbs", "hm_replicate_limbs",
 ]
 
 

@@ -37,6 +37,10 @@ def load():
         L.hh_op_buffer_names.argtypes = [vp, C.c_char_p, u32]
         L.hh_op_N.restype = u32
         L.hh_op_N.argtypes = [vp]
+        L.hh_op_plan.argtypes = [vp, C.c_char_p, u32]
+        L.hh_comm_unique_id.argtypes = [vp]
+        L.hh_op_comm_init_rccl.argtypes = [vp, vp]
+        L.hh_op_comm_init_external.argtypes = [vp, vp, vp]
         _lib = L
     return _lib
 
@@ -48,8 +52,12 @@ class HostError(RuntimeError):
 class Op:
     """One operation instance: `Op("config_4.cfg", "hmult", 45, 35, 15)` = `./Homulator.run config_4.cfg hmult 45 35 15`."""
 
-    def __init__(self, cfg, op, max_level, cur_level, alpha, backend=BACKEND_HIP, fuse=True, device=0, overrides=None, quiet=True):
+    def __init__(self, cfg, op, max_level, cur_level, alpha, backend=BACKEND_HIP, fuse=True, device=0, overrides=None, quiet=True,
+                 rank=0, world=1):
         self.L = load()
+        self.rank, self.world, self.cur_level = rank, world, cur_level
+        if world > 1:
+            overrides = dict(overrides or {}, world=world, rank=rank)
         if not os.path.isabs(cfg) and not os.path.exists(cfg):
             cfg = os.path.join(CONFIG_DIR, cfg)
         self.h = C.c_void_p()
@@ -109,9 +117,35 @@ class Op:
         self._ck(self.L.hh_op_buffer_names(self.h, buf, len(buf)))
         return [s for s in buf.value.decode().split("\n") if s]
 
+    def plan(self):
+        buf = C.create_string_buffer(1 << 20)
+        self._ck(self.L.hh_op_plan(self.h, buf, len(buf)))
+        return [s for s in buf.value.decode().split("\n") if s]
+
+    # ---- multi-GPU transports (one of them before the first execute when world > 1)
+    def comm_init_rccl(self, unique_id):
+        """unique_id: the 128 bytes of homulator_amd.host.rccl_unique_id() from rank 0, identical on every rank"""
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        self._ck(self.L.hh_op_comm_init_rccl(self.h, buf))
+
+    def comm_init_external(self, exchange_cfunc):
+        self._keep_cb = exchange_cfunc
+        self._ck(self.L.hh_op_comm_init_external(self.h, C.cast(exchange_cfunc, C.c_void_p), None))
+
+    def owned(self, n_limbs):
+        """limb indices of an n-limb buffer that live on this rank (limb e -> e % world)"""
+        return [e for e in range(n_limbs) if e % self.world == self.rank]
+
     def read(self, name):
         n = C.c_uint32()
         self._ck(self.L.hh_op_buffer_limbs(self.h, name.encode(), C.byref(n)))
         out = np.empty((n.value, self.N), dtype=np.uint64)
         self._ck(self.L.hh_op_read_buffer(self.h, name.encode(), out.ctypes.data_as(C.c_void_p)))
         return out
+
+
+def rccl_unique_id():
+    buf = C.create_string_buffer(128)
+    if load().hh_comm_unique_id(buf):
+        raise HostError(load().hh_last_error().decode())
+    return buf.raw

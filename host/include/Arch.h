@@ -38,7 +38,15 @@ public:
   ~Arch();
 
   // ---- build-specific setup (called by the Operation constructors)
-  void bindParams(uint32_t maxLevel, uint32_t alpha);  // creates the HIP context (N from the config)
+  void bindParams(uint32_t maxLevel, uint32_t curLevel, uint32_t alpha);  // creates the HIP context (N from the config)
+  // multi-GPU (config keys `world`, `rank`): limb-polys are sharded by modulus, q_i -> i % world and
+  // p_j -> (curLevel + j) % world, i.e. extended limb e -> e % world — upstream's `limb % cluster` placement
+  // (include/Driver.h:158,178).  One of the two transports must be set before prepare() when world > 1.
+  uint32_t owner(uint32_t modId) const { return modId < maxLevel_ ? modId % world_ : (curLevel_ + (modId - maxLevel_)) % world_; }
+  uint32_t rank() const { return rank_; }
+  uint32_t world() const { return world_; }
+  void commInitRccl(const void *uniqueId128);
+  void commInitExternal(void *fn, void *user);
   void registerLimbs(const std::vector<AddrType> &limbStarts);  // gives every limb-poly a place in HBM
   void addInputFill(const InputFill &f) { fills.push_back(f); }
   uint64_t modulus(uint32_t modId) const;
@@ -63,6 +71,7 @@ public:
   double timedRun(uint32_t iters);      // ns per iteration, device time
   bool readLimbs(const std::vector<AddrType> &addrs, uint64_t *host);  // download limbs (N words each)
   size_t launchCount() const { return launches.size(); }
+  std::string planText() const;  // one line per launch: kind, stage names, limb count, exchange lists (tests)
   unsigned long long algorithmicBytes() const { return algBytes; }
   Statistic *stats() { return stat; }
   uint32_t N() const { return n; }
@@ -73,6 +82,9 @@ private:
   Backend backendKind;
   bool fuse;
   uint32_t n = 0, logN = 0, clusterCount = 1;
+  uint32_t maxLevel_ = 0, curLevel_ = 0, world_ = 1, rank_ = 0;
+  bool commReady = false;
+  std::vector<void *> sliceBuffers;
   hm_ctx *ctx = nullptr;
   uint64_t *pool = nullptr;  // all limb-polys, [limb][N]
   std::map<AddrType, uint32_t> limbIndex;

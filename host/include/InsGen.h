@@ -24,7 +24,7 @@ public:
   INSGROUP GenNTT(uint32_t levelId, std::string name, INSGROUP *depInsGroup, bool ntt, AddrType op1AddrStart,
                   AddrType opOutAddrStart, uint32_t modId, bool passthrough = false);
   INSGROUP GenAUTO(uint32_t levelId, std::string name, INSGROUP *depInsGroup, AddrType op1AddrStart,
-                   AddrType opOutAddrStart, uint32_t galois);
+                   AddrType opOutAddrStart, uint32_t galois, uint32_t modId = 0);
   // address 0 = unused operand, exactly like upstream
   INSGROUP GenEWE(uint32_t levelId, std::string name, INSGROUP *dep1, INSGROUP *dep2, INSGROUP *dep3, INSGROUP *dep4,
                   AddrType op1, AddrType op2, AddrType op3, AddrType op4, AddrType out, ewe_opcode opcode,

@@ -108,7 +108,7 @@ protected:
   std::map<std::string, std::vector<AddrType>> namedInputs;   // ct1.c0, ct1.c1, ... for readBuffer
   std::map<std::string, std::vector<AddrType>> namedOutputs;  // out.c0, out.c1
 
-  OperationBase(const std::string &op, Config *cfg, Arch *_arch, uint32_t maxLevel, uint32_t alpha);
+  OperationBase(const std::string &op, Config *cfg, Arch *_arch, uint32_t maxLevel, uint32_t curLevel, uint32_t alpha);
   void dispatch(std::pair<StageMap, std::vector<std::string>> m);
   void inputCiphertext(const std::string &name, Ciphertext *ct, uint64_t seed);
   void inputPlaintext(const std::string &name, Plaintext *pt, uint64_t seed);

@@ -10,7 +10,7 @@
 
 // one C-ABI call, with its argument arrays prebuilt so that run() is a tight loop of calls
 struct Arch::Launch {
-  enum Kind { L_NTT, L_INTT, L_EWE, L_BCONV, L_AUTO, L_NTT_SUBSCALE, L_TENSOR } kind;
+  enum Kind { L_NTT, L_INTT, L_EWE, L_BCONV, L_AUTO, L_NTT_SUBSCALE, L_TENSOR, L_EXCH_IN, L_EXCH_OUT, L_REPLICATE } kind;
   std::string name;
   std::string statKey;
   int opcode = 0;
@@ -18,6 +18,10 @@ struct Arch::Launch {
   std::vector<uint32_t> a, b, c, d, out, out1, out2, mods, inMods;
   struct Prob { std::vector<uint32_t> in, inMods, out, outMods; };
   std::vector<Prob> probs;  // BCONV: independent conversions batched into one launch
+  // multi-GPU: exchange steps (limb list + owner of each limb) and the coefficient-slice buffers of a sharded BCONV
+  std::vector<uint32_t> exLimbs, exOwners;
+  uint64_t *slicesIn = nullptr, *slicesOut = nullptr;
+  uint32_t logLen = 0;
   std::vector<uint64_t> k;
   bool hasK = false;
   unsigned long long refInstructions = 0;
@@ -37,6 +41,10 @@ Arch::Arch(Config *cfg) : config(cfg) {
   uint32_t b = cfg->getValueOr("backend", BACKEND_HIP);
   if (const char *e = getenv("HOMULATOR_BACKEND")) b = (std::string(e) == "count") ? BACKEND_COUNT : BACKEND_HIP;
   backendKind = b == BACKEND_COUNT ? BACKEND_COUNT : BACKEND_HIP;
+  world_ = std::max<uint32_t>(1, cfg->getValueOr("world", 1));
+  rank_ = cfg->getValueOr("rank", 0);
+  if (rank_ >= world_) throw std::runtime_error("rank must be below world");
+  if (world_ & (world_ - 1)) throw std::runtime_error("world must be a power of two");
   fuse = cfg->getValueOr("fuse", 1) != 0;
   if (const char *e = getenv("HOMULATOR_FUSE")) fuse = std::string(e) != "0";
   stat = new Statistic();
@@ -44,6 +52,8 @@ Arch::Arch(Config *cfg) : config(cfg) {
 
 Arch::~Arch() {
   for (Launch *l : launches) delete l;
+  if (ctx)
+    for (void *p : sliceBuffers) hm_free(ctx, p);
   if (ctx) {
     if (pool) hm_free(ctx, pool);
     hm_destroy(ctx);
@@ -56,7 +66,21 @@ Arch::~Arch() {
   delete stat;
 }
 
-void Arch::bindParams(uint32_t maxLevel, uint32_t alpha) {
+void Arch::commInitRccl(const void *id) {
+  if (!ctx) throw std::runtime_error("commInitRccl: no HIP context");
+  if (hm_comm_init_rccl(ctx, (int)rank_, (int)world_, id) != HM_OK) throw std::runtime_error(std::string("hm_comm_init_rccl: ") + hm_last_error(ctx));
+  commReady = true;
+}
+void Arch::commInitExternal(void *fn, void *user) {
+  if (!ctx) throw std::runtime_error("commInitExternal: no HIP context");
+  if (hm_comm_init_external(ctx, (int)rank_, (int)world_, reinterpret_cast<hm_exchange_fn>(fn), user) != HM_OK)
+    throw std::runtime_error(std::string("hm_comm_init_external: ") + hm_last_error(ctx));
+  commReady = true;
+}
+
+void Arch::bindParams(uint32_t maxLevel, uint32_t curLevel, uint32_t alpha) {
+  maxLevel_ = maxLevel;
+  curLevel_ = curLevel;
   if (g_host.count(this)) return;
   ArchHost *h = new ArchHost;
   h->P.init(logN, maxLevel, alpha, nullptr, nullptr, nullptr);
@@ -304,6 +328,17 @@ void Arch::buildLaunches() {
       for (AddrType o : writes(i)) writerDepth[o] = d;
     }
   }
+  // ---- multi-GPU: who holds each limb-poly.  Inputs: by the modulus they were filled for; everything else: by
+  // the modulus of the instruction that writes it.
+  std::map<AddrType, uint32_t> ownerOfAddr;
+  if (world_ > 1) {
+    for (const InputFill &f : fills)
+      for (size_t i = 0; i < f.addrs.size(); ++i) ownerOfAddr[f.addrs[i]] = owner(f.mods[i]);
+    for (const Part &p : parts)
+      for (Instruction *i : p.ins)
+        for (AddrType o : writes(i)) ownerOfAddr[o] = owner(i->mod_id);
+  }
+  const uint32_t logLen = logN - (uint32_t)__builtin_ctz(world_);
   // ---- 3. coalesce and emit, level by level
   int maxDepth = 0;
   for (const Part &p : parts) maxDepth = std::max(maxDepth, p.depth);
@@ -317,9 +352,39 @@ void Arch::buildLaunches() {
       std::vector<const Part *> group;
       for (size_t pj = pi; pj < parts.size(); ++pj)
         if (parts[pj].depth == d && parts[pj].key == key) group.push_back(&parts[pj]);
+      Instruction *f = group[0]->ins[0];
+      std::vector<Part> mineParts;
+      if (world_ > 1 && f->ops != BCONV_STEP2) {
+        // (a) operands written on another rank (the rescale's r = INTT(x_last)): replicate them first — every
+        //     rank derives the same list from the global graph, so the collective is entered by all
+        std::vector<AddrType> need;
+        for (const Part *g : group)
+          for (Instruction *i : g->ins)
+            for (AddrType a : reads(i)) {
+              auto oo = ownerOfAddr.find(a);
+              if (oo != ownerOfAddr.end() && oo->second != owner(i->mod_id) && std::find(need.begin(), need.end(), a) == need.end()) need.push_back(a);
+            }
+        if (!need.empty()) {
+          Launch *R = new Launch;
+          R->kind = Launch::L_REPLICATE; R->statKey = "XCHG"; R->name = "replicate";
+          for (AddrType a : need) { R->exLimbs.push_back(limbOf(a)); R->exOwners.push_back(ownerOfAddr[a]); }
+          R->bytes = LP * need.size();
+          launches.push_back(R);
+        }
+        // (b) keep the instructions whose modulus this rank owns
+        for (const Part *g : group) {
+          Part m{g->name, g->key, {}, g->depth};
+          for (Instruction *i : g->ins)
+            if (owner(i->mod_id) == rank_) m.ins.push_back(i);
+          if (!m.ins.empty()) mineParts.push_back(m);
+        }
+        group.clear();
+        for (const Part &m : mineParts) group.push_back(&m);
+        if (group.empty()) continue;
+        f = group[0]->ins[0];
+      }
       Launch *L = new Launch;
       for (const Part *g : group) L->name += (L->name.empty() ? "" : "+") + g->name;
-      Instruction *f = group[0]->ins[0];
       size_t count = 0;
       for (const Part *g : group)
         for (Instruction *i : g->ins) { L->refInstructions += i->refInstructions * (i->ops == BCONV_STEP2 ? bconvPorts : 1ull); ++count; }
@@ -395,6 +460,37 @@ void Arch::buildLaunches() {
           }
         }
         for (auto &q : L->probs) L->bytes += LP * (q.in.size() + q.out.size());
+        if (world_ > 1) {
+          // limb-sharded -> coefficient slices -> convert every output on this rank's slice -> limb-sharded
+          Launch *XI = new Launch, *XO = new Launch;
+          XI->kind = Launch::L_EXCH_IN; XO->kind = Launch::L_EXCH_OUT; XI->statKey = XO->statKey = "XCHG";
+          XI->name = L->name + ":limbs->slices"; XO->name = L->name + ":slices->limbs";
+          std::vector<uint32_t> inOwn, outOwn;
+          for (auto &q : L->probs) {
+            for (size_t x = 0; x < q.in.size(); ++x) {
+              size_t pos = std::find(XI->exLimbs.begin(), XI->exLimbs.end(), q.in[x]) - XI->exLimbs.begin();
+              if (pos == XI->exLimbs.size()) { XI->exLimbs.push_back(q.in[x]); XI->exOwners.push_back(owner(q.inMods[x])); }
+            }
+            for (size_t x = 0; x < q.out.size(); ++x) { XO->exLimbs.push_back(q.out[x]); XO->exOwners.push_back(owner(q.outMods[x])); }
+          }
+          std::vector<uint32_t> inRows(XI->exLimbs.size()), outRows(XO->exLimbs.size());
+          hm_slice_rows(XI->exOwners.data(), (uint32_t)inRows.size(), world_, inRows.data());
+          hm_slice_rows(XO->exOwners.data(), (uint32_t)outRows.size(), world_, outRows.data());
+          size_t o = 0;
+          for (auto &q : L->probs) {
+            for (uint32_t &x : q.in) x = inRows[std::find(XI->exLimbs.begin(), XI->exLimbs.end(), x) - XI->exLimbs.begin()];
+            for (uint32_t &x : q.out) x = outRows[o++];
+          }
+          L->logLen = XI->logLen = XO->logLen = logLen;
+          XI->bytes = LP * XI->exLimbs.size() / world_;
+          XO->bytes = LP * XO->exLimbs.size() / world_;
+          L->bytes /= world_;
+          launches.push_back(XI);
+          algBytes += L->bytes;
+          launches.push_back(L);
+          launches.push_back(XO);
+          continue;
+        }
       } else {
         delete L;
         throw std::runtime_error("no unit executes op " + f->GetOpName());
@@ -417,6 +513,19 @@ void Arch::prepare() {
   void *p = nullptr;
   if (hm_malloc(ctx, bytes, &p) != HM_OK) throw std::runtime_error(std::string("hm_malloc: ") + hm_last_error(ctx));
   pool = static_cast<uint64_t *>(p);
+  if (world_ > 1) {
+    if (!commReady) throw std::runtime_error("world > 1 but no transport was set (commInitRccl / commInitExternal)");
+    for (size_t i = 0; i + 2 < launches.size() + 0; ++i) {
+      if (launches[i]->kind != Launch::L_EXCH_IN) continue;
+      Launch *xi = launches[i], *bc = launches[i + 1], *xo = launches[i + 2];
+      void *si = nullptr, *so = nullptr;
+      if (hm_malloc(ctx, (size_t)xi->exLimbs.size() * (n / world_) * 8, &si) != HM_OK || hm_malloc(ctx, (size_t)xo->exLimbs.size() * (n / world_) * 8, &so) != HM_OK)
+        throw std::runtime_error(std::string("hm_malloc (slices): ") + hm_last_error(ctx));
+      sliceBuffers.push_back(si); sliceBuffers.push_back(so);
+      xi->slicesIn = bc->slicesIn = static_cast<uint64_t *>(si);
+      bc->slicesOut = xo->slicesOut = static_cast<uint64_t *>(so);
+    }
+  }
   for (const InputFill &f : fills) {
     std::vector<uint32_t> limbs;
     for (AddrType a : f.addrs) limbs.push_back(limbOf(a));
@@ -424,6 +533,22 @@ void Arch::prepare() {
       throw std::runtime_error(std::string("hm_fill_uniform: ") + hm_last_error(ctx));
   }
   hm_sync(ctx);
+}
+
+std::string Arch::planText() const {
+  static const char *names[] = {"NTT", "INTT", "EWE", "BCONV", "AUTO", "NTT_SUBSCALE", "TENSOR", "EXCH_IN", "EXCH_OUT", "REPLICATE"};
+  std::string out;
+  for (const Launch *l : launches) {
+    size_t cnt = l->out.size();
+    if (l->kind == Launch::L_BCONV) { cnt = 0; for (auto &q : l->probs) cnt += q.out.size(); }
+    out += std::string(names[l->kind]) + " " + l->name + " n=" + std::to_string(cnt) + " ref=" + std::to_string(l->refInstructions);
+    if (!l->exLimbs.empty()) {
+      out += " limbs=";
+      for (size_t i = 0; i < l->exLimbs.size(); ++i) out += std::to_string(l->exLimbs[i]) + ":" + std::to_string(l->exOwners[i]) + ",";
+    }
+    out += "\n";
+  }
+  return out;
 }
 
 void Arch::enqueue(Launch &l) {
@@ -445,6 +570,15 @@ void Arch::enqueue(Launch &l) {
     st = hm_tensor(ctx, pool, l.a.data(), pool, l.b.data(), pool, l.c.data(), pool, l.d.data(), pool, l.out.data(), pool, l.out1.data(), pool,
                    l.out2.data(), l.mods.data(), cnt);
     break;
+  case Launch::L_EXCH_IN:
+    st = hm_limbs_to_slices(ctx, pool, l.exLimbs.data(), l.exOwners.data(), (uint32_t)l.exLimbs.size(), l.slicesIn);
+    break;
+  case Launch::L_EXCH_OUT:
+    st = hm_slices_to_limbs(ctx, l.slicesOut, pool, l.exLimbs.data(), l.exOwners.data(), (uint32_t)l.exLimbs.size());
+    break;
+  case Launch::L_REPLICATE:
+    st = hm_replicate_limbs(ctx, pool, l.exLimbs.data(), l.exOwners.data(), (uint32_t)l.exLimbs.size());
+    break;
   case Launch::L_AUTO:
     st = hm_automorph(ctx, pool, l.a.data(), pool, l.out.data(), cnt, l.galois);
     break;
@@ -454,8 +588,8 @@ void Arch::enqueue(Launch &l) {
     break;
   case Launch::L_BCONV:
     for (auto &q : l.probs)
-      descs.push_back(hm_bconv_desc{pool, q.in.data(), q.inMods.data(), (uint32_t)q.in.size(), pool, q.out.data(), q.outMods.data(),
-                                    (uint32_t)q.out.size()});
+      descs.push_back(hm_bconv_desc{l.slicesIn ? l.slicesIn : pool, q.in.data(), q.inMods.data(), (uint32_t)q.in.size(),
+                                    l.slicesOut ? l.slicesOut : pool, q.out.data(), q.outMods.data(), (uint32_t)q.out.size(), l.logLen});
     st = hm_bconv_batch(ctx, descs.data(), (uint32_t)descs.size());
     break;
   }

@@ -32,8 +32,9 @@ INSGROUP InsGen::GenNTT(uint32_t levelId, std::string name, INSGROUP *dep, bool 
   return {ins};
 }
 
-INSGROUP InsGen::GenAUTO(uint32_t levelId, std::string name, INSGROUP *dep, AddrType in, AddrType out, uint32_t galois) {
-  Instruction *ins = make(name, AUTO, levelId, 0, {dep});
+INSGROUP InsGen::GenAUTO(uint32_t levelId, std::string name, INSGROUP *dep, AddrType in, AddrType out, uint32_t galois,
+                         uint32_t modId) {
+  Instruction *ins = make(name, AUTO, levelId, modId, {dep});
   ins->operandList = {in};
   ins->OutputOperand = out;
   ins->galois = galois;

@@ -407,7 +407,7 @@ void Rescale::MulOps() {  // :877-910
 // =====================================================================================================
 // OperationBase
 // =====================================================================================================
-OperationBase::OperationBase(const std::string &op, Config *cfg, Arch *_arch, uint32_t maxLevel, uint32_t alpha)
+OperationBase::OperationBase(const std::string &op, Config *cfg, Arch *_arch, uint32_t maxLevel, uint32_t curLevel, uint32_t alpha)
     : arch(_arch), config(cfg), opName(op) {
   insgener = new InsGen(cfg);
   driver = new Driver(cfg);
@@ -416,7 +416,7 @@ OperationBase::OperationBase(const std::string &op, Config *cfg, Arch *_arch, ui
   seed = cfg->getValueOr("seed", 0x484F4D55u);
   insgener->setGlobalDatapPoll(&Datapool);
   insgener->setGlobalDataInsMap(&DataInsMap);
-  arch->bindParams(maxLevel, alpha);
+  arch->bindParams(maxLevel, curLevel, alpha);
   Datapool.push_back(BASEADDRESS);
 }
 OperationBase::~OperationBase() {
@@ -508,7 +508,7 @@ bool OperationBase::simulate() {
 // =====================================================================================================
 // reference: HMULT::HMULT :913-1023.  Wiring: KS(d2); out0 = d0 + ks0; out1 = d1 + ks1 (Appendix C item 1)
 HMULT::HMULT(std::string labelName, uint32_t maxLevel, uint32_t currentLevel, uint32_t alpha, Config *cfg, Arch *_arch)
-    : OperationBase("HMULT", cfg, _arch, maxLevel, alpha) {
+    : OperationBase("HMULT", cfg, _arch, maxLevel, currentLevel, alpha) {
   c1 = new Ciphertext(currentLevel, N, Datapool, batchSize);
   c2 = new Ciphertext(currentLevel, N, Datapool, batchSize);
   inputCiphertext("ct1", c1, seed);
@@ -550,7 +550,7 @@ HMULT::HMULT(std::string labelName, uint32_t maxLevel, uint32_t currentLevel, ui
 // reference: HROTATE::HROTATE :1271-1358.  Wiring: c'_k = sigma_g(c_k); KS(c'_1); out0 = c'_0 + ks0; out1 = ks1
 // (Appendix C item 2).  The Galois element is the config key `galois` (default 5 = rotation by one slot).
 HROTATE::HROTATE(std::string labelName, uint32_t maxLevel, uint32_t currentLevel, uint32_t alpha, Config *cfg, Arch *_arch)
-    : OperationBase("HROTATE", cfg, _arch, maxLevel, alpha) {
+    : OperationBase("HROTATE", cfg, _arch, maxLevel, currentLevel, alpha) {
   ciph = new Ciphertext(currentLevel, N, Datapool, batchSize);
   inputCiphertext("ct1", ciph, seed);
   addrManager = new AddrManage(Datapool.back() + 1, batchSize);
@@ -565,7 +565,7 @@ HROTATE::HROTATE(std::string labelName, uint32_t maxLevel, uint32_t currentLevel
     std::vector<INSGROUP> g;
     for (uint32_t l = 0; l < currentLevel; l++)
       g.push_back(insgener->GenAUTO(l, labelName + "_AUTO_Level(" + S(l) + ")_k(" + S(k) + ")", nullptr, src[l],
-                                    addrManager->getAddr("AUTOOutput(" + S(k) + ")")[l], galois));
+                                    addrManager->getAddr("AUTOOutput(" + S(k) + ")")[l], galois, l));
     autoMap["AUTO_Key(" + S(k) + ")"] = g;
     autoNames.push_back("AUTO_Key(" + S(k) + ")");
   }
@@ -589,7 +589,7 @@ HROTATE::HROTATE(std::string labelName, uint32_t maxLevel, uint32_t currentLevel
 
 // reference: HADD::HADD :1114-1176
 HADD::HADD(std::string labelName, uint32_t maxLevel, uint32_t currentLevel, uint32_t alpha, Config *cfg, Arch *_arch)
-    : OperationBase("HADD", cfg, _arch, maxLevel, alpha) {
+    : OperationBase("HADD", cfg, _arch, maxLevel, currentLevel, alpha) {
   c1 = new Ciphertext(currentLevel, N, Datapool, batchSize);
   c2 = new Ciphertext(currentLevel, N, Datapool, batchSize);
   inputCiphertext("ct1", c1, seed);
@@ -611,7 +611,7 @@ HADD::HADD(std::string labelName, uint32_t maxLevel, uint32_t currentLevel, uint
 
 // reference: PMULT::PMULT :1460-1523
 PMULT::PMULT(std::string labelName, uint32_t maxLevel, uint32_t currentLevel, uint32_t alpha, Config *cfg, Arch *_arch)
-    : OperationBase("PMULT", cfg, _arch, maxLevel, alpha) {
+    : OperationBase("PMULT", cfg, _arch, maxLevel, currentLevel, alpha) {
   ctx = new Ciphertext(currentLevel, N, Datapool, batchSize);
   ptx = new Plaintext(currentLevel, N, Datapool, batchSize);
   inputCiphertext("ct1", ctx, seed);
@@ -633,7 +633,7 @@ PMULT::PMULT(std::string labelName, uint32_t maxLevel, uint32_t currentLevel, ui
 
 // reference: PADD::PADD :1625-1680 (upstream adds the plaintext to both components; only c0 takes it)
 PADD::PADD(std::string labelName, uint32_t maxLevel, uint32_t currentLevel, uint32_t alpha, Config *cfg, Arch *_arch)
-    : OperationBase("PADD", cfg, _arch, maxLevel, alpha) {
+    : OperationBase("PADD", cfg, _arch, maxLevel, currentLevel, alpha) {
   ctx = new Ciphertext(currentLevel, N, Datapool, batchSize);
   ptx = new Plaintext(currentLevel, N, Datapool, batchSize);
   inputCiphertext("ct1", ctx, seed);

@@ -118,11 +118,45 @@ hm_status hm_bconv(hm_ctx *ctx, const uint64_t *in, const uint32_t *in_limbs, co
 typedef struct hm_bconv_desc {
   const uint64_t *in; const uint32_t *in_limbs; const uint32_t *in_ids; uint32_t n_in;
   uint64_t *out; const uint32_t *out_limbs; const uint32_t *out_ids; uint32_t n_out;
+  uint32_t log_len; /* coefficients per limb in `in`/`out` = 2^log_len; 0 = N.  N/world for coefficient slices */
 } hm_bconv_desc;
 hm_status hm_bconv_batch(hm_ctx *ctx, const hm_bconv_desc *descs, uint32_t n_desc);
 /* host-side constants of a conversion: qhat_inv[n_in], table[n_in][n_out] (either may be NULL) */
 hm_status hm_bconv_consts(hm_ctx *ctx, const uint32_t *in_ids, uint32_t n_in, const uint32_t *out_ids,
                           uint32_t n_out, uint64_t *qhat_inv, uint64_t *table);
+
+/* ---- multi-GPU: limb sharding + the one exchange of the path ----------------------------
+ * One process per GPU.  Limb-polys are sharded by modulus over the `world` ranks (the reference places limb l
+ * on cluster l % cluster, include/Driver.h:158,178); only base conversion mixes limbs, so around it the data
+ * goes limb-sharded -> coefficient-sharded -> limb-sharded with two all-to-alls (the reference's only
+ * "communication" is the modelled inter-cluster NoC fetch, src/mem.cpp:78-100).
+ * Transport: RCCL over xGMI (hm_comm_init_rccl; the 128-byte unique id comes from hm_comm_unique_id on rank 0
+ * and is distributed by the caller, e.g. through torch.distributed), or a caller-supplied exchange function
+ * (hm_comm_init_external) used by the tests to run several ranks over gloo on one GPU. */
+typedef int (*hm_exchange_fn)(void *user, const void *send_dev, const size_t *send_off, const size_t *send_bytes,
+                              void *recv_dev, const size_t *recv_off, const size_t *recv_bytes);
+/* ^ per peer p: send_bytes[p] bytes at send_dev + send_off[p] go to rank p; recv_bytes[p] bytes from rank p land at
+ *   recv_dev + recv_off[p]; the entries of the calling rank itself are 0.  Returns 0 on success. */
+hm_status hm_comm_unique_id(void *out128);
+hm_status hm_comm_init_rccl(hm_ctx *ctx, int rank, int world, const void *unique_id128);
+hm_status hm_comm_init_external(hm_ctx *ctx, int rank, int world, hm_exchange_fn fn, void *user);
+hm_status hm_comm_info(const hm_ctx *ctx, int *rank, int *world);
+/* rows of the slice layout: slices are grouped by owner rank, in list order inside an owner */
+hm_status hm_slice_rows(const uint32_t *owners, uint32_t n, uint32_t world, uint32_t *rows);
+/* n limb-polys, owners[i] = rank that holds limb i in `buf` at index limbs[i] (other entries of limbs[] are
+ * ignored on this rank).  Afterwards slices[rows[i]][0 .. N/world) = coefficients [rank*N/world, ...) of limb i,
+ * for ALL n limbs.  slices: device, n * N/world words. */
+hm_status hm_limbs_to_slices(hm_ctx *ctx, const uint64_t *buf, const uint32_t *limbs, const uint32_t *owners,
+                             uint32_t n, uint64_t *slices);
+/* the reverse: every rank holds its coefficient slice of all n limbs; afterwards the owner of limb i holds the
+ * whole limb at buf + limbs[i] * N. */
+hm_status hm_slices_to_limbs(hm_ctx *ctx, const uint64_t *slices, uint64_t *buf, const uint32_t *limbs,
+                             const uint32_t *owners, uint32_t n);
+
+/* every rank ends up with a full copy of the n limbs (owner -> everybody).  The one place the hmult path needs
+ * it is the rescale: r = INTT(x_last) lives on one rank and every other limb's NTT reads it (src/Operation.cpp:
+ * 806-822). */
+hm_status hm_replicate_limbs(hm_ctx *ctx, uint64_t *buf, const uint32_t *limbs, const uint32_t *owners, uint32_t n);
 
 /* Synthetic data: limb i = counter-based SplitMix64 stream (seed + i), uniform in
  * [0, q).  Bench/test tooling; the reference has no data at all. */

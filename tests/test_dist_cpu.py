@@ -1,0 +1,85 @@
+"""N > 1 path on the CPU (no GPU): (1) the sharded launch plans that the C++ host layer builds for every rank are
+collectively consistent (same exchange sequence, same limb lists, work partitioned exactly); (2) the slice-row
+layout helper of the HIP library; (3) GlooTransport under a real world_size-2 gloo group."""
+import ctypes as C
+import os
+import re
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch(world, args, timeout=600):
+    port = free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py")] + args, env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=timeout)[0] for p in procs]
+    return [p.returncode for p in procs], outs
+
+
+def test_gloo_transport_world2():
+    rcs, outs = launch(2, ["transport"])
+    assert rcs == [0, 0], outs
+
+
+@pytest.mark.parametrize("opname", ["hmult", "hrotate"])
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_sharded_plans_are_collectively_consistent(opname, world):
+    from homulator_amd import host
+    L, ell, alpha = 45, 35, 15
+    single = host.Op("config_4.cfg", opname, L, ell, alpha, backend=host.BACKEND_COUNT)
+    total_ref = sum(int(re.search(r"ref=(\d+)", ln).group(1)) for ln in single.plan())
+    plans = []
+    for r in range(world):
+        o = host.Op("config_4.cfg", opname, L, ell, alpha, backend=host.BACKEND_COUNT, rank=r, world=world)
+        plans.append(o.plan())
+    coll = [[ln for ln in pl if ln.split()[0] in ("EXCH_IN", "EXCH_OUT", "REPLICATE")] for pl in plans]
+    # every rank enters the same collectives, in the same order, with the same limb:owner lists
+    assert all(c == coll[0] for c in coll)
+    n_bconv = sum(1 for ln in plans[0] if ln.startswith("BCONV"))
+    assert sum(1 for ln in coll[0] if ln.startswith("EXCH_IN")) == n_bconv == sum(1 for ln in coll[0] if ln.startswith("EXCH_OUT"))
+    assert n_bconv == 2   # one all-to-all pair for ModUp (all digits), one for ModDown (both keys): SURVEY §8e
+    if opname == "hmult":
+        assert sum(1 for ln in coll[0] if ln.startswith("REPLICATE")) == 1   # rescale's r
+    # owners follow limb % world on the exchanged limbs, and the element-wise work is partitioned exactly
+    per_rank = []
+    for pl in plans:
+        n = 0
+        for ln in pl:
+            kind = ln.split()[0]
+            if kind in ("NTT", "INTT", "EWE", "AUTO", "NTT_SUBSCALE", "TENSOR"):
+                n += int(re.search(r" n=(\d+)", ln).group(1))
+        per_rank.append(n)
+    n_single = sum(int(re.search(r" n=(\d+)", ln).group(1)) for ln in single.plan() if ln.split()[0] in ("NTT", "INTT", "EWE", "AUTO", "NTT_SUBSCALE", "TENSOR"))
+    assert sum(per_rank) == n_single
+    assert max(per_rank) - min(per_rank) <= 12   # balanced up to the remainder limbs of each stage
+    assert total_ref > 0
+
+
+def test_slice_rows_layout():
+    from homulator_amd import hip
+    lib = hip.load()
+    lib.hm_slice_rows.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+    owners = np.array([0, 1, 2, 3, 0, 1, 2, 3, 0, 1], dtype=np.uint32)
+    rows = np.empty_like(owners)
+    assert lib.hm_slice_rows(owners.ctypes.data, len(owners), 4, rows.ctypes.data) == 0
+    assert rows.tolist() == [0, 3, 6, 8, 1, 4, 7, 9, 2, 5]     # grouped by owner, list order inside an owner
+    assert sorted(rows.tolist()) == list(range(10))
+    bad = np.array([0, 5], dtype=np.uint32)
+    assert lib.hm_slice_rows(bad.ctypes.data, 2, 4, rows.ctypes.data) != 0
