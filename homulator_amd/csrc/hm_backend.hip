@@ -131,6 +131,35 @@ __global__ void __launch_bounds__(256) k_ewe(HmEweArgs a) {
   *reinterpret_cast<ulonglong2 *>(a.out + (size_t)lb.out * N + x) = r;
 }
 
+template <int TERMS, int OUTS>
+__global__ void __launch_bounds__(256) k_inner_product(HmIpArgs a) {
+  const uint32_t N = 1u << a.logN;
+  const uint32_t per_limb = N / 512;
+  const uint32_t entry = blockIdx.x / per_limb, chunk = blockIdx.x % per_limb;
+  if (entry >= a.n_limbs) return;
+  const HmIpLimb &lb = a.limb[entry];
+  const HmMod m = a.mods[lb.mod];
+  const size_t off = (size_t)chunk * 512 + 2 * threadIdx.x;
+  ulonglong2 vx[TERMS], vy[OUTS][TERMS];
+#pragma unroll
+  for (int j = 0; j < TERMS; ++j) {
+    vx[j] = *reinterpret_cast<const ulonglong2 *>(a.x + (size_t)lb.x[j] * N + off);
+#pragma unroll
+    for (int k = 0; k < OUTS; ++k) vy[k][j] = *reinterpret_cast<const ulonglong2 *>(a.y + (size_t)lb.y[k][j] * N + off);
+  }
+#pragma unroll
+  for (int k = 0; k < OUTS; ++k) {
+    hm_u128 s0 = 0, s1 = 0;
+#pragma unroll
+    for (int j = 0; j < TERMS; ++j) {
+      s0 += (hm_u128)vx[j].x * vy[k][j].x;
+      s1 += (hm_u128)vx[j].y * vy[k][j].y;
+    }
+    const ulonglong2 r = {hm_barrett(s0, m), hm_barrett(s1, m)};  // TERMS <= 4 products below 2^120: within 2^(k+63)
+    *reinterpret_cast<ulonglong2 *>(a.out + (size_t)lb.out[k] * N + off) = r;
+  }
+}
+
 template <int N_IN>
 __device__ __forceinline__ void hm_bconv_block(const HmBconvArgs &a, const HmBconvProb &p, uint64_t *tab) {
   const uint32_t t0 = blockIdx.y * HM_BCONV_CHUNK;
@@ -603,6 +632,47 @@ extern "C" hm_status hm_ewe(hm_ctx *c, int op, const uint64_t *pa, const uint32_
     case HM_EWE_SUB_SCALE: launch_ewe<HM_EWE_SUB_SCALE>(c, a); break;
     case HM_EWE_COPY: launch_ewe<HM_EWE_COPY>(c, a); break;
     case HM_EWE_SUB_SCALE_ADD: launch_ewe<HM_EWE_SUB_SCALE_ADD>(c, a); break;
+    }
+    HM_HIP(c, hipGetLastError());
+  }
+  return HM_OK;
+}
+
+template <int T, int O>
+static void launch_ip(hm_ctx *c, const HmIpArgs &a) {
+  hipLaunchKernelGGL((k_inner_product<T, O>), dim3(a.n_limbs * (c->P.N / 512)), dim3(256), 0, c->stream, a);
+}
+extern "C" hm_status hm_inner_product(hm_ctx *c, const uint64_t *x, const uint32_t *x_limbs, const uint64_t *y,
+                                      const uint32_t *y_limbs, uint64_t *out, const uint32_t *out_limbs,
+                                      const uint32_t *mod_ids, uint32_t n, uint32_t n_terms, uint32_t n_out) {
+  if (!c) return HM_ERR_ARG;
+  if (!x || !y || !out || !x_limbs || !y_limbs || !out_limbs) return fail(c, HM_ERR_ARG, "hm_inner_product: null argument");
+  if (n_terms == 0 || n_terms > HM_IP_MAX_TERMS || n_out == 0 || n_out > HM_IP_MAX_OUT)
+    return fail(c, HM_ERR_ARG, "hm_inner_product: n_terms in [1,%d], n_out in [1,%d]", HM_IP_MAX_TERMS, HM_IP_MAX_OUT);
+  hm_status st;
+  if ((st = check_limbs(c, "hm_inner_product", x_limbs, n * n_terms)) || (st = check_limbs(c, "hm_inner_product", y_limbs, n * n_terms * n_out)) ||
+      (st = check_limbs(c, "hm_inner_product", out_limbs, n * n_out)) || (st = check_mods(c, "hm_inner_product", mod_ids, n)))
+    return st;
+  HM_HIP(c, hipSetDevice(c->device));
+  for (uint32_t base = 0; base < n; base += HM_IP_MAX_LIMBS) {
+    const uint32_t cnt = std::min<uint32_t>(HM_IP_MAX_LIMBS, n - base);
+    HmIpArgs a;
+    a.x = x; a.y = y; a.out = out; a.mods = c->d_mods; a.logN = c->P.logN; a.n_limbs = cnt; a.n_terms = n_terms; a.n_out = n_out;
+    for (uint32_t i = 0; i < cnt; ++i) {
+      const uint32_t g = base + i;
+      HmIpLimb &l = a.limb[i];
+      l.mod = (uint16_t)mod_ids[g]; l.pad = 0;
+      for (uint32_t j = 0; j < n_terms; ++j) l.x[j] = (uint16_t)x_limbs[g * n_terms + j];
+      for (uint32_t k = 0; k < n_out; ++k) {
+        l.out[k] = (uint16_t)out_limbs[g * n_out + k];
+        for (uint32_t j = 0; j < n_terms; ++j) l.y[k][j] = (uint16_t)y_limbs[(g * n_out + k) * n_terms + j];
+      }
+    }
+    switch (n_terms * 10 + n_out) {
+    case 11: launch_ip<1, 1>(c, a); break; case 12: launch_ip<1, 2>(c, a); break;
+    case 21: launch_ip<2, 1>(c, a); break; case 22: launch_ip<2, 2>(c, a); break;
+    case 31: launch_ip<3, 1>(c, a); break; case 32: launch_ip<3, 2>(c, a); break;
+    case 41: launch_ip<4, 1>(c, a); break; case 42: launch_ip<4, 2>(c, a); break;
     }
     HM_HIP(c, hipGetLastError());
   }

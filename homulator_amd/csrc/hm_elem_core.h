@@ -77,6 +77,26 @@ HM_HD void hm_tensor_one(uint64_t a, uint64_t b, uint64_t c, uint64_t d, const H
   d2 = hm_mulmod(c, d, m);
 }
 
+// ---- K5 inner product with the evaluation key (the reference's HPIP unit: InsGen::GenHPIP src/InsGen.cpp:356-406,
+// HPIP src/Components.cpp:571-595; in the shipped configs it runs on the EWE as beta-1 MAC groups per key,
+// KeySwitch::InnerProduceOperation src/Operation.cpp:294-414).  One pass: acc_k = sum_j x_j * y_{j,k}, k < n_out.
+#define HM_IP_MAX_TERMS 4
+#define HM_IP_MAX_OUT 2
+#define HM_IP_MAX_LIMBS 64
+struct HmIpLimb {
+  uint16_t x[HM_IP_MAX_TERMS];
+  uint16_t y[HM_IP_MAX_OUT][HM_IP_MAX_TERMS];
+  uint16_t out[HM_IP_MAX_OUT];
+  uint16_t mod, pad;
+};
+struct HmIpArgs {
+  const uint64_t *x, *y;
+  uint64_t *out;
+  const HmMod *mods;
+  uint32_t logN, n_limbs, n_terms, n_out;
+  HmIpLimb limb[HM_IP_MAX_LIMBS];
+};
+
 // ---- K4 base conversion: out[t][x] = sum_i in[i][x] * table[i][t] mod q_t
 // One launch carries up to HM_BCONV_MAX_PROB independent conversions (the beta digits of a ModUp, the two
 // keys of a ModDown): grid = (N / HM_BCONV_THREADS, output chunks, problems); one coefficient per thread.

@@ -13,7 +13,7 @@ OP_MUL, OP_MAC2, OP_MAC_ADD, OP_ADD, OP_SUB, OP_MUL_CONST, OP_SUB_SCALE, OP_COPY
 # every symbol include/homulator_hip.h declares
 SYMBOLS = [
     "hm_create", "hm_destroy", "hm_last_error", "hm_version", "hm_get_modulus", "hm_get_psi", "hm_malloc", "hm_free",
-    "hm_memcpy_h2d", "hm_memcpy_d2h", "hm_memcpy_d2d", "hm_sync", "hm_stream", "hm_ntt", "hm_ntt_sub_scale", "hm_tensor", "hm_automorph", "hm_ewe",
+    "hm_memcpy_h2d", "hm_memcpy_d2h", "hm_memcpy_d2d", "hm_sync", "hm_stream", "hm_ntt", "hm_ntt_sub_scale", "hm_tensor", "hm_inner_product", "hm_automorph", "hm_ewe",
     "hm_bconv", "hm_bconv_batch", "hm_bconv_consts", "hm_fill_uniform", "hm_timer_start", "hm_timer_stop", "hm_comm_unique_id", "hm_comm_init_rccl", "hm_comm_init_external",
     "hm_comm_info", "hm_slice_rows", "hm_limbs_to_slices", "hm_slices_to_limbs", "hm_replicate_limbs",
 ]
@@ -55,6 +55,7 @@ def load():
     L.hm_ntt.argtypes = [vp, vp, vp, vp, vp, vp, u32, i32, vp]
     L.hm_ntt_sub_scale.argtypes = [vp] + [vp] * 9 + [u32, vp]
     L.hm_tensor.argtypes = [vp] + [vp] * 15 + [u32]
+    L.hm_inner_product.argtypes = [vp] + [vp] * 7 + [u32, u32, u32]
     L.hm_automorph.argtypes = [vp, vp, vp, vp, vp, u32, u32]
     L.hm_ewe.argtypes = [vp, i32] + [vp] * 11 + [u32, vp]
     L.hm_bconv.argtypes = [vp, vp, vp, vp, u32, vp, vp, vp, u32]
@@ -180,6 +181,11 @@ class Context:
         keep = [_u32(x) for x in ls] + [_u32(mod_ids)]
         self._ck(self.L.hm_tensor(self.h, a.ptr, keep[0][1], b.ptr, keep[1][1], c.ptr, keep[2][1], d.ptr, keep[3][1], o0.ptr, keep[4][1],
                                   o1.ptr, keep[5][1], o2.ptr, keep[6][1], keep[7][1], len(mod_ids)))
+
+    def inner_product(self, x, x_limbs, y, y_limbs, out, out_limbs, mod_ids, n_terms, n_out):
+        keep = [_u32(v) for v in (x_limbs, y_limbs, out_limbs, mod_ids)]
+        self._ck(self.L.hm_inner_product(self.h, x.ptr, keep[0][1], y.ptr, keep[1][1], out.ptr, keep[2][1], keep[3][1], len(mod_ids),
+                                         n_terms, n_out))
 
     def automorph(self, src, dst, n, galois, in_limbs=None, out_limbs=None):
         k1, pi = _u32(in_limbs)

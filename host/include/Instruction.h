@@ -36,6 +36,9 @@ public:
   AddrType fMinuend = 0, fAddend = 0;  // fAddend == 0: no addend
   bool fusedTensor = false;            // MAC2 record that also produces d0 -> extraOutputs[0] and d2 -> extraOutputs[1]
   std::vector<AddrType> extraOutputs;
+  // fused inner product (ops == IP): out_k = sum_j ipX[j] * ipY[k][j]; out_0 = OutputOperand, out_1 = extraOutputs[0]
+  std::vector<AddrType> ipX;
+  std::vector<std::vector<AddrType>> ipY;
   std::vector<Instruction *> depsInsList;
 
   Instruction(std::string name, ins_ops op, uint32_t level) : ops(op), Name(std::move(name)), level_id(level) {}

@@ -10,7 +10,8 @@
 
 // one C-ABI call, with its argument arrays prebuilt so that run() is a tight loop of calls
 struct Arch::Launch {
-  enum Kind { L_NTT, L_INTT, L_EWE, L_BCONV, L_AUTO, L_NTT_SUBSCALE, L_TENSOR, L_EXCH_IN, L_EXCH_OUT, L_REPLICATE } kind;
+  enum Kind { L_NTT, L_INTT, L_EWE, L_BCONV, L_AUTO, L_NTT_SUBSCALE, L_TENSOR, L_EXCH_IN, L_EXCH_OUT, L_REPLICATE, L_IP } kind;
+  uint32_t ipTerms = 0, ipOuts = 0;
   std::string name;
   std::string statKey;
   int opcode = 0;
@@ -251,6 +252,59 @@ void Arch::fusePasses(std::vector<Stage> &st) {
         dead.insert(v->second);
       }
   }
+  // (6) inner product with the evaluation key: the chain MAC2 / MAC_ADD ... of one key collapses into a single sum
+  //     of products, and the two keys (same ext operands) into one two-output record (the HPIP unit's job)
+  {
+    struct Dot { std::vector<AddrType> x, y; std::vector<Instruction *> members; };
+    std::map<Instruction *, Dot> dots;
+    auto single = [&](AddrType a) { return uses[a] == 1; };
+    std::vector<Instruction *> order;
+    for (auto &s : st)
+      for (Instruction *i : s.ins) order.push_back(i);
+    for (Instruction *i : order) {
+      if (i->ops != MULT || dead.count(i) || i->fusedTensor) continue;
+      Dot d;
+      if (i->opcode == EWE_MUL) { d.x = {i->operandList[0]}; d.y = {i->operandList[1]}; }
+      else if (i->opcode == EWE_MAC2) { d.x = {i->operandList[0], i->operandList[2]}; d.y = {i->operandList[1], i->operandList[3]}; }
+      else if (i->opcode == EWE_MAC_ADD) {
+        auto p = producer.find(i->operandList[2]);
+        if (p == producer.end() || !dots.count(p->second) || !single(i->operandList[2]) || p->second->mod_id != i->mod_id) continue;
+        d = dots[p->second];
+        d.x.push_back(i->operandList[0]);
+        d.y.push_back(i->operandList[1]);
+      } else continue;
+      d.members.push_back(i);
+      dots[i] = d;
+    }
+    // keep the dots that end a chain (nobody extends them) and have a partner with the same x list or >= 3 terms
+    std::set<Instruction *> extended;
+    for (auto &kv : dots)
+      for (size_t m = 0; m + 1 < kv.second.members.size(); ++m) extended.insert(kv.second.members[m]);
+    std::map<std::pair<uint32_t, std::vector<AddrType>>, Instruction *> byX;
+    for (Instruction *i : order) {
+      auto it = dots.find(i);
+      if (it == dots.end() || extended.count(i) || it->second.x.size() > 4) continue;
+      Dot &d = it->second;
+      auto key = std::make_pair(i->mod_id, d.x);
+      auto partner = byX.find(key);
+      if (partner == byX.end()) { byX[key] = i; continue; }
+      Instruction *a = partner->second;  // first key
+      Dot &da = dots[a];
+      if (a->ops == IP) continue;        // already paired
+      // `i` (the later one) carries the fused record so that it is scheduled after every member of both chains
+      const AddrType outFirst = a->OutputOperand, outSecond = i->OutputOperand;
+      i->ops = IP;
+      i->ipX = d.x;
+      i->ipY = {da.y, d.y};
+      i->OutputOperand = outFirst;
+      i->extraOutputs = {outSecond};
+      producer[outFirst] = i;
+      for (Instruction *m : da.members) { i->refInstructions += m->refInstructions; dead.insert(m); }
+      for (Instruction *m : d.members)
+        if (m != i) { i->refInstructions += m->refInstructions; dead.insert(m); }
+      byX.erase(partner);
+    }
+  }
   // drop dead instructions and empty stages; upstream instructions of eliminated pass-through records are
   // accounted on the first surviving instruction so that the retired total still matches getTotalIns()
   unsigned long long orphan = 0;
@@ -285,7 +339,7 @@ void Arch::buildLaunches() {
   for (const Stage &s : st) {
     size_t first = parts.size();
     for (Instruction *i : s.ins) {
-      int key = i->fusedTensor ? 200 : i->fusedSubScale ? (i->fAddend ? 201 : 202) : i->ops == MULT ? 100 + i->opcode : (i->ops == NTT && i->passthrough) ? 100 + EWE_COPY : i->ops == AUTO ? 1000 + (int)i->galois : (int)i->ops;
+      int key = i->ops == IP && !i->ipX.empty() ? 300 + (int)i->ipX.size() * 10 + (int)i->ipY.size() : i->fusedTensor ? 200 : i->fusedSubScale ? (i->fAddend ? 201 : 202) : i->ops == MULT ? 100 + i->opcode : (i->ops == NTT && i->passthrough) ? 100 + EWE_COPY : i->ops == AUTO ? 1000 + (int)i->galois : (int)i->ops;
       size_t p = first;
       for (; p < parts.size(); ++p)
         if (parts[p].key == key) break;
@@ -299,6 +353,11 @@ void Arch::buildLaunches() {
   // the stage ORDER it fixes is only a topological order of this graph.
   auto reads = [&](Instruction *i) {
     std::vector<AddrType> v;
+    if (i->ops == IP && !i->ipX.empty()) {
+      v = i->ipX;
+      for (auto &y : i->ipY) v.insert(v.end(), y.begin(), y.end());
+      return v;
+    }
     if (i->ops == BCONV_STEP2) v.assign(i->operandList.begin(), i->operandList.end() - 1);
     else if (i->ops == MULT) { for (int b = 0; b < 4; ++b) if (useMask[i->opcode] & (1 << b)) v.push_back(i->operandList[b]); }
     else v.push_back(i->operandList[0]);
@@ -388,7 +447,19 @@ void Arch::buildLaunches() {
       size_t count = 0;
       for (const Part *g : group)
         for (Instruction *i : g->ins) { L->refInstructions += i->refInstructions * (i->ops == BCONV_STEP2 ? bconvPorts : 1ull); ++count; }
-      if (f->fusedTensor) {
+      if (f->ops == IP && !f->ipX.empty()) {
+        L->kind = Launch::L_IP; L->statKey = "EWE";
+        L->ipTerms = (uint32_t)f->ipX.size(); L->ipOuts = (uint32_t)f->ipY.size();
+        for (const Part *g : group)
+          for (Instruction *i : g->ins) {
+            for (AddrType x : i->ipX) L->a.push_back(limbOf(x));
+            for (auto &y : i->ipY) for (AddrType yy : y) L->b.push_back(limbOf(yy));
+            L->out.push_back(limbOf(i->OutputOperand));
+            for (AddrType o : i->extraOutputs) L->out.push_back(limbOf(o));
+            L->mods.push_back(i->mod_id);
+          }
+        L->bytes = (unsigned long long)(L->ipTerms * (1 + L->ipOuts) + L->ipOuts) * LP * count;
+      } else if (f->fusedTensor) {
         L->kind = Launch::L_TENSOR; L->statKey = "EWE";
         for (const Part *g : group)
           for (Instruction *i : g->ins) {  // a = c00 (P), b = c10 (T), c = c01 (R), d = c11 (S)
@@ -536,11 +607,12 @@ void Arch::prepare() {
 }
 
 std::string Arch::planText() const {
-  static const char *names[] = {"NTT", "INTT", "EWE", "BCONV", "AUTO", "NTT_SUBSCALE", "TENSOR", "EXCH_IN", "EXCH_OUT", "REPLICATE"};
+  static const char *names[] = {"NTT", "INTT", "EWE", "BCONV", "AUTO", "NTT_SUBSCALE", "TENSOR", "EXCH_IN", "EXCH_OUT", "REPLICATE", "IP"};
   std::string out;
   for (const Launch *l : launches) {
     size_t cnt = l->out.size();
     if (l->kind == Launch::L_BCONV) { cnt = 0; for (auto &q : l->probs) cnt += q.out.size(); }
+    if (l->kind == Launch::L_IP) cnt = l->mods.size();
     out += std::string(names[l->kind]) + " " + l->name + " n=" + std::to_string(cnt) + " ref=" + std::to_string(l->refInstructions);
     if (!l->exLimbs.empty()) {
       out += " limbs=";
@@ -565,6 +637,9 @@ void Arch::enqueue(Launch &l) {
   case Launch::L_NTT_SUBSCALE:
     st = hm_ntt_sub_scale(ctx, pool, l.a.data(), pool, l.b.data(), l.c.empty() ? nullptr : pool, l.c.empty() ? nullptr : l.c.data(), pool,
                           l.out.data(), l.mods.data(), cnt, l.k.data());
+    break;
+  case Launch::L_IP:
+    st = hm_inner_product(ctx, pool, l.a.data(), pool, l.b.data(), pool, l.out.data(), l.mods.data(), (uint32_t)l.mods.size(), l.ipTerms, l.ipOuts);
     break;
   case Launch::L_TENSOR:
     st = hm_tensor(ctx, pool, l.a.data(), pool, l.b.data(), pool, l.c.data(), pool, l.d.data(), pool, l.out.data(), pool, l.out1.data(), pool,

@@ -105,6 +105,16 @@ hm_status hm_tensor(hm_ctx *ctx, const uint64_t *a, const uint32_t *a_limbs, con
                     uint64_t *o0, const uint32_t *o0_limbs, uint64_t *o1, const uint32_t *o1_limbs, uint64_t *o2,
                     const uint32_t *o2_limbs, const uint32_t *mod_ids, uint32_t n);
 
+/* K5 — inner product with the evaluation key in one pass: for limb i, out[i][k] = sum_{j < n_terms}
+ * x[i][j] * y[i][k][j], k < n_out (n_terms <= 4 digits, n_out <= 2 keys).  Limb lists are row-major:
+ * x_limbs[i * n_terms + j], y_limbs[(i * n_out + k) * n_terms + j], out_limbs[i * n_out + k].  Replaces
+ * issueIns(cluster, h, w, group, hpip = true) include/Arch.h:277 for InsGen::GenHPIP (src/InsGen.cpp:356-406), and
+ * the beta-1 EWE MAC groups per key of KeySwitch::InnerProduceOperation (src/Operation.cpp:294-414): every ext limb is
+ * read once for both keys and each output is reduced once. */
+hm_status hm_inner_product(hm_ctx *ctx, const uint64_t *x, const uint32_t *x_limbs, const uint64_t *y,
+                           const uint32_t *y_limbs, uint64_t *out, const uint32_t *out_limbs,
+                           const uint32_t *mod_ids, uint32_t n, uint32_t n_terms, uint32_t n_out);
+
 /* K4 — fast base conversion, matrix step: out_t = sum_i in_i * [Q_D / q_i]_t mod t for the input
  * basis in_ids (n_in <= 16) and output basis out_ids (n_out <= 64).  `in` must already hold
  * y_i = x_i * [(Q_D/q_i)^-1]_{q_i} (hm_ntt's scale or HM_OP_MUL_CONST with hm_bconv_consts).

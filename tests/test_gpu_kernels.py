@@ -165,3 +165,33 @@ def test_fused_ntt_sub_scale_and_tensor(env):
     assert np.array_equal(o2.download(), o.ewe(0, ids, ad, dd))
     for b_ in (dx, dmn, dad, ddd, out, o0, o1, o2):
         b_.free()
+
+
+@pytest.mark.parametrize("terms,outs", [(1, 2), (2, 1), (3, 2), (4, 2)])
+def test_inner_product_one_pass(env, terms, outs):
+    """K5: out[i][k] = sum_j x[i][j] * y[i][k][j], worst-case operands (q-1) included"""
+    ctx, o, _ = env
+    ids = [0, 2, o.L, o.L + 1, 5]
+    n = len(ids)
+    X = [o.fill_uniform(ids, 10 + j) for j in range(terms)]
+    Y = [[o.fill_uniform(ids, 100 + 10 * k + j) for j in range(terms)] for k in range(outs)]
+    for r, m in enumerate(ids):
+        for j in range(terms):
+            X[j][r, :2] = o.moduli[m] - 1
+            for k in range(outs):
+                Y[k][j][r, :2] = o.moduli[m] - 1
+    xb = ctx.from_host(np.concatenate(X))                      # limb of x_j[i] = j*n + i
+    yb = ctx.from_host(np.concatenate([Y[k][j] for k in range(outs) for j in range(terms)]))
+    out = ctx.alloc(n * outs)
+    xl = [j * n + i for i in range(n) for j in range(terms)]
+    yl = [(k * terms + j) * n + i for i in range(n) for k in range(outs) for j in range(terms)]
+    ol = [k * n + i for i in range(n) for k in range(outs)]
+    ctx.inner_product(xb, xl, yb, yl, out, ol, ids, terms, outs)
+    got = out.download()
+    for k in range(outs):
+        exp = o.ewe(0, ids, X[0], Y[k][0])
+        for j in range(1, terms):
+            exp = o.ewe(2, ids, X[j], Y[k][j], exp)
+        assert np.array_equal(got[k * n:(k + 1) * n], exp), (k, terms)
+    for b_ in (xb, yb, out):
+        b_.free()
