@@ -75,16 +75,19 @@ __device__ __forceinline__ void hm_ntt_pass_body(const HmNttArgs &a, const HmTw 
   }
 }
 
+#ifndef HM_NTT_MIN_WAVES
+#define HM_NTT_MIN_WAVES 1
+#endif
 template <int LOGR, bool STRIDED, bool INV, int MODE>
-__global__ void __launch_bounds__(HM_THREADS) k_ntt_pass(HmNttArgs a) {
+__global__ void __launch_bounds__(HM_THREADS, HM_NTT_MIN_WAVES) k_ntt_pass(HmNttArgs a) {
   hm_ntt_pass_body<LOGR, STRIDED, INV, MODE>(a, nullptr);
 }
 template <int LOGR>
-__global__ void __launch_bounds__(HM_THREADS) k_intt_final(HmNttArgs a, HmScale s) {
+__global__ void __launch_bounds__(HM_THREADS, HM_NTT_MIN_WAVES) k_intt_final(HmNttArgs a, HmScale s) {
   hm_ntt_pass_body<LOGR, true, true, 2>(a, s.c);
 }
 // forward ROW pass fused with out = (minuend - NTT) * k [+ addend]
-__global__ void __launch_bounds__(HM_THREADS) k_ntt_row_subscale(HmNttArgs a, HmSubScale s) {
+__global__ void __launch_bounds__(HM_THREADS, HM_NTT_MIN_WAVES) k_ntt_row_subscale(HmNttArgs a, HmSubScale s) {
   hm_ntt_pass_body<8, false, false, 3>(a, nullptr, &s);
 }
 
@@ -400,6 +403,42 @@ extern "C" hm_status hm_sync(hm_ctx *c) {
   return HM_OK;
 }
 extern "C" void *hm_stream(hm_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+struct hm_graph {
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+};
+extern "C" hm_status hm_capture_begin(hm_ctx *c) {
+  if (!c) return HM_ERR_ARG;
+  if (c->ext_fn) return fail(c, HM_ERR_UNSUPPORTED, "hm_capture_begin: an external exchange transport cannot be captured");
+  HM_HIP(c, hipSetDevice(c->device));
+  HM_HIP(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+  return HM_OK;
+}
+extern "C" hm_status hm_capture_end(hm_ctx *c, hm_graph **out) {
+  if (!c || !out) return HM_ERR_ARG;
+  hm_graph *g = new hm_graph;
+  hipError_t e = hipStreamEndCapture(c->stream, &g->graph);
+  if (e == hipSuccess) e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
+  if (e != hipSuccess) {
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    delete g;
+    return fail(c, HM_ERR_HIP, "hm_capture_end: %s", hipGetErrorString(e));
+  }
+  *out = g;
+  return HM_OK;
+}
+extern "C" hm_status hm_graph_launch(hm_ctx *c, hm_graph *g) {
+  if (!c || !g) return HM_ERR_ARG;
+  HM_HIP(c, hipGraphLaunch(g->exec, c->stream));
+  return HM_OK;
+}
+extern "C" void hm_graph_destroy(hm_graph *g) {
+  if (!g) return;
+  (void)hipGraphExecDestroy(g->exec);
+  (void)hipGraphDestroy(g->graph);
+  delete g;
+}
 
 extern "C" hm_status hm_timer_start(hm_ctx *c) {
   if (!c) return HM_ERR_ARG;

@@ -84,6 +84,9 @@ private:
   uint32_t n = 0, logN = 0, clusterCount = 1;
   uint32_t maxLevel_ = 0, curLevel_ = 0, world_ = 1, rank_ = 0;
   bool commReady = false;
+  bool useGraph = false;
+  unsigned runCount = 0;
+  void *graph = nullptr;  // hm_graph*: the whole plan captured once, replayed by run()
   std::vector<void *> sliceBuffers;
   hm_ctx *ctx = nullptr;
   uint64_t *pool = nullptr;  // all limb-polys, [limb][N]

@@ -173,6 +173,16 @@ hm_status hm_replicate_limbs(hm_ctx *ctx, uint64_t *buf, const uint32_t *limbs, 
 hm_status hm_fill_uniform(hm_ctx *ctx, uint64_t *out, const uint32_t *out_limbs, const uint32_t *mod_ids,
                           uint32_t n, uint64_t seed);
 
+/* HIP graphs: record everything enqueued on the context's stream between begin and end into a graph and replay it
+ * with one launch (the launch-bound inner loop of an op is a fixed sequence of kernels).  Calls that allocate
+ * (first use of a base-conversion table) must have run once before the capture.  Exchanges through an external
+ * transport cannot be captured. */
+typedef struct hm_graph hm_graph;
+hm_status hm_capture_begin(hm_ctx *ctx);
+hm_status hm_capture_end(hm_ctx *ctx, hm_graph **graph);
+hm_status hm_graph_launch(hm_ctx *ctx, hm_graph *graph);
+void hm_graph_destroy(hm_graph *graph);
+
 /* Timing on the context's stream (replaces Arch::getCycle include/Arch.h:271: elapsed device time in
  * nanoseconds instead of simulated cycles). */
 hm_status hm_timer_start(hm_ctx *ctx);
