@@ -66,6 +66,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--streams", type=int, default=3,
+                    help="independent hmult instances in flight on one GPU (own inputs, HBM pool and HIP stream each); "
+                         "the K timed steps are dealt round-robin over them.  1 = one op at a time (latency mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -86,12 +89,41 @@ def main():
     from homulator_amd import host
     # N > 1: ONE hmult whose limb-polys are sharded over the N GPUs (limb e -> e % N), RCCL all-to-all around the two
     # base conversions + one replicate in the rescale: strong scaling of the op's latency
-    op = host.Op(CFG, OP, L, ELL, ALPHA, device=local_rank, rank=rank, world=world)
+    streams = args.streams if world == 1 else 1
+    ops = [host.Op(CFG, OP, L, ELL, ALPHA, device=local_rank, rank=rank, world=world, overrides={"seed": host.SEED + 7 * i})
+           for i in range(streams)]
+    op = ops[0]
+    transport = "none"
     if world > 1:
-        from homulator_amd.dist import init_rccl
-        init_rccl(op)
-    op.enqueue(args.warmup)
-    op.sync()
+        from homulator_amd import dist as hdist
+        transport = os.environ.get("HOMULATOR_TRANSPORT", "rccl")
+        if transport == "rccl":
+            try:   # the HIP library's own RCCL communicator: ncclSend/ncclRecv groups on its stream (the product path)
+                hdist.init_rccl(op)
+            except Exception as e:   # reported, never silent: the JSON line names the transport actually used
+                print(f"[bench] rank {rank}: private RCCL communicator failed ({e}); using torch.distributed NCCL staging", file=sys.stderr)
+                transport = "torch-nccl-staging"
+        if transport != "rccl":
+            ok = torch.tensor([1 if transport == "rccl" else 0], device="cuda")
+        else:
+            ok = torch.tensor([1], device="cuda")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)   # all ranks must agree on the transport
+        if int(ok.item()) == 0 and transport == "rccl":
+            transport = "torch-nccl-staging"
+        if transport != "rccl":
+            tr = hdist.TorchNcclTransport()
+            op.comm_init_external(tr.cfunc)
+
+    def run(n):   # n hmult steps, round-robin over the in-flight instances; asynchronous
+        for i in range(n):
+            ops[i % streams].enqueue(1)
+
+    def sync_all():
+        for o in ops:
+            o.sync()
+
+    run(max(args.warmup, streams))
+    sync_all()
 
     def barrier():
         if dist is not None:
@@ -100,10 +132,18 @@ def main():
 
     barrier()
     t0 = time.perf_counter()
-    op.enqueue(args.steps)
-    op.sync()
+    run(args.steps)
+    sync_all()
     barrier()
     dt = time.perf_counter() - t0
+    single = None
+    if world == 1 and streams > 1:   # latency mode beside it: one op at a time
+        barrier()
+        t1 = time.perf_counter()
+        op.enqueue(args.steps)
+        op.sync()
+        barrier()
+        single = args.steps / (time.perf_counter() - t1)
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -122,7 +162,9 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": f"{CFG} {OP} L={L} l={ELL} alpha={ALPHA} (N=2^16, beta=3, full hybrid key switch + rescale)",
                        "parallelism": "single GPU" if world == 1 else f"limbs sharded over {world} GPUs (limb e -> e % {world}); RCCL all-to-all around ModUp/ModDown base conversion + replicate of the rescale residue",
-                       "launches_per_op": op.launch_count()},
+                       "launches_per_op": op.launch_count(), "streams": streams, "transport": transport,
+                       "streams_note": "independent hmult instances in flight (own inputs / pool / HIP stream); steps dealt round-robin"},
+            "single_stream_ops_per_s": single,
             "hmult_hbm_gbs_algorithmic": HMULT_ALG_BYTES / (ms * 1e-3) / 1e9,
             "hmult_frac_of_hbm_peak": HMULT_ALG_BYTES / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "roofline": {"bound": "hbm", "kernel": "forward NTT sweep, 50 limbs = k_ntt_pass<COL> + k_ntt_pass<ROW>",
@@ -132,7 +174,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-    op.close()
+    for o in ops:
+        o.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

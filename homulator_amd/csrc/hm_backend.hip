@@ -164,23 +164,17 @@ __global__ void __launch_bounds__(256) k_inner_product(HmIpArgs a) {
 }
 
 template <int N_IN>
-__device__ __forceinline__ void hm_bconv_block(const HmBconvArgs &a, const HmBconvProb &p, uint64_t *tab) {
+__device__ __forceinline__ void hm_bconv_block(const HmBconvArgs &a, const HmBconvProb &p) {
   const uint32_t t0 = blockIdx.y * HM_BCONV_CHUNK;
   if (t0 >= p.n_out) return;
   const uint32_t t1 = min(t0 + HM_BCONV_CHUNK, p.n_out);
-  for (uint32_t e = threadIdx.x; e < N_IN * HM_BCONV_CHUNK; e += HM_BCONV_THREADS) {
-    const uint32_t i = e / HM_BCONV_CHUNK, t = t0 + e % HM_BCONV_CHUNK;
-    tab[e] = t < t1 ? p.table[i * p.n_out + t] : 0;
-  }
-  __syncthreads();
-  hm_bconv_thread<N_IN>(p, a.mods, a.logN, tab, blockIdx.x * HM_BCONV_THREADS + threadIdx.x, t0, t1);
+  hm_bconv_thread<N_IN>(p, a.mods, a.logN, blockIdx.x * HM_BCONV_THREADS + threadIdx.x, t0, t1);
 }
 
 __global__ void __launch_bounds__(HM_BCONV_THREADS) k_bconv(HmBconvArgs a) {
-  __shared__ uint64_t tab[HM_BCONV_MAX_IN * HM_BCONV_CHUNK];
   const HmBconvProb &p = a.prob[blockIdx.z];
   switch (p.n_in) {  // wave-uniform: every block of one problem takes the same case
-#define HM_CASE(n) case n: hm_bconv_block<n>(a, p, tab); break;
+#define HM_CASE(n) case n: hm_bconv_block<n>(a, p); break;
     HM_CASE(1) HM_CASE(2) HM_CASE(3) HM_CASE(4) HM_CASE(5) HM_CASE(6) HM_CASE(7) HM_CASE(8)
     HM_CASE(9) HM_CASE(10) HM_CASE(11) HM_CASE(12) HM_CASE(13) HM_CASE(14) HM_CASE(15) HM_CASE(16)
 #undef HM_CASE
@@ -271,7 +265,11 @@ struct RcclApi {
 static RcclApi g_rccl;
 static const char *rccl_load() {
   if (g_rccl.h) return nullptr;
-  void *h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  // prefer an RCCL that is already mapped into the process (PyTorch ships and loads its own librccl.so): paging in a
+  // second ~0.5 GB copy took minutes on a cold box
+  void *h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
+  if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+  if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
   if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
   if (!h) return "librccl.so not found";
 #define HM_SYM(field, name) g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(h, name)); if (!g_rccl.field) return "RCCL symbol missing: " name;
@@ -765,7 +763,12 @@ extern "C" hm_status hm_bconv_batch(hm_ctx *c, const hm_bconv_desc *descs, uint3
       if (it == c->bconv_tables.end()) {
         std::vector<uint64_t> qh(d.n_in), tb((size_t)d.n_in * d.n_out);
         c->P.bconv_consts(d.in_ids, d.n_in, d.out_ids, d.n_out, qh.data(), tb.data());
-        for (uint64_t &w : tb) w = hm_bconv_pack(w);  // split-30 device format
+        {  // device format: transposed to [n_out][n_in] (one output's factors contiguous: scalar loads), split-30 packed
+          std::vector<uint64_t> tt((size_t)d.n_in * d.n_out);
+          for (uint32_t i = 0; i < d.n_in; ++i)
+            for (uint32_t t = 0; t < d.n_out; ++t) tt[(size_t)t * d.n_in + i] = hm_bconv_pack(tb[(size_t)i * d.n_out + t]);
+          tb.swap(tt);
+        }
         uint64_t *dev = nullptr;
         HM_HIP(c, hipMalloc(&dev, 8ull * d.n_in * d.n_out));
         HM_HIP(c, hipMemcpy(dev, tb.data(), 8ull * d.n_in * d.n_out, hipMemcpyHostToDevice));
@@ -773,10 +776,10 @@ extern "C" hm_status hm_bconv_batch(hm_ctx *c, const hm_bconv_desc *descs, uint3
       }
       HmBconvProb &p = a.prob[pi];
       p.in = d.in; p.out = d.out; p.table = it->second; p.n_in = d.n_in; p.n_out = d.n_out;
-      for (uint32_t i = 0; i < d.n_in; ++i) p.in_limb[i] = (uint16_t)limb_at(d.in_limbs, i);
+      for (uint32_t i = 0; i < d.n_in; ++i) p.in_limb[i] = limb_at(d.in_limbs, i);
       for (uint32_t t = 0; t < d.n_out; ++t) {
-        p.out_limb[t] = (uint16_t)limb_at(d.out_limbs, t);
-        p.out_mod[t] = (uint16_t)d.out_ids[t];
+        p.out_limb[t] = limb_at(d.out_limbs, t);
+        p.out_mod[t] = d.out_ids[t];
       }
       max_out = std::max(max_out, d.n_out);
     }

@@ -103,16 +103,19 @@ struct HmIpArgs {
 #define HM_BCONV_MAX_IN 16
 #define HM_BCONV_MAX_OUT 64
 #define HM_BCONV_MAX_PROB 4
-#define HM_BCONV_CHUNK 8    // output limbs per block (table slice staged in LDS)
+#define HM_BCONV_CHUNK 8    // output limbs per block
 #define HM_BCONV_THREADS 256
 struct HmBconvProb {
   const uint64_t *in;
   uint64_t *out;
-  const uint64_t *table;  // device, [n_in][n_out] row-major
+  const uint64_t *table;  // device, [n_out][n_in], entries packed by hm_bconv_pack
   uint32_t n_in, n_out;
-  uint16_t in_limb[HM_BCONV_MAX_IN];
-  uint16_t out_limb[HM_BCONV_MAX_OUT];
-  uint16_t out_mod[HM_BCONV_MAX_OUT];
+  // 32-bit entries: indexed by the (wave-uniform) output counter, they must be scalar loads from the kernarg
+  // segment; 16-bit entries made hipcc emit a VECTOR load per output, and the modulus record load that depends on it
+  // was a second serialised global-memory round trip per output (the kernel was latency-bound on these two loads)
+  uint32_t in_limb[HM_BCONV_MAX_IN];
+  uint32_t out_limb[HM_BCONV_MAX_OUT];
+  uint32_t out_mod[HM_BCONV_MAX_OUT];
 };
 struct HmBconvArgs {
   const HmMod *mods;
@@ -126,11 +129,31 @@ struct HmBconvArgs {
 // output.  Device table entries are pre-split: low word = w0, high word = w1 (hm_bconv_pack).
 HM_HD uint64_t hm_bconv_pack(uint64_t w) { return (w & 0x3FFFFFFFull) | ((w >> 30) << 32); }
 
-// coefficient x for outputs [t0, t1); tab = packed table slice [N_IN][HM_BCONV_CHUNK]
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const HmMod __attribute__((address_space(4))) *HmConstMod;
+#define HM_CONST_MODS(p) ((HmConstMod)(uintptr_t)(p))
+#else
+typedef const HmMod *HmConstMod;
+#define HM_CONST_MODS(p) (p)
+#endif
+// The conversion table is read through the SCALAR cache: every lane of a wave needs the same entries, so they are
+// s_load'ed into SGPRs (asynchronously, no VGPRs, no LDS, no barrier) and feed v_mad_u64_u32 as scalar operands.
+// hipcc only emits scalar loads for memory it knows to be constant, hence the constant-address-space view of the
+// table pointer.  Device layout: [n_out][n_in] packed entries (a row = the n_in factors of one output limb).
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const uint64_t __attribute__((address_space(4))) *HmConstU64;
+#define HM_CONST_VIEW(p) ((HmConstU64)(uintptr_t)(p))
+#else
+typedef const uint64_t *HmConstU64;
+#define HM_CONST_VIEW(p) (p)
+#endif
+
+// coefficient x for outputs [t0, t1)
 template <int N_IN>
-HM_HD void hm_bconv_thread(const HmBconvProb &p, const HmMod *mods, uint32_t logN, const uint64_t *tab, uint32_t x,
-                           uint32_t t0, uint32_t t1) {
+HM_HD void hm_bconv_thread(const HmBconvProb &p, const HmMod *mods, uint32_t logN, uint32_t x, uint32_t t0, uint32_t t1) {
   const size_t N = (size_t)1 << logN;
+  HmConstU64 tab = HM_CONST_VIEW(p.table);
+  HmConstMod cmods = HM_CONST_MODS(mods);
   uint32_t yl[N_IN], yh[N_IN];
 #pragma unroll
   for (int i = 0; i < N_IN; ++i) {
@@ -139,20 +162,19 @@ HM_HD void hm_bconv_thread(const HmBconvProb &p, const HmMod *mods, uint32_t log
     yh[i] = (uint32_t)(v >> 30);
   }
   for (uint32_t t = t0; t < t1; ++t) {
-    uint64_t w[N_IN];
-#pragma unroll
-    for (int i = 0; i < N_IN; ++i) w[i] = tab[i * HM_BCONV_CHUNK + (t - t0)];
     uint64_t s00 = 0, s01 = 0, s10 = 0, s11 = 0;
 #pragma unroll
     for (int i = 0; i < N_IN; ++i) {
-      const uint32_t wl = (uint32_t)w[i], wh = (uint32_t)(w[i] >> 32);
+      const uint64_t w = tab[t * N_IN + i];
+      const uint32_t wl = (uint32_t)w, wh = (uint32_t)(w >> 32);
       s00 += (uint64_t)yl[i] * wl;
       s01 += (uint64_t)yl[i] * wh;
       s10 += (uint64_t)yh[i] * wl;
       s11 += (uint64_t)yh[i] * wh;
     }
     const hm_u128 acc = (hm_u128)s00 + (((hm_u128)s01 + s10) << 30) + ((hm_u128)s11 << 60);
-    p.out[(size_t)p.out_limb[t] * N + x] = hm_barrett_wide(acc, mods[p.out_mod[t]]);
+    const HmMod m = cmods[p.out_mod[t]];
+    p.out[(size_t)p.out_limb[t] * N + x] = hm_barrett_wide(acc, m);
   }
 }
 

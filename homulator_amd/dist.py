@@ -45,17 +45,34 @@ def host_memcpy():
     return cp, cp
 
 
+def _hip_memcpy_d2d():
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipMemcpy.restype = C.c_int
+
+    def cp(dst, src, n):
+        if hip.hipMemcpy(dst, src, n, 3):
+            raise RuntimeError("hipMemcpy D2D failed")
+    return cp, cp
+
+
 class GlooTransport:
     """hm_exchange_fn implemented with torch.distributed P2P ops on host staging tensors."""
+
+    staging_device = "cpu"
 
     def __init__(self, group=None, memcpy=None):
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
-        self.d2h, self.h2d = memcpy if memcpy is not None else _hip_memcpy()
+        self.d2h, self.h2d = memcpy if memcpy is not None else self._default_memcpy()
         self.calls = 0
         self.bytes_sent = 0
         self.cfunc = EXCHANGE_FN(self._exchange)
+
+    @staticmethod
+    def _default_memcpy():
+        return _hip_memcpy()
 
     def _exchange(self, user, send_dev, send_off, send_bytes, recv_dev, recv_off, recv_bytes):
         try:
@@ -65,18 +82,20 @@ class GlooTransport:
                     continue
                 nb = send_bytes[p]
                 if nb:
-                    t = torch.empty(nb, dtype=torch.uint8)
+                    t = torch.empty(nb, dtype=torch.uint8, device=self.staging_device)
                     self.d2h(t.data_ptr(), send_dev + send_off[p], nb)
                     ops.append(dist.P2POp(dist.isend, t, p, self.group))
                     self.bytes_sent += nb
                 nb = recv_bytes[p]
                 if nb:
-                    r = torch.empty(nb, dtype=torch.uint8)
+                    r = torch.empty(nb, dtype=torch.uint8, device=self.staging_device)
                     ops.append(dist.P2POp(dist.irecv, r, p, self.group))
                     recvs.append((r, recv_off[p], nb))
             if ops:
                 for w in dist.batch_isend_irecv(ops):
                     w.wait()
+                if self.staging_device != "cpu":
+                    torch.cuda.synchronize()
             for r, off, nb in recvs:
                 self.h2d(recv_dev + off, r.data_ptr(), nb)
             self.calls += 1
@@ -84,3 +103,13 @@ class GlooTransport:
         except Exception as e:  # never let an exception cross the C boundary
             print("GlooTransport failed:", repr(e), flush=True)
             return 1
+
+
+class TorchNcclTransport(GlooTransport):
+    """the same exchange through torch.distributed's own NCCL (= RCCL) process group on device staging tensors: a
+    fallback for multi-GPU runs when the HIP library's private communicator cannot be created.  Slower than
+    hm_comm_init_rccl (host synchronisation per exchange), never used silently: bench.py labels it."""
+
+    def __init__(self, group=None):
+        self.staging_device = torch.device("cuda", torch.cuda.current_device())
+        super().__init__(group, memcpy=_hip_memcpy_d2d())

@@ -48,14 +48,13 @@ static void run_ntt(const Emu &e, uint32_t mod, const uint64_t *in, uint64_t *ou
 
 template <int N_IN>
 static void emu_bconv_n(Emu &e, HmBconvProb &p, const std::vector<uint64_t> &tb) {
-  std::vector<uint64_t> tab(HM_BCONV_MAX_IN * HM_BCONV_CHUNK);
+  std::vector<uint64_t> tt((size_t)p.n_in * p.n_out);  // device format: [n_out][n_in], packed
+  for (uint32_t i = 0; i < p.n_in; ++i)
+    for (uint32_t t = 0; t < p.n_out; ++t) tt[(size_t)t * p.n_in + i] = hm_bconv_pack(tb[(size_t)i * p.n_out + t]);
+  p.table = tt.data();
   for (uint32_t t0 = 0; t0 < p.n_out; t0 += HM_BCONV_CHUNK) {
     uint32_t t1 = t0 + HM_BCONV_CHUNK < p.n_out ? t0 + HM_BCONV_CHUNK : p.n_out;
-    for (uint32_t el = 0; el < N_IN * HM_BCONV_CHUNK; ++el) {
-      uint32_t i = el / HM_BCONV_CHUNK, t = t0 + el % HM_BCONV_CHUNK;
-      tab[el] = t < t1 ? hm_bconv_pack(tb[i * p.n_out + t]) : 0;
-    }
-    for (uint32_t x = 0; x < e.P.N; ++x) hm_bconv_thread<N_IN>(p, e.P.modc.data(), e.P.logN, tab.data(), x, t0, t1);
+    for (uint32_t x = 0; x < e.P.N; ++x) hm_bconv_thread<N_IN>(p, e.P.modc.data(), e.P.logN, x, t0, t1);
   }
 }
 
@@ -144,8 +143,8 @@ void emu_bconv(void *h, const uint32_t *in_ids, uint32_t n_in, const uint32_t *o
   e.P.bconv_consts(in_ids, n_in, out_ids, n_out, qh.data(), tb.data());
   HmBconvProb p;
   p.in = in; p.out = out; p.table = tb.data(); p.n_in = n_in; p.n_out = n_out;
-  for (uint32_t i = 0; i < n_in; ++i) p.in_limb[i] = (uint16_t)i;
-  for (uint32_t t = 0; t < n_out; ++t) { p.out_limb[t] = (uint16_t)t; p.out_mod[t] = (uint16_t)out_ids[t]; }
+  for (uint32_t i = 0; i < n_in; ++i) p.in_limb[i] = i;
+  for (uint32_t t = 0; t < n_out; ++t) { p.out_limb[t] = t; p.out_mod[t] = out_ids[t]; }
   switch (n_in) {
 #define HM_CASE(n) case n: emu_bconv_n<n>(e, p, tb); break;
     HM_CASE(1) HM_CASE(2) HM_CASE(3) HM_CASE(4) HM_CASE(5) HM_CASE(6) HM_CASE(7) HM_CASE(8)

@@ -25,6 +25,7 @@ def test_rccl_loads_and_world1_communicator():
     """the RCCL transport itself cannot run two ranks on one GPU; check that librccl loads, a unique id can be drawn,
     a 1-rank communicator is created inside the HIP library and the op still runs bit-exact with it"""
     import numpy as np
+    import torch  # noqa: F401  (maps PyTorch's own librccl.so, which the HIP library then reuses instead of loading another copy)
     from homulator_amd import host
     from oracle.homoracle import Oracle
     uid = host.rccl_unique_id()
