@@ -24,6 +24,10 @@ LP = (1 << LOGN) * 8                       # one limb-poly, bytes
 HMULT_ALG_BYTES = 1_102_577_664            # 2 103 LP
 NTT_ALG_BYTES = 2 * LP                     # per limb-NTT
 HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md
+# HBM bytes of one 50-limb forward NTT sweep from the PMC counters (profiles/r01_pmc_ntt_sweep.txt: separate --pmc passes;
+# FETCH_SIZE in KiB doubled as MI355X_MICROARCH.md §HBM prescribes for gfx950, WRITE_SIZE in KiB exact):
+#   ROW pass FETCH 38 370 KiB x 2 (data + 16-byte twiddles), COL pass FETCH 12 970 KiB x 2, WRITE 25 600 KiB per pass
+NTT_SWEEP50_TRAFFIC_BYTES = int((38370 * 2 + 12970 * 2 + 25600 * 2) * 1024)
 
 
 def measure_ntt_sweep(n_limbs, iters=50):
@@ -169,7 +173,7 @@ def main():
             "hmult_frac_of_hbm_peak": HMULT_ALG_BYTES / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "roofline": {"bound": "hbm", "kernel": "forward NTT sweep, 50 limbs = k_ntt_pass<COL> + k_ntt_pass<ROW>",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "us_per_launch": ntt_ns * 1e-3,
+                         "traffic": NTT_SWEEP50_TRAFFIC_BYTES if sweep_limbs == 50 else None, "us_per_launch": ntt_ns * 1e-3,
                          "algorithmic_bytes_per_launch": NTT_ALG_BYTES * sweep_limbs},
         }
         if world == 1 and not args.no_cpu_baseline:
