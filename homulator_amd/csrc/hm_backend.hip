@@ -177,6 +177,8 @@ __global__ void __launch_bounds__(HM_BCONV_THREADS) k_bconv(HmBconvArgs a) {
 #define HM_CASE(n) case n: hm_bconv_block<n>(a, p); break;
     HM_CASE(1) HM_CASE(2) HM_CASE(3) HM_CASE(4) HM_CASE(5) HM_CASE(6) HM_CASE(7) HM_CASE(8)
     HM_CASE(9) HM_CASE(10) HM_CASE(11) HM_CASE(12) HM_CASE(13) HM_CASE(14) HM_CASE(15) HM_CASE(16)
+    HM_CASE(17) HM_CASE(18) HM_CASE(19) HM_CASE(20) HM_CASE(21) HM_CASE(22) HM_CASE(23) HM_CASE(24)
+    HM_CASE(25) HM_CASE(26) HM_CASE(27) HM_CASE(28) HM_CASE(29) HM_CASE(30) HM_CASE(31) HM_CASE(32)
 #undef HM_CASE
   }
 }

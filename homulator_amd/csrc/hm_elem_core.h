@@ -100,7 +100,7 @@ struct HmIpArgs {
 // ---- K4 base conversion: out[t][x] = sum_i in[i][x] * table[i][t] mod q_t
 // One launch carries up to HM_BCONV_MAX_PROB independent conversions (the beta digits of a ModUp, the two
 // keys of a ModDown): grid = (N / HM_BCONV_THREADS, output chunks, problems); one coefficient per thread.
-#define HM_BCONV_MAX_IN 16
+#define HM_BCONV_MAX_IN 32   // parameter set A converts from a 28-limb basis (alpha = 28)
 #define HM_BCONV_MAX_OUT 64
 #define HM_BCONV_MAX_PROB 4
 #define HM_BCONV_CHUNK 8    // output limbs per block
@@ -162,17 +162,21 @@ HM_HD void hm_bconv_thread(const HmBconvProb &p, const HmMod *mods, uint32_t log
     yh[i] = (uint32_t)(v >> 30);
   }
   for (uint32_t t = t0; t < t1; ++t) {
-    uint64_t s00 = 0, s01 = 0, s10 = 0, s11 = 0;
+    hm_u128 acc = 0;
 #pragma unroll
-    for (int i = 0; i < N_IN; ++i) {
-      const uint64_t w = tab[t * N_IN + i];
-      const uint32_t wl = (uint32_t)w, wh = (uint32_t)(w >> 32);
-      s00 += (uint64_t)yl[i] * wl;
-      s01 += (uint64_t)yl[i] * wh;
-      s10 += (uint64_t)yh[i] * wl;
-      s11 += (uint64_t)yh[i] * wh;
+    for (int g = 0; g < N_IN; g += 16) {  // 16 terms per carry-free column group (each column stays below 2^64)
+      uint64_t s00 = 0, s01 = 0, s10 = 0, s11 = 0;
+#pragma unroll
+      for (int i = g; i < (g + 16 < N_IN ? g + 16 : N_IN); ++i) {
+        const uint64_t w = tab[t * N_IN + i];
+        const uint32_t wl = (uint32_t)w, wh = (uint32_t)(w >> 32);
+        s00 += (uint64_t)yl[i] * wl;
+        s01 += (uint64_t)yl[i] * wh;
+        s10 += (uint64_t)yh[i] * wl;
+        s11 += (uint64_t)yh[i] * wh;
+      }
+      acc += (hm_u128)s00 + (((hm_u128)s01 + s10) << 30) + ((hm_u128)s11 << 60);   // 32 products of < 2^120: below 2^125
     }
-    const hm_u128 acc = (hm_u128)s00 + (((hm_u128)s01 + s10) << 30) + ((hm_u128)s11 << 60);
     const HmMod m = cmods[p.out_mod[t]];
     p.out[(size_t)p.out_limb[t] * N + x] = hm_barrett_wide(acc, m);
   }

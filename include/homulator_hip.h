@@ -116,7 +116,7 @@ hm_status hm_inner_product(hm_ctx *ctx, const uint64_t *x, const uint32_t *x_lim
                            const uint32_t *mod_ids, uint32_t n, uint32_t n_terms, uint32_t n_out);
 
 /* K4 — fast base conversion, matrix step: out_t = sum_i in_i * [Q_D / q_i]_t mod t for the input
- * basis in_ids (n_in <= 16) and output basis out_ids (n_out <= 64).  `in` must already hold
+ * basis in_ids (n_in <= 32) and output basis out_ids (n_out <= 64).  `in` must already hold
  * y_i = x_i * [(Q_D/q_i)^-1]_{q_i} (hm_ntt's scale or HM_OP_MUL_CONST with hm_bconv_consts).
  * Replaces issueIns(cluster, h, w, group, ...) include/Arch.h:277 for InsGen::GenBCONV
  * (src/InsGen.cpp:263-313; stages src/Operation.cpp:137-188, 489-519). */

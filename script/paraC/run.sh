@@ -1,0 +1,3 @@
+#!/bin/bash
+# same entry point as the reference script/paraC/run.sh: all five operations on 4 clusters
+python3 "$(dirname "$0")/../sweep.py" --set C --cluster "${1:-4}"

@@ -147,6 +147,24 @@ def test_emu_ewe_bconv_auto_fill(emu):
         emu.emu_destroy(h)
 
 
+def test_emu_bconv_28_inputs_parameter_set_A(emu):
+    """alpha = 28 (parameter set A): two carry-free column groups per output, all inputs at q_i - 1"""
+    logN, L, K = 13, 30, 28
+    o = Oracle(logN, L, K)
+    h = emu.emu_create(logN, L, K)
+    try:
+        in_ids, out_ids = [L + i for i in range(28)], [0, 1, 2, 29]
+        x = o.fill_uniform(in_ids, 5)
+        for r, m in enumerate(in_ids):
+            x[r, :8] = o.moduli[m] - 1
+        ii, oi = np.array(in_ids, dtype=np.uint32), np.array(out_ids, dtype=np.uint32)
+        out = np.empty((len(out_ids), o.N), dtype=np.uint64)
+        emu.emu_bconv(h, p(ii), 28, p(oi), len(oi), p(x), p(out))
+        assert np.array_equal(out, o.bconv_matmul(in_ids, out_ids, x))
+    finally:
+        emu.emu_destroy(h)
+
+
 def test_emu_bconv_widest_accumulator(emu):
     """16 input limbs all at q_i - 1: the 128-bit accumulator reaches ~2^124 (fold path of hm_barrett_wide)."""
     logN, L, K = 13, 20, 2
