@@ -89,6 +89,7 @@ private:
   void *graph = nullptr;  // hm_graph*: the whole plan captured once, replayed by run()
   std::vector<void *> sliceBuffers;
   hm_ctx *ctx = nullptr;
+  void *hostParams = nullptr;  // hm::Params: moduli / roots / conversion constants on the host (both backends)
   uint64_t *pool = nullptr;  // all limb-polys, [limb][N]
   std::map<AddrType, uint32_t> limbIndex;
   std::vector<Stage> stages;

@@ -29,10 +29,7 @@ struct Arch::Launch {
   unsigned long long bytes = 0;  // operand limb-polys read + written x N x 8
 };
 
-struct ArchHost {
-  hm::Params P;
-};
-static std::map<const Arch *, ArchHost *> g_host;  // host-side parameter set per Arch (kept out of the header)
+static hm::Params &hostP(void *p) { return *static_cast<hm::Params *>(p); }
 
 Arch::Arch(Config *cfg) : config(cfg) {
   n = cfg->getValue("N");
@@ -62,11 +59,7 @@ Arch::~Arch() {
     if (pool) hm_free(ctx, pool);
     hm_destroy(ctx);
   }
-  auto it = g_host.find(this);
-  if (it != g_host.end()) {
-    delete it->second;
-    g_host.erase(it);
-  }
+  delete static_cast<hm::Params *>(hostParams);
   delete stat;
 }
 
@@ -85,10 +78,10 @@ void Arch::commInitExternal(void *fn, void *user) {
 void Arch::bindParams(uint32_t maxLevel, uint32_t curLevel, uint32_t alpha) {
   maxLevel_ = maxLevel;
   curLevel_ = curLevel;
-  if (g_host.count(this)) return;
-  ArchHost *h = new ArchHost;
-  h->P.init(logN, maxLevel, alpha, nullptr, nullptr, nullptr);
-  g_host[this] = h;
+  if (hostParams) return;
+  hm::Params *hp = new hm::Params;
+  hp->init(logN, maxLevel, alpha, nullptr, nullptr, nullptr);
+  hostParams = hp;
   if (backendKind == BACKEND_HIP) {
     hm_params p = {logN, maxLevel, alpha, (int32_t)config->getValueOr("device", 0), nullptr, nullptr, nullptr};
     if (const char *e = getenv("HOMULATOR_DEVICE")) p.device = atoi(e);
@@ -97,11 +90,11 @@ void Arch::bindParams(uint32_t maxLevel, uint32_t curLevel, uint32_t alpha) {
   }
 }
 
-uint64_t Arch::modulus(uint32_t modId) const { return g_host.at(this)->P.mod.at(modId); }
+uint64_t Arch::modulus(uint32_t modId) const { return hostP(hostParams).mod.at(modId); }
 
 std::vector<uint64_t> Arch::bconvScale(const std::vector<uint32_t> &inMods) {
   std::vector<uint64_t> qh(inMods.size()), tb(inMods.size());
-  g_host.at(this)->P.bconv_consts(inMods.data(), (uint32_t)inMods.size(), nullptr, 0, qh.data(), tb.data());
+  hostP(hostParams).bconv_consts(inMods.data(), (uint32_t)inMods.size(), nullptr, 0, qh.data(), tb.data());
   return qh;
 }
 

