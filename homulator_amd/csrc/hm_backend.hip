@@ -163,25 +163,25 @@ __global__ void __launch_bounds__(256) k_inner_product(HmIpArgs a) {
   }
 }
 
+// One kernel per input-basis size: a single kernel switching over n_in is allocated for its largest case (140 VGPRs
+// at 32 inputs) and hipcc left the per-case input arrays in scratch; every problem of a launch has the same n_in.
 template <int N_IN>
-__device__ __forceinline__ void hm_bconv_block(const HmBconvArgs &a, const HmBconvProb &p) {
+__global__ void __launch_bounds__(HM_BCONV_THREADS) k_bconv(HmBconvArgs a) {
+  const HmBconvProb &p = a.prob[blockIdx.z];
   const uint32_t t0 = blockIdx.y * HM_BCONV_CHUNK;
   if (t0 >= p.n_out) return;
   const uint32_t t1 = min(t0 + HM_BCONV_CHUNK, p.n_out);
   hm_bconv_thread<N_IN>(p, a.mods, a.logN, blockIdx.x * HM_BCONV_THREADS + threadIdx.x, t0, t1);
 }
-
-__global__ void __launch_bounds__(HM_BCONV_THREADS) k_bconv(HmBconvArgs a) {
-  const HmBconvProb &p = a.prob[blockIdx.z];
-  switch (p.n_in) {  // wave-uniform: every block of one problem takes the same case
-#define HM_CASE(n) case n: hm_bconv_block<n>(a, p); break;
-    HM_CASE(1) HM_CASE(2) HM_CASE(3) HM_CASE(4) HM_CASE(5) HM_CASE(6) HM_CASE(7) HM_CASE(8)
-    HM_CASE(9) HM_CASE(10) HM_CASE(11) HM_CASE(12) HM_CASE(13) HM_CASE(14) HM_CASE(15) HM_CASE(16)
-    HM_CASE(17) HM_CASE(18) HM_CASE(19) HM_CASE(20) HM_CASE(21) HM_CASE(22) HM_CASE(23) HM_CASE(24)
-    HM_CASE(25) HM_CASE(26) HM_CASE(27) HM_CASE(28) HM_CASE(29) HM_CASE(30) HM_CASE(31) HM_CASE(32)
-#undef HM_CASE
-  }
-}
+typedef void (*hm_bconv_kernel)(HmBconvArgs);
+static const hm_bconv_kernel k_bconv_by_n_in[HM_BCONV_MAX_IN + 1] = {
+    nullptr,
+#define HM_K(n) k_bconv<n>,
+    HM_K(1) HM_K(2) HM_K(3) HM_K(4) HM_K(5) HM_K(6) HM_K(7) HM_K(8) HM_K(9) HM_K(10) HM_K(11) HM_K(12) HM_K(13) HM_K(14)
+    HM_K(15) HM_K(16) HM_K(17) HM_K(18) HM_K(19) HM_K(20) HM_K(21) HM_K(22) HM_K(23) HM_K(24) HM_K(25) HM_K(26)
+    HM_K(27) HM_K(28) HM_K(29) HM_K(30) HM_K(31) HM_K(32)
+#undef HM_K
+};
 
 // strided chunk copy used to pack / unpack the exchange buffers: chunk c copies `len` words
 #define HM_MAX_CHUNKS 512
@@ -736,57 +736,72 @@ extern "C" hm_status hm_bconv_batch(hm_ctx *c, const hm_bconv_desc *descs, uint3
   if (!c) return HM_ERR_ARG;
   if (!descs || n_desc == 0) return fail(c, HM_ERR_ARG, "hm_bconv_batch: no problems");
   HM_HIP(c, hipSetDevice(c->device));
-  for (uint32_t base = 0; base < n_desc; base += HM_BCONV_MAX_PROB) {
-    const uint32_t cnt = std::min<uint32_t>(HM_BCONV_MAX_PROB, n_desc - base);
-    HmBconvArgs a;
-    a.mods = c->d_mods; a.n_prob = cnt;
-    a.logN = descs[base].log_len ? descs[base].log_len : c->P.logN;
-    if (a.logN < 8 || a.logN > c->P.logN) return fail(c, HM_ERR_ARG, "hm_bconv: log_len %u", a.logN);
-    uint32_t max_out = 0;
-    for (uint32_t pi = 0; pi < cnt; ++pi) {
-      const hm_bconv_desc &d = descs[base + pi];
-      if (!d.in || !d.out) return fail(c, HM_ERR_ARG, "hm_bconv: null buffer");
-      if ((d.log_len ? d.log_len : c->P.logN) != a.logN) return fail(c, HM_ERR_ARG, "hm_bconv_batch: mixed log_len");
-      if (d.n_in == 0 || d.n_in > HM_BCONV_MAX_IN) return fail(c, HM_ERR_ARG, "hm_bconv: n_in %u not in [1,%d]", d.n_in, HM_BCONV_MAX_IN);
-      if (d.n_out == 0 || d.n_out > HM_BCONV_MAX_OUT) return fail(c, HM_ERR_ARG, "hm_bconv: n_out %u not in [1,%d]", d.n_out, HM_BCONV_MAX_OUT);
-      hm_status st;
-      if ((st = check_limbs(c, "hm_bconv", d.in_limbs, d.n_in)) || (st = check_limbs(c, "hm_bconv", d.out_limbs, d.n_out)) ||
-          (st = check_mods(c, "hm_bconv", d.in_ids, d.n_in)) || (st = check_mods(c, "hm_bconv", d.out_ids, d.n_out)))
-        return st;
-      for (uint32_t i = 0; i < d.n_in; ++i)
-        for (uint32_t t = 0; t < d.n_out; ++t)
-          if (d.in_ids[i] == d.out_ids[t]) return fail(c, HM_ERR_ARG, "hm_bconv: modulus %u is in both bases", d.in_ids[i]);
-      // conversion tables are cached per (input basis, output basis); built and uploaded on first use
-      std::vector<uint32_t> key;
-      key.push_back(d.n_in);
-      key.insert(key.end(), d.in_ids, d.in_ids + d.n_in);
-      key.insert(key.end(), d.out_ids, d.out_ids + d.n_out);
-      auto it = c->bconv_tables.find(key);
-      if (it == c->bconv_tables.end()) {
-        std::vector<uint64_t> qh(d.n_in), tb((size_t)d.n_in * d.n_out);
-        c->P.bconv_consts(d.in_ids, d.n_in, d.out_ids, d.n_out, qh.data(), tb.data());
-        {  // device format: transposed to [n_out][n_in] (one output's factors contiguous: scalar loads), split-30 packed
-          std::vector<uint64_t> tt((size_t)d.n_in * d.n_out);
-          for (uint32_t i = 0; i < d.n_in; ++i)
-            for (uint32_t t = 0; t < d.n_out; ++t) tt[(size_t)t * d.n_in + i] = hm_bconv_pack(tb[(size_t)i * d.n_out + t]);
-          tb.swap(tt);
-        }
-        uint64_t *dev = nullptr;
-        HM_HIP(c, hipMalloc(&dev, 8ull * d.n_in * d.n_out));
-        HM_HIP(c, hipMemcpy(dev, tb.data(), 8ull * d.n_in * d.n_out, hipMemcpyHostToDevice));
-        it = c->bconv_tables.emplace(key, dev).first;
+  const uint32_t logN = descs[0].log_len ? descs[0].log_len : c->P.logN;
+  if (logN < 8 || logN > c->P.logN) return fail(c, HM_ERR_ARG, "hm_bconv: log_len %u", logN);
+  std::vector<HmBconvProb> probs(n_desc);
+  for (uint32_t pi = 0; pi < n_desc; ++pi) {
+    const hm_bconv_desc &d = descs[pi];
+    if (!d.in || !d.out) return fail(c, HM_ERR_ARG, "hm_bconv: null buffer");
+    if ((d.log_len ? d.log_len : c->P.logN) != logN) return fail(c, HM_ERR_ARG, "hm_bconv_batch: mixed log_len");
+    if (d.n_in == 0 || d.n_in > HM_BCONV_MAX_IN) return fail(c, HM_ERR_ARG, "hm_bconv: n_in %u not in [1,%d]", d.n_in, HM_BCONV_MAX_IN);
+    if (d.n_out == 0 || d.n_out > HM_BCONV_MAX_OUT) return fail(c, HM_ERR_ARG, "hm_bconv: n_out %u not in [1,%d]", d.n_out, HM_BCONV_MAX_OUT);
+    hm_status st;
+    if ((st = check_limbs(c, "hm_bconv", d.in_limbs, d.n_in)) || (st = check_limbs(c, "hm_bconv", d.out_limbs, d.n_out)) ||
+        (st = check_mods(c, "hm_bconv", d.in_ids, d.n_in)) || (st = check_mods(c, "hm_bconv", d.out_ids, d.n_out)))
+      return st;
+    for (uint32_t i = 0; i < d.n_in; ++i)
+      for (uint32_t t = 0; t < d.n_out; ++t)
+        if (d.in_ids[i] == d.out_ids[t]) return fail(c, HM_ERR_ARG, "hm_bconv: modulus %u is in both bases", d.in_ids[i]);
+    // conversion tables are cached per (input basis, output basis); built and uploaded on first use
+    std::vector<uint32_t> key;
+    key.push_back(d.n_in);
+    key.insert(key.end(), d.in_ids, d.in_ids + d.n_in);
+    key.insert(key.end(), d.out_ids, d.out_ids + d.n_out);
+    auto it = c->bconv_tables.find(key);
+    if (it == c->bconv_tables.end()) {
+      std::vector<uint64_t> qh(d.n_in), tb((size_t)d.n_in * d.n_out);
+      c->P.bconv_consts(d.in_ids, d.n_in, d.out_ids, d.n_out, qh.data(), tb.data());
+      {  // device format: transposed to [n_out][n_in] (one output's factors contiguous: scalar loads), split-30 packed
+        std::vector<uint64_t> tt((size_t)d.n_in * d.n_out);
+        for (uint32_t i = 0; i < d.n_in; ++i)
+          for (uint32_t t = 0; t < d.n_out; ++t) tt[(size_t)t * d.n_in + i] = hm_bconv_pack(tb[(size_t)i * d.n_out + t]);
+        tb.swap(tt);
       }
-      HmBconvProb &p = a.prob[pi];
-      p.in = d.in; p.out = d.out; p.table = it->second; p.n_in = d.n_in; p.n_out = d.n_out;
-      for (uint32_t i = 0; i < d.n_in; ++i) p.in_limb[i] = limb_at(d.in_limbs, i);
-      for (uint32_t t = 0; t < d.n_out; ++t) {
-        p.out_limb[t] = limb_at(d.out_limbs, t);
-        p.out_mod[t] = d.out_ids[t];
-      }
-      max_out = std::max(max_out, d.n_out);
+      uint64_t *dev = nullptr;
+      HM_HIP(c, hipMalloc(&dev, 8ull * d.n_in * d.n_out));
+      HM_HIP(c, hipMemcpy(dev, tb.data(), 8ull * d.n_in * d.n_out, hipMemcpyHostToDevice));
+      it = c->bconv_tables.emplace(key, dev).first;
     }
-    dim3 grid((1u << a.logN) / HM_BCONV_THREADS, (max_out + HM_BCONV_CHUNK - 1) / HM_BCONV_CHUNK, cnt);
-    hipLaunchKernelGGL(k_bconv, grid, dim3(HM_BCONV_THREADS), 0, c->stream, a);
+    HmBconvProb &p = probs[pi];
+    p.in = d.in; p.out = d.out; p.table = it->second; p.n_in = d.n_in; p.n_out = d.n_out;
+    for (uint32_t i = 0; i < d.n_in; ++i) p.in_limb[i] = limb_at(d.in_limbs, i);
+    for (uint32_t t = 0; t < d.n_out; ++t) {
+      p.out_limb[t] = limb_at(d.out_limbs, t);
+      p.out_mod[t] = d.out_ids[t];
+    }
+  }
+  // one launch per distinct input-basis size (the digits of a ModUp differ only in the last, shorter digit),
+  // up to HM_BCONV_MAX_PROB problems each
+  std::vector<char> done(n_desc, 0);
+  for (uint32_t first = 0; first < n_desc; ++first) {
+    if (done[first]) continue;
+    const uint32_t n_in = probs[first].n_in;
+    HmBconvArgs a;
+    a.mods = c->d_mods; a.logN = logN; a.n_prob = 0;
+    uint32_t max_out = 0;
+    auto launch = [&]() {
+      dim3 grid((1u << logN) / HM_BCONV_THREADS, (max_out + HM_BCONV_CHUNK - 1) / HM_BCONV_CHUNK, a.n_prob);
+      hipLaunchKernelGGL(k_bconv_by_n_in[n_in], grid, dim3(HM_BCONV_THREADS), 0, c->stream, a);
+      a.n_prob = 0; max_out = 0;
+    };
+    for (uint32_t pi = first; pi < n_desc; ++pi) {
+      if (done[pi] || probs[pi].n_in != n_in) continue;
+      done[pi] = 1;
+      a.prob[a.n_prob++] = probs[pi];
+      max_out = std::max(max_out, probs[pi].n_out);
+      if (a.n_prob == HM_BCONV_MAX_PROB) launch();
+    }
+    if (a.n_prob) launch();
     HM_HIP(c, hipGetLastError());
   }
   return HM_OK;

@@ -163,17 +163,21 @@ HM_HD void hm_bconv_thread(const HmBconvProb &p, const HmMod *mods, uint32_t log
   }
   for (uint32_t t = t0; t < t1; ++t) {
     hm_u128 acc = 0;
+    constexpr int GROUPS = (N_IN + 15) / 16;  // 16 terms per carry-free column group (each column stays below 2^64)
 #pragma unroll
-    for (int g = 0; g < N_IN; g += 16) {  // 16 terms per carry-free column group (each column stays below 2^64)
+    for (int g = 0; g < GROUPS; ++g) {
       uint64_t s00 = 0, s01 = 0, s10 = 0, s11 = 0;
 #pragma unroll
-      for (int i = g; i < (g + 16 < N_IN ? g + 16 : N_IN); ++i) {
-        const uint64_t w = tab[t * N_IN + i];
-        const uint32_t wl = (uint32_t)w, wh = (uint32_t)(w >> 32);
-        s00 += (uint64_t)yl[i] * wl;
-        s01 += (uint64_t)yl[i] * wh;
-        s10 += (uint64_t)yh[i] * wl;
-        s11 += (uint64_t)yh[i] * wh;
+      for (int j = 0; j < 16; ++j) {
+        const int i = g * 16 + j;
+        if (i < N_IN) {
+          const uint64_t w = tab[t * N_IN + i];
+          const uint32_t wl = (uint32_t)w, wh = (uint32_t)(w >> 32);
+          s00 += (uint64_t)yl[i] * wl;
+          s01 += (uint64_t)yl[i] * wh;
+          s10 += (uint64_t)yh[i] * wl;
+          s11 += (uint64_t)yh[i] * wh;
+        }
       }
       acc += (hm_u128)s00 + (((hm_u128)s01 + s10) << 30) + ((hm_u128)s11 << 60);   // 32 products of < 2^120: below 2^125
     }

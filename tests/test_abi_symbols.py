@@ -42,4 +42,12 @@ def test_fat_binary_targets_gfx950():
         fat = os.path.join(td, "fat.bin")
         subprocess.check_call(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", hip.LIB_PATH, fat])
         out = subprocess.check_output(["/opt/rocm/lib/llvm/bin/clang-offload-bundler", "--list", "--type=o", "--input=" + fat], text=True)
-    assert "gfx950" in out and "gfx906" not in out, out
+        assert "gfx950" in out and "gfx906" not in out, out
+        # no kernel may spill to scratch (a switch over 32 base-conversion sizes once did: 2.7 KB per lane, 4x slower op)
+        co = os.path.join(td, "co.elf")
+        subprocess.check_call(["/opt/rocm/lib/llvm/bin/clang-offload-bundler", "--unbundle", "--type=o", "--input=" + fat,
+                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
+        notes = subprocess.check_output(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", co], text=True)
+    import re
+    sizes = re.findall(r"\.private_segment_fixed_size:\s*(\d+)", notes)
+    assert len(sizes) > 40 and all(int(x) == 0 for x in sizes), sizes
