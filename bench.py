@@ -148,6 +148,8 @@ def main():
         op.sync()
         barrier()
         single = args.steps / (time.perf_counter() - t1)
+    # per-launch device time of one op, each launch bracketed by its own event pair (collective when sharded)
+    stage_rows = op.stage_times(5)
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -169,6 +171,8 @@ def main():
                        "launches_per_op": op.launch_count(), "streams": streams, "transport": transport,
                        "streams_note": "independent hmult instances in flight (own inputs / pool / HIP stream); steps dealt round-robin"},
             "single_stream_ops_per_s": single,
+            "stage_us": [[kind, name, round(ns * 1e-3, 2)] for kind, name, ns in stage_rows],
+            "exchange_us_per_op": round(sum(ns for kind, _, ns in stage_rows if kind in ("EXCH_IN", "EXCH_OUT", "REPLICATE")) * 1e-3, 2),
             "hmult_hbm_gbs_algorithmic": HMULT_ALG_BYTES / (ms * 1e-3) / 1e9,
             "hmult_frac_of_hbm_peak": HMULT_ALG_BYTES / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "roofline": {"bound": "hbm", "kernel": "forward NTT sweep, 50 limbs = k_ntt_pass<COL> + k_ntt_pass<ROW>",

@@ -70,51 +70,68 @@ HM_HD uint64_t hm_barrett_wide(hm_u128 z, const HmMod &m) {
 HM_HD uint64_t hm_addmod(uint64_t a, uint64_t b, uint64_t q) { return hm_csub(a + b, q); }
 HM_HD uint64_t hm_submod(uint64_t a, uint64_t b, uint64_t q) { return a >= b ? a - b : a + q - b; }
 
-// a * b + c with 32-bit a, b and 64-bit c: one v_mad_u64_u32.  Written as inline asm on the device because
-// hipcc turns `(uint64_t)a * b >> 32` into the quarter-rate v_mul_hi_u32 (7.7 cycles vs 5.1, measured).
-HM_HD uint64_t hm_mad64(uint32_t a, uint32_t b, uint64_t c) {
+// hipcc rewrites `(uint64_t)a * b >> 32` into the quarter-rate v_mul_hi_u32 (7.7 cycles against 5.1 for
+// v_mad_u64_u32, measured) and `x + (-m)` back into a two-instruction subtract with borrow.  A zero the compiler
+// cannot see through (an SGPR pair passed through an empty asm statement, no instruction emitted) keeps the
+// cheaper forms: `a * b + z` stays one full-width v_mad_u64_u32, `x + (z - m)` one v_lshl_add_u64.
+HM_HD uint64_t hm_opaque_zero() {
+  uint64_t z = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
-  uint64_t d;
-  asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c) : "vcc");
-  return d;
-#else
-  return (uint64_t)a * b + c;
+  asm("" : "+s"(z));
 #endif
+  return z;
 }
 
-// Approximate Shoup product for the butterflies: the quotient estimate drops the low partial products of
-// x * ws (three v_mad_u64_u32, no quarter-rate v_mul_hi_u32), so it may be up to 2 too small and the lazy
-// result lies in [0, 4q) instead of [0, 2q) — still w * x mod q exactly, for ANY 64-bit x.
-HM_HD uint64_t hm_shoup_lazy4(uint64_t x, uint64_t w, uint64_t ws, uint64_t q) {
+// Per-modulus constants of the lazy butterflies (wave-uniform, SGPRs): 4q and the two's complements of q and 4q.
+struct HmBflyMod {
+  uint64_t q4, nq, nq4, z;
+};
+HM_HD HmBflyMod hm_bfly_mod(uint64_t q) {
+  HmBflyMod m;
+  m.z = hm_opaque_zero();
+  m.q4 = 4 * q;
+  m.nq = m.z - q;
+  m.nq4 = m.z - 4 * q;
+  return m;
+}
+
+// Approximate Shoup quotient for the butterflies: floor(x ws / 2^64) = x1 s1 + floor((x1 s0 + x0 s1 +
+// floor(x0 s0 / 2^32)) / 2^32); the estimate truncates the two cross terms separately and drops x0 s0 (three
+// v_mad_u64_u32, no v_mul_hi_u32), so it is at most 2 below the true quotient and the lazy product
+// w x - h q lies in [0, 4q) instead of [0, 2q) — still w x mod q exactly, for ANY 64-bit x.
+HM_HD uint64_t hm_shoup_quot(uint64_t x, uint64_t ws, uint64_t z) {
   const uint32_t x0 = (uint32_t)x, x1 = (uint32_t)(x >> 32), s0 = (uint32_t)ws, s1 = (uint32_t)(ws >> 32);
-  // floor(x ws / 2^64) = x1 s1 + floor((x1 s0 + x0 s1 + floor(x0 s0 / 2^32)) / 2^32); estimate: the two
-  // cross terms truncated separately and x0 s0 dropped, i.e. at most 2 below the true quotient
-  const uint64_t a = hm_mad64(x0, s1, 0);
-  const uint64_t b = hm_mad64(x1, s0, 0);
-  const uint64_t h = hm_mad64(x1, s1, a >> 32) + (b >> 32);
-  return x * w - h * q;
+  const uint64_t a = (uint64_t)x0 * s1 + z, b = (uint64_t)x1 * s0 + z;
+  return (uint64_t)x1 * s1 + (a >> 32) + (b >> 32);
+}
+// c + w x - h q with nq = 2^64 - q: one multiply-accumulate chain seeded with c
+HM_HD uint64_t hm_shoup_lazy4_acc(uint64_t c, uint64_t x, const HmTw &t, const HmBflyMod &m) {
+  return c + x * t.w + hm_shoup_quot(x, t.ws, m.z) * m.nq;
 }
 
-// x - m if x >= m, for x, m < 2^63: the sign of the wrapped difference decides (one 32-bit compare)
-HM_HD uint64_t hm_csub63(uint64_t x, uint64_t m) {
-  const uint64_t t = x - m;
-  return (int32_t)(t >> 32) < 0 ? x : t;
+// x - m if x >= m, given nm = 2^64 - m: when x < m the wrapped sum is larger than x, so the unsigned minimum decides
+HM_HD uint64_t hm_csub_neg(uint64_t x, uint64_t nm) {
+  const uint64_t t = x + nm;
+  return t < x ? t : x;
 }
 
-// Harvey butterflies with the approximate product (q < 2^60, so 8q < 2^63).
-// forward (Cooley-Tukey): X, Y in [0, 8q) -> X', Y' in [0, 8q); q4 = 4q
-HM_HD void hm_bfly_fwd(uint64_t &X, uint64_t &Y, const HmTw &t, uint64_t q, uint64_t q4) {
-  const uint64_t x = hm_csub63(X, q4);                    // [0, 4q)
-  const uint64_t v = hm_shoup_lazy4(Y, t.w, t.ws, q);     // [0, 4q)
-  X = x + v;
-  Y = x - v + q4;
+// Harvey butterflies with the approximate product (q < 2^60, so 8q < 2^63): 23 VALU instructions each
+// (5 v_mad_u64_u32, 4 v_mul_lo_u32), 87 cycles per wave against 109 for the subtract-with-borrow form
+// (tools/bflyrate.hip, profiles/r01_bflyrate.txt).
+// forward (Cooley-Tukey): X, Y in [0, 8q) -> X', Y' in [0, 8q)
+HM_HD void hm_bfly_fwd(uint64_t &X, uint64_t &Y, const HmTw &t, const HmBflyMod &m) {
+  const uint64_t x = hm_csub_neg(X, m.nq4);                 // [0, 4q)
+  const uint64_t xn = hm_shoup_lazy4_acc(x, Y, t, m);       // x + v, v = w Y mod q in [0, 4q)
+  Y = ((x << 1) + m.q4) - xn;                               // x - v + 4q
+  X = xn;
 }
 // inverse (Gentleman-Sande): X, Y in [0, 4q) -> X', Y' in [0, 4q)
-HM_HD void hm_bfly_inv(uint64_t &X, uint64_t &Y, const HmTw &t, uint64_t q, uint64_t q4) {
-  const uint64_t s = hm_csub63(X + Y, q4);
-  const uint64_t d = X - Y + q4;
-  X = s;
-  Y = hm_shoup_lazy4(d, t.w, t.ws, q);
+HM_HD void hm_bfly_inv(uint64_t &X, uint64_t &Y, const HmTw &t, const HmBflyMod &m) {
+  const uint64_t d = (X + m.q4) - Y;
+  X = hm_csub_neg(X + Y, m.nq4);
+  Y = hm_shoup_lazy4_acc(0, d, t, m);
 }
 // [0, 8q) -> [0, q)
-HM_HD uint64_t hm_reduce8(uint64_t x, uint64_t q) { return hm_csub63(hm_csub63(hm_csub63(x, 4 * q), 2 * q), q); }
+HM_HD uint64_t hm_reduce8(uint64_t x, uint64_t q) {
+  return hm_csub(hm_csub(hm_csub(x, 4 * q), 2 * q), q);
+}

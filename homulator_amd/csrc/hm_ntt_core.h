@@ -225,7 +225,7 @@ HM_HD void hm_ph_store_lds(const HmNttState &st, int tid, uint64_t *lds) {
 template <int LOGR, bool STRIDED, int R, bool INV>
 HM_HD void hm_ph_compute(HmNttState &st, uint64_t q) {
   using G = HmRound<LOGR, STRIDED, R>;
-  const uint64_t q2 = 4 * q;  // lazy ranges: forward [0, 8q), inverse [0, 4q)
+  const HmBflyMod m = hm_bfly_mod(q);  // lazy ranges: forward [0, 8q), inverse [0, 4q)
 #pragma unroll
   for (int u = 0; u < G::GPT; ++u) {
 #pragma unroll
@@ -236,8 +236,8 @@ HM_HD void hm_ph_compute(HmNttState &st, uint64_t q) {
       for (int e = 0; e < G::E; ++e) {
         if (e & (1 << pb)) continue;
         const HmTw t = st.tw[R][u][(1 << j) - 1 + (e >> (G::NB - j))];
-        if (INV) hm_bfly_inv(st.v[u][e], st.v[u][e | (1 << pb)], t, q, q2);
-        else     hm_bfly_fwd(st.v[u][e], st.v[u][e | (1 << pb)], t, q, q2);
+        if (INV) hm_bfly_inv(st.v[u][e], st.v[u][e | (1 << pb)], t, m);
+        else     hm_bfly_fwd(st.v[u][e], st.v[u][e | (1 << pb)], t, m);
       }
     }
   }

@@ -23,8 +23,22 @@ def init_rccl(op, group=None):
     op.comm_init_rccl(obj[0])
 
 
+def _hip_runtime():
+    """the HIP runtime this process already uses (torch bundles its own copy; loading a second one by name would give
+    the staging copies a different runtime from the one that owns the buffers)"""
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                path = line.split()[-1]
+                if "libamdhip64.so" in path:
+                    return C.CDLL(path)
+    except OSError:
+        pass
+    return C.CDLL("libamdhip64.so")
+
+
 def _hip_memcpy():
-    hip = C.CDLL("libamdhip64.so")
+    hip = _hip_runtime()
     hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
     hip.hipMemcpy.restype = C.c_int
 
@@ -46,7 +60,7 @@ def host_memcpy():
 
 
 def _hip_memcpy_d2d():
-    hip = C.CDLL("libamdhip64.so")
+    hip = _hip_runtime()
     hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
     hip.hipMemcpy.restype = C.c_int
 

@@ -38,6 +38,7 @@ def load():
         L.hh_op_N.restype = u32
         L.hh_op_N.argtypes = [vp]
         L.hh_op_plan.argtypes = [vp, C.c_char_p, u32]
+        L.hh_op_stage_times.argtypes = [vp, u32, C.c_char_p, u32]
         L.hh_comm_unique_id.argtypes = [vp]
         L.hh_op_comm_init_rccl.argtypes = [vp, vp]
         L.hh_op_comm_init_external.argtypes = [vp, vp, vp]
@@ -121,6 +122,19 @@ class Op:
         buf = C.create_string_buffer(1 << 20)
         self._ck(self.L.hh_op_plan(self.h, buf, len(buf)))
         return [s for s in buf.value.decode().split("\n") if s]
+
+    def stage_times(self, iters=5):
+        """[(kind, stage names, ns)] per launch of the plan, each launch bracketed by its own HIP event pair (collective
+        when sharded: every rank calls it with the same iters)"""
+        buf = C.create_string_buffer(1 << 20)
+        self._ck(self.L.hh_op_stage_times(self.h, iters, buf, len(buf)))
+        rows = []
+        for s in buf.value.decode().split("\n"):
+            if s:
+                kind, rest = s.split(" ", 1)
+                name, ns = rest.rsplit(" ", 1)
+                rows.append((kind, name, int(ns)))
+        return rows
 
     # ---- multi-GPU transports (one of them before the first execute when world > 1)
     def comm_init_rccl(self, unique_id):

@@ -71,6 +71,7 @@ public:
   double timedRun(uint32_t iters);      // ns per iteration, device time
   bool readLimbs(const std::vector<AddrType> &addrs, uint64_t *host);  // download limbs (N words each)
   size_t launchCount() const { return launches.size(); }
+  std::string stageTimes(uint32_t iters);  // one line per launch: "<kind> <stage names> <ns>", each launch timed alone
   std::string planText() const;  // one line per launch: kind, stage names, limb count, exchange lists (tests)
   unsigned long long algorithmicBytes() const { return algBytes; }
   Statistic *stats() { return stat; }

@@ -32,6 +32,7 @@ int hh_op_read_buffer(hh_op *op, const char *name, uint64_t *host); /* [n_limbs]
 int hh_op_buffer_names(hh_op *op, char *out, uint32_t cap); /* '\n'-separated */
 uint32_t hh_op_N(hh_op *op);
 int hh_op_plan(hh_op *op, char *out, uint32_t cap);          /* launch plan, one line per launch */
+int hh_op_stage_times(hh_op *op, uint32_t iters, char *out, uint32_t cap); /* "<kind> <stages> <ns>" per launch, each timed alone */
 /* multi-GPU (overrides "world=W;rank=R" at creation): set the transport before the first execute */
 int hh_comm_unique_id(void *out128);
 int hh_op_comm_init_rccl(hh_op *op, const void *unique_id128);

@@ -602,8 +602,30 @@ void Arch::prepare() {
   hm_sync(ctx);
 }
 
+static const char *const kLaunchKindNames[] = {"NTT", "INTT", "EWE", "BCONV", "AUTO", "NTT_SUBSCALE", "TENSOR", "EXCH_IN", "EXCH_OUT", "REPLICATE", "IP"};
+
+// Per-launch device time (SURVEY.md §8d "per-stage hipEvent times", exchange time at N > 1): every launch of the plan
+// bracketed by its own event pair, in plan order so that the data dependencies (and, sharded, the collectives) line up.
+std::string Arch::stageTimes(uint32_t iters) {
+  if (!prepared) prepare();
+  if (backendKind != BACKEND_HIP) return "";
+  std::vector<uint64_t> total(launches.size(), 0);
+  for (uint32_t it = 0; it < iters; ++it)
+    for (size_t i = 0; i < launches.size(); ++i) {
+      hm_timer_start(ctx);
+      enqueue(*launches[i]);
+      uint64_t ns = 0;
+      hm_timer_stop(ctx, &ns);
+      total[i] += ns;
+    }
+  std::string out;
+  for (size_t i = 0; i < launches.size(); ++i)
+    out += std::string(kLaunchKindNames[launches[i]->kind]) + " " + launches[i]->name + " " + std::to_string(total[i] / (iters ? iters : 1)) + "\n";
+  return out;
+}
+
 std::string Arch::planText() const {
-  static const char *names[] = {"NTT", "INTT", "EWE", "BCONV", "AUTO", "NTT_SUBSCALE", "TENSOR", "EXCH_IN", "EXCH_OUT", "REPLICATE", "IP"};
+  const char *const *names = kLaunchKindNames;
   std::string out;
   for (const Launch *l : launches) {
     size_t cnt = l->out.size();

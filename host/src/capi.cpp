@@ -89,6 +89,10 @@ int hh_op_plan(hh_op *h, char *out, uint32_t cap) {
   HH_TRY(h->op->prepare(); std::string s = h->arch->planText(); if (s.size() + 1 > cap) throw std::runtime_error("buffer too small");
          memcpy(out, s.c_str(), s.size() + 1))
 }
+int hh_op_stage_times(hh_op *h, uint32_t iters, char *out, uint32_t cap) {
+  HH_TRY(h->op->prepare(); std::string s = h->arch->stageTimes(iters); if (s.size() + 1 > cap) throw std::runtime_error("buffer too small");
+         memcpy(out, s.c_str(), s.size() + 1))
+}
 extern "C" int hm_comm_unique_id(void *);
 int hh_comm_unique_id(void *out) { if (hm_comm_unique_id(out)) { g_err = "hm_comm_unique_id failed (is librccl.so available?)"; return 1; } return 0; }
 int hh_op_comm_init_rccl(hh_op *h, const void *id) { HH_TRY(h->arch->commInitRccl(id)) }
