@@ -34,6 +34,9 @@ def load():
         L.hh_op_stage_bytes.argtypes = [vp, u64p]
         L.hh_op_buffer_limbs.argtypes = [vp, C.c_char_p, C.POINTER(u32)]
         L.hh_op_read_buffer.argtypes = [vp, C.c_char_p, vp]
+        L.hh_op_read_buffer_copy.argtypes = [vp, C.c_char_p, u32, vp]
+        L.hh_op_batch.restype = u32
+        L.hh_op_batch.argtypes = [vp]
         L.hh_op_buffer_names.argtypes = [vp, C.c_char_p, u32]
         L.hh_op_N.restype = u32
         L.hh_op_N.argtypes = [vp]
@@ -150,12 +153,17 @@ class Op:
         """limb indices of an n-limb buffer that live on this rank (limb e -> e % world)"""
         return [e for e in range(n_limbs) if e % self.world == self.rank]
 
-    def read(self, name):
+    def read(self, name, copy=0):
+        """limbs of buffer `name` of op `copy` of the batch (overrides={"batch": B}: every launch carries B independent ops)"""
         n = C.c_uint32()
         self._ck(self.L.hh_op_buffer_limbs(self.h, name.encode(), C.byref(n)))
         out = np.empty((n.value, self.N), dtype=np.uint64)
-        self._ck(self.L.hh_op_read_buffer(self.h, name.encode(), out.ctypes.data_as(C.c_void_p)))
+        self._ck(self.L.hh_op_read_buffer_copy(self.h, name.encode(), copy, out.ctypes.data_as(C.c_void_p)))
         return out
+
+    @property
+    def batch(self):
+        return self.L.hh_op_batch(self.h)
 
 
 def rccl_unique_id():

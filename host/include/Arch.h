@@ -28,6 +28,7 @@ struct InputFill {
   std::vector<AddrType> addrs;
   std::vector<uint32_t> mods;
   uint64_t seed;
+  bool shared = false;  // batch > 1: one copy serves every op of the batch (the evaluation key)
 };
 
 class Arch {
@@ -69,7 +70,8 @@ public:
   void run();                           // enqueue every launch once (asynchronous)
   void sync();
   double timedRun(uint32_t iters);      // ns per iteration, device time
-  bool readLimbs(const std::vector<AddrType> &addrs, uint64_t *host);  // download limbs (N words each)
+  bool readLimbs(const std::vector<AddrType> &addrs, uint64_t *host, uint32_t copy = 0);  // download limbs (N words each) of op `copy` of the batch
+  uint32_t batch() const { return batch_; }
   size_t launchCount() const { return launches.size(); }
   std::string stageTimes(uint32_t iters);  // one line per launch: "<kind> <stage names> <ns>", each launch timed alone
   std::string planText() const;  // one line per launch: kind, stage names, limb count, exchange lists (tests)
@@ -84,6 +86,7 @@ private:
   bool fuse;
   uint32_t n = 0, logN = 0, clusterCount = 1;
   uint32_t maxLevel_ = 0, curLevel_ = 0, world_ = 1, rank_ = 0;
+  uint32_t batch_ = 1;  // config key `batch`: independent ops (own inputs, shared evaluation key) carried by every launch
   bool commReady = false;
   bool useGraph = false;
   unsigned runCount = 0;
@@ -105,5 +108,6 @@ private:
   void buildLaunches();
   void fusePasses(std::vector<Stage> &st);
   void enqueue(Launch &l);
+  void replicateForBatch();
 };
 #endif

@@ -120,7 +120,7 @@ public:
   void prepare();    // issue stages + allocate/fill/fuse (idempotent)
   double execute(uint32_t iters);  // ns per iteration of the whole op (device time)
   std::vector<AddrType> bufferAddrs(const std::string &name) const;  // named buffer (Malloc name, input or output alias)
-  bool readBuffer(const std::string &name, uint64_t *host);
+  bool readBuffer(const std::string &name, uint64_t *host, uint32_t copy = 0);  // copy: op of the batch (config key `batch`)
   unsigned long long totalInstructions();
   Arch *getArch() { return arch; }
   std::vector<std::string> bufferNames() const;

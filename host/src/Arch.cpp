@@ -45,6 +45,8 @@ Arch::Arch(Config *cfg) : config(cfg) {
   if (world_ & (world_ - 1)) throw std::runtime_error("world must be a power of two");
   useGraph = cfg->getValueOr("graph", 0) != 0;  // measured: no gain on one GPU (the op is GPU-bound: 2 440 vs 2 422 ops/s)
   if (const char *e = getenv("HOMULATOR_GRAPH")) useGraph = std::string(e) != "0";
+  batch_ = std::max<uint32_t>(1, cfg->getValueOr("batch", 1));
+  if (const char *e = getenv("HOMULATOR_BATCH")) batch_ = std::max(1, atoi(e));
   fuse = cfg->getValueOr("fuse", 1) != 0;
   if (const char *e = getenv("HOMULATOR_FUSE")) fuse = std::string(e) != "0";
   stat = new Statistic();
@@ -568,15 +570,73 @@ void Arch::buildLaunches() {
   }
 }
 
+// batch > 1: every launch carries the limb-polys of `batch` independent ops.  Op c lives in its own copy of the
+// buffer plan (limb index + c * limbs-per-op) with its own inputs (fill seed + c * kBatchSeedStride); buffers
+// marked shared (the evaluation key: all ops of a batch are under the same key) exist once.  Larger launches
+// amortise the per-launch latency and pair up same-modulus limb-polys across ops (one twiddle fetch per pair).
+static const uint64_t kBatchSeedStride = 100000;
+void Arch::replicateForBatch() {
+  const uint32_t per = (uint32_t)limbIndex.size();
+  std::set<uint32_t> sharedLimbs;
+  for (const InputFill &f : fills)
+    if (f.shared)
+      for (AddrType a : f.addrs) sharedLimbs.insert(limbOf(a));
+  auto rep = [&](std::vector<uint32_t> &v, bool isLimb) {
+    const size_t n0 = v.size();
+    for (uint32_t c = 1; c < batch_; ++c)
+      for (size_t i = 0; i < n0; ++i) v.push_back(isLimb && !sharedLimbs.count(v[i]) ? v[i] + c * per : v[i]);
+  };
+  for (Launch *l : launches) {
+    if (l->kind == Launch::L_IP) {
+      // entry e: ipTerms x limbs, ipTerms * ipOuts y limbs, ipOuts outputs.  Entry-major order (entry e of every op
+      // side by side): the ops share the key limbs, so the second and later readers of a key chunk find it in L2
+      auto inter = [&](std::vector<uint32_t> &v, size_t width, bool isLimb) {
+        const size_t n0 = v.size() / width;
+        std::vector<uint32_t> o;
+        for (size_t e = 0; e < n0; ++e)
+          for (uint32_t c = 0; c < batch_; ++c)
+            for (size_t w = 0; w < width; ++w) {
+              const uint32_t x = v[e * width + w];
+              o.push_back(isLimb && c && !sharedLimbs.count(x) ? x + c * per : x);
+            }
+        v.swap(o);
+      };
+      inter(l->a, l->ipTerms, true); inter(l->b, (size_t)l->ipTerms * l->ipOuts, true); inter(l->out, l->ipOuts, true); inter(l->mods, 1, false);
+    } else {
+      rep(l->a, true); rep(l->b, true); rep(l->c, true); rep(l->d, true);
+      rep(l->out, true); rep(l->out1, true); rep(l->out2, true); rep(l->mods, false);
+      const size_t k0 = l->k.size();
+      for (uint32_t c = 1; c < batch_; ++c)
+        for (size_t i = 0; i < k0; ++i) l->k.push_back(l->k[i]);
+      const size_t p0 = l->probs.size();
+      for (uint32_t c = 1; c < batch_; ++c)
+        for (size_t i = 0; i < p0; ++i) {
+          Launch::Prob q = l->probs[i];
+          for (uint32_t &x : q.in) x += c * per;
+          for (uint32_t &x : q.out) x += c * per;
+          l->probs.push_back(q);
+        }
+    }
+    l->refInstructions *= batch_;
+    l->bytes *= batch_;
+  }
+  algBytes *= batch_;
+}
+
 void Arch::prepare() {
   if (prepared) return;
   prepared = true;
   buildLaunches();
+  if (batch_ > 1) {
+    if (world_ > 1) throw std::runtime_error("batch > 1 is a single-GPU mode (world = 1)");
+    replicateForBatch();
+    stat->setStat("Batch", batch_);
+  }
   stat->setStat("Launches", launches.size());
   stat->setStat("LimbPolys_resident", limbIndex.size());
   stat->setStat("HBM_stage_bytes", algBytes);
   if (backendKind != BACKEND_HIP) return;
-  const size_t bytes = (size_t)limbIndex.size() * n * 8;
+  const size_t bytes = (size_t)limbIndex.size() * batch_ * n * 8;
   void *p = nullptr;
   if (hm_malloc(ctx, bytes, &p) != HM_OK) throw std::runtime_error(std::string("hm_malloc: ") + hm_last_error(ctx));
   pool = static_cast<uint64_t *>(p);
@@ -593,12 +653,13 @@ void Arch::prepare() {
       bc->slicesOut = xo->slicesOut = static_cast<uint64_t *>(so);
     }
   }
-  for (const InputFill &f : fills) {
-    std::vector<uint32_t> limbs;
-    for (AddrType a : f.addrs) limbs.push_back(limbOf(a));
-    if (hm_fill_uniform(ctx, pool, limbs.data(), f.mods.data(), (uint32_t)limbs.size(), f.seed) != HM_OK)
-      throw std::runtime_error(std::string("hm_fill_uniform: ") + hm_last_error(ctx));
-  }
+  for (const InputFill &f : fills)
+    for (uint32_t c = 0; c < (f.shared ? 1u : batch_); ++c) {
+      std::vector<uint32_t> limbs;
+      for (AddrType a : f.addrs) limbs.push_back(limbOf(a) + c * (uint32_t)limbIndex.size());
+      if (hm_fill_uniform(ctx, pool, limbs.data(), f.mods.data(), (uint32_t)limbs.size(), f.seed + c * kBatchSeedStride) != HM_OK)
+        throw std::runtime_error(std::string("hm_fill_uniform: ") + hm_last_error(ctx));
+    }
   hm_sync(ctx);
 }
 
@@ -754,9 +815,9 @@ double Arch::timedRun(uint32_t iters) {
   return (double)ns / iters;
 }
 
-bool Arch::readLimbs(const std::vector<AddrType> &addrs, uint64_t *host) {
-  if (backendKind != BACKEND_HIP || !pool) return false;
+bool Arch::readLimbs(const std::vector<AddrType> &addrs, uint64_t *host, uint32_t copy) {
+  if (backendKind != BACKEND_HIP || !pool || copy >= batch_) return false;
   for (size_t i = 0; i < addrs.size(); ++i)
-    if (hm_memcpy_d2h(ctx, host + i * n, pool + (size_t)limbOf(addrs[i]) * n, (size_t)n * 8) != HM_OK) return false;
+    if (hm_memcpy_d2h(ctx, host + i * n, pool + ((size_t)limbOf(addrs[i]) + (size_t)copy * limbIndex.size()) * n, (size_t)n * 8) != HM_OK) return false;
   return true;
 }

@@ -140,7 +140,7 @@ void KeySwitch::InnerProduceOperation(uint64_t evkSeed) {
     for (uint32_t be = 0; be < Beta; be++) {
       memMange->MallocMem("IP_Key" + K + "_" + S(be), E);
       // evaluation key limbs are inputs: deterministic synthetic stream (same layout as the oracle's synth_evk)
-      arch->addInputFill(InputFill{memMange->getAddr("IP_Key" + K + "_" + S(be)), extMods, evkSeed + (be * 2 + k) * 1000ull});
+      arch->addInputFill(InputFill{memMange->getAddr("IP_Key" + K + "_" + S(be)), extMods, evkSeed + (be * 2 + k) * 1000ull, /*shared=*/true});
       if (Beta != 1 && be <= Beta - 2) memMange->MallocMem("InnerProduceOut_temp(" + S(be) + ")_Key" + K, E);
     }
     auto ext = [&](uint32_t j) { return memMange->getAddr("NTTOut_beta(" + S(j) + ")"); };
@@ -463,7 +463,7 @@ std::vector<std::string> OperationBase::bufferNames() const {
   for (auto &n : addrManager->names()) v.push_back(n);
   return v;
 }
-bool OperationBase::readBuffer(const std::string &name, uint64_t *host) { return arch->readLimbs(bufferAddrs(name), host); }
+bool OperationBase::readBuffer(const std::string &name, uint64_t *host, uint32_t copy) { return arch->readLimbs(bufferAddrs(name), host, copy); }
 unsigned long long OperationBase::totalInstructions() { prepare(); return driver->getTotalIns(); }
 
 void OperationBase::prepare() {

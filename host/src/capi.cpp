@@ -84,6 +84,10 @@ int hh_op_buffer_names(hh_op *h, char *out, uint32_t cap) {
   HH_TRY(std::string s; for (auto &n : h->op->bufferNames()) s += n + "\n"; if (s.size() + 1 > cap) throw std::runtime_error("buffer too small");
          memcpy(out, s.c_str(), s.size() + 1))
 }
+int hh_op_read_buffer_copy(hh_op *h, const char *name, uint32_t copy, uint64_t *host) {
+  HH_TRY(if (!h->op->readBuffer(name, host, copy)) throw std::runtime_error("buffer not readable (count backend, not prepared, or copy >= batch)"))
+}
+uint32_t hh_op_batch(hh_op *h) { return h->arch->batch(); }
 uint32_t hh_op_N(hh_op *h) { return h->arch->N(); }
 int hh_op_plan(hh_op *h, char *out, uint32_t cap) {
   HH_TRY(h->op->prepare(); std::string s = h->arch->planText(); if (s.size() + 1 > cap) throw std::runtime_error("buffer too small");

@@ -147,3 +147,34 @@ def test_graph_replay_matches_direct_launches():
         op.execute(1)
         assert np.array_equal(op.read("out.c0"), exp[0]) and np.array_equal(op.read("out.c1"), exp[1])
     op.close()
+
+
+BATCH_SEED_STRIDE = 100000   # host/src/Arch.cpp kBatchSeedStride
+
+
+@pytest.mark.parametrize("cfg,logN,L,ell,alpha,batch", [("config_4_N15.cfg", 15, 6, 5, 2, 3), ("config_4_N15.cfg", 15, 16, 10, 4, 2),
+                                                         ("config_4.cfg", 16, 45, 35, 15, 3)])
+@pytest.mark.parametrize("opname", ["hmult", "hrotate"])
+def test_batched_ops_bit_exact(cfg, logN, L, ell, alpha, batch, opname):
+    """config key batch = B: every launch carries B independent ops (own inputs, ONE evaluation key); op c must equal
+    the oracle on the inputs of seed + c * stride, and the stage byte / instruction accounting scales by B"""
+    from homulator_amd import host
+    o = oracle(logN, L, alpha)
+    evk = o.synth_evk(ell, SEED + 10000)
+    single = host.Op(cfg, opname, L, ell, alpha, backend=host.BACKEND_COUNT)
+    op = host.Op(cfg, opname, L, ell, alpha, overrides={"batch": batch})
+    assert op.batch == batch
+    op.execute(2)
+    assert op.launch_count() == single.launch_count()
+    assert op.stage_bytes() == batch * single.stage_bytes()
+    for c in range(batch):
+        s = SEED + c * BATCH_SEED_STRIDE
+        ct1, ct2 = o.synth_ct(ell, s), o.synth_ct(ell, s + 2000)
+        assert np.array_equal(op.read("ct1.c1", copy=c), ct1[1])
+        exp = o.hmult(ell, ct1, ct2, evk, rescale=True) if opname == "hmult" else o.hrotate(ell, ct1, 5, evk)
+        assert np.array_equal(op.read("out.c0", copy=c), exp[0]), f"copy {c}"
+        assert np.array_equal(op.read("out.c1", copy=c), exp[1]), f"copy {c}"
+    with pytest.raises(host.HostError):
+        op.read("out.c0", copy=batch)
+    op.close()
+    single.close()
