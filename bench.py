@@ -70,9 +70,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--streams", type=int, default=3,
+    ap.add_argument("--streams", type=int, default=2,
                     help="independent hmult instances in flight on one GPU (own inputs, HBM pool and HIP stream each); "
                          "the K timed steps are dealt round-robin over them.  1 = one op at a time (latency mode)")
+    ap.add_argument("--batch", type=int, default=4,
+                    help="independent hmults carried by every launch of an instance (config key `batch`: own inputs, one "
+                         "evaluation key); a step is still ONE hmult, an enqueue advances `batch` steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -94,9 +97,13 @@ def main():
     # N > 1: ONE hmult whose limb-polys are sharded over the N GPUs (limb e -> e % N), RCCL all-to-all around the two
     # base conversions + one replicate in the rescale: strong scaling of the op's latency
     streams = args.streams if world == 1 else 1
-    ops = [host.Op(CFG, OP, L, ELL, ALPHA, device=local_rank, rank=rank, world=world, overrides={"seed": host.SEED + 7 * i})
+    batch = args.batch if world == 1 else 1
+    ops = [host.Op(CFG, OP, L, ELL, ALPHA, device=local_rank, rank=rank, world=world,
+                   overrides={"seed": host.SEED + 7 * i, **({"batch": batch} if batch > 1 else {})})
            for i in range(streams)]
     op = ops[0]
+    # steps that do not fill a batch run through a one-op instance, so that EXACTLY --steps hmults are timed
+    tail_op = host.Op(CFG, OP, L, ELL, ALPHA, device=local_rank, overrides={"seed": host.SEED + 999}) if batch > 1 else None
     transport = "none"
     if world > 1:
         from homulator_amd import dist as hdist
@@ -119,14 +126,20 @@ def main():
             op.comm_init_external(tr.cfunc)
 
     def run(n):   # n hmult steps, round-robin over the in-flight instances; asynchronous
-        for i in range(n):
+        for i in range(n // batch):
             ops[i % streams].enqueue(1)
+        if n % batch:
+            tail_op.enqueue(n % batch)
 
     def sync_all():
         for o in ops:
             o.sync()
+        if tail_op is not None:
+            tail_op.sync()
 
-    run(max(args.warmup, streams))
+    run(max(args.warmup, streams * batch))
+    if tail_op is not None:
+        tail_op.enqueue(1)
     sync_all()
 
     def barrier():
@@ -141,15 +154,16 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     single = None
-    if world == 1 and streams > 1:   # latency mode beside it: one op at a time
+    if world == 1 and (streams > 1 or batch > 1):   # latency mode beside it: one op at a time
+        lat_op = tail_op if tail_op is not None else op
         barrier()
         t1 = time.perf_counter()
-        op.enqueue(args.steps)
-        op.sync()
+        lat_op.enqueue(args.steps)
+        lat_op.sync()
         barrier()
         single = args.steps / (time.perf_counter() - t1)
     # per-launch device time of one op, each launch bracketed by its own event pair (collective when sharded)
-    stage_rows = op.stage_times(5)
+    stage_rows = (tail_op if tail_op is not None else op).stage_times(5)
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -168,8 +182,8 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": f"{CFG} {OP} L={L} l={ELL} alpha={ALPHA} (N=2^16, beta=3, full hybrid key switch + rescale)",
                        "parallelism": "single GPU" if world == 1 else f"limbs sharded over {world} GPUs (limb e -> e % {world}); RCCL all-to-all around ModUp/ModDown base conversion + replicate of the rescale residue",
-                       "launches_per_op": op.launch_count(), "streams": streams, "transport": transport,
-                       "streams_note": "independent hmult instances in flight (own inputs / pool / HIP stream); steps dealt round-robin"},
+                       "launches_per_op": op.launch_count(), "streams": streams, "batch": batch, "transport": transport,
+                       "streams_note": "`streams` instances in flight (own HBM pool / HIP stream each), each carrying `batch` independent hmults per launch (own inputs, one evaluation key); a step is one hmult"},
             "single_stream_ops_per_s": single,
             "stage_us": [[kind, name, round(ns * 1e-3, 2)] for kind, name, ns in stage_rows],
             "exchange_us_per_op": round(sum(ns for kind, _, ns in stage_rows if kind in ("EXCH_IN", "EXCH_OUT", "REPLICATE")) * 1e-3, 2),
@@ -184,6 +198,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline()
     for o in ops:
         o.close()
+    if tail_op is not None:
+        tail_op.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

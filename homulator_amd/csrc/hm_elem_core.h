@@ -97,7 +97,7 @@ struct HmIpArgs {
   HmIpLimb limb[HM_IP_MAX_LIMBS];
 };
 
-// ---- K4 base conversion: out[t][x] = sum_i in[i][x] * table[i][t] mod q_t
+// ---- K4 base conversion: out[t][x] = sum_i in[i][x] * table[i][t] mod q_t (device table: hm_bconv_entry form)
 // One launch carries up to HM_BCONV_MAX_PROB independent conversions (the beta digits of a ModUp, the two
 // keys of a ModDown): grid = (N / HM_BCONV_THREADS, output chunks, problems); one coefficient per thread.
 #define HM_BCONV_MAX_IN 32   // parameter set A converts from a 28-limb basis (alpha = 28)
@@ -128,6 +128,9 @@ struct HmBconvArgs {
 // v_mad_u64_u32 into plain 64-bit accumulators with no carry chain; the columns are recombined once per
 // output.  Device table entries are pre-split: low word = w0, high word = w1 (hm_bconv_pack).
 HM_HD uint64_t hm_bconv_pack(uint64_t w) { return (w & 0x3FFFFFFFull) | ((w >> 30) << 32); }
+// device form of a conversion factor w for output modulus m: Montgomery form (the accumulator is reduced by
+// hm_redc_wide, which divides by 2^64), split-30 packed
+HM_HD uint64_t hm_bconv_entry(uint64_t w, const HmMod &m) { return hm_bconv_pack(hm_mulmod(w, m.r64, m)); }
 
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef const HmMod __attribute__((address_space(4))) *HmConstMod;
@@ -182,7 +185,7 @@ HM_HD void hm_bconv_thread(const HmBconvProb &p, const HmMod *mods, uint32_t log
       acc += (hm_u128)s00 + (((hm_u128)s01 + s10) << 30) + ((hm_u128)s11 << 60);   // 32 products of < 2^120: below 2^125
     }
     const HmMod m = cmods[p.out_mod[t]];
-    p.out[(size_t)p.out_limb[t] * N + x] = hm_barrett_wide(acc, m);
+    p.out[(size_t)p.out_limb[t] * N + x] = hm_redc_wide(acc, m);
   }
 }
 

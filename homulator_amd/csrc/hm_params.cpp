@@ -94,6 +94,11 @@ void Params::init(uint32_t logN_, uint32_t L_, uint32_t K_, const uint64_t *q, c
     c.mu = (uint64_t)((((u128)1) << (k + 63)) / qm);
     c.r64 = (uint64_t)((((u128)1) << 64) % qm);
     c.r64s = shoup(c.r64, qm);
+    {  // -q^-1 mod 2^64 by Newton iteration (q odd): x <- x (2 - q x) doubles the correct low bits, 3 -> 96
+      uint64_t x = qm;
+      for (int it = 0; it < 5; ++it) x *= 2 - qm * x;
+      c.nqinv = 0 - x;
+    }
     c.ninv = invmod(N, qm);
     c.ninvs = shoup(c.ninv, qm);
   }

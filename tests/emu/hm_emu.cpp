@@ -50,7 +50,7 @@ template <int N_IN>
 static void emu_bconv_n(Emu &e, HmBconvProb &p, const std::vector<uint64_t> &tb) {
   std::vector<uint64_t> tt((size_t)p.n_in * p.n_out);  // device format: [n_out][n_in], packed
   for (uint32_t i = 0; i < p.n_in; ++i)
-    for (uint32_t t = 0; t < p.n_out; ++t) tt[(size_t)t * p.n_in + i] = hm_bconv_pack(tb[(size_t)i * p.n_out + t]);
+    for (uint32_t t = 0; t < p.n_out; ++t) tt[(size_t)t * p.n_in + i] = hm_bconv_entry(tb[(size_t)i * p.n_out + t], e.P.modc[p.out_mod[t]]);
   p.table = tt.data();
   for (uint32_t t0 = 0; t0 < p.n_out; t0 += HM_BCONV_CHUNK) {
     uint32_t t1 = t0 + HM_BCONV_CHUNK < p.n_out ? t0 + HM_BCONV_CHUNK : p.n_out;
