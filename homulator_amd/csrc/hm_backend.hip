@@ -761,15 +761,16 @@ extern "C" hm_status hm_bconv_batch(hm_ctx *c, const hm_bconv_desc *descs, uint3
     if (it == c->bconv_tables.end()) {
       std::vector<uint64_t> qh(d.n_in), tb((size_t)d.n_in * d.n_out);
       c->P.bconv_consts(d.in_ids, d.n_in, d.out_ids, d.n_out, qh.data(), tb.data());
-      {  // device format: transposed to [n_out][n_in] (one output's factors contiguous: scalar loads), Montgomery form, split-30 packed
-        std::vector<uint64_t> tt((size_t)d.n_in * d.n_out);
+      const uint32_t row = HM_BCONV_ROW(d.n_in);
+      {  // device format: [n_out][row] (one output's factors contiguous and padded: wide scalar loads), Montgomery form, split-30 packed
+        std::vector<uint64_t> tt((size_t)row * d.n_out, 0);
         for (uint32_t i = 0; i < d.n_in; ++i)
-          for (uint32_t t = 0; t < d.n_out; ++t) tt[(size_t)t * d.n_in + i] = hm_bconv_entry(tb[(size_t)i * d.n_out + t], c->P.modc[d.out_ids[t]]);
+          for (uint32_t t = 0; t < d.n_out; ++t) tt[(size_t)t * row + i] = hm_bconv_entry(tb[(size_t)i * d.n_out + t], c->P.modc[d.out_ids[t]]);
         tb.swap(tt);
       }
       uint64_t *dev = nullptr;
-      HM_HIP(c, hipMalloc(&dev, 8ull * d.n_in * d.n_out));
-      HM_HIP(c, hipMemcpy(dev, tb.data(), 8ull * d.n_in * d.n_out, hipMemcpyHostToDevice));
+      HM_HIP(c, hipMalloc(&dev, 8ull * row * d.n_out));
+      HM_HIP(c, hipMemcpy(dev, tb.data(), 8ull * row * d.n_out, hipMemcpyHostToDevice));
       it = c->bconv_tables.emplace(key, dev).first;
     }
     HmBconvProb &p = probs[pi];

@@ -108,7 +108,7 @@ struct HmIpArgs {
 struct HmBconvProb {
   const uint64_t *in;
   uint64_t *out;
-  const uint64_t *table;  // device, [n_out][n_in], entries packed by hm_bconv_pack
+  const uint64_t *table;  // device, [n_out][HM_BCONV_ROW(n_in)], entries in hm_bconv_entry form, rows zero-padded
   uint32_t n_in, n_out;
   // 32-bit entries: indexed by the (wave-uniform) output counter, they must be scalar loads from the kernarg
   // segment; 16-bit entries made hipcc emit a VECTOR load per output, and the modulus record load that depends on it
@@ -142,20 +142,55 @@ typedef const HmMod *HmConstMod;
 // The conversion table is read through the SCALAR cache: every lane of a wave needs the same entries, so they are
 // s_load'ed into SGPRs (asynchronously, no VGPRs, no LDS, no barrier) and feed v_mad_u64_u32 as scalar operands.
 // hipcc only emits scalar loads for memory it knows to be constant, hence the constant-address-space view of the
-// table pointer.  Device layout: [n_out][n_in] packed entries (a row = the n_in factors of one output limb).
+// table pointer.  Device layout: [n_out][HM_BCONV_ROW(n_in)] entries (hm_bconv_entry form), a row = the factors of
+// one output limb padded with zeros to a multiple of 8 entries, so that a row is fetched by 64-byte scalar loads
+// (s_load_dwordx16) instead of one 8-byte load plus three address instructions per entry.
+struct HmRow8 {
+  uint64_t w[8];
+};
+#define HM_BCONV_ROW(n_in) ((((n_in) + 7u) / 8u) * 8u)
 #if defined(__HIP_DEVICE_COMPILE__)
-typedef const uint64_t __attribute__((address_space(4))) *HmConstU64;
-#define HM_CONST_VIEW(p) ((HmConstU64)(uintptr_t)(p))
+typedef const HmRow8 __attribute__((address_space(4))) *HmConstRow8;
+#define HM_CONST_ROWS(p) ((HmConstRow8)(uintptr_t)(p))
 #else
-typedef const uint64_t *HmConstU64;
-#define HM_CONST_VIEW(p) (p)
+typedef const HmRow8 *HmConstRow8;
+#define HM_CONST_ROWS(p) ((const HmRow8 *)(p))
 #endif
+
+// one output limb of one coefficient: sum_i y_i w_i with the split-30 columns, Montgomery-reduced
+template <int N_IN>
+HM_HD uint64_t hm_bconv_dot(const uint32_t (&yl)[N_IN], const uint32_t (&yh)[N_IN], const HmRow8 (&row)[(N_IN + 7) / 8], uint64_t q, uint64_t nqinv) {
+  hm_u128 acc = 0;
+  constexpr int GROUPS = (N_IN + 15) / 16;  // 16 terms per carry-free column group (each column stays below 2^64)
+#pragma unroll
+  for (int g = 0; g < GROUPS; ++g) {
+    uint64_t s00 = 0, s01 = 0, s10 = 0, s11 = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int i = g * 16 + j;
+      if (i < N_IN) {
+        const uint64_t w = row[i >> 3].w[i & 7];
+        const uint32_t wl = (uint32_t)w, wh = (uint32_t)(w >> 32);
+        s00 += (uint64_t)yl[i] * wl;
+        s01 += (uint64_t)yl[i] * wh;
+        s10 += (uint64_t)yh[i] * wl;
+        s11 += (uint64_t)yh[i] * wh;
+      }
+    }
+    acc += (hm_u128)s00 + (((hm_u128)s01 + s10) << 30) + ((hm_u128)s11 << 60);   // 32 products of < 2^120: below 2^125
+  }
+  HmMod m;
+  m.q = q;
+  m.nqinv = nqinv;
+  return hm_redc_wide(acc, m);
+}
 
 // coefficient x for outputs [t0, t1)
 template <int N_IN>
 HM_HD void hm_bconv_thread(const HmBconvProb &p, const HmMod *mods, uint32_t logN, uint32_t x, uint32_t t0, uint32_t t1) {
   const size_t N = (size_t)1 << logN;
-  HmConstU64 tab = HM_CONST_VIEW(p.table);
+  constexpr int NG = (N_IN + 7) / 8;  // 8-entry groups per row
+  HmConstRow8 tab = HM_CONST_ROWS(p.table);
   HmConstMod cmods = HM_CONST_MODS(mods);
   uint32_t yl[N_IN], yh[N_IN];
 #pragma unroll
@@ -164,28 +199,13 @@ HM_HD void hm_bconv_thread(const HmBconvProb &p, const HmMod *mods, uint32_t log
     yl[i] = (uint32_t)v & 0x3FFFFFFFu;
     yh[i] = (uint32_t)(v >> 30);
   }
-  for (uint32_t t = t0; t < t1; ++t) {
-    hm_u128 acc = 0;
-    constexpr int GROUPS = (N_IN + 15) / 16;  // 16 terms per carry-free column group (each column stays below 2^64)
+  {  // (double-buffering the row in SGPRs gained 3 %: scalar loads return out of order, so the dependent modulus load drains the prefetch)
+    for (uint32_t t = t0; t < t1; ++t) {
+      HmRow8 row[NG];
 #pragma unroll
-    for (int g = 0; g < GROUPS; ++g) {
-      uint64_t s00 = 0, s01 = 0, s10 = 0, s11 = 0;
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const int i = g * 16 + j;
-        if (i < N_IN) {
-          const uint64_t w = tab[t * N_IN + i];
-          const uint32_t wl = (uint32_t)w, wh = (uint32_t)(w >> 32);
-          s00 += (uint64_t)yl[i] * wl;
-          s01 += (uint64_t)yl[i] * wh;
-          s10 += (uint64_t)yh[i] * wl;
-          s11 += (uint64_t)yh[i] * wh;
-        }
-      }
-      acc += (hm_u128)s00 + (((hm_u128)s01 + s10) << 30) + ((hm_u128)s11 << 60);   // 32 products of < 2^120: below 2^125
+      for (int g = 0; g < NG; ++g) row[g] = tab[t * NG + g];
+      p.out[(size_t)p.out_limb[t] * N + x] = hm_bconv_dot<N_IN>(yl, yh, row, cmods[p.out_mod[t]].q, cmods[p.out_mod[t]].nqinv);
     }
-    const HmMod m = cmods[p.out_mod[t]];
-    p.out[(size_t)p.out_limb[t] * N + x] = hm_redc_wide(acc, m);
   }
 }
 

@@ -48,9 +48,10 @@ static void run_ntt(const Emu &e, uint32_t mod, const uint64_t *in, uint64_t *ou
 
 template <int N_IN>
 static void emu_bconv_n(Emu &e, HmBconvProb &p, const std::vector<uint64_t> &tb) {
-  std::vector<uint64_t> tt((size_t)p.n_in * p.n_out);  // device format: [n_out][n_in], packed
+  const uint32_t row = HM_BCONV_ROW(p.n_in);
+  std::vector<uint64_t> tt((size_t)row * p.n_out, 0);  // device format: [n_out][row], Montgomery form, packed, zero-padded rows
   for (uint32_t i = 0; i < p.n_in; ++i)
-    for (uint32_t t = 0; t < p.n_out; ++t) tt[(size_t)t * p.n_in + i] = hm_bconv_entry(tb[(size_t)i * p.n_out + t], e.P.modc[p.out_mod[t]]);
+    for (uint32_t t = 0; t < p.n_out; ++t) tt[(size_t)t * row + i] = hm_bconv_entry(tb[(size_t)i * p.n_out + t], e.P.modc[p.out_mod[t]]);
   p.table = tt.data();
   for (uint32_t t0 = 0; t0 < p.n_out; t0 += HM_BCONV_CHUNK) {
     uint32_t t1 = t0 + HM_BCONV_CHUNK < p.n_out ? t0 + HM_BCONV_CHUNK : p.n_out;
