@@ -49,7 +49,7 @@ __device__ __forceinline__ void hm_ntt_pass_body(const HmNttArgs &a, const HmTw 
   const size_t N = (size_t)1 << a.logN;
   const uint64_t q = a.mods[lb.mod].q;
   const HmTw *twl = a.tw + (size_t)lb.mod * N;
-  const uint32_t s0 = STRIDED ? 0u : (a.logN - 8u);
+  const uint32_t s0 = STRIDED ? 0u : (a.logN - HM_ROW_LOG);
   const uint32_t prefix0 = STRIDED ? 0u : (tile << (HM_TILE_LOG - LOGR));
   // the first pass of a transform reads `in`, the second works in place on `out`
   constexpr bool FIRST = (STRIDED != INV);
@@ -88,7 +88,7 @@ __global__ void __launch_bounds__(HM_THREADS, HM_NTT_MIN_WAVES) k_intt_final(HmN
 }
 // forward ROW pass fused with out = (minuend - NTT) * k [+ addend]
 __global__ void __launch_bounds__(HM_THREADS, HM_NTT_MIN_WAVES) k_ntt_row_subscale(HmNttArgs a, HmSubScale s) {
-  hm_ntt_pass_body<8, false, false, 3>(a, nullptr, &s);
+  hm_ntt_pass_body<HM_ROW_LOG, false, false, 3>(a, nullptr, &s);
 }
 
 __global__ void __launch_bounds__(256) k_tensor(HmTensorArgs a) {
@@ -479,9 +479,9 @@ static void launch_ntt(hm_ctx *c, const HmNttArgs &a, const HmScale *sc, const H
   if (!inverse) {
     hipLaunchKernelGGL((k_ntt_pass<LOG1, true, false, 0>), grid, block, 0, c->stream, a);
     if (ss) hipLaunchKernelGGL(k_ntt_row_subscale, grid, block, 0, c->stream, a, *ss);
-    else hipLaunchKernelGGL((k_ntt_pass<8, false, false, 1>), grid, block, 0, c->stream, a);
+    else hipLaunchKernelGGL((k_ntt_pass<HM_ROW_LOG, false, false, 1>), grid, block, 0, c->stream, a);
   } else {
-    hipLaunchKernelGGL((k_ntt_pass<8, false, true, 0>), grid, block, 0, c->stream, a);
+    hipLaunchKernelGGL((k_ntt_pass<HM_ROW_LOG, false, true, 0>), grid, block, 0, c->stream, a);
     hipLaunchKernelGGL((k_intt_final<LOG1>), grid, block, 0, c->stream, a, *sc);
   }
 }
@@ -545,7 +545,7 @@ static hm_status ntt_common(hm_ctx *c, const char *what, const uint64_t *in, con
         }
       }
     }
-    switch (c->P.logN - 8) {
+    switch (c->P.logN - HM_ROW_LOG) {
     case 5: launch_ntt<5>(c, a, &sc, fused ? &ss : nullptr, inverse); break;
     case 6: launch_ntt<6>(c, a, &sc, fused ? &ss : nullptr, inverse); break;
     case 7: launch_ntt<7>(c, a, &sc, fused ? &ss : nullptr, inverse); break;

@@ -23,6 +23,9 @@
 #define HM_THREADS 512
 #endif
 #define HM_MAX_LIMBS 128
+#ifndef HM_ROW_LOG
+#define HM_ROW_LOG 8  // log2 of the contiguous sub-transform length (pass ROW)
+#endif
 
 struct HmLimb {  // one limb-poly of a launch: limb indices into the in/out bases, modulus id
   uint16_t in, out, mod, aux;
@@ -67,7 +70,7 @@ HM_HD uint32_t hm_tile_gidx(uint32_t tile, uint32_t lin) {
   if (STRIDED) {  // lin = x * C + c ; global = x * 256 + tile * C + c
     const int LOGC = HM_TILE_LOG - LOGR;
     uint32_t x = lin >> LOGC, c = lin & ((1u << LOGC) - 1);
-    return (x << 8) + (tile << LOGC) + c;
+    return (x << HM_ROW_LOG) + (tile << LOGC) + c;
   }
   return (tile << HM_TILE_LOG) + lin;
 }
@@ -121,7 +124,7 @@ struct HmRound {
     xb = (hi << (K + NB)) | lo;
   }
   static HM_HD uint32_t gidx(uint32_t tile, int x, int c) {
-    if (STRIDED) return ((uint32_t)x << 8) + (tile << LOGC) + (uint32_t)c;
+    if (STRIDED) return ((uint32_t)x << HM_ROW_LOG) + (tile << LOGC) + (uint32_t)c;
     return (tile << HM_TILE_LOG) + ((uint32_t)c << LOGR) + (uint32_t)x;
   }
 };

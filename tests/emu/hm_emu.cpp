@@ -21,7 +21,7 @@ static void run_pass(const Emu &e, uint32_t mod, const uint64_t *src, uint64_t *
   const uint32_t tiles = e.P.N >> HM_TILE_LOG;
   const uint64_t q = e.P.mod[mod];
   const HmTw *twl = (INV ? e.inv : e.fwd)[mod].data();
-  const uint32_t s0 = STRIDED ? 0u : (e.P.logN - 8u);
+  const uint32_t s0 = STRIDED ? 0u : (e.P.logN - HM_ROW_LOG);
   std::vector<uint64_t> lds(HM_LDS_WORDS);
   std::vector<HmNttState> st(HM_THREADS);
   // a pass may run in place (src == dst): every thread reads its elements before any thread writes its own
@@ -39,9 +39,9 @@ template <int LOG1>
 static void run_ntt(const Emu &e, uint32_t mod, const uint64_t *in, uint64_t *out, int inverse, HmTw sc) {
   if (!inverse) {
     run_pass<LOG1, true, false, 0>(e, mod, in, out, sc);
-    run_pass<8, false, false, 1>(e, mod, out, out, sc);
+    run_pass<HM_ROW_LOG, false, false, 1>(e, mod, out, out, sc);
   } else {
-    run_pass<8, false, true, 0>(e, mod, in, out, sc);
+    run_pass<HM_ROW_LOG, false, true, 0>(e, mod, in, out, sc);
     run_pass<LOG1, true, true, 2>(e, mod, out, out, sc);
   }
 }
@@ -80,7 +80,7 @@ int emu_ntt(void *h, uint32_t mod, const uint64_t *in, uint64_t *out, int invers
   uint64_t q = e.P.mod[mod], k = e.P.modc[mod].ninv;
   if (has_scale) k = hm::mulmod(k, scale, q);
   HmTw sc = {k, hm::shoup(k, q)};
-  switch (e.P.logN - 8) {
+  switch (e.P.logN - HM_ROW_LOG) {
   case 5: run_ntt<5>(e, mod, in, out, inverse, sc); break;
   case 6: run_ntt<6>(e, mod, in, out, inverse, sc); break;
   case 7: run_ntt<7>(e, mod, in, out, inverse, sc); break;
@@ -98,7 +98,7 @@ int emu_ntt_sub_scale(void *h, uint32_t mod, const uint64_t *in, const uint64_t 
   const uint64_t q = e.P.mod[mod];
   HmTw sc = {k, hm::shoup(k, q)};
   HmEpi ep = {minuend, addend};
-  switch (e.P.logN - 8) {
+  switch (e.P.logN - HM_ROW_LOG) {
   case 5: run_pass<5, true, false, 0>(e, mod, in, out, sc); break;
   case 6: run_pass<6, true, false, 0>(e, mod, in, out, sc); break;
   case 7: run_pass<7, true, false, 0>(e, mod, in, out, sc); break;
@@ -106,7 +106,7 @@ int emu_ntt_sub_scale(void *h, uint32_t mod, const uint64_t *in, const uint64_t 
   case 9: run_pass<9, true, false, 0>(e, mod, in, out, sc); break;
   default: return 1;
   }
-  run_pass<8, false, false, 3>(e, mod, out, out, sc, ep);
+  run_pass<HM_ROW_LOG, false, false, 3>(e, mod, out, out, sc, ep);
   return 0;
 }
 void emu_tensor(void *h, uint32_t mod, const uint64_t *a, const uint64_t *b, const uint64_t *c, const uint64_t *d, uint64_t *o0,
