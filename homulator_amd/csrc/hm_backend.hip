@@ -238,7 +238,7 @@ struct hm_ctx {
   hm::Params P;
   int device = 0;
   hipStream_t stream = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_done = nullptr;
   HmTw *d_tw_fwd = nullptr, *d_tw_inv = nullptr;
   HmMod *d_mods = nullptr;
   std::map<std::vector<uint32_t>, uint64_t *> bconv_tables;  // key: n_in, in_ids..., out_ids...
@@ -353,6 +353,7 @@ extern "C" void hm_destroy(hm_ctx *c) {
   (void)hipFree(c->d_mods);
   (void)hipEventDestroy(c->ev0);
   (void)hipEventDestroy(c->ev1);
+  if (c->ev_done) (void)hipEventDestroy(c->ev_done);
   (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -403,6 +404,16 @@ extern "C" hm_status hm_sync(hm_ctx *c) {
   return HM_OK;
 }
 extern "C" void *hm_stream(hm_ctx *c) { return c ? (void *)c->stream : nullptr; }
+extern "C" hm_status hm_wait_for(hm_ctx *c, hm_ctx *producer) {
+  if (!c || !producer) return HM_ERR_ARG;
+  if (c == producer) return HM_OK;  // same stream: already ordered
+  if (c->device != producer->device) return fail(c, HM_ERR_ARG, "hm_wait_for: contexts on different devices");
+  HM_HIP(c, hipSetDevice(c->device));
+  if (!producer->ev_done) HM_HIP(c, hipEventCreateWithFlags(&producer->ev_done, hipEventDisableTiming));
+  HM_HIP(c, hipEventRecord(producer->ev_done, producer->stream));
+  HM_HIP(c, hipStreamWaitEvent(c->stream, producer->ev_done, 0));
+  return HM_OK;
+}
 
 struct hm_graph {
   hipGraph_t graph = nullptr;

@@ -13,7 +13,7 @@ OP_MUL, OP_MAC2, OP_MAC_ADD, OP_ADD, OP_SUB, OP_MUL_CONST, OP_SUB_SCALE, OP_COPY
 # every symbol include/homulator_hip.h declares
 SYMBOLS = [
     "hm_create", "hm_destroy", "hm_last_error", "hm_version", "hm_get_modulus", "hm_get_psi", "hm_malloc", "hm_free",
-    "hm_memcpy_h2d", "hm_memcpy_d2h", "hm_memcpy_d2d", "hm_sync", "hm_stream", "hm_ntt", "hm_ntt_sub_scale", "hm_tensor", "hm_inner_product", "hm_automorph", "hm_ewe",
+    "hm_memcpy_h2d", "hm_memcpy_d2h", "hm_memcpy_d2d", "hm_sync", "hm_stream", "hm_wait_for", "hm_ntt", "hm_ntt_sub_scale", "hm_tensor", "hm_inner_product", "hm_automorph", "hm_ewe",
     "hm_bconv", "hm_bconv_batch", "hm_bconv_consts", "hm_fill_uniform", "hm_timer_start", "hm_timer_stop", "hm_comm_unique_id", "hm_comm_init_rccl", "hm_comm_init_external",
     "hm_capture_begin", "hm_capture_end", "hm_graph_launch", "hm_graph_destroy", "hm_comm_info", "hm_slice_rows", "hm_limbs_to_slices", "hm_slices_to_limbs", "hm_replicate_limbs",
 ]
@@ -52,6 +52,7 @@ def load():
     L.hm_sync.argtypes = [vp]
     L.hm_stream.restype = vp
     L.hm_stream.argtypes = [vp]
+    L.hm_wait_for.argtypes = [vp, vp]
     L.hm_ntt.argtypes = [vp, vp, vp, vp, vp, vp, u32, i32, vp]
     L.hm_ntt_sub_scale.argtypes = [vp] + [vp] * 9 + [u32, vp]
     L.hm_tensor.argtypes = [vp] + [vp] * 15 + [u32]

@@ -42,6 +42,15 @@ def load():
         L.hh_op_N.argtypes = [vp]
         L.hh_op_plan.argtypes = [vp, C.c_char_p, u32]
         L.hh_op_stage_times.argtypes = [vp, u32, C.c_char_p, u32]
+        L.hh_op_bind_input.argtypes = [vp, C.c_char_p, vp]
+        L.hh_chain_create.argtypes = [C.POINTER(vp), C.c_char_p, C.c_char_p, u32, u32, u32, C.c_char_p, C.c_int]
+        L.hh_chain_destroy.argtypes = [vp]
+        L.hh_chain_size.restype = u32
+        L.hh_chain_size.argtypes = [vp]
+        L.hh_chain_op.restype = vp
+        L.hh_chain_op.argtypes = [vp, u32]
+        L.hh_chain_execute.argtypes = [vp, u32, C.POINTER(C.c_double)]
+        L.hh_chain_simulate.argtypes = [vp]
         L.hh_comm_unique_id.argtypes = [vp]
         L.hh_op_comm_init_rccl.argtypes = [vp, vp]
         L.hh_op_comm_init_external.argtypes = [vp, vp, vp]
@@ -78,8 +87,13 @@ class Op:
 
     def close(self):
         if self.h:
-            self.L.hh_op_destroy(self.h)
+            if not getattr(self, "borrowed", False):
+                self.L.hh_op_destroy(self.h)
             self.h = None
+
+    def bind_input(self, input_name, producer):
+        """continuous execution: this op's input ciphertext (\"ct1\" / \"ct2\") is `producer`'s output, kept in HBM"""
+        self._ck(self.L.hh_op_bind_input(self.h, input_name.encode(), producer.h))
 
     def __del__(self):
         try:
@@ -164,6 +178,53 @@ class Op:
     @property
     def batch(self):
         return self.L.hh_op_batch(self.h)
+
+
+class Chain:
+    """Continuous execution: `Chain("config_4.cfg", "hmult,hrotate,hadd", 45, 35, 15)` runs the ops back to back with
+    the ciphertext resident in HBM (op k+1's ct1 = op k's output; levels follow the data).  `chain[i]` is a borrowed Op
+    view for `read(...)`."""
+
+    def __init__(self, cfg, ops, max_level, cur_level, alpha, overrides=None, quiet=True):
+        self.L = load()
+        if not os.path.isabs(cfg) and not os.path.exists(cfg):
+            cfg = os.path.join(CONFIG_DIR, cfg)
+        self.h = C.c_void_p()
+        ov = None if not overrides else ";".join(f"{k}={v}" for k, v in overrides.items()).encode()
+        if self.L.hh_chain_create(C.byref(self.h), cfg.encode(), ops.encode(), max_level, cur_level, alpha, ov, 1 if quiet else 0):
+            raise HostError(self.L.hh_last_error().decode())
+        self.views = []
+        for i in range(self.L.hh_chain_size(self.h)):
+            v = Op.__new__(Op)
+            v.L, v.h, v.borrowed = self.L, C.c_void_p(self.L.hh_chain_op(self.h, i)), True
+            v.N = self.L.hh_op_N(v.h)
+            self.views.append(v)
+
+    def __len__(self):
+        return len(self.views)
+
+    def __getitem__(self, i):
+        return self.views[i]
+
+    def execute(self, iters=1):
+        """runs the whole chain `iters` times; returns wall ns per pass"""
+        ns = C.c_double()
+        if self.L.hh_chain_execute(self.h, iters, C.byref(ns)):
+            raise HostError(self.L.hh_last_error().decode())
+        return ns.value
+
+    def close(self):
+        if self.h:
+            for v in self.views:
+                v.h = None
+            self.L.hh_chain_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def rccl_unique_id():

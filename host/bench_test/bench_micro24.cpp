@@ -17,6 +17,15 @@ int main(int argc, char *argv[]) {
   uint32_t alpha = std::atoi(argv[5]);
   if (argc > 6) config->setValue("cluster", std::atoi(argv[6]));
 
+  if (ops.find(',') != std::string::npos) {  // build extension: "hmult,hrotate,hadd" = a chain with the ciphertext resident in HBM
+    try {
+      OpChain chain(path, ops, maxlevel, currentlevel, alpha, argc > 6 ? std::map<std::string, uint32_t>{{"cluster", (uint32_t)std::atoi(argv[6])}} : std::map<std::string, uint32_t>{});
+      chain.simulate();
+    } catch (const std::exception &e) {
+      std::cout << e.what() << "\n";
+    }
+    return 0;
+  }
   Arch *arch = new Arch(config);
   if (ops == "hmult") {
     HMULT *hmult = new HMULT("test_hmult", maxlevel, currentlevel, alpha, config, arch);

@@ -50,6 +50,9 @@ public:
   void commInitExternal(void *fn, void *user);
   void registerLimbs(const std::vector<AddrType> &limbStarts);  // gives every limb-poly a place in HBM
   void addInputFill(const InputFill &f) { fills.push_back(f); }
+  // continuous execution: before every run, limb-polys `dst` of this op are copied (device to device, stream-ordered after
+  // the producer's work) from limb-polys `srcAddrs` of `src`; the synthetic fill of `dst` is dropped
+  void bindInput(const std::vector<AddrType> &dst, Arch *src, const std::vector<AddrType> &srcAddrs);
   uint64_t modulus(uint32_t modId) const;
   // constants of a base conversion (host side): qhat_inv[n_in]
   std::vector<uint64_t> bconvScale(const std::vector<uint32_t> &inMods);
@@ -98,6 +101,8 @@ private:
   std::map<AddrType, uint32_t> limbIndex;
   std::vector<Stage> stages;
   std::vector<InputFill> fills;
+  struct Binding { std::vector<AddrType> dst; Arch *src; std::vector<AddrType> srcAddrs; std::vector<uint32_t> dstLimbs, srcLimbs, mods; };
+  std::vector<Binding> bindings;
   std::vector<Launch *> launches;
   size_t nextLaunch = 0;
   bool prepared = false;

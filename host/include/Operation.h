@@ -124,6 +124,10 @@ public:
   unsigned long long totalInstructions();
   Arch *getArch() { return arch; }
   std::vector<std::string> bufferNames() const;
+  // continuous execution: this op's input ciphertext `input` ("ct1", "ct2") is the output ciphertext of `producer`
+  void bindInput(const std::string &input, OperationBase *producer);
+  uint32_t outputLevel() const;  // limbs of out.c0
+  const std::string &name() const { return opName; }
 };
 
 class HMULT : public OperationBase {
@@ -150,5 +154,28 @@ class PADD : public OperationBase {
   Ciphertext *ctx; Plaintext *ptx;
 public:
   PADD(std::string labelName, uint32_t maxLevel, uint32_t currentLevel, uint32_t alpha, Config *cfg, Arch *_arch);
+};
+
+// Continuous multi-op execution.  Upstream cannot chain operations ("NotSuppotr the continuous
+// operation simulate", src/Operation.cpp:636): every op starts from freshly allocated inputs.  A chain keeps the
+// ciphertext resident in HBM: op k+1's first input ciphertext IS op k's output (copied device to device,
+// stream-ordered, no host round trip); its level follows the data (an hmult's rescale drops one limb).  Second
+// operands (ct2 of hmult / hadd, the plaintext of pmult / padd) and the evaluation keys are synthetic as for single ops.
+class OpChain {
+  std::vector<Config *> cfgs;
+  std::vector<Arch *> archs;
+  std::vector<OperationBase *> ops;
+public:
+  // ops: comma-separated list of hmult | hrotate | hadd | pmult | padd, e.g. "hmult,hrotate,hadd,hmult"
+  OpChain(const std::string &cfgPath, const std::string &opList, uint32_t maxLevel, uint32_t curLevel, uint32_t alpha,
+          const std::map<std::string, uint32_t> &overrides = {});
+  ~OpChain();
+  size_t size() const { return ops.size(); }
+  OperationBase *op(size_t i) { return ops.at(i); }
+  void prepare();
+  void run();                        // one pass over the whole chain, asynchronous
+  void sync();
+  double execute(uint32_t iters);    // wall ns per pass over the chain (host clock around enqueue + sync)
+  bool simulate();                   // CLI: per-op banners and stat blocks, then the chain total
 };
 #endif

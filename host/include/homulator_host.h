@@ -36,6 +36,18 @@ int hh_op_read_buffer_copy(hh_op *op, const char *name, uint32_t copy, uint64_t 
 uint32_t hh_op_batch(hh_op *op);
 int hh_op_plan(hh_op *op, char *out, uint32_t cap);          /* launch plan, one line per launch */
 int hh_op_stage_times(hh_op *op, uint32_t iters, char *out, uint32_t cap); /* "<kind> <stages> <ns>" per launch, each timed alone */
+/* continuous execution: `dst`'s input ciphertext `input` ("ct1" / "ct2") becomes `src`'s output ciphertext,
+ * copied device to device before every run of `dst`, stream-ordered after `src`; call before the first execute of `dst` and after `src` was
+ * executed or prepared.  A chain builds the ops itself: op_list = "hmult,hrotate,hadd,...", levels follow the data. */
+int hh_op_bind_input(hh_op *dst, const char *input, hh_op *src);
+typedef struct hh_chain hh_chain;
+int hh_chain_create(hh_chain **out, const char *cfg_path, const char *op_list, uint32_t maxLevel, uint32_t curLevel, uint32_t alpha,
+                    const char *overrides, int quiet);
+void hh_chain_destroy(hh_chain *c);
+uint32_t hh_chain_size(hh_chain *c);
+hh_op *hh_chain_op(hh_chain *c, uint32_t i);   /* borrowed handle of op i (read buffers, plan); do not destroy */
+int hh_chain_execute(hh_chain *c, uint32_t iters, double *ns_per_pass);
+int hh_chain_simulate(hh_chain *c);
 /* multi-GPU (overrides "world=W;rank=R" at creation): set the transport before the first execute */
 int hh_comm_unique_id(void *out128);
 int hh_op_comm_init_rccl(hh_op *op, const void *unique_id128);

@@ -114,6 +114,15 @@ uint32_t Arch::limbOf(AddrType a) const {
   return it->second;
 }
 
+void Arch::bindInput(const std::vector<AddrType> &dst, Arch *src, const std::vector<AddrType> &srcAddrs) {
+  if (prepared) throw std::runtime_error("bindInput after prepare()");
+  if (!src || src == this) throw std::runtime_error("bindInput: bad producer");
+  if (dst.size() != srcAddrs.size()) throw std::runtime_error("bindInput: " + std::to_string(srcAddrs.size()) + " limb-polys produced, " + std::to_string(dst.size()) + " expected (levels differ)");
+  if (src->n != n || src->batch_ != batch_ || src->world_ != world_ || src->rank_ != rank_ || src->backendKind != backendKind)
+    throw std::runtime_error("bindInput: producer and consumer differ in N, batch, sharding or backend");
+  bindings.push_back(Binding{dst, src, srcAddrs, {}, {}, {}});
+}
+
 void Arch::issueIns(uint32_t, const std::string &, const Stage &stage) {
   if (prepared) throw std::runtime_error("issueIns after prepare()");
   stages.push_back(stage);
@@ -653,8 +662,20 @@ void Arch::prepare() {
       bc->slicesOut = xo->slicesOut = static_cast<uint64_t *>(so);
     }
   }
+  std::set<AddrType> bound;
+  for (Binding &b : bindings) {
+    if (!b.src->prepared) throw std::runtime_error("bindInput: prepare the producer first");
+    for (size_t i = 0; i < b.dst.size(); ++i)
+      for (uint32_t c = 0; c < batch_; ++c) {
+        b.dstLimbs.push_back(limbOf(b.dst[i]) + c * (uint32_t)limbIndex.size());
+        b.srcLimbs.push_back(b.src->limbOf(b.srcAddrs[i]) + c * (uint32_t)b.src->limbIndex.size());
+        b.mods.push_back(0);
+      }
+    bound.insert(b.dst.begin(), b.dst.end());
+  }
   for (const InputFill &f : fills)
     for (uint32_t c = 0; c < (f.shared ? 1u : batch_); ++c) {
+      if (!f.addrs.empty() && bound.count(f.addrs[0])) continue;  // this input comes from another op
       std::vector<uint32_t> limbs;
       for (AddrType a : f.addrs) limbs.push_back(limbOf(a) + c * (uint32_t)limbIndex.size());
       if (hm_fill_uniform(ctx, pool, limbs.data(), f.mods.data(), (uint32_t)limbs.size(), f.seed + c * kBatchSeedStride) != HM_OK)
@@ -782,6 +803,12 @@ void Arch::shownStat() {
 
 void Arch::run() {
   if (backendKind != BACKEND_HIP) return;
+  for (Binding &b : bindings) {  // stream-ordered after the producer; one gather-copy launch per bound ciphertext part
+    if (hm_wait_for(ctx, b.src->ctx) != HM_OK) throw std::runtime_error(std::string("hm_wait_for: ") + hm_last_error(ctx));
+    if (hm_ewe(ctx, EWE_COPY, b.src->pool, b.srcLimbs.data(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, pool, b.dstLimbs.data(),
+               b.mods.data(), (uint32_t)b.dstLimbs.size(), nullptr) != HM_OK)
+      throw std::runtime_error(std::string("bound input copy: ") + hm_last_error(ctx));
+  }
   // single GPU: the plan is a fixed sequence of kernels -> captured into a HIP graph on the second run (the first
   // one warms the base-conversion table cache, which allocates) and replayed with one launch afterwards.
   // Sharded runs enqueue directly: the RCCL groups stay outside graphs.

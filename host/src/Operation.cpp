@@ -3,6 +3,9 @@
 // SURVEY.md Appendix A (upstream only needs shapes, and mislabels several operands: Appendix C).
 #include "Operation.h"
 
+#include <chrono>
+#include <sstream>
+
 static std::string S(uint32_t v) { return std::to_string(v); }
 
 // =====================================================================================================
@@ -465,6 +468,20 @@ std::vector<std::string> OperationBase::bufferNames() const {
 }
 bool OperationBase::readBuffer(const std::string &name, uint64_t *host, uint32_t copy) { return arch->readLimbs(bufferAddrs(name), host, copy); }
 unsigned long long OperationBase::totalInstructions() { prepare(); return driver->getTotalIns(); }
+void OperationBase::bindInput(const std::string &input, OperationBase *producer) {
+  for (const char *part : {".c0", ".c1"}) {
+    auto in = namedInputs.find(input + part);
+    auto out = producer->namedOutputs.find(std::string("out") + part);
+    if (in == namedInputs.end()) throw std::runtime_error(opName + " has no input ciphertext " + input);
+    if (out == producer->namedOutputs.end()) throw std::runtime_error(producer->opName + " has no output ciphertext");
+    arch->bindInput(in->second, producer->arch, out->second);
+  }
+}
+uint32_t OperationBase::outputLevel() const {
+  auto o = namedOutputs.find("out.c0");
+  if (o == namedOutputs.end()) throw std::runtime_error(opName + " has no output ciphertext");
+  return (uint32_t)o->second.size();
+}
 
 void OperationBase::prepare() {
   driver->IssueInsFromDramToChip(arch);
@@ -653,4 +670,71 @@ PADD::PADD(std::string labelName, uint32_t maxLevel, uint32_t currentLevel, uint
     namedOutputs[k == 0 ? "out.c0" : "out.c1"] = addrManager->getAddr("PADDOutput(" + S(k) + ")");
   }
   finishConstruction();
+}
+
+// =====================================================================================================
+// continuous execution
+// =====================================================================================================
+static OperationBase *makeOp(const std::string &o, uint32_t maxLevel, uint32_t level, uint32_t alpha, Config *cfg, Arch *arch) {
+  if (o == "hmult") return new HMULT("test_hmult", maxLevel, level, alpha, cfg, arch);
+  if (o == "hrotate") return new HROTATE("test_hrotate", maxLevel, level, alpha, cfg, arch);
+  if (o == "hadd") return new HADD("test_hadd", maxLevel, level, alpha, cfg, arch);
+  if (o == "pmult") return new PMULT("test_pmult", maxLevel, level, alpha, cfg, arch);
+  if (o == "padd") return new PADD("test_ADD", maxLevel, level, alpha, cfg, arch);
+  throw std::runtime_error("Error operation requirement, please double confirm!");
+}
+
+OpChain::OpChain(const std::string &cfgPath, const std::string &opList, uint32_t maxLevel, uint32_t curLevel, uint32_t alpha,
+                 const std::map<std::string, uint32_t> &overrides) {
+  std::stringstream ss(opList);
+  std::string name;
+  uint32_t level = curLevel;
+  try {
+    while (std::getline(ss, name, ',')) {
+      if (name.empty()) continue;
+      if (level == 0) throw std::runtime_error("chain: no limbs left for " + name);
+      Config *cfg = new Config(cfgPath);
+      cfgs.push_back(cfg);
+      cfg->getValue("N");
+      for (auto &kv : overrides) cfg->setValue(kv.first, kv.second);
+      // every op draws its own second operand; the first op's first operand is the chain input
+      cfg->setValue("seed", cfg->getValueOr("seed", 0x484F4D55u) + 31u * (uint32_t)ops.size());
+      Arch *arch = new Arch(cfg);
+      archs.push_back(arch);
+      OperationBase *op = makeOp(name, maxLevel, level, alpha, cfg, arch);
+      if (!ops.empty()) op->bindInput("ct1", ops.back());
+      ops.push_back(op);
+      level = op->outputLevel();
+    }
+    if (ops.empty()) throw std::runtime_error("chain: empty op list");
+  } catch (...) {
+    for (auto *o : ops) delete o;
+    for (auto *a : archs) delete a;
+    for (auto *c : cfgs) delete c;
+    throw;
+  }
+}
+OpChain::~OpChain() {
+  for (auto *o : ops) delete o;
+  for (auto *a : archs) delete a;
+  for (auto *c : cfgs) delete c;
+}
+void OpChain::prepare() { for (auto *o : ops) o->prepare(); }
+void OpChain::run() { for (auto *a : archs) a->run(); }
+void OpChain::sync() { for (auto *a : archs) a->sync(); }
+double OpChain::execute(uint32_t iters) {
+  prepare();
+  run();
+  sync();
+  const auto t0 = std::chrono::steady_clock::now();
+  for (uint32_t i = 0; i < iters; ++i) run();
+  sync();
+  return std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t0).count() / (iters ? iters : 1);
+}
+bool OpChain::simulate() {
+  prepare();
+  for (auto *o : ops) o->simulate();
+  const double ns = execute(20);
+  std::cout << "\nChain of " << ops.size() << " operations, ciphertext resident in HBM: " << (unsigned long long)ns << " ns per pass\n";
+  return true;
 }

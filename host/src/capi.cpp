@@ -97,6 +97,52 @@ int hh_op_stage_times(hh_op *h, uint32_t iters, char *out, uint32_t cap) {
   HH_TRY(h->op->prepare(); std::string s = h->arch->stageTimes(iters); if (s.size() + 1 > cap) throw std::runtime_error("buffer too small");
          memcpy(out, s.c_str(), s.size() + 1))
 }
+int hh_op_bind_input(hh_op *dst, const char *input, hh_op *src) { HH_TRY(dst->op->bindInput(input, src->op)) }
+
+struct hh_chain {
+  OpChain *chain = nullptr;
+  std::vector<hh_op *> views;  // non-owning per-op handles for the read / plan calls
+};
+int hh_chain_create(hh_chain **out, const char *cfg_path, const char *op_list, uint32_t maxLevel, uint32_t curLevel, uint32_t alpha,
+                    const char *overrides, int quiet) {
+  if (!out || !cfg_path || !op_list) { g_err = "null argument"; return 1; }
+  *out = nullptr;
+  try {
+    QuietScope qs(quiet != 0);
+    std::map<std::string, uint32_t> ov;
+    if (overrides) {
+      std::stringstream ss(overrides);
+      std::string kv;
+      while (std::getline(ss, kv, ';')) {
+        size_t eq = kv.find('=');
+        if (eq != std::string::npos) ov[kv.substr(0, eq)] = (uint32_t)std::stoul(kv.substr(eq + 1));
+      }
+    }
+    hh_chain *h = new hh_chain;
+    h->chain = new OpChain(cfg_path, op_list, maxLevel, curLevel, alpha, ov);
+    for (size_t i = 0; i < h->chain->size(); ++i) {
+      hh_op *v = new hh_op;
+      v->op = h->chain->op(i);
+      v->arch = v->op->getArch();
+      h->views.push_back(v);
+    }
+    *out = h;
+    return 0;
+  } catch (const std::exception &e) {
+    g_err = e.what();
+    return 1;
+  }
+}
+void hh_chain_destroy(hh_chain *h) {
+  if (!h) return;
+  for (hh_op *v : h->views) delete v;  // views own nothing
+  delete h->chain;
+  delete h;
+}
+uint32_t hh_chain_size(hh_chain *h) { return (uint32_t)h->chain->size(); }
+hh_op *hh_chain_op(hh_chain *h, uint32_t i) { return i < h->views.size() ? h->views[i] : nullptr; }
+int hh_chain_execute(hh_chain *h, uint32_t iters, double *ns) { HH_TRY(double t = h->chain->execute(iters); if (ns) *ns = t) }
+int hh_chain_simulate(hh_chain *h) { HH_TRY(h->chain->simulate()) }
 extern "C" int hm_comm_unique_id(void *);
 int hh_comm_unique_id(void *out) { if (hm_comm_unique_id(out)) { g_err = "hm_comm_unique_id failed (is librccl.so available?)"; return 1; } return 0; }
 int hh_op_comm_init_rccl(hh_op *h, const void *id) { HH_TRY(h->arch->commInitRccl(id)) }

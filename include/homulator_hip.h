@@ -53,6 +53,9 @@ hm_status hm_memcpy_d2h(hm_ctx *ctx, void *dst, const void *src, size_t bytes);
 hm_status hm_memcpy_d2d(hm_ctx *ctx, void *dst, const void *src, size_t bytes);
 hm_status hm_sync(hm_ctx *ctx);
 void *hm_stream(hm_ctx *ctx); /* the context's hipStream_t */
+/* work enqueued on `ctx` after this call starts only when everything enqueued so far on `producer` has finished
+ * (an event on the producer's stream; no host synchronisation): chains ops that live in different contexts */
+hm_status hm_wait_for(hm_ctx *ctx, hm_ctx *producer);
 
 /* Limb lists: every compute call takes n limb-polys; operand X of limb i lives at
  * X_base + X_limbs[i] * N (X_limbs == NULL means 0,1,..,n-1); mod_ids[i] selects the modulus. */
