@@ -87,49 +87,61 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP backend has no CPU fallback")
+    # rehearsal on a one-GPU box (never the driver's configuration): HOMULATOR_DIST_BACKEND=gloo puts every rank on GPU 0
+    # and carries the exchanges over gloo, because RCCL refuses two ranks per device
+    rehearsal = world > 1 and os.environ.get("HOMULATOR_DIST_BACKEND", "nccl") == "gloo"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
+    red_dev = "cpu" if rehearsal else "cuda"
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from homulator_amd import host
     # N > 1: ONE hmult whose limb-polys are sharded over the N GPUs (limb e -> e % N), RCCL all-to-all around the two
     # base conversions + one replicate in the rescale: strong scaling of the op's latency
+    import math
     streams = args.streams if world == 1 else 1
-    batch = args.batch if world == 1 else 1
+    # sharded: the ops of a batch share the exchanges around each base conversion; a batch that divides --steps, so that
+    # exactly --steps hmults are timed without a second (communicating) instance for the remainder
+    batch = args.batch if world == 1 else max(1, math.gcd(args.batch, args.steps))
     ops = [host.Op(CFG, OP, L, ELL, ALPHA, device=local_rank, rank=rank, world=world,
                    overrides={"seed": host.SEED + 7 * i, **({"batch": batch} if batch > 1 else {})})
            for i in range(streams)]
     op = ops[0]
     # steps that do not fill a batch run through a one-op instance, so that EXACTLY --steps hmults are timed
-    tail_op = host.Op(CFG, OP, L, ELL, ALPHA, device=local_rank, overrides={"seed": host.SEED + 999}) if batch > 1 else None
+    tail_op = host.Op(CFG, OP, L, ELL, ALPHA, device=local_rank, overrides={"seed": host.SEED + 999}) if batch > 1 and world == 1 else None
     transport = "none"
     if world > 1:
         from homulator_amd import dist as hdist
-        transport = os.environ.get("HOMULATOR_TRANSPORT", "rccl")
+        transport = "gloo-rehearsal" if rehearsal else os.environ.get("HOMULATOR_TRANSPORT", "rccl")
         if transport == "rccl":
             try:   # the HIP library's own RCCL communicator: ncclSend/ncclRecv groups on its stream (the product path)
                 hdist.init_rccl(op)
             except Exception as e:   # reported, never silent: the JSON line names the transport actually used
                 print(f"[bench] rank {rank}: private RCCL communicator failed ({e}); using torch.distributed NCCL staging", file=sys.stderr)
                 transport = "torch-nccl-staging"
-        if transport != "rccl":
-            ok = torch.tensor([1 if transport == "rccl" else 0], device="cuda")
-        else:
-            ok = torch.tensor([1], device="cuda")
+        ok = torch.tensor([1 if transport == "rccl" else 0], device=red_dev)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)   # all ranks must agree on the transport
         if int(ok.item()) == 0 and transport == "rccl":
             transport = "torch-nccl-staging"
         if transport != "rccl":
-            tr = hdist.TorchNcclTransport()
+            tr = hdist.GlooTransport() if rehearsal else hdist.TorchNcclTransport()
             op.comm_init_external(tr.cfunc)
 
     def run(n):   # n hmult steps, round-robin over the in-flight instances; asynchronous
         for i in range(n // batch):
             ops[i % streams].enqueue(1)
         if n % batch:
-            tail_op.enqueue(n % batch)
+            if tail_op is not None:
+                tail_op.enqueue(n % batch)
+            else:   # sharded warm-up only (the timed step count is a multiple of the batch): one more full batch
+                ops[0].enqueue(1)
 
     def sync_all():
         for o in ops:
@@ -163,9 +175,9 @@ def main():
         barrier()
         single = args.steps / (time.perf_counter() - t1)
     # per-launch device time of one op, each launch bracketed by its own event pair (collective when sharded)
-    stage_rows = (tail_op if tail_op is not None else op).stage_times(5)
+    stage_rows = (tail_op if tail_op is not None else op).stage_times(5)   # sharded: of one batch
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -181,12 +193,12 @@ def main():
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": f"{CFG} {OP} L={L} l={ELL} alpha={ALPHA} (N=2^16, beta=3, full hybrid key switch + rescale)",
-                       "parallelism": "single GPU" if world == 1 else f"limbs sharded over {world} GPUs (limb e -> e % {world}); RCCL all-to-all around ModUp/ModDown base conversion + replicate of the rescale residue",
+                       "parallelism": "single GPU" if world == 1 else f"limbs sharded over {world} GPUs (limb e -> e % {world}); RCCL all-to-all around ModUp/ModDown base conversion + replicate of the rescale residue; {batch} hmults per launch share the exchanges",
                        "launches_per_op": op.launch_count(), "streams": streams, "batch": batch, "transport": transport,
                        "streams_note": "`streams` instances in flight (own HBM pool / HIP stream each), each carrying `batch` independent hmults per launch (own inputs, one evaluation key); a step is one hmult"},
             "single_stream_ops_per_s": single,
             "stage_us": [[kind, name, round(ns * 1e-3, 2)] for kind, name, ns in stage_rows],
-            "exchange_us_per_op": round(sum(ns for kind, _, ns in stage_rows if kind in ("EXCH_IN", "EXCH_OUT", "REPLICATE")) * 1e-3, 2),
+            "exchange_us_per_op": round(sum(ns for kind, _, ns in stage_rows if kind in ("EXCH_IN", "EXCH_OUT", "REPLICATE")) * 1e-3 / (batch if world > 1 else 1), 2),
             "hmult_hbm_gbs_algorithmic": HMULT_ALG_BYTES / (ms * 1e-3) / 1e9,
             "hmult_frac_of_hbm_peak": HMULT_ALG_BYTES / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "roofline": {"bound": "hbm", "kernel": "forward NTT sweep, 50 limbs = k_ntt_pass<COL> + k_ntt_pass<ROW>",

@@ -537,6 +537,18 @@ void Arch::buildLaunches() {
             pr->outMods.push_back(i->mod_id);
           }
         }
+        if (world_ > 1 && batch_ > 1) {  // sharded batch: the ops of the batch share the exchanges around the conversion
+          const uint32_t per = (uint32_t)limbIndex.size();
+          const size_t p0 = L->probs.size();
+          for (uint32_t c = 1; c < batch_; ++c)
+            for (size_t i = 0; i < p0; ++i) {
+              Launch::Prob q = L->probs[i];
+              for (uint32_t &x : q.in) x += c * per;
+              for (uint32_t &x : q.out) x += c * per;
+              L->probs.push_back(q);
+            }
+          L->refInstructions *= batch_;
+        }
         for (auto &q : L->probs) L->bytes += LP * (q.in.size() + q.out.size());
         if (world_ > 1) {
           // limb-sharded -> coefficient slices -> convert every output on this rank's slice -> limb-sharded
@@ -596,6 +608,14 @@ void Arch::replicateForBatch() {
       for (size_t i = 0; i < n0; ++i) v.push_back(isLimb && !sharedLimbs.count(v[i]) ? v[i] + c * per : v[i]);
   };
   for (Launch *l : launches) {
+    if (world_ > 1 && (l->kind == Launch::L_BCONV || l->kind == Launch::L_EXCH_IN || l->kind == Launch::L_EXCH_OUT)) continue;  // built batched
+    if (l->kind == Launch::L_REPLICATE) {
+      const size_t n0 = l->exLimbs.size();
+      for (uint32_t c = 1; c < batch_; ++c)
+        for (size_t i = 0; i < n0; ++i) { l->exLimbs.push_back(l->exLimbs[i] + c * per); l->exOwners.push_back(l->exOwners[i]); }
+      l->bytes *= batch_;
+      continue;
+    }
     if (l->kind == Launch::L_IP) {
       // entry e: ipTerms x limbs, ipTerms * ipOuts y limbs, ipOuts outputs.  Entry-major order (entry e of every op
       // side by side): the ops share the key limbs, so the second and later readers of a key chunk find it in L2
@@ -637,7 +657,6 @@ void Arch::prepare() {
   prepared = true;
   buildLaunches();
   if (batch_ > 1) {
-    if (world_ > 1) throw std::runtime_error("batch > 1 is a single-GPU mode (world = 1)");
     replicateForBatch();
     stat->setStat("Batch", batch_);
   }

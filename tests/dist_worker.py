@@ -12,9 +12,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def gather_buffer(op, name, n_limbs, N):
+def gather_buffer(op, name, n_limbs, N, copy=0):
     """every rank contributes the limbs it owns; rank 0 returns the assembled [n_limbs][N] array"""
-    mine = op.read(name)
+    mine = op.read(name, copy=copy)
     full = torch.zeros((n_limbs, N), dtype=torch.int64)
     own = op.owned(n_limbs)
     full[own] = torch.from_numpy(mine[own].view(np.int64))
@@ -22,28 +22,29 @@ def gather_buffer(op, name, n_limbs, N):
     return full.numpy().view(np.uint64)
 
 
-def run_gpu(cfg, opname, L, ell, alpha, logN):
+def run_gpu(cfg, opname, L, ell, alpha, logN, batch=1):
     from homulator_amd import host
     from homulator_amd.dist import GlooTransport
     rank, world = dist.get_rank(), dist.get_world_size()
-    op = host.Op(cfg, opname, L, ell, alpha, rank=rank, world=world)
+    op = host.Op(cfg, opname, L, ell, alpha, rank=rank, world=world, overrides={"batch": batch} if batch > 1 else None)
     tr = GlooTransport()
     op.comm_init_external(tr.cfunc)
     op.execute(1)
     op.execute(1)  # the plan must be re-runnable
     N = 1 << logN
     n_out = ell - 1 if opname == "hmult" else ell
-    out0 = gather_buffer(op, "out.c0", n_out, N)
-    out1 = gather_buffer(op, "out.c1", n_out, N)
+    outs = [(gather_buffer(op, "out.c0", n_out, N, c), gather_buffer(op, "out.c1", n_out, N, c)) for c in range(batch)]
     ok = True
     if rank == 0:
         from oracle.homoracle import Oracle
         o = Oracle(logN, L, alpha)
         o.set_threads(4)
-        S = host.SEED
-        ct1, ct2, evk = o.synth_ct(ell, S), o.synth_ct(ell, S + 2000), o.synth_evk(ell, S + 10000)
-        exp = o.hmult(ell, ct1, ct2, evk) if opname == "hmult" else o.hrotate(ell, ct1, 5, evk)
-        ok = bool(np.array_equal(out0, exp[0]) and np.array_equal(out1, exp[1]))
+        evk = o.synth_evk(ell, host.SEED + 10000)   # one evaluation key for the whole batch
+        for c in range(batch):
+            S = host.SEED + c * 100000              # host/src/Arch.cpp kBatchSeedStride
+            ct1, ct2 = o.synth_ct(ell, S), o.synth_ct(ell, S + 2000)
+            exp = o.hmult(ell, ct1, ct2, evk) if opname == "hmult" else o.hrotate(ell, ct1, 5, evk)
+            ok = ok and bool(np.array_equal(outs[c][0], exp[0]) and np.array_equal(outs[c][1], exp[1]))
         print(f"sharded {opname} world={world} {cfg} L={L} l={ell} alpha={alpha}: {'OK' if ok else 'MISMATCH'}; "
               f"exchanges={tr.calls} bytes_sent_rank0={tr.bytes_sent}", flush=True)
     flag = torch.tensor([1 if ok else 0])
@@ -85,7 +86,7 @@ def main():
     dist.init_process_group("gloo")
     if mode == "gpu":
         cfg, opname, L, ell, alpha, logN = sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]), int(sys.argv[7])
-        ok = run_gpu(cfg, opname, L, ell, alpha, logN)
+        ok = run_gpu(cfg, opname, L, ell, alpha, logN, int(sys.argv[8]) if len(sys.argv) > 8 else 1)
     else:
         ok = run_transport()
     dist.barrier()

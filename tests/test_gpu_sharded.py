@@ -21,6 +21,17 @@ def test_sharded_op_matches_oracle(world, cfg, opname, L, ell, alpha, logN):
     assert "OK" in outs[0]
 
 
+@pytest.mark.parametrize("world,cfg,opname,L,ell,alpha,logN,batch", [
+    (2, "config_4_N15.cfg", "hmult", 16, 10, 4, 15, 3),
+    (4, "config_4_N15.cfg", "hrotate", 6, 5, 2, 15, 2),
+])
+def test_sharded_batch_matches_oracle(world, cfg, opname, L, ell, alpha, logN, batch):
+    """batch > 1 under sharding: the ops of a batch share the exchanges around each base conversion and the replicate"""
+    rcs, outs = launch(world, ["gpu", cfg, opname, str(L), str(ell), str(alpha), str(logN), str(batch)], timeout=900)
+    assert all(rc == 0 for rc in rcs), "\n".join(outs)
+    assert "OK" in outs[0]
+
+
 def test_rccl_loads_and_world1_communicator():
     """the RCCL transport itself cannot run two ranks on one GPU; check that librccl loads, a unique id can be drawn,
     a 1-rank communicator is created inside the HIP library and the op still runs bit-exact with it"""
