@@ -11,7 +11,7 @@
 // forward = COL then ROW (Cooley-Tukey, natural in, bit-reversed out);
 // inverse = ROW then COL (Gentleman-Sande, bit-reversed in, natural out, then * scale).
 //
-// A workgroup of 256 threads owns a tile of HM_TILE = 4096 coefficients (32 KiB) in LDS and runs
+// A workgroup of HM_THREADS = 512 threads owns a tile of HM_TILE = 4096 coefficients (32 KiB) in LDS and runs
 // the rounds LDS -> registers -> LDS with one barrier per round; the phase functions below carry no
 // register state across barriers, so the host emulator (tests/emu) can run them thread by thread.
 #pragma once
