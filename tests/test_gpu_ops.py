@@ -178,3 +178,22 @@ def test_batched_ops_bit_exact(cfg, logN, L, ell, alpha, batch, opname):
         op.read("out.c0", copy=batch)
     op.close()
     single.close()
+
+
+def test_concurrent_instances_stay_bit_exact():
+    """bench.py's throughput mode: instances with their own HBM pool and HIP stream run concurrently on one GPU; their
+    kernels interleave on the chip, the results must not (200 interleaved enqueues, outputs checked afterwards)"""
+    from homulator_amd import host
+    o = oracle(15, 16, 4)
+    evk = o.synth_evk(10, SEED + 10000)
+    ops = [host.Op("config_4_N15.cfg", "hmult", 16, 10, 4, overrides={"seed": SEED + 7 * i, "batch": 1 + i}) for i in range(3)]
+    for it in range(200):
+        ops[it % 3].enqueue(1)
+    for op in ops:
+        op.sync()
+    for i, op in enumerate(ops):
+        for c in range(op.batch):
+            s = SEED + 7 * i + c * BATCH_SEED_STRIDE
+            exp = o.hmult(10, o.synth_ct(10, s), o.synth_ct(10, s + 2000), o.synth_evk(10, SEED + 7 * i + 10000))
+            assert np.array_equal(op.read("out.c0", copy=c), exp[0]) and np.array_equal(op.read("out.c1", copy=c), exp[1]), (i, c)
+        op.close()
