@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <tuple>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -39,7 +40,7 @@ __device__ __forceinline__ bool hm_block_map(uint32_t tiles_per_limb, uint32_t n
 }
 
 template <int LOGR, bool STRIDED, bool INV, int MODE>
-__device__ __forceinline__ void hm_ntt_pass_body(const HmNttArgs &a, const HmTw *scale, const HmSubScale *ss = nullptr) {
+__device__ __forceinline__ void hm_ntt_pass_body(const HmNttArgs &a, const HmTw *scale, const HmSubScale *ss = nullptr, const HmMix *mx = nullptr) {
   __shared__ __attribute__((aligned(16))) uint64_t lds[HM_LDS_WORDS];
   uint32_t entry, tile;
   if (!hm_block_map(1u << (a.logN - HM_TILE_LOG), a.n_limbs, entry, tile)) return;
@@ -57,12 +58,18 @@ __device__ __forceinline__ void hm_ntt_pass_body(const HmNttArgs &a, const HmTw 
   uint64_t *dst = a.out + (size_t)lb.out * N;
 
   HmTw sc = {0, 0};
-  HmEpi ep = {nullptr, nullptr};
+  HmEpi ep = hm_epi_none();
   if constexpr (MODE == 2) sc = scale[entry];
   if constexpr (MODE == 3) {
-    sc = ss->k[entry];
+    const uint32_t ki = ss->kidx[entry];
+    sc = ss->k[ki];
     ep.a = ss->minuend + (size_t)ss->mlimb[entry] * N;
     ep.d = ss->addend ? ss->addend + (size_t)ss->alimb[entry] * N : nullptr;
+    if (ss->has_ak) ep.dk = ss->ak[ki];
+  }
+  if constexpr (MODE == 4) {
+    ep.b = mx->mix + (size_t)mx->limb[entry] * N;
+    ep.bk = mx->k[entry];
   }
   HmNttState st;
   hm_ntt_phase<LOGR, STRIDED, INV, MODE, 0>(st, tid, lds, src, dst, tile, twl, s0, prefix0, q, sc, ep);
@@ -86,9 +93,14 @@ template <int LOGR>
 __global__ void __launch_bounds__(HM_THREADS, HM_NTT_MIN_WAVES) k_intt_final(HmNttArgs a, HmScale s) {
   hm_ntt_pass_body<LOGR, true, true, 2>(a, s.c);
 }
-// forward ROW pass fused with out = (minuend - NTT) * k [+ addend]
+// forward ROW pass fused with out = (minuend - NTT) * k [+ addend * addend_k]
 __global__ void __launch_bounds__(HM_THREADS, HM_NTT_MIN_WAVES) k_ntt_row_subscale(HmNttArgs a, HmSubScale s) {
   hm_ntt_pass_body<HM_ROW_LOG, false, false, 3>(a, nullptr, &s);
+}
+// forward COL pass with the prologue x = in + k * mix
+template <int LOGR>
+__global__ void __launch_bounds__(HM_THREADS, HM_NTT_MIN_WAVES) k_ntt_col_mix(HmNttArgs a, HmMix m) {
+  hm_ntt_pass_body<LOGR, true, false, 4>(a, nullptr, nullptr, &m);
 }
 
 __global__ void __launch_bounds__(256) k_tensor(HmTensorArgs a) {
@@ -484,11 +496,12 @@ static hm_status check_mods(hm_ctx *c, const char *what, const uint32_t *m, uint
 }
 
 template <int LOG1>
-static void launch_ntt(hm_ctx *c, const HmNttArgs &a, const HmScale *sc, const HmSubScale *ss, bool inverse) {
+static void launch_ntt(hm_ctx *c, const HmNttArgs &a, const HmScale *sc, const HmSubScale *ss, const HmMix *mx, bool inverse) {
   const uint32_t tiles = c->P.N >> HM_TILE_LOG;
   dim3 grid(a.n_limbs * tiles), block(HM_THREADS);  // n_limbs = entries, a multiple of 16 (pairs x 8 XCDs)
   if (!inverse) {
-    hipLaunchKernelGGL((k_ntt_pass<LOG1, true, false, 0>), grid, block, 0, c->stream, a);
+    if (mx) hipLaunchKernelGGL((k_ntt_col_mix<LOG1>), grid, block, 0, c->stream, a, *mx);
+    else hipLaunchKernelGGL((k_ntt_pass<LOG1, true, false, 0>), grid, block, 0, c->stream, a);
     if (ss) hipLaunchKernelGGL(k_ntt_row_subscale, grid, block, 0, c->stream, a, *ss);
     else hipLaunchKernelGGL((k_ntt_pass<HM_ROW_LOG, false, false, 1>), grid, block, 0, c->stream, a);
   } else {
@@ -497,18 +510,35 @@ static void launch_ntt(hm_ctx *c, const HmNttArgs &a, const HmScale *sc, const H
   }
 }
 
-// common body of hm_ntt / hm_ntt_sub_scale.  `k`: inverse -> optional extra scale; fused forward -> the
-// mandatory per-limb constant of out = (minuend - NTT(in)) * k [+ addend]
+// operands of the fused forward transform: x = NTT(in [+ mix_k * mix]); out = (minuend - x) * k [+ addend [* addend_k]]
+struct NttFused {
+  const uint64_t *minuend = nullptr;
+  const uint32_t *minuend_limbs = nullptr;
+  const uint64_t *addend = nullptr;
+  const uint32_t *addend_limbs = nullptr;
+  const uint64_t *addend_k = nullptr;
+  const uint64_t *mix = nullptr;
+  const uint32_t *mix_limbs = nullptr;
+  const uint64_t *mix_k = nullptr;
+};
+
+// common body of hm_ntt / hm_ntt_sub_scale / hm_ntt_mix_sub_scale.  `k`: inverse -> optional extra scale; fused forward ->
+// the mandatory per-limb constant of the epilogue
 static hm_status ntt_common(hm_ctx *c, const char *what, const uint64_t *in, const uint32_t *in_limbs, uint64_t *out,
                             const uint32_t *out_limbs, const uint32_t *mod_ids, uint32_t n, int inverse, const uint64_t *k,
-                            const uint64_t *minuend, const uint32_t *minuend_limbs, const uint64_t *addend,
-                            const uint32_t *addend_limbs) {
-  const bool fused = minuend != nullptr;
+                            const NttFused &f) {
+  const bool fused = f.minuend != nullptr;
   hm_status st;
   if ((st = check_limbs(c, what, in_limbs, n)) || (st = check_limbs(c, what, out_limbs, n)) ||
-      (st = check_limbs(c, what, minuend_limbs, n)) || (st = check_limbs(c, what, addend_limbs, n)) ||
-      (st = check_mods(c, what, mod_ids, n)))
+      (st = check_limbs(c, what, f.minuend_limbs, n)) || (st = check_limbs(c, what, f.addend_limbs, n)) ||
+      (st = check_limbs(c, what, f.mix_limbs, n)) || (st = check_mods(c, what, mod_ids, n)))
     return st;
+  for (uint32_t g = 0; g < n; ++g) {
+    const uint64_t q = c->P.mod[mod_ids[g]];
+    if ((k && k[g] >= q) || (f.addend_k && f.addend_k[g] >= q) || (f.mix_k && f.mix_k[g] >= q))
+      return fail(c, HM_ERR_ARG, "%s: constant [%u] is not reduced", what, g);
+    if (f.addend_k && f.addend_k[g] == 0) return fail(c, HM_ERR_ARG, "%s: addend_k[%u] is zero (pass addend = NULL instead)", what, g);
+  }
   HM_HIP(c, hipSetDevice(c->device));
   // pair up limb-polys that share a modulus (see hm_block_map), then the leftovers with each other
   std::vector<std::pair<int, int>> pairs;  // indices into the caller's lists, -1 = empty
@@ -525,8 +555,20 @@ static hm_status ntt_common(hm_ctx *c, const char *what, const uint64_t *in, con
     for (size_t i = 0; i < singles.size(); i += 2) pairs.emplace_back(singles[i], i + 1 < singles.size() ? singles[i + 1] : -1);
   }
   const uint32_t PAIRS_PER_LAUNCH = HM_MAX_LIMBS / 2;
-  for (uint32_t base = 0; base < pairs.size(); base += PAIRS_PER_LAUNCH) {
-    const uint32_t np = std::min<uint32_t>(PAIRS_PER_LAUNCH, (uint32_t)pairs.size() - base);
+  for (uint32_t base = 0; base < pairs.size();) {
+    // a launch takes up to PAIRS_PER_LAUNCH pairs and, fused, up to HM_EPI_CONSTS distinct epilogue constant pairs
+    std::map<std::tuple<uint32_t, uint64_t, uint64_t>, uint32_t> consts;
+    uint32_t np = 0;
+    while (np < PAIRS_PER_LAUNCH && base + np < pairs.size()) {
+      if (fused) {
+        auto trial = consts;
+        for (int gi : {pairs[base + np].first, pairs[base + np].second})
+          if (gi >= 0) trial.emplace(std::make_tuple(mod_ids[gi], k[gi], f.addend_k ? f.addend_k[gi] : 0ull), (uint32_t)trial.size());
+        if (trial.size() > HM_EPI_CONSTS) break;
+        consts.swap(trial);
+      }
+      ++np;
+    }
     const uint32_t cnt = ((np + 7) / 8) * 16;  // entries: groups of 8 pairs = 16 entries
     HmNttArgs a;
     a.in = in; a.out = out;
@@ -535,7 +577,14 @@ static hm_status ntt_common(hm_ctx *c, const char *what, const uint64_t *in, con
     a.logN = c->P.logN; a.n_limbs = cnt;
     HmScale sc;
     HmSubScale ss;
-    ss.minuend = minuend; ss.addend = addend;
+    HmMix mx;
+    ss.minuend = f.minuend; ss.addend = f.addend; ss.has_ak = f.addend_k != nullptr;
+    mx.mix = f.mix;
+    for (auto &kv : consts) {
+      const uint64_t q = c->P.mod[std::get<0>(kv.first)], kk = std::get<1>(kv.first), ak = std::get<2>(kv.first);
+      ss.k[kv.second] = HmTw{kk, hm::shoup(kk, q)};
+      ss.ak[kv.second] = HmTw{ak, hm::shoup(ak, q)};
+    }
     for (uint32_t e = 0; e < cnt; ++e) a.limb[e] = HmLimb{0, 0, (uint16_t)HM_NTT_INVALID, 0};
     for (uint32_t kk = 0; kk < np; ++kk) {
       for (int which = 0; which < 2; ++which) {
@@ -544,27 +593,33 @@ static hm_status ntt_common(hm_ctx *c, const char *what, const uint64_t *in, con
         const uint32_t g = (uint32_t)gi, e = (kk / 8) * 16 + which * 8 + (kk % 8), m = mod_ids[g];
         const uint64_t q = c->P.mod[m];
         a.limb[e] = HmLimb{(uint16_t)limb_at(in_limbs, g), (uint16_t)limb_at(out_limbs, g), (uint16_t)m, 0};
-        if (k && k[g] >= q) return fail(c, HM_ERR_ARG, "%s: constant [%u] is not reduced", what, g);
         if (inverse) {
           uint64_t v = c->P.modc[m].ninv;
           if (k) v = hm::mulmod(v, k[g], q);
           sc.c[e] = HmTw{v, hm::shoup(v, q)};
         } else if (fused) {
-          ss.k[e] = HmTw{k[g], hm::shoup(k[g], q)};
-          ss.mlimb[e] = (uint16_t)limb_at(minuend_limbs, g);
-          ss.alimb[e] = (uint16_t)limb_at(addend_limbs, g);
+          ss.kidx[e] = (uint8_t)consts.at(std::make_tuple(m, k[g], f.addend_k ? f.addend_k[g] : 0ull));
+          ss.mlimb[e] = (uint16_t)limb_at(f.minuend_limbs, g);
+          ss.alimb[e] = (uint16_t)limb_at(f.addend_limbs, g);
+          if (f.mix) {
+            mx.limb[e] = (uint16_t)limb_at(f.mix_limbs, g);
+            mx.k[e] = HmTw{f.mix_k[g], hm::shoup(f.mix_k[g], q)};
+          }
         }
       }
     }
+    const HmSubScale *pss = fused ? &ss : nullptr;
+    const HmMix *pmx = fused && f.mix ? &mx : nullptr;
     switch (c->P.logN - HM_ROW_LOG) {
-    case 5: launch_ntt<5>(c, a, &sc, fused ? &ss : nullptr, inverse); break;
-    case 6: launch_ntt<6>(c, a, &sc, fused ? &ss : nullptr, inverse); break;
-    case 7: launch_ntt<7>(c, a, &sc, fused ? &ss : nullptr, inverse); break;
-    case 8: launch_ntt<8>(c, a, &sc, fused ? &ss : nullptr, inverse); break;
-    case 9: launch_ntt<9>(c, a, &sc, fused ? &ss : nullptr, inverse); break;
+    case 5: launch_ntt<5>(c, a, &sc, pss, pmx, inverse); break;
+    case 6: launch_ntt<6>(c, a, &sc, pss, pmx, inverse); break;
+    case 7: launch_ntt<7>(c, a, &sc, pss, pmx, inverse); break;
+    case 8: launch_ntt<8>(c, a, &sc, pss, pmx, inverse); break;
+    case 9: launch_ntt<9>(c, a, &sc, pss, pmx, inverse); break;
     default: return fail(c, HM_ERR_UNSUPPORTED, "%s: logN %u", what, c->P.logN);
     }
     HM_HIP(c, hipGetLastError());
+    base += np;
   }
   return HM_OK;
 }
@@ -575,7 +630,7 @@ extern "C" hm_status hm_ntt(hm_ctx *c, const uint64_t *in, const uint32_t *in_li
   if (!c) return HM_ERR_ARG;
   if (!in || !out) return fail(c, HM_ERR_ARG, "hm_ntt: null buffer");
   if (scale && !inverse) return fail(c, HM_ERR_ARG, "hm_ntt: scale is only defined for the inverse transform");
-  return ntt_common(c, "hm_ntt", in, in_limbs, out, out_limbs, mod_ids, n, inverse, scale, nullptr, nullptr, nullptr, nullptr);
+  return ntt_common(c, "hm_ntt", in, in_limbs, out, out_limbs, mod_ids, n, inverse, scale, NttFused{});
 }
 
 extern "C" hm_status hm_ntt_sub_scale(hm_ctx *c, const uint64_t *in, const uint32_t *in_limbs, const uint64_t *minuend,
@@ -584,7 +639,20 @@ extern "C" hm_status hm_ntt_sub_scale(hm_ctx *c, const uint64_t *in, const uint3
                                       const uint64_t *k) {
   if (!c) return HM_ERR_ARG;
   if (!in || !out || !minuend || !k) return fail(c, HM_ERR_ARG, "hm_ntt_sub_scale: null argument");
-  return ntt_common(c, "hm_ntt_sub_scale", in, in_limbs, out, out_limbs, mod_ids, n, 0, k, minuend, minuend_limbs, addend, addend_limbs);
+  NttFused f;
+  f.minuend = minuend; f.minuend_limbs = minuend_limbs; f.addend = addend; f.addend_limbs = addend_limbs;
+  return ntt_common(c, "hm_ntt_sub_scale", in, in_limbs, out, out_limbs, mod_ids, n, 0, k, f);
+}
+
+extern "C" hm_status hm_ntt_mix_sub_scale(hm_ctx *c, const hm_ntt_fused_desc *d) {
+  if (!c) return HM_ERR_ARG;
+  if (!d || !d->in || !d->out || !d->minuend || !d->k) return fail(c, HM_ERR_ARG, "hm_ntt_mix_sub_scale: null argument");
+  if ((d->mix != nullptr) != (d->mix_k != nullptr)) return fail(c, HM_ERR_ARG, "hm_ntt_mix_sub_scale: mix and mix_k go together");
+  if (d->addend_k && !d->addend) return fail(c, HM_ERR_ARG, "hm_ntt_mix_sub_scale: addend_k without addend");
+  NttFused f;
+  f.minuend = d->minuend; f.minuend_limbs = d->minuend_limbs; f.addend = d->addend; f.addend_limbs = d->addend_limbs;
+  f.addend_k = d->addend_k; f.mix = d->mix; f.mix_limbs = d->mix_limbs; f.mix_k = d->mix_k;
+  return ntt_common(c, "hm_ntt_mix_sub_scale", d->in, d->in_limbs, d->out, d->out_limbs, d->mod_ids, d->n, 0, d->k, f);
 }
 
 extern "C" hm_status hm_tensor(hm_ctx *c, const uint64_t *pa, const uint32_t *la, const uint64_t *pb, const uint32_t *lb,

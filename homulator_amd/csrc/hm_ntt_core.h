@@ -43,15 +43,31 @@ struct HmNttArgs {
 struct HmScale {  // per-limb epilogue constant of the inverse transform: c = N^-1 * extra, Shoup form
   HmTw c[HM_MAX_LIMBS];
 };
-// fused forward epilogue (MODE 3): out = (minuend - NTT(in)) * k [+ addend]   (ModDown finish, rescale)
+// fused forward transform (ModDown finish, rescale, or both merged):
+//   first pass, MODE 4:  x = in + mix_k * mix       (coefficient domain, before the first butterfly)
+//   last pass,  MODE 3:  out = (minuend - NTT(x)) * k [+ addend * addend_k]
+// Per-limb constants are indices into a table of at most HM_EPI_CONSTS distinct (k, addend_k) pairs, so that the kernel
+// argument stays below 4 KiB with 128 limb-polys per launch (an op has one pair per modulus).
+#define HM_EPI_CONSTS 60
 struct HmSubScale {
   const uint64_t *minuend, *addend;  // addend may be null
   uint16_t mlimb[HM_MAX_LIMBS], alimb[HM_MAX_LIMBS];
+  uint8_t kidx[HM_MAX_LIMBS];
+  uint8_t has_ak, pad[7];
+  HmTw k[HM_EPI_CONSTS], ak[HM_EPI_CONSTS];
+};
+struct HmMix {  // prologue operand of the first pass
+  const uint64_t *mix;
+  uint16_t limb[HM_MAX_LIMBS];
   HmTw k[HM_MAX_LIMBS];
 };
-struct HmEpi {  // the epilogue operands of one limb-poly, resolved by the kernel
-  const uint64_t *a, *d;
+struct HmEpi {  // the prologue / epilogue operands of one limb-poly, resolved by the kernel
+  const uint64_t *a, *d;     // minuend, addend (MODE 3)
+  HmTw dk;                   // addend constant; dk.w == 0: none
+  const uint64_t *b;         // mix operand (MODE 4)
+  HmTw bk;
 };
+HM_HD HmEpi hm_epi_none() { return HmEpi{nullptr, nullptr, HmTw{0, 0}, nullptr, HmTw{0, 0}}; }
 
 // LDS image of a tile.  STRIDED: [x][c] with the C columns contiguous (a plain copy of C-element
 // row segments).  CONTIG: [c][x] with 4 words of padding per 32 so that stride-32 column reads of the
@@ -159,6 +175,21 @@ HM_HD void hm_ph_load_global(HmNttState &st, int tid, const uint64_t *g, uint32_
     for (int e = 0; e < G::E; ++e) st.v[u][e] = g[G::gidx(tile, xb | (e << G::K), c)];
   }
 }
+// MODE 4: the same with the linear prologue x = in + k * mix (both reduced; x reduced)
+template <int LOGR, bool STRIDED, int R>
+HM_HD void hm_ph_load_global_mix(HmNttState &st, int tid, const uint64_t *g, uint32_t tile, uint64_t q, HmEpi ep) {
+  using G = HmRound<LOGR, STRIDED, R>;
+#pragma unroll
+  for (int u = 0; u < G::GPT; ++u) {
+    int c, hi, xb;
+    G::coords(tid, u, c, hi, xb);
+#pragma unroll
+    for (int e = 0; e < G::E; ++e) {
+      const uint32_t gi = G::gidx(tile, xb | (e << G::K), c);
+      st.v[u][e] = hm_addmod(g[gi], hm_shoup(ep.b[gi], ep.bk.w, ep.bk.ws, q), q);
+    }
+  }
+}
 
 // MODE 3: request the epilogue operands of the elements this thread will store (same coordinates as the store)
 template <int LOGR, bool STRIDED, int R>
@@ -177,7 +208,8 @@ HM_HD void hm_ph_load_epi(HmNttState &st, int tid, uint32_t tile, HmEpi ep) {
   }
 }
 
-// MODE 0: store as is (lazy values, hand-off between the two passes); 1: forward final, reduce [0,8q) ->
+// MODE 0 / 4: store as is (lazy values, hand-off between the two passes; 4 = first pass with the mix prologue);
+// 1: forward final, reduce [0,8q) ->
 // [0,q); 2: inverse final, multiply by the per-limb constant and reduce to [0,q); 3: forward final fused with
 // out = (minuend - x) * k [+ addend]
 template <int LOGR, bool STRIDED, int R, int MODE>
@@ -195,7 +227,7 @@ HM_HD void hm_ph_store_global(const HmNttState &st, int tid, uint64_t *g, uint32
       const uint32_t gi = G::gidx(tile, xb | (e << G::K), c);
       if (MODE == 3) {  // a in [0, 8q): minuend - a + 8q stays positive and below 2^64; the product reduces it
         a = hm_shoup(st.ea[u][e] + 8 * q - a, sc.w, sc.ws, q);
-        if (ep.d) a = hm_addmod(a, st.ed[u][e], q);
+        if (ep.d) a = hm_addmod(a, ep.dk.w ? hm_shoup(st.ed[u][e], ep.dk.w, ep.dk.ws, q) : st.ed[u][e], q);
       }
       g[gi] = a;
     }
@@ -260,7 +292,8 @@ HM_HD void hm_ntt_phase(HmNttState &st, int tid, uint64_t *lds, const uint64_t *
   constexpr int r0 = INV ? n - 1 : 0, r1 = INV ? n - 2 : 1, r2 = INV ? 0 : 2;  // r2 only when n == 3
   if (PHASE == 0) {
     hm_ph_load_tw<LOGR, STRIDED, r0>(st, tid, twl, s0, prefix0);
-    hm_ph_load_global<LOGR, STRIDED, r0>(st, tid, src, tile);
+    if (MODE == 4) hm_ph_load_global_mix<LOGR, STRIDED, r0>(st, tid, src, tile, q, ep);
+    else hm_ph_load_global<LOGR, STRIDED, r0>(st, tid, src, tile);
     hm_ph_load_tw<LOGR, STRIDED, r1>(st, tid, twl, s0, prefix0);
   } else if (PHASE == 1) {
     hm_ph_compute<LOGR, STRIDED, r0, INV>(st, q);

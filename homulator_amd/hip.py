@@ -13,10 +13,17 @@ OP_MUL, OP_MAC2, OP_MAC_ADD, OP_ADD, OP_SUB, OP_MUL_CONST, OP_SUB_SCALE, OP_COPY
 # every symbol include/homulator_hip.h declares
 SYMBOLS = [
     "hm_create", "hm_destroy", "hm_last_error", "hm_version", "hm_get_modulus", "hm_get_psi", "hm_malloc", "hm_free",
-    "hm_memcpy_h2d", "hm_memcpy_d2h", "hm_memcpy_d2d", "hm_sync", "hm_stream", "hm_wait_for", "hm_ntt", "hm_ntt_sub_scale", "hm_tensor", "hm_inner_product", "hm_automorph", "hm_ewe",
+    "hm_memcpy_h2d", "hm_memcpy_d2h", "hm_memcpy_d2d", "hm_sync", "hm_stream", "hm_wait_for", "hm_ntt", "hm_ntt_sub_scale", "hm_ntt_mix_sub_scale", "hm_tensor", "hm_inner_product", "hm_automorph", "hm_ewe",
     "hm_bconv", "hm_bconv_batch", "hm_bconv_consts", "hm_fill_uniform", "hm_timer_start", "hm_timer_stop", "hm_comm_unique_id", "hm_comm_init_rccl", "hm_comm_init_external",
     "hm_capture_begin", "hm_capture_end", "hm_graph_launch", "hm_graph_destroy", "hm_comm_info", "hm_slice_rows", "hm_limbs_to_slices", "hm_slices_to_limbs", "hm_replicate_limbs",
 ]
+
+
+class hm_ntt_fused_desc(C.Structure):
+    _fields_ = [("in_", C.c_void_p), ("in_limbs", C.c_void_p), ("mix", C.c_void_p), ("mix_limbs", C.c_void_p), ("mix_k", C.c_void_p),
+                ("minuend", C.c_void_p), ("minuend_limbs", C.c_void_p), ("addend", C.c_void_p), ("addend_limbs", C.c_void_p),
+                ("addend_k", C.c_void_p), ("out", C.c_void_p), ("out_limbs", C.c_void_p), ("mod_ids", C.c_void_p), ("n", C.c_uint32),
+                ("k", C.c_void_p)]
 
 
 class hm_params(C.Structure):
@@ -55,6 +62,7 @@ def load():
     L.hm_wait_for.argtypes = [vp, vp]
     L.hm_ntt.argtypes = [vp, vp, vp, vp, vp, vp, u32, i32, vp]
     L.hm_ntt_sub_scale.argtypes = [vp] + [vp] * 9 + [u32, vp]
+    L.hm_ntt_mix_sub_scale.argtypes = [vp, C.POINTER(hm_ntt_fused_desc)]
     L.hm_tensor.argtypes = [vp] + [vp] * 15 + [u32]
     L.hm_inner_product.argtypes = [vp] + [vp] * 7 + [u32, u32, u32]
     L.hm_automorph.argtypes = [vp, vp, vp, vp, vp, u32, u32]
@@ -176,6 +184,16 @@ class Context:
         kk, pk = _u64(k)
         self._ck(self.L.hm_ntt_sub_scale(self.h, src.ptr, keep[0][1], minuend.ptr, keep[1][1], None if addend is None else addend.ptr,
                                          keep[2][1], out.ptr, keep[3][1], keep[4][1], len(mod_ids), pk))
+
+    def ntt_mix_sub_scale(self, src, minuend, out, mod_ids, k, mix=None, mix_k=None, addend=None, addend_k=None, in_limbs=None,
+                          mix_limbs=None, minuend_limbs=None, addend_limbs=None, out_limbs=None):
+        """out = (minuend - NTT(src + mix_k * mix)) * k + addend * addend_k (merged ModDown + rescale of one limb)"""
+        keep = [_u32(x) for x in (in_limbs, mix_limbs, minuend_limbs, addend_limbs, out_limbs, mod_ids)]
+        ks = [_u64(x) for x in (mix_k, addend_k, k)]
+        ptr = lambda v: None if v is None else v.ptr
+        d = hm_ntt_fused_desc(src.ptr, keep[0][1], ptr(mix), keep[1][1], ks[0][1], minuend.ptr, keep[2][1], ptr(addend), keep[3][1], ks[1][1],
+                              out.ptr, keep[4][1], keep[5][1], len(mod_ids), ks[2][1])
+        self._ck(self.L.hm_ntt_mix_sub_scale(self.h, C.byref(d)))
 
     def tensor(self, a, b, c, d, o0, o1, o2, mod_ids, limbs=None):
         ls = limbs or [None] * 7

@@ -34,6 +34,9 @@ public:
   // set by the backend's fusion passes (Arch::fusePasses), never by the generators:
   bool fusedSubScale = false;          // forward NTT whose epilogue is out = (minuend - NTT(in)) * constant [+ addend]
   AddrType fMinuend = 0, fAddend = 0;  // fAddend == 0: no addend
+  // merged ModDown + rescale: the transform's input is in + fMixConst * fMix, the addend is scaled by fAddendConst
+  AddrType fMix = 0;                   // 0: no prologue
+  uint64_t fMixConst = 0, fAddendConst = 0;  // fAddendConst == 0: addend as is
   bool fusedTensor = false;            // MAC2 record that also produces d0 -> extraOutputs[0] and d2 -> extraOutputs[1]
   std::vector<AddrType> extraOutputs;
   // fused inner product (ops == IP): out_k = sum_j ipX[j] * ipY[k][j]; out_0 = OutputOperand, out_1 = extraOutputs[0]

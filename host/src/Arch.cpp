@@ -23,7 +23,7 @@ struct Arch::Launch {
   std::vector<uint32_t> exLimbs, exOwners;
   uint64_t *slicesIn = nullptr, *slicesOut = nullptr;
   uint32_t logLen = 0;
-  std::vector<uint64_t> k;
+  std::vector<uint64_t> k, mixK, addK;  // mixK / addK: prologue and addend constants of the merged ModDown + rescale transform
   bool hasK = false;
   unsigned long long refInstructions = 0;
   unsigned long long bytes = 0;  // operand limb-polys read + written x N x 8
@@ -240,6 +240,30 @@ void Arch::fusePasses(std::vector<Stage> &st) {
       producer[out] = t;
       dead.insert(i);
     }
+  // (4b) ModDown finish followed by the rescale of the same limb.  T: h = (ip - NTT(conv)) * kT + d and
+  //      R: out = (h - NTT(r)) * kR with r = INTT(last limb of h) are both linear in the coefficient domain:
+  //      out = (ip - NTT(conv + kT^-1 * r)) * (kT kR) + d * kR — ONE transform per limb instead of two, and h never
+  //      exists (the last limb keeps T: r comes from it).  Bit-identical: everything is exact modular arithmetic.
+  for (auto &s : st)
+    for (Instruction *R : s.ins) {
+      if (R->ops != NTT || !R->fusedSubScale || R->fAddend || R->fMix || dead.count(R)) continue;
+      auto p = producer.find(R->fMinuend);
+      if (p == producer.end() || p->second == R || !p->second->fusedSubScale || p->second->fMix || dead.count(p->second) ||
+          p->second->mod_id != R->mod_id || uses[R->fMinuend] != 1)
+        continue;
+      Instruction *T = p->second;
+      const uint64_t q = modulus(R->mod_id);
+      // R survives (its stage comes after the INTT that produces r, so the stage list stays a topological order)
+      R->fMix = R->operandList[0];
+      R->fMixConst = hm::invmod(T->constant, q);
+      R->operandList[0] = T->operandList[0];
+      R->fMinuend = T->fMinuend;
+      R->fAddend = T->fAddend;
+      R->fAddendConst = T->fAddend ? R->constant : 0;
+      R->constant = hm::mulmod(T->constant, R->constant, q);
+      R->refInstructions += T->refInstructions;
+      dead.insert(T);
+    }
   // (5) tensor product: d1 = p*s + r*t (MAC2) with d0 = p*t and d2 = r*s (MUL) of the same limb -> one pass
   {
     std::map<std::pair<AddrType, AddrType>, Instruction *> muls;
@@ -346,7 +370,7 @@ void Arch::buildLaunches() {
   for (const Stage &s : st) {
     size_t first = parts.size();
     for (Instruction *i : s.ins) {
-      int key = i->ops == IP && !i->ipX.empty() ? 300 + (int)i->ipX.size() * 10 + (int)i->ipY.size() : i->fusedTensor ? 200 : i->fusedSubScale ? (i->fAddend ? 201 : 202) : i->ops == MULT ? 100 + i->opcode : (i->ops == NTT && i->passthrough) ? 100 + EWE_COPY : i->ops == AUTO ? 1000 + (int)i->galois : (int)i->ops;
+      int key = i->ops == IP && !i->ipX.empty() ? 300 + (int)i->ipX.size() * 10 + (int)i->ipY.size() : i->fusedTensor ? 200 : i->fusedSubScale ? (i->fMix ? (i->fAddend ? 203 : 204) : i->fAddend ? 201 : 202) : i->ops == MULT ? 100 + i->opcode : (i->ops == NTT && i->passthrough) ? 100 + EWE_COPY : i->ops == AUTO ? 1000 + (int)i->galois : (int)i->ops;
       size_t p = first;
       for (; p < parts.size(); ++p)
         if (parts[p].key == key) break;
@@ -368,7 +392,7 @@ void Arch::buildLaunches() {
     if (i->ops == BCONV_STEP2) v.assign(i->operandList.begin(), i->operandList.end() - 1);
     else if (i->ops == MULT) { for (int b = 0; b < 4; ++b) if (useMask[i->opcode] & (1 << b)) v.push_back(i->operandList[b]); }
     else v.push_back(i->operandList[0]);
-    if (i->fusedSubScale) { v.push_back(i->fMinuend); if (i->fAddend) v.push_back(i->fAddend); }
+    if (i->fusedSubScale) { v.push_back(i->fMinuend); if (i->fAddend) v.push_back(i->fAddend); if (i->fMix) v.push_back(i->fMix); }
     return v;
   };
   auto writes = [&](Instruction *i) {
@@ -487,6 +511,10 @@ void Arch::buildLaunches() {
             L->a.push_back(limbOf(i->operandList[0])); L->b.push_back(limbOf(i->fMinuend));
             if (anyAddend) L->c.push_back(limbOf(i->fAddend));
             L->out.push_back(limbOf(i->OutputOperand)); L->mods.push_back(i->mod_id); L->k.push_back(i->constant);
+            if (f->fMix) {  // the part key keeps merged and plain records apart
+              L->d.push_back(limbOf(i->fMix)); L->mixK.push_back(i->fMixConst);
+              if (anyAddend) L->addK.push_back(i->fAddendConst);
+            }
           }
         L->hasK = true;
         L->bytes = (anyAddend ? 4 : 3) * LP * count;
@@ -634,9 +662,11 @@ void Arch::replicateForBatch() {
     } else {
       rep(l->a, true); rep(l->b, true); rep(l->c, true); rep(l->d, true);
       rep(l->out, true); rep(l->out1, true); rep(l->out2, true); rep(l->mods, false);
-      const size_t k0 = l->k.size();
-      for (uint32_t c = 1; c < batch_; ++c)
-        for (size_t i = 0; i < k0; ++i) l->k.push_back(l->k[i]);
+      for (std::vector<uint64_t> *kv : {&l->k, &l->mixK, &l->addK}) {
+        const size_t k0 = kv->size();
+        for (uint32_t c = 1; c < batch_; ++c)
+          for (size_t i = 0; i < k0; ++i) kv->push_back((*kv)[i]);
+      }
       const size_t p0 = l->probs.size();
       for (uint32_t c = 1; c < batch_; ++c)
         for (size_t i = 0; i < p0; ++i) {
@@ -754,8 +784,15 @@ void Arch::enqueue(Launch &l) {
     st = hm_ntt(ctx, pool, l.a.data(), pool, l.out.data(), l.mods.data(), cnt, 1, l.hasK ? l.k.data() : nullptr);
     break;
   case Launch::L_NTT_SUBSCALE:
-    st = hm_ntt_sub_scale(ctx, pool, l.a.data(), pool, l.b.data(), l.c.empty() ? nullptr : pool, l.c.empty() ? nullptr : l.c.data(), pool,
-                          l.out.data(), l.mods.data(), cnt, l.k.data());
+    if (!l.mixK.empty()) {
+      hm_ntt_fused_desc d = {pool, l.a.data(), pool, l.d.data(), l.mixK.data(), pool, l.b.data(), l.c.empty() ? nullptr : pool,
+                             l.c.empty() ? nullptr : l.c.data(), l.addK.empty() ? nullptr : l.addK.data(), pool, l.out.data(), l.mods.data(), cnt,
+                             l.k.data()};
+      st = hm_ntt_mix_sub_scale(ctx, &d);
+    } else {
+      st = hm_ntt_sub_scale(ctx, pool, l.a.data(), pool, l.b.data(), l.c.empty() ? nullptr : pool, l.c.empty() ? nullptr : l.c.data(), pool,
+                            l.out.data(), l.mods.data(), cnt, l.k.data());
+    }
     break;
   case Launch::L_IP:
     st = hm_inner_product(ctx, pool, l.a.data(), pool, l.b.data(), pool, l.out.data(), l.mods.data(), (uint32_t)l.mods.size(), l.ipTerms, l.ipOuts);

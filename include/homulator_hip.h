@@ -78,6 +78,25 @@ hm_status hm_ntt_sub_scale(hm_ctx *ctx, const uint64_t *in, const uint32_t *in_l
                            uint64_t *out, const uint32_t *out_limbs, const uint32_t *mod_ids, uint32_t n,
                            const uint64_t *k);
 
+/* The same with a linear prologue and a constant on the addend — ModDown and rescale merged into ONE transform per
+ * limb (both are linear in the coefficient domain):
+ *     x   = NTT(in + mix_k * mix)                       mix, mix_k optional (both or neither)
+ *     out = (minuend - x) * k  [+ addend [* addend_k]]   addend optional; addend_k optional (NULL = 1)
+ * With in = the P->Q conversion, mix = r = INTT(last limb of the key-switch sum), mix_k = P, k = (P q_last)^-1,
+ * addend = the tensor part, addend_k = q_last^-1 this is ModDowNTT + ModDownSub + add + Rescale_NTT + Rescale_SUB +
+ * Rescale_Mul of one limb (src/Operation.cpp:521-590, 967-1005, 806-910) in one pass over HBM.  All constants are
+ * host arrays of n residues mod the limb's modulus.  `out` must not alias `in`, `mix`, `minuend` or `addend`. */
+typedef struct hm_ntt_fused_desc {
+  const uint64_t *in;      const uint32_t *in_limbs;
+  const uint64_t *mix;     const uint32_t *mix_limbs;     const uint64_t *mix_k;
+  const uint64_t *minuend; const uint32_t *minuend_limbs;
+  const uint64_t *addend;  const uint32_t *addend_limbs;  const uint64_t *addend_k;
+  uint64_t *out;           const uint32_t *out_limbs;
+  const uint32_t *mod_ids; uint32_t n;
+  const uint64_t *k;
+} hm_ntt_fused_desc;
+hm_status hm_ntt_mix_sub_scale(hm_ctx *ctx, const hm_ntt_fused_desc *desc);
+
 /* K2 — automorphism X -> X^galois in evaluation form.  Replaces issueIns(..., "AUTO", ...) for
  * InsGen::GenAUTO (src/InsGen.cpp:46-71).  in must not alias out. */
 hm_status hm_automorph(hm_ctx *ctx, const uint64_t *in, const uint32_t *in_limbs, uint64_t *out,

@@ -17,7 +17,7 @@ struct Emu {
 };
 
 template <int LOGR, bool STRIDED, bool INV, int MODE>
-static void run_pass(const Emu &e, uint32_t mod, const uint64_t *src, uint64_t *dst, HmTw sc, HmEpi ep = HmEpi{nullptr, nullptr}) {
+static void run_pass(const Emu &e, uint32_t mod, const uint64_t *src, uint64_t *dst, HmTw sc, HmEpi ep = hm_epi_none()) {
   const uint32_t tiles = e.P.N >> HM_TILE_LOG;
   const uint64_t q = e.P.mod[mod];
   const HmTw *twl = (INV ? e.inv : e.fwd)[mod].data();
@@ -91,19 +91,20 @@ int emu_ntt(void *h, uint32_t mod, const uint64_t *in, uint64_t *out, int invers
   return 0;
 }
 
-// fused forward transform: out = (minuend - NTT(in)) * k [+ addend]
+// fused forward transform: out = (minuend - NTT(in [+ mix_k * mix])) * k [+ addend [* addend_k]]   (mix_k / addend_k = 0: none)
 int emu_ntt_sub_scale(void *h, uint32_t mod, const uint64_t *in, const uint64_t *minuend, const uint64_t *addend, uint64_t *out,
-                      uint64_t k) {
+                      uint64_t k, const uint64_t *mix, uint64_t mix_k, uint64_t addend_k) {
   Emu &e = *(Emu *)h;
   const uint64_t q = e.P.mod[mod];
   HmTw sc = {k, hm::shoup(k, q)};
-  HmEpi ep = {minuend, addend};
+  HmEpi ep = hm_epi_none();
+  ep.a = minuend; ep.d = addend;
+  if (addend_k) ep.dk = HmTw{addend_k, hm::shoup(addend_k, q)};
+  if (mix) { ep.b = mix; ep.bk = HmTw{mix_k, hm::shoup(mix_k, q)}; }
   switch (e.P.logN - HM_ROW_LOG) {
-  case 5: run_pass<5, true, false, 0>(e, mod, in, out, sc); break;
-  case 6: run_pass<6, true, false, 0>(e, mod, in, out, sc); break;
-  case 7: run_pass<7, true, false, 0>(e, mod, in, out, sc); break;
-  case 8: run_pass<8, true, false, 0>(e, mod, in, out, sc); break;
-  case 9: run_pass<9, true, false, 0>(e, mod, in, out, sc); break;
+#define HM_CASE(n) case n: if (mix) run_pass<n, true, false, 4>(e, mod, in, out, sc, ep); else run_pass<n, true, false, 0>(e, mod, in, out, sc); break;
+    HM_CASE(5) HM_CASE(6) HM_CASE(7) HM_CASE(8) HM_CASE(9)
+#undef HM_CASE
   default: return 1;
   }
   run_pass<HM_ROW_LOG, false, false, 3>(e, mod, out, out, sc, ep);

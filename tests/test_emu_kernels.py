@@ -26,7 +26,7 @@ def emu():
     L.emu_psi.restype = C.c_uint64
     L.emu_psi.argtypes = [C.c_void_p, C.c_uint32]
     L.emu_ntt.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_int]
-    L.emu_ntt_sub_scale.argtypes = [C.c_void_p, C.c_uint32] + [C.c_void_p] * 4 + [C.c_uint64]
+    L.emu_ntt_sub_scale.argtypes = [C.c_void_p, C.c_uint32] + [C.c_void_p] * 4 + [C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64]
     L.emu_tensor.argtypes = [C.c_void_p, C.c_uint32] + [C.c_void_p] * 7
     L.emu_ewe.argtypes = [C.c_void_p, C.c_int, C.c_uint32] + [C.c_void_p] * 4 + [C.c_uint64, C.c_void_p]
     L.emu_bconv.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
@@ -84,10 +84,17 @@ def test_emu_fused_ntt_sub_scale_and_tensor(emu, logN):
             ntt = o.ntt([m], x[None])
             exp = o.ewe(6, [m], mn[None], None, ntt, k=[k])
             out = np.empty_like(x)
-            assert emu.emu_ntt_sub_scale(h, m, p(x), p(mn), None, p(out), k) == 0
+            assert emu.emu_ntt_sub_scale(h, m, p(x), p(mn), None, p(out), k, None, 0, 0) == 0
             assert np.array_equal(out, exp[0])
-            assert emu.emu_ntt_sub_scale(h, m, p(x), p(mn), p(ad), p(out), k) == 0
+            assert emu.emu_ntt_sub_scale(h, m, p(x), p(mn), p(ad), p(out), k, None, 0, 0) == 0
             assert np.array_equal(out, o.ewe(3, [m], exp, None, ad[None])[0])
+            # merged ModDown + rescale form: prologue x + mk * d, constant on the addend
+            mk, ak = (k * 7 + 3) % q, (k * 11 + 5) % q
+            xin = o.ewe(3, [m], x[None], None, o.ewe(5, [m], d[None], k=[mk]))            # x + mk * d
+            body = o.ewe(6, [m], mn[None], None, o.ntt([m], xin), k=[k])                   # (mn - NTT(.)) * k
+            exp2 = o.ewe(3, [m], body, None, o.ewe(5, [m], ad[None], k=[ak]))              # + ak * ad
+            assert emu.emu_ntt_sub_scale(h, m, p(x), p(mn), p(ad), p(out), k, p(d), mk, ak) == 0
+            assert np.array_equal(out, exp2[0])
             o0, o1, o2 = (np.empty_like(x) for _ in range(3))
             emu.emu_tensor(h, m, p(x), p(mn), p(ad), p(d), p(o0), p(o1), p(o2))
             assert np.array_equal(o0, o.ewe(0, [m], x[None], mn[None])[0])

@@ -141,7 +141,7 @@ def test_errors_are_loud(env):
 
 def test_fused_ntt_sub_scale_and_tensor(env):
     """fused forward NTT epilogue out = (minuend - NTT(in)) * k [+ addend] and the one-pass tensor product"""
-    ctx, o, _ = env
+    ctx, o, hip = env
     ids = [0, 0, 3, o.L, o.L, 5, 2]            # pairs of equal moduli + singles: exercises the XCD pairing
     n = len(ids)
     x, mn, ad, dd = (o.fill_uniform(ids, s) for s in (1, 2, 3, 4))
@@ -158,6 +158,21 @@ def test_fused_ntt_sub_scale_and_tensor(env):
     assert np.array_equal(out.download(), exp)
     ctx.ntt_sub_scale(dx, dmn, out, ids, k, addend=dad)
     assert np.array_equal(out.download(), o.ewe(3, ids, exp, None, ad))
+    # merged ModDown + rescale form: prologue x + mk * dd, constant on the addend, mixed limb lists
+    mk = [(kk * 7 + 3) % o.moduli[m] for kk, m in zip(k, ids)]
+    ak = [(kk * 11 + 5) % o.moduli[m] for kk, m in zip(k, ids)]
+    xin = o.ewe(3, ids, x, None, o.ewe(5, ids, dd, k=mk))
+    exp2 = o.ewe(3, ids, o.ewe(6, ids, mn, None, o.ntt(ids, xin), k=k), None, o.ewe(5, ids, ad, k=ak))
+    ctx.ntt_mix_sub_scale(dx, dmn, out, ids, k, mix=ddd, mix_k=mk, addend=dad, addend_k=ak)
+    assert np.array_equal(out.download(), exp2)
+    ctx.ntt_mix_sub_scale(dx, dmn, out, ids, k, mix=ddd, mix_k=mk)                      # no addend
+    assert np.array_equal(out.download(), o.ewe(6, ids, mn, None, o.ntt(ids, xin), k=k))
+    ctx.ntt_mix_sub_scale(dx, dmn, out, ids, k, addend=dad, addend_k=ak)                # no prologue
+    assert np.array_equal(out.download(), o.ewe(3, ids, exp, None, o.ewe(5, ids, ad, k=ak)))
+    with pytest.raises(hip.HmError):
+        ctx.ntt_mix_sub_scale(dx, dmn, out, ids, k, mix=ddd)                            # mix without mix_k
+    with pytest.raises(hip.HmError):
+        ctx.ntt_mix_sub_scale(dx, dmn, out, ids, k, addend=dad, addend_k=[0] * n)       # zero constant
     o0, o1, o2 = ctx.alloc(n), ctx.alloc(n), ctx.alloc(n)
     ctx.tensor(dx, dmn, dad, ddd, o0, o1, o2, ids)
     assert np.array_equal(o0.download(), o.ewe(0, ids, x, mn))
