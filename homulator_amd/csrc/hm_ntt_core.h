@@ -108,7 +108,6 @@ HM_HD int hm_tile_lidx(uint32_t lin) {
 struct HmNttState {
   uint64_t v[HM_MAX_GPT][8];
   HmTw tw[3][HM_MAX_GPT][7];
-  uint64_t ea[HM_MAX_GPT][8], ed[HM_MAX_GPT][8];  // MODE 3 only: epilogue operands, requested before the last round
 };
 
 // Round schedule per sub-transform length: bits are consumed from the top for the forward transform
@@ -191,23 +190,6 @@ HM_HD void hm_ph_load_global_mix(HmNttState &st, int tid, const uint64_t *g, uin
   }
 }
 
-// MODE 3: request the epilogue operands of the elements this thread will store (same coordinates as the store)
-template <int LOGR, bool STRIDED, int R>
-HM_HD void hm_ph_load_epi(HmNttState &st, int tid, uint32_t tile, HmEpi ep) {
-  using G = HmRound<LOGR, STRIDED, R>;
-#pragma unroll
-  for (int u = 0; u < G::GPT; ++u) {
-    int c, hi, xb;
-    G::coords(tid, u, c, hi, xb);
-#pragma unroll
-    for (int e = 0; e < G::E; ++e) {
-      const uint32_t gi = G::gidx(tile, xb | (e << G::K), c);
-      st.ea[u][e] = ep.a[gi];
-      st.ed[u][e] = ep.d ? ep.d[gi] : 0;
-    }
-  }
-}
-
 // MODE 0 / 4: store as is (lazy values, hand-off between the two passes; 4 = first pass with the mix prologue);
 // 1: forward final, reduce [0,8q) ->
 // [0,q); 2: inverse final, multiply by the per-limb constant and reduce to [0,q); 3: forward final fused with
@@ -219,6 +201,17 @@ HM_HD void hm_ph_store_global(const HmNttState &st, int tid, uint64_t *g, uint32
   for (int u = 0; u < G::GPT; ++u) {
     int c, hi, xb;
     G::coords(tid, u, c, hi, xb);
+    // MODE 3: the epilogue operands of one group are requested right before they are used (group by group, with a
+    // scheduling fence in between): prefetching all of them before the last round cost 32 registers and a workgroup per CU
+    uint64_t ea[G::E], ed[G::E];
+    if (MODE == 3) {
+#pragma unroll
+      for (int e = 0; e < G::E; ++e) {
+        const uint32_t gi = G::gidx(tile, xb | (e << G::K), c);
+        ea[e] = ep.a[gi];
+        ed[e] = ep.d ? ep.d[gi] : 0;
+      }
+    }
 #pragma unroll
     for (int e = 0; e < G::E; ++e) {
       uint64_t a = st.v[u][e];
@@ -226,11 +219,15 @@ HM_HD void hm_ph_store_global(const HmNttState &st, int tid, uint64_t *g, uint32
       else if (MODE == 2) a = hm_shoup(a, sc.w, sc.ws, q);
       const uint32_t gi = G::gidx(tile, xb | (e << G::K), c);
       if (MODE == 3) {  // a in [0, 8q): minuend - a + 8q stays positive and below 2^64; the product reduces it
-        a = hm_shoup(st.ea[u][e] + 8 * q - a, sc.w, sc.ws, q);
-        if (ep.d) a = hm_addmod(a, ep.dk.w ? hm_shoup(st.ed[u][e], ep.dk.w, ep.dk.ws, q) : st.ed[u][e], q);
+        const uint64_t va = ea[e], vd = ed[e];
+        a = hm_shoup(va + 8 * q - a, sc.w, sc.ws, q);
+        if (ep.d) a = hm_addmod(a, ep.dk.w ? hm_shoup(vd, ep.dk.w, ep.dk.ws, q) : vd, q);
       }
       g[gi] = a;
     }
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (MODE == 3) __builtin_amdgcn_sched_barrier(0);
+#endif
   }
 }
 
@@ -300,14 +297,12 @@ HM_HD void hm_ntt_phase(HmNttState &st, int tid, uint64_t *lds, const uint64_t *
     hm_ph_store_lds<LOGR, STRIDED, r0>(st, tid, lds);
   } else if (PHASE == 2) {
     if (n == 3) hm_ph_load_tw<LOGR, STRIDED, (n == 3 ? r2 : r1)>(st, tid, twl, s0, prefix0);
-    if (n == 2 && MODE == 3) hm_ph_load_epi<LOGR, STRIDED, r1>(st, tid, tile, ep);
     hm_ph_load_lds<LOGR, STRIDED, r1>(st, tid, lds);
     hm_ph_compute<LOGR, STRIDED, r1, INV>(st, q);
     if (n == 3) hm_ph_store_lds<LOGR, STRIDED, r1>(st, tid, lds);
     else hm_ph_store_global<LOGR, STRIDED, r1, MODE>(st, tid, dst, tile, q, sc, ep);
   } else if (PHASE == 3) {
     if (n == 3) {
-      if (MODE == 3) hm_ph_load_epi<LOGR, STRIDED, (n == 3 ? r2 : r1)>(st, tid, tile, ep);
       hm_ph_load_lds<LOGR, STRIDED, (n == 3 ? r2 : r1)>(st, tid, lds);
       hm_ph_compute<LOGR, STRIDED, (n == 3 ? r2 : r1), INV>(st, q);
       hm_ph_store_global<LOGR, STRIDED, (n == 3 ? r2 : r1), MODE>(st, tid, dst, tile, q, sc, ep);

@@ -36,7 +36,7 @@ __global__ void __launch_bounds__(HM_THREADS) k_pass(HmNttArgs a, uint64_t *stam
   const uint64_t *src = FIRST ? a.in + (size_t)lb.in * N : a.out + (size_t)lb.out * N;
   uint64_t *dst = a.out + (size_t)lb.out * N;
   HmTw sc = {0, 0};
-  HmEpi ep = {nullptr, nullptr};
+  HmEpi ep = hm_epi_none();
   HmNttState st;
   hm_ntt_phase<LOGR, STRIDED, INV, MODE, 0>(st, tid, lds, src, dst, tile, twl, s0, prefix0, q, sc, ep);
   ts[1] = now();                       // loads issued
