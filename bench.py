@@ -105,11 +105,14 @@ def main():
     from homulator_amd import host
     # N > 1: ONE hmult whose limb-polys are sharded over the N GPUs (limb e -> e % N), RCCL all-to-all around the two
     # base conversions + one replicate in the rescale: strong scaling of the op's latency
-    import math
     streams = args.streams if world == 1 else 1
     # sharded: the ops of a batch share the exchanges around each base conversion; a batch that divides --steps, so that
     # exactly --steps hmults are timed without a second (communicating) instance for the remainder
-    batch = args.batch if world == 1 else max(1, math.gcd(args.batch, args.steps))
+    if world == 1:
+        batch = args.batch
+    else:   # per-rank launches shrink with the rank count: a proportionally larger batch keeps them (and the exchanges) big
+        target = max(1, min(16, args.batch * world // 2))
+        batch = max(d for d in range(1, target + 1) if args.steps % d == 0)
     ops = [host.Op(CFG, OP, L, ELL, ALPHA, device=local_rank, rank=rank, world=world,
                    overrides={"seed": host.SEED + 7 * i, **({"batch": batch} if batch > 1 else {})})
            for i in range(streams)]
