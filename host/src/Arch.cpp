@@ -264,6 +264,52 @@ void Arch::fusePasses(std::vector<Stage> &st) {
       R->refInstructions += T->refInstructions;
       dead.insert(T);
     }
+  // (4c) the residue r = INTT(h_last) that the merged records mix in.  h_last = (ip - NTT(conv)) * kT + d is only ever
+  //      needed in coefficient form, where it is (INTT(ip) - conv) * kT + INTT(d): conv never has to be transformed and
+  //      brought back.  INTT(ip) and INTT(d) depend on nothing after the inner product, so they join the ModDown INTT
+  //      launch (equal dependency depth), and one element-wise SUB_SCALE_ADD on the last limb replaces the two
+  //      latency-bound single-limb transforms T_last and INTT(h_last).
+  {
+    struct Rewrite { Instruction *T, *X; size_t stage; };
+    std::vector<Rewrite> todo;
+    for (size_t si = 0; si < st.size(); ++si)
+      for (Instruction *X : st[si].ins) {
+        if (X->ops != INTT || X->hasConstant || dead.count(X)) continue;
+        auto p = producer.find(X->operandList[0]);
+        if (p == producer.end() || dead.count(p->second) || !p->second->fusedSubScale || p->second->fMix || p->second->ops != NTT ||
+            uses[X->operandList[0]] != 1)
+          continue;
+        bool mixedIn = false;
+        for (auto &s2 : st)
+          for (Instruction *i : s2.ins) mixedIn |= !dead.count(i) && i->fMix == X->OutputOperand;
+        if (mixedIn) todo.push_back(Rewrite{p->second, X, si});
+      }
+    AddrType fresh = limbIndex.empty() ? 1 : limbIndex.rbegin()->first + 1;
+    for (const Rewrite &w : todo) {
+      Instruction *T = w.T, *X = w.X;
+      const AddrType h = X->operandList[0], r = X->OutputOperand;
+      Instruction *ia = new Instruction("INTT", INTT, T->level_id);   // wa = INTT(ip_last), kept in h's limb
+      ia->mod_id = T->mod_id; ia->operandList = {T->fMinuend}; ia->OutputOperand = h; ia->refInstructions = T->refInstructions;
+      st[w.stage].ins.push_back(ia);
+      AddrType wb = 0;
+      if (T->fAddend) {                                               // wb = INTT(d_last), in a limb of its own
+        wb = fresh++;
+        registerLimbs({wb});
+        Instruction *ib = new Instruction("INTT", INTT, T->level_id);
+        ib->mod_id = T->mod_id; ib->operandList = {T->fAddend}; ib->OutputOperand = wb;
+        st[w.stage].ins.push_back(ib);
+      }
+      Instruction *e = new Instruction("MULT", MULT, T->level_id);    // r = (wa - conv_last) * kT [+ wb]
+      e->mod_id = T->mod_id;
+      e->opcode = wb ? EWE_SUB_SCALE_ADD : EWE_SUB_SCALE;
+      e->operandList = {h, 0, T->operandList[0], wb};
+      e->hasConstant = true; e->constant = T->constant;
+      e->OutputOperand = r; e->refInstructions = X->refInstructions;
+      st[w.stage].ins.push_back(e);
+      producer[h] = ia; producer[r] = e;
+      dead.insert(T); dead.insert(X);
+    }
+  }
   // (5) tensor product: d1 = p*s + r*t (MAC2) with d0 = p*t and d2 = r*s (MUL) of the same limb -> one pass
   {
     std::map<std::pair<AddrType, AddrType>, Instruction *> muls;
