@@ -64,7 +64,7 @@ __device__ __forceinline__ void hm_ntt_pass_body(const HmNttArgs &a, const HmTw 
     const uint32_t ki = ss->kidx[entry];
     sc = ss->k[ki];
     ep.a = ss->minuend + (size_t)ss->mlimb[entry] * N;
-    ep.d = ss->addend ? ss->addend + (size_t)ss->alimb[entry] * N : nullptr;
+    ep.d = ss->addend && ss->alimb[entry] != HM_NTT_INVALID ? ss->addend + (size_t)ss->alimb[entry] * N : nullptr;  // per limb-poly
     if (ss->has_ak) ep.dk = ss->ak[ki];
   }
   if constexpr (MODE == 4) {
@@ -530,9 +530,11 @@ static hm_status ntt_common(hm_ctx *c, const char *what, const uint64_t *in, con
   const bool fused = f.minuend != nullptr;
   hm_status st;
   if ((st = check_limbs(c, what, in_limbs, n)) || (st = check_limbs(c, what, out_limbs, n)) ||
-      (st = check_limbs(c, what, f.minuend_limbs, n)) || (st = check_limbs(c, what, f.addend_limbs, n)) ||
+      (st = check_limbs(c, what, f.minuend_limbs, n)) ||
       (st = check_limbs(c, what, f.mix_limbs, n)) || (st = check_mods(c, what, mod_ids, n)))
     return st;
+  for (uint32_t g = 0; f.addend_limbs && g < n; ++g)
+    if (f.addend_limbs[g] != HM_NO_LIMB && f.addend_limbs[g] >= 0xFFFFu) return fail(c, HM_ERR_ARG, "%s: addend limb index %u exceeds 65534", what, f.addend_limbs[g]);
   for (uint32_t g = 0; g < n; ++g) {
     const uint64_t q = c->P.mod[mod_ids[g]];
     if ((k && k[g] >= q) || (f.addend_k && f.addend_k[g] >= q) || (f.mix_k && f.mix_k[g] >= q))
@@ -600,7 +602,7 @@ static hm_status ntt_common(hm_ctx *c, const char *what, const uint64_t *in, con
         } else if (fused) {
           ss.kidx[e] = (uint8_t)consts.at(std::make_tuple(m, k[g], f.addend_k ? f.addend_k[g] : 0ull));
           ss.mlimb[e] = (uint16_t)limb_at(f.minuend_limbs, g);
-          ss.alimb[e] = (uint16_t)limb_at(f.addend_limbs, g);
+          ss.alimb[e] = f.addend_limbs && f.addend_limbs[g] == HM_NO_LIMB ? (uint16_t)HM_NTT_INVALID : (uint16_t)limb_at(f.addend_limbs, g);
           if (f.mix) {
             mx.limb[e] = (uint16_t)limb_at(f.mix_limbs, g);
             mx.k[e] = HmTw{f.mix_k[g], hm::shoup(f.mix_k[g], q)};

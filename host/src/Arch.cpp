@@ -416,7 +416,7 @@ void Arch::buildLaunches() {
   for (const Stage &s : st) {
     size_t first = parts.size();
     for (Instruction *i : s.ins) {
-      int key = i->ops == IP && !i->ipX.empty() ? 300 + (int)i->ipX.size() * 10 + (int)i->ipY.size() : i->fusedTensor ? 200 : i->fusedSubScale ? (i->fMix ? (i->fAddend ? 203 : 204) : i->fAddend ? 201 : 202) : i->ops == MULT ? 100 + i->opcode : (i->ops == NTT && i->passthrough) ? 100 + EWE_COPY : i->ops == AUTO ? 1000 + (int)i->galois : (int)i->ops;
+      int key = i->ops == IP && !i->ipX.empty() ? 300 + (int)i->ipX.size() * 10 + (int)i->ipY.size() : i->fusedTensor ? 200 : i->fusedSubScale ? (i->fMix ? 203 : 201) : i->ops == MULT ? 100 + i->opcode : (i->ops == NTT && i->passthrough) ? 100 + EWE_COPY : i->ops == AUTO ? 1000 + (int)i->galois : (int)i->ops;
       size_t p = first;
       for (; p < parts.size(); ++p)
         if (parts[p].key == key) break;
@@ -548,18 +548,17 @@ void Arch::buildLaunches() {
         L->bytes = 7 * LP * count;
       } else if (f->fusedSubScale) {
         L->kind = Launch::L_NTT_SUBSCALE; L->statKey = "NTT";
-        bool anyAddend = false, allAddend = true;
+        bool anyAddend = false;   // the addend is per limb-poly (hrotate: key 0 adds the rotated c0, key 1 nothing)
         for (const Part *g : group)
-          for (Instruction *i : g->ins) { anyAddend |= i->fAddend != 0; allAddend &= i->fAddend != 0; }
-        if (anyAddend != allAddend) throw std::runtime_error("fused NTT stage mixes epilogues with and without addend");
+          for (Instruction *i : g->ins) anyAddend |= i->fAddend != 0;
         for (const Part *g : group)
           for (Instruction *i : g->ins) {
             L->a.push_back(limbOf(i->operandList[0])); L->b.push_back(limbOf(i->fMinuend));
-            if (anyAddend) L->c.push_back(limbOf(i->fAddend));
+            if (anyAddend) L->c.push_back(i->fAddend ? limbOf(i->fAddend) : HM_NO_LIMB);
             L->out.push_back(limbOf(i->OutputOperand)); L->mods.push_back(i->mod_id); L->k.push_back(i->constant);
             if (f->fMix) {  // the part key keeps merged and plain records apart
               L->d.push_back(limbOf(i->fMix)); L->mixK.push_back(i->fMixConst);
-              if (anyAddend) L->addK.push_back(i->fAddendConst);
+              if (anyAddend) L->addK.push_back(i->fAddendConst ? i->fAddendConst : 1);
             }
           }
         L->hasK = true;
@@ -679,7 +678,7 @@ void Arch::replicateForBatch() {
   auto rep = [&](std::vector<uint32_t> &v, bool isLimb) {
     const size_t n0 = v.size();
     for (uint32_t c = 1; c < batch_; ++c)
-      for (size_t i = 0; i < n0; ++i) v.push_back(isLimb && !sharedLimbs.count(v[i]) ? v[i] + c * per : v[i]);
+      for (size_t i = 0; i < n0; ++i) v.push_back(isLimb && v[i] != HM_NO_LIMB && !sharedLimbs.count(v[i]) ? v[i] + c * per : v[i]);
   };
   for (Launch *l : launches) {
     if (world_ > 1 && (l->kind == Launch::L_BCONV || l->kind == Launch::L_EXCH_IN || l->kind == Launch::L_EXCH_OUT)) continue;  // built batched

@@ -85,7 +85,9 @@ hm_status hm_ntt_sub_scale(hm_ctx *ctx, const uint64_t *in, const uint32_t *in_l
  * With in = the P->Q conversion, mix = r = INTT(last limb of the key-switch sum), mix_k = P, k = (P q_last)^-1,
  * addend = the tensor part, addend_k = q_last^-1 this is ModDowNTT + ModDownSub + add + Rescale_NTT + Rescale_SUB +
  * Rescale_Mul of one limb (src/Operation.cpp:521-590, 967-1005, 806-910) in one pass over HBM.  All constants are
- * host arrays of n residues mod the limb's modulus.  `out` must not alias `in`, `mix`, `minuend` or `addend`. */
+ * host arrays of n residues mod the limb's modulus.  `out` must not alias `in`, `mix`, `minuend` or `addend`.
+ * addend_limbs[i] == HM_NO_LIMB drops the addend for limb-poly i only (both this call and hm_ntt_sub_scale). */
+#define HM_NO_LIMB 0xFFFFFFFFu
 typedef struct hm_ntt_fused_desc {
   const uint64_t *in;      const uint32_t *in_limbs;
   const uint64_t *mix;     const uint32_t *mix_limbs;     const uint64_t *mix_k;

@@ -169,6 +169,13 @@ def test_fused_ntt_sub_scale_and_tensor(env):
     assert np.array_equal(out.download(), o.ewe(6, ids, mn, None, o.ntt(ids, xin), k=k))
     ctx.ntt_mix_sub_scale(dx, dmn, out, ids, k, addend=dad, addend_k=ak)                # no prologue
     assert np.array_equal(out.download(), o.ewe(3, ids, exp, None, o.ewe(5, ids, ad, k=ak)))
+    # per-limb optional addend: HM_NO_LIMB drops it for that limb-poly only
+    NO = 0xFFFFFFFF
+    al = [NO if r % 2 else r for r in range(n)]
+    ctx.ntt_sub_scale(dx, dmn, out, ids, k, addend=dad, addend_limbs=al)
+    got, with_add = out.download(), o.ewe(3, ids, exp, None, ad)
+    for r in range(n):
+        assert np.array_equal(got[r], exp[r] if r % 2 else with_add[r]), r
     with pytest.raises(hip.HmError):
         ctx.ntt_mix_sub_scale(dx, dmn, out, ids, k, mix=ddd)                            # mix without mix_k
     with pytest.raises(hip.HmError):
