@@ -189,6 +189,22 @@ def test_fused_ntt_sub_scale_and_tensor(env):
         b_.free()
 
 
+def test_fused_ntt_epilogue_constant_table_split(env):
+    """more distinct (modulus, k, addend_k) triples than one launch's constant table holds (60): the call must split"""
+    ctx, o, hip = env
+    n = 70
+    ids = [r % (o.L + o.K) for r in range(n)]
+    x, mn, ad = (o.fill_uniform(ids, s) for s in (11, 12, 13))
+    k = [o.moduli[m] - 2 - r for r, m in enumerate(ids)]          # all different
+    ak = [(kk * 5 + 1) % o.moduli[m] for kk, m in zip(k, ids)]
+    dx, dmn, dad, out = ctx.from_host(x), ctx.from_host(mn), ctx.from_host(ad), ctx.alloc(n)
+    ctx.ntt_mix_sub_scale(dx, dmn, out, ids, k, addend=dad, addend_k=ak)
+    exp = o.ewe(3, ids, o.ewe(6, ids, mn, None, o.ntt(ids, x), k=k), None, o.ewe(5, ids, ad, k=ak))
+    assert np.array_equal(out.download(), exp)
+    for b_ in (dx, dmn, dad, out):
+        b_.free()
+
+
 @pytest.mark.parametrize("terms,outs", [(1, 2), (2, 1), (3, 2), (4, 2)])
 def test_inner_product_one_pass(env, terms, outs):
     """K5: out[i][k] = sum_j x[i][j] * y[i][k][j], worst-case operands (q-1) included"""
