@@ -30,7 +30,6 @@
 // launch has them (the two keys of a ModDown, two digits of a ModUp, c0/c1 of a rescale): the pair's blocks
 // for one tile sit in adjacent dispatch slots of one XCD, so the second one finds the row twiddles (1 MiB per
 // limb-NTT, as much as the data) in L2 instead of fetching them from HBM again.
-#define HM_NTT_INVALID 0xFFFFu
 __device__ __forceinline__ bool hm_block_map(uint32_t tiles_per_limb, uint32_t n_entries, uint32_t &entry, uint32_t &tile) {
   const uint32_t b = blockIdx.x, xcd = b & 7u, slot = b >> 3;
   const uint32_t pair = slot / (2u * tiles_per_limb), within = slot % (2u * tiles_per_limb);
@@ -40,16 +39,17 @@ __device__ __forceinline__ bool hm_block_map(uint32_t tiles_per_limb, uint32_t n
 }
 
 template <int LOGR, bool STRIDED, bool INV, int MODE>
-__device__ __forceinline__ void hm_ntt_pass_body(const HmNttArgs &a, const HmTw *scale, const HmSubScale *ss = nullptr, const HmMix *mx = nullptr) {
+__device__ __forceinline__ void hm_ntt_pass_body(const HmNttArgs &a) {
   __shared__ __attribute__((aligned(16))) uint64_t lds[HM_LDS_WORDS];
   uint32_t entry, tile;
   if (!hm_block_map(1u << (a.logN - HM_TILE_LOG), a.n_limbs, entry, tile)) return;
   const int tid = threadIdx.x;
   const HmLimb lb = a.limb[entry];
-  if (lb.mod == HM_NTT_INVALID) return;
+  const uint32_t mod = lb.mod;
+  if (mod == HM_NTT_NONE) return;
   const size_t N = (size_t)1 << a.logN;
-  const uint64_t q = a.mods[lb.mod].q;
-  const HmTw *twl = a.tw + (size_t)lb.mod * N;
+  const uint64_t q = a.mods[mod].q;
+  const HmTw *twl = a.tw + (size_t)mod * N;
   const uint32_t s0 = STRIDED ? 0u : (a.logN - HM_ROW_LOG);
   const uint32_t prefix0 = STRIDED ? 0u : (tile << (HM_TILE_LOG - LOGR));
   // the first pass of a transform reads `in`, the second works in place on `out`
@@ -59,17 +59,18 @@ __device__ __forceinline__ void hm_ntt_pass_body(const HmNttArgs &a, const HmTw 
 
   HmTw sc = {0, 0};
   HmEpi ep = hm_epi_none();
-  if constexpr (MODE == 2) sc = scale[entry];
+  if constexpr (MODE == 2) sc = a.entry[entry].sc;
   if constexpr (MODE == 3) {
-    const uint32_t ki = ss->kidx[entry];
-    sc = ss->k[ki];
-    ep.a = ss->minuend + (size_t)ss->mlimb[entry] * N;
-    ep.d = ss->addend && ss->alimb[entry] != HM_NTT_INVALID ? ss->addend + (size_t)ss->alimb[entry] * N : nullptr;  // per limb-poly
-    if (ss->has_ak) ep.dk = ss->ak[ki];
+    const HmNttEntry &en = a.entry[entry];
+    sc = en.sc;
+    ep.a = a.minuend + (size_t)lb.aux * N;
+    ep.d = a.addend && en.alimb != HM_NTT_NONE ? a.addend + (size_t)en.alimb * N : nullptr;  // per limb-poly
+    ep.dk = en.ak;
   }
   if constexpr (MODE == 4) {
-    ep.b = mx->mix + (size_t)mx->limb[entry] * N;
-    ep.bk = mx->k[entry];
+    const HmNttEntry &en = a.entry[entry];
+    ep.b = a.mix + (size_t)en.mixlimb * N;
+    ep.bk = en.mixk;
   }
   HmNttState st;
   hm_ntt_phase<LOGR, STRIDED, INV, MODE, 0>(st, tid, lds, src, dst, tile, twl, s0, prefix0, q, sc, ep);
@@ -85,22 +86,11 @@ __device__ __forceinline__ void hm_ntt_pass_body(const HmNttArgs &a, const HmTw 
 #ifndef HM_NTT_MIN_WAVES
 #define HM_NTT_MIN_WAVES 1
 #endif
+// MODE 0: first pass / plain hand-off; 1: forward final; 2: inverse final (x scale); 3: forward final with the fused
+// epilogue; 4: forward first pass with the mix prologue
 template <int LOGR, bool STRIDED, bool INV, int MODE>
 __global__ void __launch_bounds__(HM_THREADS, HM_NTT_MIN_WAVES) k_ntt_pass(HmNttArgs a) {
-  hm_ntt_pass_body<LOGR, STRIDED, INV, MODE>(a, nullptr);
-}
-template <int LOGR>
-__global__ void __launch_bounds__(HM_THREADS, HM_NTT_MIN_WAVES) k_intt_final(HmNttArgs a, HmScale s) {
-  hm_ntt_pass_body<LOGR, true, true, 2>(a, s.c);
-}
-// forward ROW pass fused with out = (minuend - NTT) * k [+ addend * addend_k]
-__global__ void __launch_bounds__(HM_THREADS, HM_NTT_MIN_WAVES) k_ntt_row_subscale(HmNttArgs a, HmSubScale s) {
-  hm_ntt_pass_body<HM_ROW_LOG, false, false, 3>(a, nullptr, &s);
-}
-// forward COL pass with the prologue x = in + k * mix
-template <int LOGR>
-__global__ void __launch_bounds__(HM_THREADS, HM_NTT_MIN_WAVES) k_ntt_col_mix(HmNttArgs a, HmMix m) {
-  hm_ntt_pass_body<LOGR, true, false, 4>(a, nullptr, nullptr, &m);
+  hm_ntt_pass_body<LOGR, STRIDED, INV, MODE>(a);
 }
 
 __global__ void __launch_bounds__(256) k_tensor(HmTensorArgs a) {
@@ -254,6 +244,7 @@ struct hm_ctx {
   HmTw *d_tw_fwd = nullptr, *d_tw_inv = nullptr;
   HmMod *d_mods = nullptr;
   std::map<std::vector<uint32_t>, uint64_t *> bconv_tables;  // key: n_in, in_ids..., out_ids...
+  std::map<std::string, HmNttEntry *> ntt_tables;            // key: the bytes of a launch's entry table
   std::string err;
   // multi-GPU
   int rank = 0, world = 1;
@@ -360,6 +351,7 @@ extern "C" void hm_destroy(hm_ctx *c) {
   if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
   (void)hipFree(c->stage_send);
   (void)hipFree(c->stage_recv);
+  for (auto &kv : c->ntt_tables) (void)hipFree(kv.second);
   (void)hipFree(c->d_tw_fwd);
   (void)hipFree(c->d_tw_inv);
   (void)hipFree(c->d_mods);
@@ -496,18 +488,37 @@ static hm_status check_mods(hm_ctx *c, const char *what, const uint32_t *m, uint
 }
 
 template <int LOG1>
-static void launch_ntt(hm_ctx *c, const HmNttArgs &a, const HmScale *sc, const HmSubScale *ss, const HmMix *mx, bool inverse) {
+static void launch_ntt(hm_ctx *c, const HmNttArgs &a, bool fusedEpilogue, bool mixPrologue, bool inverse) {
   const uint32_t tiles = c->P.N >> HM_TILE_LOG;
   dim3 grid(a.n_limbs * tiles), block(HM_THREADS);  // n_limbs = entries, a multiple of 16 (pairs x 8 XCDs)
   if (!inverse) {
-    if (mx) hipLaunchKernelGGL((k_ntt_col_mix<LOG1>), grid, block, 0, c->stream, a, *mx);
+    if (mixPrologue) hipLaunchKernelGGL((k_ntt_pass<LOG1, true, false, 4>), grid, block, 0, c->stream, a);
     else hipLaunchKernelGGL((k_ntt_pass<LOG1, true, false, 0>), grid, block, 0, c->stream, a);
-    if (ss) hipLaunchKernelGGL(k_ntt_row_subscale, grid, block, 0, c->stream, a, *ss);
+    if (fusedEpilogue) hipLaunchKernelGGL((k_ntt_pass<HM_ROW_LOG, false, false, 3>), grid, block, 0, c->stream, a);
     else hipLaunchKernelGGL((k_ntt_pass<HM_ROW_LOG, false, false, 1>), grid, block, 0, c->stream, a);
   } else {
     hipLaunchKernelGGL((k_ntt_pass<HM_ROW_LOG, false, true, 0>), grid, block, 0, c->stream, a);
-    hipLaunchKernelGGL((k_intt_final<LOG1>), grid, block, 0, c->stream, a, *sc);
+    hipLaunchKernelGGL((k_ntt_pass<LOG1, true, true, 2>), grid, block, 0, c->stream, a);
   }
+}
+
+// device copy of a launch's entry table, cached by content; uploaded (synchronously) on first use
+static hm_status ntt_table(hm_ctx *c, const std::vector<HmNttEntry> &tab, const HmNttEntry **out) {
+  const std::string key(reinterpret_cast<const char *>(tab.data()), sizeof(HmNttEntry) * tab.size());
+  auto it = c->ntt_tables.find(key);
+  if (it == c->ntt_tables.end()) {
+    if (c->ntt_tables.size() >= 512) {  // callers that never repeat a launch (tests): start over rather than grow without bound
+      HM_HIP(c, hipStreamSynchronize(c->stream));
+      for (auto &kv : c->ntt_tables) (void)hipFree(kv.second);
+      c->ntt_tables.clear();
+    }
+    HmNttEntry *dev = nullptr;
+    HM_HIP(c, hipMalloc(&dev, key.size()));
+    HM_HIP(c, hipMemcpy(dev, tab.data(), key.size(), hipMemcpyHostToDevice));
+    it = c->ntt_tables.emplace(key, dev).first;
+  }
+  *out = it->second;
+  return HM_OK;
 }
 
 // operands of the fused forward transform: x = NTT(in [+ mix_k * mix]); out = (minuend - x) * k [+ addend [* addend_k]]
@@ -556,72 +567,62 @@ static hm_status ntt_common(hm_ctx *c, const char *what, const uint64_t *in, con
     }
     for (size_t i = 0; i < singles.size(); i += 2) pairs.emplace_back(singles[i], i + 1 < singles.size() ? singles[i + 1] : -1);
   }
-  const uint32_t PAIRS_PER_LAUNCH = HM_MAX_LIMBS / 2;
-  for (uint32_t base = 0; base < pairs.size();) {
-    // a launch takes up to PAIRS_PER_LAUNCH pairs and, fused, up to HM_EPI_CONSTS distinct epilogue constant pairs
-    std::map<std::tuple<uint32_t, uint64_t, uint64_t>, uint32_t> consts;
-    uint32_t np = 0;
-    while (np < PAIRS_PER_LAUNCH && base + np < pairs.size()) {
-      if (fused) {
-        auto trial = consts;
-        for (int gi : {pairs[base + np].first, pairs[base + np].second})
-          if (gi >= 0) trial.emplace(std::make_tuple(mod_ids[gi], k[gi], f.addend_k ? f.addend_k[gi] : 0ull), (uint32_t)trial.size());
-        if (trial.size() > HM_EPI_CONSTS) break;
-        consts.swap(trial);
-      }
-      ++np;
-    }
+  // As few launches as the kernel-argument segment allows (HM_NTT_MAX_ENTRIES records), of equal size; the constants
+  // of a launch live in a device table cached by content (plans repeat their launches)
+  const uint32_t maxPairs = HM_NTT_MAX_ENTRIES / 2;
+  const uint32_t nLaunch = ((uint32_t)pairs.size() + maxPairs - 1) / maxPairs;
+  const uint32_t perLaunch = nLaunch ? (((uint32_t)pairs.size() + nLaunch - 1) / nLaunch + 7) / 8 * 8 : 0;  // whole groups of 8 pairs
+  for (uint32_t base = 0; base < pairs.size(); base += perLaunch) {
+    const uint32_t np = std::min<uint32_t>(perLaunch, (uint32_t)pairs.size() - base);
     const uint32_t cnt = ((np + 7) / 8) * 16;  // entries: groups of 8 pairs = 16 entries
+    std::vector<HmNttEntry> tab(cnt);
+    memset(tab.data(), 0, sizeof(HmNttEntry) * cnt);
     HmNttArgs a;
-    a.in = in; a.out = out;
-    a.tw = inverse ? c->d_tw_inv : c->d_tw_fwd;
-    a.mods = c->d_mods;
-    a.logN = c->P.logN; a.n_limbs = cnt;
-    HmScale sc;
-    HmSubScale ss;
-    HmMix mx;
-    ss.minuend = f.minuend; ss.addend = f.addend; ss.has_ak = f.addend_k != nullptr;
-    mx.mix = f.mix;
-    for (auto &kv : consts) {
-      const uint64_t q = c->P.mod[std::get<0>(kv.first)], kk = std::get<1>(kv.first), ak = std::get<2>(kv.first);
-      ss.k[kv.second] = HmTw{kk, hm::shoup(kk, q)};
-      ss.ak[kv.second] = HmTw{ak, hm::shoup(ak, q)};
-    }
-    for (uint32_t e = 0; e < cnt; ++e) a.limb[e] = HmLimb{0, 0, (uint16_t)HM_NTT_INVALID, 0};
+    for (uint32_t e = 0; e < cnt; ++e) a.limb[e] = HmLimb{0, 0, (uint16_t)HM_NTT_NONE, 0};
     for (uint32_t kk = 0; kk < np; ++kk) {
       for (int which = 0; which < 2; ++which) {
         const int gi = which ? pairs[base + kk].second : pairs[base + kk].first;
         if (gi < 0) continue;
         const uint32_t g = (uint32_t)gi, e = (kk / 8) * 16 + which * 8 + (kk % 8), m = mod_ids[g];
         const uint64_t q = c->P.mod[m];
+        HmNttEntry &t = tab[e];
         a.limb[e] = HmLimb{(uint16_t)limb_at(in_limbs, g), (uint16_t)limb_at(out_limbs, g), (uint16_t)m, 0};
         if (inverse) {
           uint64_t v = c->P.modc[m].ninv;
           if (k) v = hm::mulmod(v, k[g], q);
-          sc.c[e] = HmTw{v, hm::shoup(v, q)};
+          t.sc = HmTw{v, hm::shoup(v, q)};
         } else if (fused) {
-          ss.kidx[e] = (uint8_t)consts.at(std::make_tuple(m, k[g], f.addend_k ? f.addend_k[g] : 0ull));
-          ss.mlimb[e] = (uint16_t)limb_at(f.minuend_limbs, g);
-          ss.alimb[e] = f.addend_limbs && f.addend_limbs[g] == HM_NO_LIMB ? (uint16_t)HM_NTT_INVALID : (uint16_t)limb_at(f.addend_limbs, g);
+          t.sc = HmTw{k[g], hm::shoup(k[g], q)};
+          a.limb[e].aux = (uint16_t)limb_at(f.minuend_limbs, g);
+          t.alimb = f.addend_limbs && f.addend_limbs[g] == HM_NO_LIMB ? (uint16_t)HM_NTT_NONE : (uint16_t)limb_at(f.addend_limbs, g);
+          if (f.addend_k) t.ak = HmTw{f.addend_k[g], hm::shoup(f.addend_k[g], q)};
           if (f.mix) {
-            mx.limb[e] = (uint16_t)limb_at(f.mix_limbs, g);
-            mx.k[e] = HmTw{f.mix_k[g], hm::shoup(f.mix_k[g], q)};
+            t.mixlimb = (uint16_t)limb_at(f.mix_limbs, g);
+            t.mixk = HmTw{f.mix_k[g], hm::shoup(f.mix_k[g], q)};
           }
         }
       }
     }
-    const HmSubScale *pss = fused ? &ss : nullptr;
-    const HmMix *pmx = fused && f.mix ? &mx : nullptr;
+    const HmNttEntry *dtab = nullptr;
+    if (inverse || fused) {   // the plain forward transform needs no per-limb constants
+      if ((st = ntt_table(c, tab, &dtab))) return st;
+    }
+    a.in = in; a.out = out;
+    a.tw = inverse ? c->d_tw_inv : c->d_tw_fwd;
+    a.mods = c->d_mods;
+    a.entry = dtab;
+    a.minuend = f.minuend; a.addend = f.addend; a.mix = f.mix;
+    a.logN = c->P.logN; a.n_limbs = cnt;
+    const bool mixPro = fused && f.mix;
     switch (c->P.logN - HM_ROW_LOG) {
-    case 5: launch_ntt<5>(c, a, &sc, pss, pmx, inverse); break;
-    case 6: launch_ntt<6>(c, a, &sc, pss, pmx, inverse); break;
-    case 7: launch_ntt<7>(c, a, &sc, pss, pmx, inverse); break;
-    case 8: launch_ntt<8>(c, a, &sc, pss, pmx, inverse); break;
-    case 9: launch_ntt<9>(c, a, &sc, pss, pmx, inverse); break;
+    case 5: launch_ntt<5>(c, a, fused, mixPro, inverse); break;
+    case 6: launch_ntt<6>(c, a, fused, mixPro, inverse); break;
+    case 7: launch_ntt<7>(c, a, fused, mixPro, inverse); break;
+    case 8: launch_ntt<8>(c, a, fused, mixPro, inverse); break;
+    case 9: launch_ntt<9>(c, a, fused, mixPro, inverse); break;
     default: return fail(c, HM_ERR_UNSUPPORTED, "%s: logN %u", what, c->P.logN);
     }
     HM_HIP(c, hipGetLastError());
-    base += np;
   }
   return HM_OK;
 }

@@ -27,39 +27,41 @@
 #define HM_ROW_LOG 8  // log2 of the contiguous sub-transform length (pass ROW)
 #endif
 
-struct HmLimb {  // one limb-poly of a launch: limb indices into the in/out bases, modulus id
+struct HmLimb {  // one limb-poly of an automorphism / fill launch: limb indices into the in/out bases, modulus id
   uint16_t in, out, mod, aux;
 };
+
+// One limb-poly of a transform launch.  The constants of a launch form a table in device memory (cached by content: the
+// plans of this datapath repeat the same launches), so a launch carries up to HM_NTT_MAX_ENTRIES limb-polys instead of
+// 128 (the kernel-argument segment is 4 KiB): the limb-polys of a batch go into one or two grids instead of 128-entry
+// pieces with their ramp-up and tail.
+// Fused forward transform (ModDown finish, rescale, or both merged):
+//   first pass, MODE 4:  x = in + mixk * mix         (coefficient domain, before the first butterfly)
+//   last pass,  MODE 3:  out = (minuend - NTT(x)) * sc [+ addend * ak]
+struct HmNttEntry {                  // the part of a record that is not needed to start loading (device table)
+  uint16_t alimb, mixlimb;           // MODE 3 addend limb (HM_NTT_NONE: no addend), MODE 4 operand limb
+  uint16_t pad[2];
+  uint64_t pad1;
+  HmTw sc;                           // inverse: N^-1 * extra scale; fused forward: the epilogue constant k
+  HmTw ak;                           // fused forward: addend constant (w == 0: none)
+  HmTw mixk;                         // MODE 4 prologue constant
+};
+#define HM_NTT_NONE 0xFFFFu
+#define HM_NTT_MAX_ENTRIES 448       // records in the kernel-argument segment (8 bytes each, 4 KiB limit)
 
 struct HmNttArgs {
   const uint64_t *in;
   uint64_t *out;
   const HmTw *tw;      // [n_mod][N] forward or inverse table (chosen by the host)
   const HmMod *mods;   // [n_mod]
+  const HmNttEntry *entry;                // [n_limbs], device
+  const uint64_t *minuend, *addend, *mix; // bases of the MODE 3 / MODE 4 operands (addend may be null)
   uint32_t logN;
-  uint32_t n_limbs;
-  HmLimb limb[HM_MAX_LIMBS];
-};
-struct HmScale {  // per-limb epilogue constant of the inverse transform: c = N^-1 * extra, Shoup form
-  HmTw c[HM_MAX_LIMBS];
-};
-// fused forward transform (ModDown finish, rescale, or both merged):
-//   first pass, MODE 4:  x = in + mix_k * mix       (coefficient domain, before the first butterfly)
-//   last pass,  MODE 3:  out = (minuend - NTT(x)) * k [+ addend * addend_k]
-// Per-limb constants are indices into a table of at most HM_EPI_CONSTS distinct (k, addend_k) pairs, so that the kernel
-// argument stays below 4 KiB with 128 limb-polys per launch (an op has one pair per modulus).
-#define HM_EPI_CONSTS 60
-struct HmSubScale {
-  const uint64_t *minuend, *addend;  // addend may be null
-  uint16_t mlimb[HM_MAX_LIMBS], alimb[HM_MAX_LIMBS];
-  uint8_t kidx[HM_MAX_LIMBS];
-  uint8_t has_ak, pad[7];
-  HmTw k[HM_EPI_CONSTS], ak[HM_EPI_CONSTS];
-};
-struct HmMix {  // prologue operand of the first pass
-  const uint64_t *mix;
-  uint16_t limb[HM_MAX_LIMBS];
-  HmTw k[HM_MAX_LIMBS];
+  uint32_t n_limbs;    // entries, a multiple of 16 (pairs x 8 XCDs, see hm_block_map)
+  // what a workgroup needs before it can issue its first load rides in the kernel arguments (a dependent read of the
+  // device table at workgroup start cost 5 % on the whole op): in / out limbs, modulus id (HM_NTT_NONE: empty slot) and,
+  // in aux, the MODE 3 minuend limb
+  HmLimb limb[HM_NTT_MAX_ENTRIES];
 };
 struct HmEpi {  // the prologue / epilogue operands of one limb-poly, resolved by the kernel
   const uint64_t *a, *d;     // minuend, addend (MODE 3)

@@ -189,8 +189,8 @@ def test_fused_ntt_sub_scale_and_tensor(env):
         b_.free()
 
 
-def test_fused_ntt_epilogue_constant_table_split(env):
-    """more distinct (modulus, k, addend_k) triples than one launch's constant table holds (60): the call must split"""
+def test_fused_ntt_epilogue_all_distinct_constants(env):
+    """every limb-poly with its own (k, addend_k): the per-limb constants come from the launch's device table"""
     ctx, o, hip = env
     n = 70
     ids = [r % (o.L + o.K) for r in range(n)]

@@ -26,7 +26,7 @@ __global__ void __launch_bounds__(HM_THREADS) k_pass(HmNttArgs a, uint64_t *stam
   if (entry >= a.n_limbs) return;
   const int tid = threadIdx.x;
   const HmLimb lb = a.limb[entry];
-  if (lb.mod == 0xFFFFu) return;
+  if (lb.mod == HM_NTT_NONE) return;
   const size_t N = (size_t)1 << a.logN;
   const uint64_t q = a.mods[lb.mod].q;
   const HmTw *twl = a.tw + (size_t)lb.mod * N;
@@ -80,7 +80,8 @@ int main(int argc, char **argv) {
   HmNttArgs a; a.in = d_in; a.out = d_out; a.tw = d_tw; a.mods = d_mods; a.logN = 16;
   const uint32_t np = (n + 1) / 2, cnt = ((np + 7) / 8) * 16;   // singles paired with each other, like ntt_common
   a.n_limbs = cnt;
-  for (uint32_t e = 0; e < cnt; ++e) a.limb[e] = HmLimb{0, 0, 0xFFFF, 0};
+  a.entry = nullptr; a.minuend = a.addend = a.mix = nullptr;
+  for (uint32_t e = 0; e < cnt; ++e) a.limb[e] = HmLimb{0, 0, (uint16_t)HM_NTT_NONE, 0};
   for (uint32_t g = 0; g < n; ++g) { const uint32_t kk = g / 2, which = g & 1, e = (kk / 8) * 16 + which * 8 + (kk % 8); a.limb[e] = HmLimb{(uint16_t)g, (uint16_t)g, (uint16_t)(g % M), 0}; }
   const uint32_t tiles = N >> HM_TILE_LOG, grid = cnt * tiles, waves = HM_THREADS / 64;
   CK(hipMalloc(&d_st, 8ull * NSTAMP * grid * waves)); CK(hipMemset(d_st, 0, 8ull * NSTAMP * grid * waves));
