@@ -39,15 +39,16 @@ def test_gloo_transport_world2():
 
 
 @pytest.mark.parametrize("opname", ["hmult", "hrotate"])
-@pytest.mark.parametrize("world", [2, 4, 8])
-def test_sharded_plans_are_collectively_consistent(opname, world):
+@pytest.mark.parametrize("world,batch", [(2, 1), (4, 1), (8, 1), (2, 4), (8, 16)])
+def test_sharded_plans_are_collectively_consistent(opname, world, batch):
     from homulator_amd import host
     L, ell, alpha = 45, 35, 15
-    single = host.Op("config_4.cfg", opname, L, ell, alpha, backend=host.BACKEND_COUNT)
+    ov = {"batch": batch} if batch > 1 else None
+    single = host.Op("config_4.cfg", opname, L, ell, alpha, backend=host.BACKEND_COUNT, overrides=ov)
     total_ref = sum(int(re.search(r"ref=(\d+)", ln).group(1)) for ln in single.plan())
     plans = []
     for r in range(world):
-        o = host.Op("config_4.cfg", opname, L, ell, alpha, backend=host.BACKEND_COUNT, rank=r, world=world)
+        o = host.Op("config_4.cfg", opname, L, ell, alpha, backend=host.BACKEND_COUNT, rank=r, world=world, overrides=ov)
         plans.append(o.plan())
     coll = [[ln for ln in pl if ln.split()[0] in ("EXCH_IN", "EXCH_OUT", "REPLICATE")] for pl in plans]
     # every rank enters the same collectives, in the same order, with the same limb:owner lists
@@ -68,7 +69,7 @@ def test_sharded_plans_are_collectively_consistent(opname, world):
         per_rank.append(n)
     n_single = sum(int(re.search(r" n=(\d+)", ln).group(1)) for ln in single.plan() if ln.split()[0] in ("NTT", "INTT", "EWE", "AUTO", "NTT_SUBSCALE", "TENSOR"))
     assert sum(per_rank) == n_single
-    assert max(per_rank) - min(per_rank) <= 12   # balanced up to the remainder limbs of each stage
+    assert max(per_rank) - min(per_rank) <= 12 * batch   # balanced up to the remainder limbs of each stage
     assert total_ref > 0
 
 
