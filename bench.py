@@ -22,6 +22,7 @@ CFG, OP, L, ELL, ALPHA = "config_4.cfg", "hmult", 45, 35, 15
 LOGN = 16
 LP = (1 << LOGN) * 8                       # one limb-poly, bytes
 HMULT_ALG_BYTES = 1_102_577_664            # 2 103 LP
+HROTATE_ALG_BYTES = 883_425_280            # 1 685 LP
 NTT_ALG_BYTES = 2 * LP                     # per limb-NTT
 HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md
 # HBM bytes of one 50-limb forward NTT sweep from the PMC counters (profiles/r01_pmc_ntt_sweep.txt: separate --pmc passes;
@@ -49,20 +50,21 @@ def measure_ntt_sweep(n_limbs, iters=50):
     return ns
 
 
-def cpu_baseline(sample_ops=3):
+def cpu_baseline(opn="hmult", sample_ops=3):
     from oracle.homoracle import Oracle
     from homulator_amd import host
     cores = min(16, os.cpu_count() or 1)
     o = Oracle(LOGN, L, ALPHA)
     o.set_threads(cores)
     ct1, ct2, evk = o.synth_ct(ELL, host.SEED), o.synth_ct(ELL, host.SEED + 2000), o.synth_evk(ELL, host.SEED + 10000)
-    o.hmult(ELL, ct1, ct2, evk)  # warm
+    run = (lambda: o.hmult(ELL, ct1, ct2, evk)) if opn == "hmult" else (lambda: o.hrotate(ELL, ct1, 5, evk))
+    run()  # warm
     t0 = time.time()
     for _ in range(sample_ops):
-        o.hmult(ELL, ct1, ct2, evk)
+        run()
     dt = (time.time() - t0) / sample_ops
     return {"value": 1.0 / dt, "unit": "ops/s", "cores": cores, "kind": "port",
-            "sample": f"{sample_ops} full hmult ops (N=2^16, l=35, alpha=15) on the CPU oracle, OpenMP over limbs"}
+            "sample": f"{sample_ops} full {opn} ops (N=2^16, l=35, alpha=15) on the CPU oracle, OpenMP over limbs"}
 
 
 def main():
@@ -76,6 +78,8 @@ def main():
     ap.add_argument("--batch", type=int, default=4,
                     help="independent hmults carried by every launch of an instance (config key `batch`: own inputs, one "
                          "evaluation key); a step is still ONE hmult, an enqueue advances `batch` steps")
+    ap.add_argument("--op", default=OP, choices=["hmult", "hrotate"],
+                    help="hmult = BASELINE.json's metric (default); hrotate = BASELINE configs[3], for information")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -113,12 +117,14 @@ def main():
     else:   # per-rank launches shrink with the rank count: a proportionally larger batch keeps them (and the exchanges) big
         target = max(1, min(16, args.batch * world // 2))
         batch = max(d for d in range(1, target + 1) if args.steps % d == 0)
-    ops = [host.Op(CFG, OP, L, ELL, ALPHA, device=local_rank, rank=rank, world=world,
+    opn = args.op
+    alg_bytes = HMULT_ALG_BYTES if opn == "hmult" else HROTATE_ALG_BYTES
+    ops = [host.Op(CFG, opn, L, ELL, ALPHA, device=local_rank, rank=rank, world=world,
                    overrides={"seed": host.SEED + 7 * i, **({"batch": batch} if batch > 1 else {})})
            for i in range(streams)]
     op = ops[0]
     # steps that do not fill a batch run through a one-op instance, so that EXACTLY --steps hmults are timed
-    tail_op = host.Op(CFG, OP, L, ELL, ALPHA, device=local_rank, overrides={"seed": host.SEED + 999}) if batch > 1 and world == 1 else None
+    tail_op = host.Op(CFG, opn, L, ELL, ALPHA, device=local_rank, overrides={"seed": host.SEED + 999}) if batch > 1 and world == 1 else None
     transport = "none"
     if world > 1:
         from homulator_amd import dist as hdist
@@ -192,25 +198,25 @@ def main():
         ntt_ns = measure_ntt_sweep(sweep_limbs)
         achieved = NTT_ALG_BYTES * sweep_limbs / ntt_ns  # B/ns = GB/s
         out = {
-            "metric": "hmult+key-switch ops/sec", "value": value, "unit": "ops/s", "n_gpus": world, "steps": args.steps,
+            "metric": "hmult+key-switch ops/sec" if opn == "hmult" else "hrotate+key-switch ops/sec", "value": value, "unit": "ops/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": f"{CFG} {OP} L={L} l={ELL} alpha={ALPHA} (N=2^16, beta=3, full hybrid key switch + rescale)",
+            "config": {"workload": f"{CFG} {opn} L={L} l={ELL} alpha={ALPHA} (N=2^16, beta=3, " + ("full hybrid key switch + rescale)" if opn == "hmult" else "automorphism + full hybrid key switch)"),
                        "parallelism": "single GPU" if world == 1 else f"limbs sharded over {world} GPUs (limb e -> e % {world}); RCCL all-to-all around ModUp/ModDown base conversion + replicate of the rescale residue; {batch} hmults per launch share the exchanges",
                        "launches_per_op": op.launch_count(), "streams": streams, "batch": batch, "transport": transport,
                        "streams_note": "`streams` instances in flight (own HBM pool / HIP stream each), each carrying `batch` independent hmults per launch (own inputs, one evaluation key); a step is one hmult"},
             "single_stream_ops_per_s": single,
             "stage_us": [[kind, name, round(ns * 1e-3, 2)] for kind, name, ns in stage_rows],
             "exchange_us_per_op": round(sum(ns for kind, _, ns in stage_rows if kind in ("EXCH_IN", "EXCH_OUT", "REPLICATE")) * 1e-3 / (batch if world > 1 else 1), 2),
-            "hmult_hbm_gbs_algorithmic": HMULT_ALG_BYTES / (ms * 1e-3) / 1e9,
-            "hmult_frac_of_hbm_peak": HMULT_ALG_BYTES / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "hmult_hbm_gbs_algorithmic": alg_bytes / (ms * 1e-3) / 1e9,
+            "hmult_frac_of_hbm_peak": alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "roofline": {"bound": "hbm", "kernel": "forward NTT sweep, 50 limbs = k_ntt_pass<COL> + k_ntt_pass<ROW>",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": NTT_SWEEP50_TRAFFIC_BYTES if sweep_limbs == 50 else None, "us_per_launch": ntt_ns * 1e-3,
                          "algorithmic_bytes_per_launch": NTT_ALG_BYTES * sweep_limbs},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(opn)
     for o in ops:
         o.close()
     if tail_op is not None:
