@@ -53,3 +53,25 @@ def test_sweep_runner_layout(tmp_path):
             assert log.exists()
             txt = log.read_text()
             assert "Completed Simulate!" in txt and "Remaining 0 instructions!" in txt
+
+
+@pytest.mark.parametrize("alpha", [1, 2, 3, 5, 13])
+def test_every_level_small_ring(alpha):
+    """hmult and hrotate at EVERY level of a 13-limb chain on a small ring (N = 2^13 through the `N` config override):
+    all digit shapes (beta = 1 .. 13, short last digits, a one-limb last digit) go through the fused plan, including
+    the merged ModDown + rescale transform, and must equal the oracle bit for bit"""
+    from homulator_amd import host
+    L, logN = 13, 13
+    o = Oracle(logN, L, alpha)
+    o.set_threads(4)
+    for ell in range(1, L + 1):
+        ct1, ct2, evk = o.synth_ct(ell, SEED), o.synth_ct(ell, SEED + 2000), o.synth_evk(ell, SEED + 10000)
+        for name in ("hmult", "hrotate"):
+            if name == "hmult" and ell < 2:
+                continue
+            op = host.Op("config_4_N15.cfg", name, L, ell, alpha, overrides={"N": 1 << logN})
+            op.execute(1)
+            exp = o.hmult(ell, ct1, ct2, evk) if name == "hmult" else o.hrotate(ell, ct1, 5, evk)
+            assert np.array_equal(op.read("out.c0"), exp[0]), (name, ell, alpha)
+            assert np.array_equal(op.read("out.c1"), exp[1]), (name, ell, alpha)
+            op.close()
