@@ -40,9 +40,10 @@ __device__ __forceinline__ bool hm_block_map(uint32_t tiles_per_limb, uint32_t n
 
 template <int LOGR, bool STRIDED, bool INV, int MODE>
 __device__ __forceinline__ void hm_ntt_pass_body(const HmNttArgs &a) {
-  __shared__ __attribute__((aligned(16))) uint64_t lds[HM_LDS_WORDS];
+  constexpr int TL = HM_TL(STRIDED);
+  __shared__ __attribute__((aligned(16))) uint64_t lds[HmLds<TL, LOGR, STRIDED>::WORDS];
   uint32_t entry, tile;
-  if (!hm_block_map(1u << (a.logN - HM_TILE_LOG), a.n_limbs, entry, tile)) return;
+  if (!hm_block_map(1u << (a.logN - TL), a.n_limbs, entry, tile)) return;
   const int tid = threadIdx.x;
   const HmLimb lb = a.limb[entry];
   const uint32_t mod = lb.mod;
@@ -51,7 +52,8 @@ __device__ __forceinline__ void hm_ntt_pass_body(const HmNttArgs &a) {
   const uint64_t q = a.mods[mod].q;
   const HmTw *twl = a.tw + (size_t)mod * N;
   const uint32_t s0 = STRIDED ? 0u : (a.logN - HM_ROW_LOG);
-  const uint32_t prefix0 = STRIDED ? 0u : (tile << (HM_TILE_LOG - LOGR));
+  const uint32_t prefix0 = STRIDED ? 0u : (tile << (TL - LOGR));
+  const HmTw *twt = STRIDED ? nullptr : a.twist + ((size_t)mod * (N >> HM_ROW_LOG) + prefix0) * 3;  // the tile's first row
   // the first pass of a transform reads `in`, the second works in place on `out`
   constexpr bool FIRST = (STRIDED != INV);
   const uint64_t *src = FIRST ? a.in + (size_t)lb.in * N : a.out + (size_t)lb.out * N;
@@ -73,23 +75,23 @@ __device__ __forceinline__ void hm_ntt_pass_body(const HmNttArgs &a) {
     ep.bk = en.mixk;
   }
   HmNttState st;
-  hm_ntt_phase<LOGR, STRIDED, INV, MODE, 0>(st, tid, lds, src, dst, tile, twl, s0, prefix0, q, sc, ep);
-  hm_ntt_phase<LOGR, STRIDED, INV, MODE, 1>(st, tid, lds, src, dst, tile, twl, s0, prefix0, q, sc, ep);
+  hm_ntt_phase<TL, LOGR, STRIDED, INV, MODE, 0>(st, tid, lds, src, dst, tile, twl, twt, s0, prefix0, q, sc, ep);
+  hm_ntt_phase<TL, LOGR, STRIDED, INV, MODE, 1>(st, tid, lds, src, dst, tile, twl, twt, s0, prefix0, q, sc, ep);
   __syncthreads();
-  hm_ntt_phase<LOGR, STRIDED, INV, MODE, 2>(st, tid, lds, src, dst, tile, twl, s0, prefix0, q, sc, ep);
+  hm_ntt_phase<TL, LOGR, STRIDED, INV, MODE, 2>(st, tid, lds, src, dst, tile, twl, twt, s0, prefix0, q, sc, ep);
   if constexpr (HmRounds<LOGR>::n == 3) {
     __syncthreads();
-    hm_ntt_phase<LOGR, STRIDED, INV, MODE, 3>(st, tid, lds, src, dst, tile, twl, s0, prefix0, q, sc, ep);
+    hm_ntt_phase<TL, LOGR, STRIDED, INV, MODE, 3>(st, tid, lds, src, dst, tile, twl, twt, s0, prefix0, q, sc, ep);
   }
 }
 
 #ifndef HM_NTT_MIN_WAVES
-#define HM_NTT_MIN_WAVES 1
+#define HM_NTT_MIN_WAVES 4  // 4 workgroups of 256 threads per CU (36 KiB of LDS each): up to 128 VGPRs
 #endif
 // MODE 0: first pass / plain hand-off; 1: forward final; 2: inverse final (x scale); 3: forward final with the fused
 // epilogue; 4: forward first pass with the mix prologue
 template <int LOGR, bool STRIDED, bool INV, int MODE>
-__global__ void __launch_bounds__(HM_THREADS, HM_NTT_MIN_WAVES) k_ntt_pass(HmNttArgs a) {
+__global__ void __launch_bounds__((1 << HM_TL(STRIDED)) / HM_EPT, HM_NTT_MIN_WAVES) k_ntt_pass(HmNttArgs a) {
   hm_ntt_pass_body<LOGR, STRIDED, INV, MODE>(a);
 }
 
@@ -242,6 +244,7 @@ struct hm_ctx {
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_done = nullptr;
   HmTw *d_tw_fwd = nullptr, *d_tw_inv = nullptr;
+  HmTw *d_twist_fwd = nullptr, *d_twist_inv = nullptr;  // [L+K][N/256][3], hm::Params::make_twist
   HmMod *d_mods = nullptr;
   std::map<std::vector<uint32_t>, uint64_t *> bconv_tables;  // key: n_in, in_ids..., out_ids...
   std::map<std::string, HmNttEntry *> ntt_tables;            // key: the bytes of a launch's entry table
@@ -331,8 +334,15 @@ extern "C" hm_status hm_create(hm_ctx **out, const hm_params *p) {
   HM_HIP(nullptr, hipMalloc(&cc->d_tw_fwd, sizeof(HmTw) * (size_t)M * N));
   HM_HIP(nullptr, hipMalloc(&cc->d_tw_inv, sizeof(HmTw) * (size_t)M * N));
   HM_HIP(nullptr, hipMalloc(&cc->d_mods, sizeof(HmMod) * M));
+  const size_t twistRow = (size_t)(N >> HM_ROW_LOG) * 3;
+  HM_HIP(nullptr, hipMalloc(&cc->d_twist_fwd, sizeof(HmTw) * M * twistRow));
+  HM_HIP(nullptr, hipMalloc(&cc->d_twist_inv, sizeof(HmTw) * M * twistRow));
   std::vector<HmTw> tmp(N);
   for (uint32_t m = 0; m < M; ++m) {
+    cc->P.make_twist(m, false, tmp.data());
+    HM_HIP(nullptr, hipMemcpy(cc->d_twist_fwd + m * twistRow, tmp.data(), sizeof(HmTw) * twistRow, hipMemcpyHostToDevice));
+    cc->P.make_twist(m, true, tmp.data());
+    HM_HIP(nullptr, hipMemcpy(cc->d_twist_inv + m * twistRow, tmp.data(), sizeof(HmTw) * twistRow, hipMemcpyHostToDevice));
     cc->P.make_table(m, false, tmp.data());
     HM_HIP(nullptr, hipMemcpy(cc->d_tw_fwd + (size_t)m * N, tmp.data(), sizeof(HmTw) * N, hipMemcpyHostToDevice));
     cc->P.make_table(m, true, tmp.data());
@@ -354,6 +364,8 @@ extern "C" void hm_destroy(hm_ctx *c) {
   for (auto &kv : c->ntt_tables) (void)hipFree(kv.second);
   (void)hipFree(c->d_tw_fwd);
   (void)hipFree(c->d_tw_inv);
+  (void)hipFree(c->d_twist_fwd);
+  (void)hipFree(c->d_twist_inv);
   (void)hipFree(c->d_mods);
   (void)hipEventDestroy(c->ev0);
   (void)hipEventDestroy(c->ev1);
@@ -489,16 +501,17 @@ static hm_status check_mods(hm_ctx *c, const char *what, const uint32_t *m, uint
 
 template <int LOG1>
 static void launch_ntt(hm_ctx *c, const HmNttArgs &a, bool fusedEpilogue, bool mixPrologue, bool inverse) {
-  const uint32_t tiles = c->P.N >> HM_TILE_LOG;
-  dim3 grid(a.n_limbs * tiles), block(HM_THREADS);  // n_limbs = entries, a multiple of 16 (pairs x 8 XCDs)
+  // n_limbs = entries, a multiple of 16 (pairs x 8 XCDs); one workgroup per tile of each pass
+  const dim3 gridC(a.n_limbs * (c->P.N >> HM_TL_COL)), blockC((1 << HM_TL_COL) / HM_EPT);
+  const dim3 gridR(a.n_limbs * (c->P.N >> HM_TL_ROW)), blockR((1 << HM_TL_ROW) / HM_EPT);
   if (!inverse) {
-    if (mixPrologue) hipLaunchKernelGGL((k_ntt_pass<LOG1, true, false, 4>), grid, block, 0, c->stream, a);
-    else hipLaunchKernelGGL((k_ntt_pass<LOG1, true, false, 0>), grid, block, 0, c->stream, a);
-    if (fusedEpilogue) hipLaunchKernelGGL((k_ntt_pass<HM_ROW_LOG, false, false, 3>), grid, block, 0, c->stream, a);
-    else hipLaunchKernelGGL((k_ntt_pass<HM_ROW_LOG, false, false, 1>), grid, block, 0, c->stream, a);
+    if (mixPrologue) hipLaunchKernelGGL((k_ntt_pass<LOG1, true, false, 4>), gridC, blockC, 0, c->stream, a);
+    else hipLaunchKernelGGL((k_ntt_pass<LOG1, true, false, 0>), gridC, blockC, 0, c->stream, a);
+    if (fusedEpilogue) hipLaunchKernelGGL((k_ntt_pass<HM_ROW_LOG, false, false, 3>), gridR, blockR, 0, c->stream, a);
+    else hipLaunchKernelGGL((k_ntt_pass<HM_ROW_LOG, false, false, 1>), gridR, blockR, 0, c->stream, a);
   } else {
-    hipLaunchKernelGGL((k_ntt_pass<HM_ROW_LOG, false, true, 0>), grid, block, 0, c->stream, a);
-    hipLaunchKernelGGL((k_ntt_pass<LOG1, true, true, 2>), grid, block, 0, c->stream, a);
+    hipLaunchKernelGGL((k_ntt_pass<HM_ROW_LOG, false, true, 0>), gridR, blockR, 0, c->stream, a);
+    hipLaunchKernelGGL((k_ntt_pass<LOG1, true, true, 2>), gridC, blockC, 0, c->stream, a);
   }
 }
 
@@ -609,6 +622,7 @@ static hm_status ntt_common(hm_ctx *c, const char *what, const uint64_t *in, con
     }
     a.in = in; a.out = out;
     a.tw = inverse ? c->d_tw_inv : c->d_tw_fwd;
+    a.twist = inverse ? c->d_twist_inv : c->d_twist_fwd;
     a.mods = c->d_mods;
     a.entry = dtab;
     a.minuend = f.minuend; a.addend = f.addend; a.mix = f.mix;

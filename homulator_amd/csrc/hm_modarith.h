@@ -93,7 +93,7 @@ HM_HD uint64_t hm_opaque_zero() {
 
 // Per-modulus constants of the lazy butterflies (wave-uniform, SGPRs): 4q and the two's complements of q and 4q.
 struct HmBflyMod {
-  uint64_t q4, nq, nq4, z;
+  uint64_t q4, nq, nq4, nq8, z;
 };
 HM_HD HmBflyMod hm_bfly_mod(uint64_t q) {
   HmBflyMod m;
@@ -101,6 +101,7 @@ HM_HD HmBflyMod hm_bfly_mod(uint64_t q) {
   m.q4 = 4 * q;
   m.nq = m.z - q;
   m.nq4 = m.z - 4 * q;
+  m.nq8 = m.z - 8 * q;
   return m;
 }
 
@@ -132,6 +133,22 @@ HM_HD void hm_bfly_fwd(uint64_t &X, uint64_t &Y, const HmTw &t, const HmBflyMod 
   const uint64_t x = hm_csub_neg(X, m.nq4);                 // [0, 4q)
   const uint64_t xn = hm_shoup_lazy4_acc(x, Y, t, m);       // x + v, v = w Y mod q in [0, 4q)
   Y = ((x << 1) + m.q4) - xn;                               // x - v + 4q
+  X = xn;
+}
+// The same with the conditional subtraction SCHEDULED over the stages (q < 2^60: 16q fits a word).  Y goes through the
+// product, which takes any 64-bit value; only X needs a bound, and the outputs are at most (bound of X) + 4q:
+//   kind 0: no subtraction        X < 12q        ->  X', Y' < 16q
+//   kind 1: X -= 8q if X >= 8q    X < 16q        ->  X', Y' < 12q
+//   kind 2: both 8q and 4q        X < 16q        ->  X', Y' <  8q   (last stage of a transform: hm_reduce8 follows)
+// Alternating 0 / 1 halves the subtractions (4 of the 23 instructions of a butterfly).  2X + 4q may wrap around 2^64;
+// the difference with X' = X + v is exact all the same, the true value X + 4q - v being below 16q.
+template <int KIND>
+HM_HD void hm_bfly_fwd_k(uint64_t &X, uint64_t &Y, const HmTw &t, const HmBflyMod &m) {
+  uint64_t x = X;
+  if (KIND >= 1) x = hm_csub_neg(x, m.nq8);
+  if (KIND == 2) x = hm_csub_neg(x, m.nq4);
+  const uint64_t xn = hm_shoup_lazy4_acc(x, Y, t, m);
+  Y = ((x << 1) + m.q4) - xn;
   X = xn;
 }
 // inverse (Gentleman-Sande): X, Y in [0, 4q) -> X', Y' in [0, 4q)

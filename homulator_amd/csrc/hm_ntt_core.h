@@ -1,5 +1,5 @@
 // hm_ntt_core.h — K1: negacyclic NTT / INTT over one RNS limb as two global passes of LDS-tiled
-// radix-8/4/2 rounds.  Replaces the reference's NTTU timing model (src/Components.cpp:380-436:
+// radix-8/4 rounds.  Replaces the reference's NTTU timing model (src/Components.cpp:380-436:
 // 8 butterfly stages, transpose, 8 butterfly stages) and InsGen::GenNTT (src/InsGen.cpp:17-44)
 // with real arithmetic; the ordering convention is SURVEY.md Appendix A (1).
 //
@@ -11,20 +11,50 @@
 // forward = COL then ROW (Cooley-Tukey, natural in, bit-reversed out);
 // inverse = ROW then COL (Gentleman-Sande, bit-reversed in, natural out, then * scale).
 //
-// A workgroup of HM_THREADS = 512 threads owns a tile of HM_TILE = 4096 coefficients (32 KiB) in LDS and runs
-// the rounds LDS -> registers -> LDS with one barrier per round; the phase functions below carry no
-// register state across barriers, so the host emulator (tests/emu) can run them thread by thread.
+// A workgroup of 2^TL / 16 threads owns a tile of 2^TL coefficients (TL = 12: 256 threads, 32 KiB) in LDS; a thread
+// holds 16 of them: two (radix-8 round) or four (radix-4 round) butterfly groups.  The groups of a thread come in
+// PAIRS that are adjacent in the memory-contiguous coordinate (two neighbouring columns in the COL pass, two
+// neighbouring x2 in the ROW pass), so that
+//   * every global and LDS access moves 16 bytes per lane (8-byte accesses run at about half the rate on gfx950),
+//   * the two groups of a pair use the same twiddles: one twiddle fetch serves 16 coefficients.
+// The LDS image is XOR-swizzled (no padding) so that the 16-byte accesses of all three rounds are conflict-free.
+//
+// Twiddles.  The table of a modulus is w[k] = psi^brev(k), k < N.  Stage s uses w[2^s + g], g < 2^s.
+//   * COL pass: the 2^LOG1 - 1 twiddles w[1 .. 2^LOG1) are the same for every column.  They are staged through LDS
+//     once per workgroup; only the first round (which runs before the first barrier) reads them from global memory.
+//   * ROW pass, local stage sigma < 8 of row r (global stage LOG1 + sigma, butterfly block h < 2^sigma):
+//         w[2^(LOG1+sigma) + r 2^sigma + h]  =  alpha_r^(2^(7-sigma)) * w[h],      alpha_r = psi^(1 + 2 brev(r)).
+//     The second factor is shared by all rows; the first is a per-row constant of the stage.  The last two local
+//     stages hold 75 % of a row's twiddles (64 + 128 of 255, 16 bytes each with the Shoup companion: as many bytes
+//     as the data itself over a whole pass).  For them the per-row factor is applied to the DATA instead: element j
+//     of the row is multiplied by alpha_r^(j mod 4) before the last forward round (three Shoup products per four
+//     coefficients; `twist` table, 3 constants per row), after which the two stages are plain butterflies with the
+//     shared twiddles w[h] (LDS-resident: the first 128 entries of the table).  The inverse pass runs its first
+//     round with the shared inverse twiddles and multiplies by alpha_r^-(j mod 4) afterwards.  Bit-identical to the
+//     table-driven transform: everything is exact arithmetic mod q.
 #pragma once
 #include "hm_modarith.h"
 
-#define HM_TILE 4096
-#define HM_TILE_LOG 12
-#ifndef HM_THREADS
-#define HM_THREADS 512
+#define HM_EPT 16                      // coefficients per thread
+#define HM_UNITS (HM_EPT / 2)          // 16-byte access units per thread
+#define HM_MAX_THREADS 256
+// Tile size per pass (log2 of the coefficients a workgroup owns; threads = tile / 16).  More, smaller workgroups per CU
+// overlap better: a workgroup alternates between waiting for memory and computing, and with k of them resident a CU
+// keeps both busy about k / (k + 1) of the time (measured: 3 x 512 threads 0.55 us per limb-NTT, 4 x 256 0.51).
+// ROW tiles are contiguous in memory at any size; COL tiles of 2048 have 64-byte row segments.
+#ifndef HM_TL_COL
+#define HM_TL_COL 12
 #endif
+#ifndef HM_TL_ROW
+#define HM_TL_ROW 12
+#endif
+#define HM_TL(STRIDED) ((STRIDED) ? HM_TL_COL : HM_TL_ROW)
 #define HM_MAX_LIMBS 128
 #ifndef HM_ROW_LOG
 #define HM_ROW_LOG 8  // log2 of the contiguous sub-transform length (pass ROW)
+#endif
+#ifndef HM_TW_IN_LDS
+#define HM_TW_IN_LDS 1  // shared twiddles of the later rounds come from an LDS copy (0: from global memory)
 #endif
 
 struct HmLimb {  // one limb-poly of an automorphism / fill launch: limb indices into the in/out bases, modulus id
@@ -53,6 +83,7 @@ struct HmNttArgs {
   const uint64_t *in;
   uint64_t *out;
   const HmTw *tw;      // [n_mod][N] forward or inverse table (chosen by the host)
+  const HmTw *twist;   // [n_mod][N / 256][3] per-row constants alpha_r^k (forward) or alpha_r^-k (inverse), k = 1..3
   const HmMod *mods;   // [n_mod]
   const HmNttEntry *entry;                // [n_limbs], device
   const uint64_t *minuend, *addend, *mix; // bases of the MODE 3 / MODE 4 operands (addend may be null)
@@ -71,45 +102,98 @@ struct HmEpi {  // the prologue / epilogue operands of one limb-poly, resolved b
 };
 HM_HD HmEpi hm_epi_none() { return HmEpi{nullptr, nullptr, HmTw{0, 0}, nullptr, HmTw{0, 0}}; }
 
-// LDS image of a tile.  STRIDED: [x][c] with the C columns contiguous (a plain copy of C-element
-// row segments).  CONTIG: [c][x] with 4 words of padding per 32 so that stride-32 column reads of the
-// middle round spread over all 64 banks.
-template <int LOGR, bool STRIDED>
-HM_HD int hm_lds_idx(int x, int c) {
-  if (STRIDED) return (x << (HM_TILE_LOG - LOGR)) | c;
-  int i = (c << LOGR) | x;
-  return i + ((i >> 5) << 2);
+// 16-byte accesses (two adjacent words; p is 16-byte aligned)
+HM_HD void hm_ld2(const uint64_t *p, uint64_t &a, uint64_t &b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const ulonglong2 t = *reinterpret_cast<const ulonglong2 *>(p);
+  a = t.x; b = t.y;
+#else
+  a = p[0]; b = p[1];
+#endif
 }
-#define HM_LDS_WORDS (HM_TILE + (HM_TILE >> 5) * 4)
+HM_HD void hm_st2(uint64_t *p, uint64_t a, uint64_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  ulonglong2 t; t.x = a; t.y = b;
+  *reinterpret_cast<ulonglong2 *>(p) = t;
+#else
+  p[0] = a; p[1] = b;
+#endif
+}
 
-// global index of tile-linear element `lin` (the order in which the tile is copied)
-template <int LOGR, bool STRIDED>
-HM_HD uint32_t hm_tile_gidx(uint32_t tile, uint32_t lin) {
-  if (STRIDED) {  // lin = x * C + c ; global = x * 256 + tile * C + c
-    const int LOGC = HM_TILE_LOG - LOGR;
-    uint32_t x = lin >> LOGC, c = lin & ((1u << LOGC) - 1);
-    return (x << HM_ROW_LOG) + (tile << LOGC) + c;
+// Global access of unit a of round G: buffer instructions take a wave-uniform descriptor (the limb-poly's base), a scalar
+// offset (tile, element number) and ONE 32-bit lane offset per pair / group — no 64-bit address register pair per unit
+// (flat addressing cost 16 VGPRs per operand stream and pushed the pipelined kernel into scratch).
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef unsigned hm_u32x4 __attribute__((ext_vector_type(4)));
+HM_HD __amdgpu_buffer_rsrc_t hm_rsrc(const uint64_t *base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint64_t *>(base), 0, -1, 0x00020000);
+}
+#endif
+template <class G>
+HM_HD void hm_gld2(const uint64_t *g, uint32_t tile, int tid, int a, uint64_t &v0, uint64_t &v1) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const hm_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(hm_rsrc(g), G::gthr(tid, a) << 3, G::guni(tile, a) << 3, 0);
+  v0 = (uint64_t)t.x | ((uint64_t)t.y << 32);
+  v1 = (uint64_t)t.z | ((uint64_t)t.w << 32);
+#else
+  hm_ld2(g + G::guni(tile, a) + G::gthr(tid, a), v0, v1);
+#endif
+}
+template <class G>
+HM_HD void hm_gst2(uint64_t *g, uint32_t tile, int tid, int a, uint64_t v0, uint64_t v1) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  hm_u32x4 t;
+  t.x = (unsigned)v0; t.y = (unsigned)(v0 >> 32); t.z = (unsigned)v1; t.w = (unsigned)(v1 >> 32);
+  // NO scalar offset on stores: a 16-byte buffer store with an SGPR soffset, followed at once by a VALU write to its data
+  // registers, stored the new values for the lanes read last on gfx950 (hipcc only guards the immediate-soffset form of
+  // this hazard: seen as 16 wrong coefficients in random tiles, different ones every run).  The uniform part goes into
+  // the descriptor's base instead (two scalar adds).
+  __builtin_amdgcn_raw_buffer_store_b128(t, hm_rsrc(g + G::guni(tile, a)), G::gthr(tid, a) << 3, 0, 0);
+#else
+  hm_st2(g + G::guni(tile, a) + G::gthr(tid, a), v0, v1);
+#endif
+}
+
+// LDS image of a tile: word index of coefficient (x, c), x = position inside the sub-transform, c = which sub-transform.
+// STRIDED: [x][c] with the C columns contiguous; CONTIG: [c][x].  Swizzles (bijections that keep word pairs together):
+//   CONTIG (256-point rows): bits 2..4 ^= x[7:5], bit 1 ^= x[5] — the middle round reads 16-byte units at a 256-byte
+//     stride (x = hi*32 + e*4 + ..) and the last one 32 contiguous bytes per lane: both become conflict-free;
+//   STRIDED with 16 columns: row x swaps with its neighbour when x[2] is set (8 columns: two bits, 4 columns: three) —
+//     the last round's rows are 4 apart (x = 4 xr + e), i.e. 512 bytes with 16 columns: without the swizzle two lanes
+//     of a 16-lane group share a bank.
+template <int TL, int LOGR, bool STRIDED>
+HM_HD int hm_lds_idx(int x, int c) {
+  if (STRIDED) {
+    constexpr int LOGC = TL - LOGR;
+    int w = (x << LOGC) | c;
+    if (LOGC <= 4) w ^= ((x >> 2) & ((1 << (5 - LOGC)) - 1)) << LOGC;  // a row is 2^(LOGC+3) bytes; 256 bytes span all banks
+    return w;
   }
-  return (tile << HM_TILE_LOG) + lin;
+  int w = (c << LOGR) | x;
+  if (LOGR == 8) w ^= (((x >> 5) & 7) << 2) ^ (((x >> 5) & 1) << 1);
+  return w;
 }
-template <int LOGR, bool STRIDED>
-HM_HD int hm_tile_lidx(uint32_t lin) {
-  if (STRIDED) return (int)lin;
-  return (int)(lin + ((lin >> 5) << 2));
-}
+// LDS words of a pass: the tile, then the staged shared twiddles (2 words each)
+template <int TL, int LOGR, bool STRIDED>
+struct HmLds {
+  static constexpr int TILE = 1 << TL, THREADS = TILE / HM_EPT;
+  static constexpr int NTW = STRIDED ? (1 << LOGR) : 128;  // staged entries: w[0 .. NTW) of the modulus
+  static constexpr int WORDS = TILE + 2 * NTW;
+};
 
 // ---------------------------------------------------------------------------------------------------
 // Per-thread phases.  A round = NB butterfly stages on local bits [K, K+NB) of x, done in registers by the
 // thread that owns the 2^NB elements of a group.  The first round of a pass reads its elements straight
 // from global memory and the last one writes straight back; only the exchanges between rounds go through
-// LDS (one barrier each).  Twiddles of round r+1 are requested before round r is computed, so that their
-// HBM latency overlaps the butterflies.  HmNttState is the per-thread register state (the host emulator
-// keeps one per thread).
+// LDS (one barrier each).  Twiddles that come from global memory are requested one round ahead, so that their
+// latency overlaps the butterflies.  HmNttState is the per-thread register state (the host emulator keeps one per
+// thread).
 // ---------------------------------------------------------------------------------------------------
-#define HM_MAX_GPT 2  // groups per thread in one round (HM_TILE >> NB) / HM_THREADS
+#define HM_MAX_TW 14  // twiddles of one round of one thread: a pair of radix-8 groups 7, four radix-4 groups 12
 struct HmNttState {
-  uint64_t v[HM_MAX_GPT][8];
-  HmTw tw[3][HM_MAX_GPT][7];
+  uint64_t v[HM_EPT];
+  HmTw tw[3][HM_MAX_TW];
+  HmTw tws[3];  // twist constants of the thread's row (ROW pass)
 };
 
 // Round schedule per sub-transform length: bits are consumed from the top for the forward transform
@@ -122,110 +206,232 @@ template <> struct HmRounds<8> { static constexpr int n = 3; static constexpr in
 template <> struct HmRounds<9> { static constexpr int n = 3; static constexpr int nb[3] = {3, 3, 3}; static constexpr int k[3] = {6, 3, 0}; };
 
 // geometry of round R of a pass
-template <int LOGR, bool STRIDED, int R>
+template <int TL, int LOGR, bool STRIDED, int R>
 struct HmRound {
   static constexpr int NB = HmRounds<LOGR>::nb[R], K = HmRounds<LOGR>::k[R];
   static constexpr int E = 1 << NB;
-  static constexpr int LOGC = HM_TILE_LOG - LOGR, C = 1 << LOGC;
-  static constexpr int GPT = (HM_TILE >> NB) / HM_THREADS;
-  static constexpr int XR = (1 << LOGR) >> NB;  // groups per sub-transform
-  static_assert(GPT >= 1 && GPT <= HM_MAX_GPT, "tile / thread geometry");
-  // group u of thread tid: column c, high/low parts of the group index
+  static constexpr int THREADS = (1 << TL) / HM_EPT;
+  static constexpr int LOGC = TL - LOGR, C = 1 << LOGC;
+  static constexpr int NG = HM_EPT / E;             // groups per thread
+  static constexpr int XR = (1 << LOGR) >> NB;      // groups per sub-transform
+  // groups 2v, 2v+1 of a thread are neighbours in memory and share their twiddles.  Not so in the CONTIG round on the
+  // lowest bits (K == 0): there the E elements of ONE group are contiguous.
+  static constexpr bool PAIRED = STRIDED || K >= 1;
+  static constexpr int SETS = PAIRED ? NG / 2 : NG;  // twiddle sets of a thread, E - 1 twiddles each
+  static_assert(SETS * (E - 1) <= HM_MAX_TW, "twiddle registers");
+  static_assert(C >= 2, "a pair needs two columns");
+  // group u of thread tid: sub-transform c, group index xr inside it
+  static HM_HD void group(int tid, int u, int &c, int &xr) {
+    if (STRIDED) {
+      const int pid = tid + THREADS * (u >> 1);
+      c = ((pid & (C / 2 - 1)) << 1) | (u & 1);
+      xr = pid >> (LOGC - 1);
+    } else if (K >= 1) {
+      const int pid = tid + THREADS * (u >> 1);
+      xr = ((pid & (XR / 2 - 1)) << 1) | (u & 1);
+      c = pid / (XR / 2);
+    } else {
+      constexpr int LPR = XR / NG;  // lanes per row
+      xr = (tid & (LPR - 1)) + LPR * u;
+      c = tid / LPR;
+    }
+  }
   static HM_HD void coords(int tid, int u, int &c, int &hi, int &xb) {
-    const int gid = tid + HM_THREADS * u;
     int xr;
-    if (STRIDED) { c = gid & (C - 1); xr = gid >> LOGC; }
-    else         { xr = gid & (XR - 1); c = gid / XR; }
+    group(tid, u, c, xr);
     const int lo = xr & ((1 << K) - 1);
     hi = xr >> K;
     xb = (hi << (K + NB)) | lo;
   }
+  static constexpr int twslot(int u) { return (PAIRED ? (u >> 1) : u) * (E - 1); }
+  // access unit a < 8 of thread tid: register indices of its two words and the coordinates of the first one
+  static HM_HD void unit(int tid, int a, int &i0, int &i1, int &x, int &c) {
+    int hi, xb;
+    if (PAIRED) {
+      const int v = a / E, e = a % E;
+      i0 = (2 * v) * E + e;
+      i1 = (2 * v + 1) * E + e;
+      coords(tid, 2 * v, c, hi, xb);
+      x = xb | (e << K);
+    } else {
+      const int u = a / (E / 2), h = a % (E / 2);
+      i0 = u * E + 2 * h;
+      i1 = i0 + 1;
+      coords(tid, u, c, hi, xb);
+      x = xb | (2 * h);
+    }
+  }
   static HM_HD uint32_t gidx(uint32_t tile, int x, int c) {
     if (STRIDED) return ((uint32_t)x << HM_ROW_LOG) + (tile << LOGC) + (uint32_t)c;
-    return (tile << HM_TILE_LOG) + ((uint32_t)c << LOGR) + (uint32_t)x;
+    return (tile << TL) + ((uint32_t)c << LOGR) + (uint32_t)x;
+  }
+  // the same index for access unit a, split into a wave-uniform part (tile, element number: scalar registers, folded
+  // into the base pointer) and the thread's part (one 32-bit register per pair / group): global accesses then take the
+  // `scalar base + 32-bit lane offset` form instead of a 64-bit address register pair per unit
+  static HM_HD uint32_t guni(uint32_t tile, int a) {
+    if (PAIRED) {
+      const int e = a % E;
+      return STRIDED ? ((uint32_t)e << (K + HM_ROW_LOG)) + (tile << LOGC) : (tile << TL) + ((uint32_t)e << K);
+    }
+    return (tile << TL) + 2u * (uint32_t)(a % (E / 2));
+  }
+  static HM_HD uint32_t gthr(int tid, int a) {
+    int c, hi, xb;
+    coords(tid, PAIRED ? 2 * (a / E) : a / (E / 2), c, hi, xb);
+    return STRIDED ? ((uint32_t)xb << HM_ROW_LOG) + (uint32_t)c : ((uint32_t)c << LOGR) + (uint32_t)xb;
   }
 };
 
-// request the twiddles of round R: sub-stage j needs 2^j of them, indexed by the top j bits of e
-template <int LOGR, bool STRIDED, int R>
+// Forward transform: which kind of butterfly (hm_bfly_fwd_k) local stage sigma of a pass runs.  Bounds in units of q:
+// the COL pass starts from reduced data (1), its first two stages need no subtraction (5, 9); from there on the stages
+// alternate so that the pass ENDS on a subtracting stage (12 out); the ROW pass (8 stages, 12 in) alternates 0 / 1 and
+// ends with kind 2 (8 out).  hm_fwd_bound replays the bounds at compile time: every stage is checked below.
+constexpr int hm_fwd_kind(bool strided, int logr, int sigma) {
+  if (strided) return sigma <= 1 ? 0 : (((logr - 1 - sigma) & 1) == 0 ? 1 : 0);
+  return sigma == logr - 1 ? 2 : (sigma & 1);
+}
+constexpr int hm_fwd_bound(bool strided, int logr, int upto) {  // bound (in q) of the values entering local stage `upto`
+  int b = strided ? 1 : 12;
+  for (int s = 0; s < upto; ++s) {
+    const int k = hm_fwd_kind(strided, logr, s);
+    if (k == 0 ? b > 12 : b > 16) return 1000;                  // the stage's input condition
+    b = (k == 0 ? b : k == 1 ? 8 : 4) + 4;
+  }
+  return b;
+}
+static_assert(hm_fwd_bound(true, 5, 5) == 12 && hm_fwd_bound(true, 6, 6) == 12 && hm_fwd_bound(true, 7, 7) == 12 &&
+              hm_fwd_bound(true, 8, 8) == 12 && hm_fwd_bound(true, 9, 9) == 12, "COL pass hands over values below 12q");
+static_assert(hm_fwd_bound(false, 8, 8) == 8, "ROW pass ends below 8q");
+
+// Where the twiddles of a pass come from.  exec(i) = the i-th round executed.
+template <int LOGR, bool STRIDED, bool INV>
+struct HmPass {
+  static constexpr int n = HmRounds<LOGR>::n;
+  static constexpr int exec(int i) { return INV ? n - 1 - i : i; }
+  // the ROW round on the lowest two bits runs with the shared twiddles (data twisted by alpha^(j mod 4))
+  static constexpr int twistRound = (!STRIDED && LOGR == 8) ? n - 1 : -1;
+  static constexpr bool shared(int R) { return STRIDED || R == twistRound; }
+  static constexpr bool fromLds(int R) { return HM_TW_IN_LDS && shared(R) && R != exec(0); }
+  static constexpr bool anyLds() { return fromLds(exec(1)) || (n == 3 && fromLds(exec(2))); }
+};
+
+// request the twiddles of round R: sub-stage j needs 2^j of them, indexed by the top j bits of e.
+// SHARED ROW round: the row-independent factor w[h]; otherwise the full table entry.
+template <int TL, int LOGR, bool STRIDED, int R, bool SHARED>
 HM_HD void hm_ph_load_tw(HmNttState &st, int tid, const HmTw *twl, uint32_t s0, uint32_t prefix0) {
-  using G = HmRound<LOGR, STRIDED, R>;
+  using G = HmRound<TL, LOGR, STRIDED, R>;
 #pragma unroll
-  for (int u = 0; u < G::GPT; ++u) {
+  for (int v = 0; v < G::SETS; ++v) {
     int c, hi, xb;
-    G::coords(tid, u, c, hi, xb);
-    const uint32_t prefix = STRIDED ? 0u : (prefix0 + (uint32_t)c);
+    G::coords(tid, G::PAIRED ? 2 * v : v, c, hi, xb);
+    const uint32_t prefix = (STRIDED || SHARED) ? 0u : (prefix0 + (uint32_t)c);
 #pragma unroll
     for (int j = 0; j < G::NB; ++j) {
       const int sigma = LOGR - G::K - G::NB + j;  // local stage index
-      const uint32_t twbase = (1u << (s0 + sigma)) + (prefix << sigma) + ((uint32_t)hi << j);
+      const uint32_t twbase = ((!STRIDED && SHARED) ? 0u : (1u << (s0 + sigma))) + (prefix << sigma) + ((uint32_t)hi << j);
 #pragma unroll
-      for (int t = 0; t < (1 << j); ++t) st.tw[R][u][(1 << j) - 1 + t] = twl[twbase + (uint32_t)t];
+      for (int t = 0; t < (1 << j); ++t) {
+#if defined(HM_ABL_NOTW)
+        st.tw[R][v * (G::E - 1) + (1 << j) - 1 + t] = HmTw{(uint64_t)(twbase + t) * 0x9E3779B97F4A7C15ull >> 5, (uint64_t)(twbase + t) * 0xD1342543DE82EF95ull};
+#else
+        st.tw[R][v * (G::E - 1) + (1 << j) - 1 + t] = twl[twbase + (uint32_t)t];
+#endif
+      }
+    }
+  }
+}
+// the three twist constants of the thread's row (the K == 0 ROW round: all groups of a thread lie in one row)
+template <int TL, int LOGR, bool STRIDED, int R>
+HM_HD void hm_ph_load_twist(HmNttState &st, int tid, const HmTw *twist_tile) {
+  using G = HmRound<TL, LOGR, STRIDED, R>;
+  int c, xr;
+  G::group(tid, 0, c, xr);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) st.tws[k] = twist_tile[c * 3 + k];
+}
+// copy the shared twiddles w[0 .. NTW) of the modulus into LDS (visible after the next barrier)
+template <int TL, int LOGR, bool STRIDED>
+HM_HD void hm_ph_stage_tw(int tid, uint64_t *lds, const HmTw *twl) {
+  using LD = HmLds<TL, LOGR, STRIDED>;
+#pragma unroll
+  for (int i = 0; i < (LD::NTW + LD::THREADS - 1) / LD::THREADS; ++i) {
+    const int k = tid + LD::THREADS * i;
+    if (k < LD::NTW) {
+      const HmTw t = twl[k];
+      hm_st2(lds + LD::TILE + 2 * k, t.w, t.ws);
     }
   }
 }
 
-template <int LOGR, bool STRIDED, int R>
+template <int TL, int LOGR, bool STRIDED, int R>
 HM_HD void hm_ph_load_global(HmNttState &st, int tid, const uint64_t *g, uint32_t tile) {
-  using G = HmRound<LOGR, STRIDED, R>;
+  using G = HmRound<TL, LOGR, STRIDED, R>;
 #pragma unroll
-  for (int u = 0; u < G::GPT; ++u) {
-    int c, hi, xb;
-    G::coords(tid, u, c, hi, xb);
-#pragma unroll
-    for (int e = 0; e < G::E; ++e) st.v[u][e] = g[G::gidx(tile, xb | (e << G::K), c)];
+  for (int a = 0; a < HM_UNITS; ++a) {
+    int i0, i1, x, c;
+    G::unit(tid, a, i0, i1, x, c);
+#if defined(HM_ABL_NOMEM)   // timing-only ablation build (tools/ablate.sh): no data traffic
+    st.v[i0] = (uint64_t)G::gidx(tile, x, c) * 0x9E3779B97F4A7C15ull >> 5; st.v[i1] = st.v[i0] ^ 0x5555;
+#else
+    hm_gld2<G>(g, tile, tid, a, st.v[i0], st.v[i1]);
+#endif
   }
 }
 // MODE 4: the same with the linear prologue x = in + k * mix (both reduced; x reduced)
-template <int LOGR, bool STRIDED, int R>
+template <int TL, int LOGR, bool STRIDED, int R>
 HM_HD void hm_ph_load_global_mix(HmNttState &st, int tid, const uint64_t *g, uint32_t tile, uint64_t q, HmEpi ep) {
-  using G = HmRound<LOGR, STRIDED, R>;
+  using G = HmRound<TL, LOGR, STRIDED, R>;
 #pragma unroll
-  for (int u = 0; u < G::GPT; ++u) {
-    int c, hi, xb;
-    G::coords(tid, u, c, hi, xb);
-#pragma unroll
-    for (int e = 0; e < G::E; ++e) {
-      const uint32_t gi = G::gidx(tile, xb | (e << G::K), c);
-      st.v[u][e] = hm_addmod(g[gi], hm_shoup(ep.b[gi], ep.bk.w, ep.bk.ws, q), q);
-    }
+  for (int a = 0; a < HM_UNITS; ++a) {
+    int i0, i1, x, c;
+    G::unit(tid, a, i0, i1, x, c);
+    uint64_t p0, p1, b0, b1;
+    hm_gld2<G>(g, tile, tid, a, p0, p1);
+    hm_gld2<G>(ep.b, tile, tid, a, b0, b1);
+    st.v[i0] = hm_addmod(p0, hm_shoup(b0, ep.bk.w, ep.bk.ws, q), q);
+    st.v[i1] = hm_addmod(p1, hm_shoup(b1, ep.bk.w, ep.bk.ws, q), q);
   }
 }
 
-// MODE 0 / 4: store as is (lazy values, hand-off between the two passes; 4 = first pass with the mix prologue);
-// 1: forward final, reduce [0,8q) ->
-// [0,q); 2: inverse final, multiply by the per-limb constant and reduce to [0,q); 3: forward final fused with
-// out = (minuend - x) * k [+ addend]
-template <int LOGR, bool STRIDED, int R, int MODE>
+// the epilogue of one coefficient.  MODE 0 / 4: store as is (lazy values, hand-off between the two passes; 4 = first
+// pass with the mix prologue); 1: forward final, reduce [0,8q) -> [0,q); 2: inverse final, multiply by the per-limb
+// constant and reduce to [0,q); 3: forward final fused with out = (minuend - x) * k [+ addend [* ak]]
+template <int MODE>
+HM_HD uint64_t hm_epilogue(uint64_t a, uint64_t va, uint64_t vd, uint64_t q, HmTw sc, const HmEpi &ep) {
+  if (MODE == 1) return hm_reduce8(a, q);
+  if (MODE == 2) return hm_shoup(a, sc.w, sc.ws, q);
+  if (MODE == 3) {  // a in [0, 8q): minuend - a + 8q stays positive and below 2^64; the product reduces it
+    a = hm_shoup(va + 8 * q - a, sc.w, sc.ws, q);
+    if (ep.d) a = hm_addmod(a, ep.dk.w ? hm_shoup(vd, ep.dk.w, ep.dk.ws, q) : vd, q);
+  }
+  return a;
+}
+template <int TL, int LOGR, bool STRIDED, int R, int MODE>
 HM_HD void hm_ph_store_global(const HmNttState &st, int tid, uint64_t *g, uint32_t tile, uint64_t q, HmTw sc, HmEpi ep) {
-  using G = HmRound<LOGR, STRIDED, R>;
+  using G = HmRound<TL, LOGR, STRIDED, R>;
+  // MODE 3: the epilogue operands are requested two units at a time, right before they are used (with a scheduling
+  // fence in between): prefetching all of them before the last round costs 32 registers
 #pragma unroll
-  for (int u = 0; u < G::GPT; ++u) {
-    int c, hi, xb;
-    G::coords(tid, u, c, hi, xb);
-    // MODE 3: the epilogue operands of one group are requested right before they are used (group by group, with a
-    // scheduling fence in between): prefetching all of them before the last round cost 32 registers and a workgroup per CU
-    uint64_t ea[G::E], ed[G::E];
+  for (int a2 = 0; a2 < HM_UNITS; a2 += 2) {
+    uint64_t ea[4] = {0, 0, 0, 0}, ed[4] = {0, 0, 0, 0};
     if (MODE == 3) {
 #pragma unroll
-      for (int e = 0; e < G::E; ++e) {
-        const uint32_t gi = G::gidx(tile, xb | (e << G::K), c);
-        ea[e] = ep.a[gi];
-        ed[e] = ep.d ? ep.d[gi] : 0;
+      for (int k = 0; k < 2; ++k) {
+        int i0, i1, x, c;
+        G::unit(tid, a2 + k, i0, i1, x, c);
+        hm_gld2<G>(ep.a, tile, tid, a2 + k, ea[2 * k], ea[2 * k + 1]);
+        if (ep.d) hm_gld2<G>(ep.d, tile, tid, a2 + k, ed[2 * k], ed[2 * k + 1]);
       }
     }
 #pragma unroll
-    for (int e = 0; e < G::E; ++e) {
-      uint64_t a = st.v[u][e];
-      if (MODE == 1) a = hm_reduce8(a, q);
-      else if (MODE == 2) a = hm_shoup(a, sc.w, sc.ws, q);
-      const uint32_t gi = G::gidx(tile, xb | (e << G::K), c);
-      if (MODE == 3) {  // a in [0, 8q): minuend - a + 8q stays positive and below 2^64; the product reduces it
-        const uint64_t va = ea[e], vd = ed[e];
-        a = hm_shoup(va + 8 * q - a, sc.w, sc.ws, q);
-        if (ep.d) a = hm_addmod(a, ep.dk.w ? hm_shoup(vd, ep.dk.w, ep.dk.ws, q) : vd, q);
-      }
-      g[gi] = a;
+    for (int k = 0; k < 2; ++k) {
+      int i0, i1, x, c;
+      G::unit(tid, a2 + k, i0, i1, x, c);
+#if defined(HM_ABL_NOMEM)
+      if (st.v[i0] == 0x123456789ull)   // never true in practice: keeps the values alive without the store traffic
+#endif
+      hm_gst2<G>(g, tile, tid, a2 + k, hm_epilogue<MODE>(st.v[i0], ea[2 * k], ed[2 * k], q, sc, ep),
+                 hm_epilogue<MODE>(st.v[i1], ea[2 * k + 1], ed[2 * k + 1], q, sc, ep));
     }
 #if defined(__HIP_DEVICE_COMPILE__)
     if (MODE == 3) __builtin_amdgcn_sched_barrier(0);
@@ -233,81 +439,110 @@ HM_HD void hm_ph_store_global(const HmNttState &st, int tid, uint64_t *g, uint32
   }
 }
 
-template <int LOGR, bool STRIDED, int R>
+template <int TL, int LOGR, bool STRIDED, int R>
 HM_HD void hm_ph_load_lds(HmNttState &st, int tid, const uint64_t *lds) {
-  using G = HmRound<LOGR, STRIDED, R>;
+  using G = HmRound<TL, LOGR, STRIDED, R>;
 #pragma unroll
-  for (int u = 0; u < G::GPT; ++u) {
-    int c, hi, xb;
-    G::coords(tid, u, c, hi, xb);
-#pragma unroll
-    for (int e = 0; e < G::E; ++e) st.v[u][e] = lds[hm_lds_idx<LOGR, STRIDED>(xb | (e << G::K), c)];
+  for (int a = 0; a < HM_UNITS; ++a) {
+    int i0, i1, x, c;
+    G::unit(tid, a, i0, i1, x, c);
+    hm_ld2(lds + hm_lds_idx<TL, LOGR, STRIDED>(x, c), st.v[i0], st.v[i1]);
   }
 }
-template <int LOGR, bool STRIDED, int R>
+template <int TL, int LOGR, bool STRIDED, int R>
 HM_HD void hm_ph_store_lds(const HmNttState &st, int tid, uint64_t *lds) {
-  using G = HmRound<LOGR, STRIDED, R>;
+  using G = HmRound<TL, LOGR, STRIDED, R>;
 #pragma unroll
-  for (int u = 0; u < G::GPT; ++u) {
-    int c, hi, xb;
-    G::coords(tid, u, c, hi, xb);
-#pragma unroll
-    for (int e = 0; e < G::E; ++e) lds[hm_lds_idx<LOGR, STRIDED>(xb | (e << G::K), c)] = st.v[u][e];
+  for (int a = 0; a < HM_UNITS; ++a) {
+    int i0, i1, x, c;
+    G::unit(tid, a, i0, i1, x, c);
+    hm_st2(lds + hm_lds_idx<TL, LOGR, STRIDED>(x, c), st.v[i0], st.v[i1]);
   }
 }
 
-template <int LOGR, bool STRIDED, int R, bool INV>
+template <int TL, int LOGR, bool STRIDED, int R, bool INV>
 HM_HD void hm_ph_compute(HmNttState &st, uint64_t q) {
-  using G = HmRound<LOGR, STRIDED, R>;
+  using G = HmRound<TL, LOGR, STRIDED, R>;
+#if defined(HM_ABL_NOCOMPUTE)
+  st.v[0] ^= st.tw[R][0].w;  // keeps the twiddle loads alive
+  return;
+#endif
   const HmBflyMod m = hm_bfly_mod(q);  // lazy ranges: forward [0, 8q), inverse [0, 4q)
 #pragma unroll
-  for (int u = 0; u < G::GPT; ++u) {
+  for (int jj = 0; jj < G::NB; ++jj) {
+    const int j = INV ? (G::NB - 1 - jj) : jj;  // sub-stage j combines e-bit (NB-1-j)
+    const int pb = G::NB - 1 - j;
 #pragma unroll
-    for (int jj = 0; jj < G::NB; ++jj) {
-      const int j = INV ? (G::NB - 1 - jj) : jj;  // sub-stage j combines e-bit (NB-1-j)
-      const int pb = G::NB - 1 - j;
+    for (int u = 0; u < G::NG; ++u) {
 #pragma unroll
       for (int e = 0; e < G::E; ++e) {
         if (e & (1 << pb)) continue;
-        const HmTw t = st.tw[R][u][(1 << j) - 1 + (e >> (G::NB - j))];
-        if (INV) hm_bfly_inv(st.v[u][e], st.v[u][e | (1 << pb)], t, m);
-        else     hm_bfly_fwd(st.v[u][e], st.v[u][e | (1 << pb)], t, m);
+        const HmTw t = st.tw[R][G::twslot(u) + (1 << j) - 1 + (e >> (G::NB - j))];
+        constexpr int sigma = LOGR - G::K - G::NB;  // + j: the local stage (j is a constant once unrolled)
+        if (INV) hm_bfly_inv(st.v[u * G::E + e], st.v[u * G::E + (e | (1 << pb))], t, m);
+        else if (hm_fwd_kind(STRIDED, LOGR, sigma + j) == 0) hm_bfly_fwd_k<0>(st.v[u * G::E + e], st.v[u * G::E + (e | (1 << pb))], t, m);
+        else if (hm_fwd_kind(STRIDED, LOGR, sigma + j) == 1) hm_bfly_fwd_k<1>(st.v[u * G::E + e], st.v[u * G::E + (e | (1 << pb))], t, m);
+        else hm_bfly_fwd_k<2>(st.v[u * G::E + e], st.v[u * G::E + (e | (1 << pb))], t, m);
       }
     }
   }
+}
+// multiply element j of the row by tws[(j mod 4) - 1] (the K == 0, NB == 2 ROW round: v[4 u + e] is element 4 hi + e).
+// Lazy product: any 64-bit input, result in [0, 4q) — inside the input range of both butterfly forms.
+HM_HD void hm_ph_twist(HmNttState &st, uint64_t q) {
+#if defined(HM_ABL_NOCOMPUTE)
+  st.v[1] ^= st.tws[0].w ^ st.tws[1].w ^ st.tws[2].w;
+  return;
+#endif
+  const HmBflyMod m = hm_bfly_mod(q);
+#pragma unroll
+  for (int u = 0; u < HM_EPT / 4; ++u)
+#pragma unroll
+    for (int k = 1; k < 4; ++k) st.v[4 * u + k] = hm_shoup_lazy4_acc(0, st.v[4 * u + k], st.tws[k - 1], m);
 }
 
 // The whole pass of one thread, phase by phase.  `sync` is __syncthreads() on the GPU; the emulator calls the
 // phases itself (see tests/emu/hm_emu.cpp) in the same order, one phase for all threads at a time.
 // Phase list (forward; the inverse walks the rounds from the last to the first):
-//   P0: tw[r0], global -> v, tw[r1]          P1: compute r0, v -> LDS            | barrier
-//   P2: tw[r2] (3 rounds), LDS -> v, compute r1, then  (2 rounds) v -> global    or  v -> LDS | barrier
-//   P3: LDS -> v, compute r2, v -> global
-template <int LOGR, bool STRIDED, bool INV, int MODE, int PHASE>
+//   P0: stage shared tw -> LDS, tw[r0], global -> v, tw[r1] (if global)   P1: compute r0, v -> LDS        | barrier
+//   P2: tw[r2] (if global), tw[r1] (if LDS), LDS -> v, compute r1, then (2 rounds) v -> global  or  v -> LDS | barrier
+//   P3: tw[r2] (if LDS), LDS -> v, compute r2, v -> global
+// twl = table of the modulus; twist_tile = twist constants of the tile's first row (ROW pass)
+template <int TL, int LOGR, bool STRIDED, bool INV, int MODE, int PHASE>
 HM_HD void hm_ntt_phase(HmNttState &st, int tid, uint64_t *lds, const uint64_t *src, uint64_t *dst, uint32_t tile,
-                        const HmTw *twl, uint32_t s0, uint32_t prefix0, uint64_t q, HmTw sc, HmEpi ep) {
-  using RS = HmRounds<LOGR>;
-  constexpr int n = RS::n;
-  constexpr int r0 = INV ? n - 1 : 0, r1 = INV ? n - 2 : 1, r2 = INV ? 0 : 2;  // r2 only when n == 3
+                        const HmTw *twl, const HmTw *twist_tile, uint32_t s0, uint32_t prefix0, uint64_t q, HmTw sc, HmEpi ep) {
+  using PS = HmPass<LOGR, STRIDED, INV>;
+  constexpr int n = PS::n;
+  constexpr int r0 = PS::exec(0), r1 = PS::exec(1), r2 = n == 3 ? PS::exec(2) : PS::exec(1);  // r2 only when n == 3
+  constexpr int TWR = PS::twistRound;
+  const HmTw *ltw = reinterpret_cast<const HmTw *>(lds + (1 << TL));
   if (PHASE == 0) {
-    hm_ph_load_tw<LOGR, STRIDED, r0>(st, tid, twl, s0, prefix0);
-    if (MODE == 4) hm_ph_load_global_mix<LOGR, STRIDED, r0>(st, tid, src, tile, q, ep);
-    else hm_ph_load_global<LOGR, STRIDED, r0>(st, tid, src, tile);
-    hm_ph_load_tw<LOGR, STRIDED, r1>(st, tid, twl, s0, prefix0);
+    if (PS::anyLds()) hm_ph_stage_tw<TL, LOGR, STRIDED>(tid, lds, twl);
+    hm_ph_load_tw<TL, LOGR, STRIDED, r0, PS::shared(r0)>(st, tid, twl, s0, prefix0);
+    if (MODE == 4) hm_ph_load_global_mix<TL, LOGR, STRIDED, r0>(st, tid, src, tile, q, ep);
+    else hm_ph_load_global<TL, LOGR, STRIDED, r0>(st, tid, src, tile);
+    if (TWR >= 0 && (INV || n == 2)) hm_ph_load_twist<TL, LOGR, STRIDED, (TWR >= 0 ? TWR : 0)>(st, tid, twist_tile);
+    if (!PS::fromLds(r1)) hm_ph_load_tw<TL, LOGR, STRIDED, r1, PS::shared(r1)>(st, tid, twl, s0, prefix0);
   } else if (PHASE == 1) {
-    hm_ph_compute<LOGR, STRIDED, r0, INV>(st, q);
-    hm_ph_store_lds<LOGR, STRIDED, r0>(st, tid, lds);
+    hm_ph_compute<TL, LOGR, STRIDED, r0, INV>(st, q);
+    if (INV && r0 == TWR) hm_ph_twist(st, q);
+    hm_ph_store_lds<TL, LOGR, STRIDED, r0>(st, tid, lds);
   } else if (PHASE == 2) {
-    if (n == 3) hm_ph_load_tw<LOGR, STRIDED, (n == 3 ? r2 : r1)>(st, tid, twl, s0, prefix0);
-    hm_ph_load_lds<LOGR, STRIDED, r1>(st, tid, lds);
-    hm_ph_compute<LOGR, STRIDED, r1, INV>(st, q);
-    if (n == 3) hm_ph_store_lds<LOGR, STRIDED, r1>(st, tid, lds);
-    else hm_ph_store_global<LOGR, STRIDED, r1, MODE>(st, tid, dst, tile, q, sc, ep);
+    if (n == 3 && !PS::fromLds(r2)) hm_ph_load_tw<TL, LOGR, STRIDED, r2, PS::shared(r2)>(st, tid, twl, s0, prefix0);
+    if (TWR >= 0 && !INV && n == 3) hm_ph_load_twist<TL, LOGR, STRIDED, (TWR >= 0 ? TWR : 0)>(st, tid, twist_tile);  // used in the next phase
+    if (PS::fromLds(r1)) hm_ph_load_tw<TL, LOGR, STRIDED, r1, PS::shared(r1)>(st, tid, ltw, s0, prefix0);
+    hm_ph_load_lds<TL, LOGR, STRIDED, r1>(st, tid, lds);
+    if (!INV && n == 2 && r1 == TWR) hm_ph_twist(st, q);
+    hm_ph_compute<TL, LOGR, STRIDED, r1, INV>(st, q);
+    if (n == 3) hm_ph_store_lds<TL, LOGR, STRIDED, r1>(st, tid, lds);
+    else hm_ph_store_global<TL, LOGR, STRIDED, r1, MODE>(st, tid, dst, tile, q, sc, ep);
   } else if (PHASE == 3) {
     if (n == 3) {
-      hm_ph_load_lds<LOGR, STRIDED, (n == 3 ? r2 : r1)>(st, tid, lds);
-      hm_ph_compute<LOGR, STRIDED, (n == 3 ? r2 : r1), INV>(st, q);
-      hm_ph_store_global<LOGR, STRIDED, (n == 3 ? r2 : r1), MODE>(st, tid, dst, tile, q, sc, ep);
+      if (PS::fromLds(r2)) hm_ph_load_tw<TL, LOGR, STRIDED, r2, PS::shared(r2)>(st, tid, ltw, s0, prefix0);
+      hm_ph_load_lds<TL, LOGR, STRIDED, r2>(st, tid, lds);
+      if (!INV && r2 == TWR) hm_ph_twist(st, q);
+      hm_ph_compute<TL, LOGR, STRIDED, r2, INV>(st, q);
+      hm_ph_store_global<TL, LOGR, STRIDED, r2, MODE>(st, tid, dst, tile, q, sc, ep);
     }
   }
 }

@@ -116,6 +116,20 @@ void Params::make_table(uint32_t m, bool inverse, HmTw *out) const {
   }
 }
 
+void Params::make_twist(uint32_t m, bool inverse, HmTw *out) const {
+  const uint64_t q = mod[m];
+  const uint64_t base = inverse ? invmod(psi[m], q) : psi[m];
+  const uint32_t rows = N >> 8, bits = logN - 8;
+  for (uint32_t r = 0; r < rows; ++r) {
+    const uint64_t a = powmod(base, 1 + 2ull * bitrev(r, bits), q);
+    uint64_t p = 1;
+    for (uint32_t k = 0; k < 3; ++k) {
+      p = mulmod(p, a, q);
+      out[3 * r + k] = HmTw{p, shoup(p, q)};
+    }
+  }
+}
+
 void Params::bconv_consts(const uint32_t *in_ids, uint32_t n_in, const uint32_t *out_ids, uint32_t n_out,
                           uint64_t *qhat_inv, uint64_t *table) const {
   for (uint32_t i = 0; i < n_in; ++i) {

@@ -27,6 +27,9 @@ struct Params {
   void init(uint32_t logN, uint32_t L, uint32_t K, const uint64_t *q, const uint64_t *p, const uint64_t *psi);
   // forward (inverse=false) or inverse twiddle table of one modulus, N entries, bit-reversed order
   void make_table(uint32_t mod_id, bool inverse, HmTw *out) const;
+  // per-row constants of the ROW pass (hm_ntt_core.h): out[3 r + k - 1] = alpha_r^k (inverse: alpha_r^-k), k = 1..3,
+  // alpha_r = psi^(1 + 2 brev(r)), r < N / 256
+  void make_twist(uint32_t mod_id, bool inverse, HmTw *out) const;
   // base conversion constants for an input basis -> output basis
   void bconv_consts(const uint32_t *in_ids, uint32_t n_in, const uint32_t *out_ids, uint32_t n_out,
                     uint64_t *qhat_inv, uint64_t *table) const;

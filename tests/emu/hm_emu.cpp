@@ -13,25 +13,28 @@
 
 struct Emu {
   hm::Params P;
-  std::vector<std::vector<HmTw>> fwd, inv;
+  std::vector<std::vector<HmTw>> fwd, inv, twf, twi;
 };
 
 template <int LOGR, bool STRIDED, bool INV, int MODE>
 static void run_pass(const Emu &e, uint32_t mod, const uint64_t *src, uint64_t *dst, HmTw sc, HmEpi ep = hm_epi_none()) {
-  const uint32_t tiles = e.P.N >> HM_TILE_LOG;
+  constexpr int TL = HM_TL(STRIDED), THREADS = (1 << TL) / HM_EPT;
+  const uint32_t tiles = e.P.N >> TL;
   const uint64_t q = e.P.mod[mod];
   const HmTw *twl = (INV ? e.inv : e.fwd)[mod].data();
   const uint32_t s0 = STRIDED ? 0u : (e.P.logN - HM_ROW_LOG);
-  std::vector<uint64_t> lds(HM_LDS_WORDS);
-  std::vector<HmNttState> st(HM_THREADS);
+  std::vector<uint64_t> lds(HmLds<TL, LOGR, STRIDED>::WORDS);
+  std::vector<HmNttState> st(THREADS);
+  const HmTw *twist = (INV ? e.twi : e.twf)[mod].data();
   // a pass may run in place (src == dst): every thread reads its elements before any thread writes its own
   for (uint32_t tile = 0; tile < tiles; ++tile) {
-    const uint32_t prefix0 = STRIDED ? 0u : (tile << (HM_TILE_LOG - LOGR));
-    for (int t = 0; t < HM_THREADS; ++t) hm_ntt_phase<LOGR, STRIDED, INV, MODE, 0>(st[t], t, lds.data(), src, dst, tile, twl, s0, prefix0, q, sc, ep);
-    for (int t = 0; t < HM_THREADS; ++t) hm_ntt_phase<LOGR, STRIDED, INV, MODE, 1>(st[t], t, lds.data(), src, dst, tile, twl, s0, prefix0, q, sc, ep);
-    for (int t = 0; t < HM_THREADS; ++t) hm_ntt_phase<LOGR, STRIDED, INV, MODE, 2>(st[t], t, lds.data(), src, dst, tile, twl, s0, prefix0, q, sc, ep);
+    const uint32_t prefix0 = STRIDED ? 0u : (tile << (TL - LOGR));
+    const HmTw *twt = twist + (size_t)prefix0 * 3;
+    for (int t = 0; t < THREADS; ++t) hm_ntt_phase<TL, LOGR, STRIDED, INV, MODE, 0>(st[t], t, lds.data(), src, dst, tile, twl, twt, s0, prefix0, q, sc, ep);
+    for (int t = 0; t < THREADS; ++t) hm_ntt_phase<TL, LOGR, STRIDED, INV, MODE, 1>(st[t], t, lds.data(), src, dst, tile, twl, twt, s0, prefix0, q, sc, ep);
+    for (int t = 0; t < THREADS; ++t) hm_ntt_phase<TL, LOGR, STRIDED, INV, MODE, 2>(st[t], t, lds.data(), src, dst, tile, twl, twt, s0, prefix0, q, sc, ep);
     if (HmRounds<LOGR>::n == 3)
-      for (int t = 0; t < HM_THREADS; ++t) hm_ntt_phase<LOGR, STRIDED, INV, MODE, 3>(st[t], t, lds.data(), src, dst, tile, twl, s0, prefix0, q, sc, ep);
+      for (int t = 0; t < THREADS; ++t) hm_ntt_phase<TL, LOGR, STRIDED, INV, MODE, 3>(st[t], t, lds.data(), src, dst, tile, twl, twt, s0, prefix0, q, sc, ep);
   }
 }
 
@@ -63,9 +66,12 @@ extern "C" {
 void *emu_create(uint32_t logN, uint32_t L, uint32_t K) {
   Emu *e = new Emu;
   e->P.init(logN, L, K, nullptr, nullptr, nullptr);
-  e->fwd.resize(L + K); e->inv.resize(L + K);
+  e->fwd.resize(L + K); e->inv.resize(L + K); e->twf.resize(L + K); e->twi.resize(L + K);
   for (uint32_t m = 0; m < L + K; ++m) {
     e->fwd[m].resize(e->P.N); e->inv[m].resize(e->P.N);
+    e->twf[m].resize((e->P.N >> 8) * 3); e->twi[m].resize((e->P.N >> 8) * 3);
+    e->P.make_twist(m, false, e->twf[m].data());
+    e->P.make_twist(m, true, e->twi[m].data());
     e->P.make_table(m, false, e->fwd[m].data());
     e->P.make_table(m, true, e->inv[m].data());
   }

@@ -48,6 +48,14 @@ def test_fat_binary_targets_gfx950():
         subprocess.check_call(["/opt/rocm/lib/llvm/bin/clang-offload-bundler", "--unbundle", "--type=o", "--input=" + fat,
                                "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
         notes = subprocess.check_output(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", co], text=True)
+        disasm = subprocess.check_output(["/opt/rocm/lib/llvm/bin/llvm-objdump", "-d", "--mcpu=gfx950", co], text=True)
     import re
     sizes = re.findall(r"\.private_segment_fixed_size:\s*(\d+)", notes)
     assert len(sizes) > 40 and all(int(x) == 0 for x in sizes), sizes
+    # gfx950 hazard (found as 16 wrong coefficients in random tiles, a different set every run): a 12/16-byte buffer store
+    # whose soffset is an SGPR, followed at once by a VALU write to its data registers, stores the NEW values for the
+    # lanes read last; hipcc only guards the immediate-soffset form.  No wide buffer store may carry a scalar offset.
+    stores = [l for l in disasm.splitlines() if re.search(r"buffer_store_dwordx[34]", l)]
+    assert len(stores) > 50, len(stores)
+    bad = [l for l in stores if not re.search(r"\],\s*0\b", l)]
+    assert not bad, bad[:3]
