@@ -25,46 +25,80 @@ HMULT_ALG_BYTES = 1_102_577_664            # 2 103 LP
 HROTATE_ALG_BYTES = 883_425_280            # 1 685 LP
 NTT_ALG_BYTES = 2 * LP                     # per limb-NTT
 HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md
-# HBM bytes of one 50-limb forward NTT sweep from the PMC counters (profiles/r01_pmc_ntt_sweep.txt: separate --pmc passes;
-# FETCH_SIZE in KiB doubled as MI355X_MICROARCH.md §HBM prescribes for gfx950, WRITE_SIZE in KiB exact):
-#   ROW pass FETCH 38 370 KiB x 2 (data + 16-byte twiddles), COL pass FETCH 12 970 KiB x 2, WRITE 25 600 KiB per pass
-NTT_SWEEP50_TRAFFIC_BYTES = int((38370 * 2 + 12970 * 2 + 25600 * 2) * 1024)
+BFLY_PER_LIMB_NTT = (1 << LOGN) // 2 * LOGN  # butterflies of one limb-NTT: N/2 per stage, logN stages
 
 
-def measure_ntt_sweep(n_limbs, iters=50):
+def roofline_inputs():
+    """figures that come from profiler runs of HEAD, committed under profiles/ (never typed into this file):
+    `ntt_sweep50_traffic_bytes` = HBM bytes of the 50-limb forward sweep from the PMC counters (separate --pmc passes,
+    FETCH_SIZE doubled as MI355X_MICROARCH.md §HBM prescribes for gfx950); `wave_butterfly_ns` = full-chip time per
+    wave-butterfly of the shipped butterfly mix (tools/bflyrate: 1024 SIMDs busy, no memory traffic)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "roofline_inputs.json")) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return {}
+
+
+def measure_ntt_sweep(n_limbs, iters=48, sets=6):
     """forward NTT sweep over the extended basis (l + alpha limbs): device time per sweep, HIP events on the
-    backend stream.  One sweep = one hm_ntt call = the two pass kernels k_ntt_pass<COL> + k_ntt_pass<ROW>."""
+    backend stream.  One sweep = one hm_ntt call = the two pass kernels k_ntt_pass<COL> + k_ntt_pass<ROW>.
+    The sweeps rotate over `sets` input/output buffer pairs (6 x 2 x 26 MB = 315 MB > the 256 MiB Infinity Cache), so
+    that every sweep reads its input from HBM rather than from a cache the previous replay left warm."""
     from homulator_amd import hip
     ctx = hip.Context(LOGN, L, ALPHA)
     ids = ctx.ext_ids(ELL)[:n_limbs]
-    a, b = ctx.alloc(n_limbs), ctx.alloc(n_limbs)
-    ctx.fill_uniform(a, ids, 1)
-    for _ in range(5):
+    bufs = [(ctx.alloc(n_limbs), ctx.alloc(n_limbs)) for _ in range(sets)]
+    for i, (a, _) in enumerate(bufs):
+        ctx.fill_uniform(a, ids, 1 + i)
+    for a, b in bufs:
         ctx.ntt(a, b, ids)
     ctx.sync()
     ctx.timer_start()
-    for _ in range(iters):
+    for i in range(iters):
+        a, b = bufs[i % sets]
         ctx.ntt(a, b, ids)
     ns = ctx.timer_stop() / iters
-    a.free(); b.free(); ctx.close()
+    for a, b in bufs:
+        a.free(); b.free()
+    ctx.close()
     return ns
 
 
-def cpu_baseline(opn="hmult", sample_ops=3):
+def cpu_baseline(opn="hmult", runs=5):
+    """the CPU functional path (the oracle: the reference has no arithmetic to time) on the identical
+    inputs, single thread and all host cores, median of `runs` after one warm-up each."""
     from oracle.homoracle import Oracle
     from homulator_amd import host
     cores = min(16, os.cpu_count() or 1)
     o = Oracle(LOGN, L, ALPHA)
-    o.set_threads(cores)
     ct1, ct2, evk = o.synth_ct(ELL, host.SEED), o.synth_ct(ELL, host.SEED + 2000), o.synth_evk(ELL, host.SEED + 10000)
     run = (lambda: o.hmult(ELL, ct1, ct2, evk)) if opn == "hmult" else (lambda: o.hrotate(ELL, ct1, 5, evk))
-    run()  # warm
-    t0 = time.time()
-    for _ in range(sample_ops):
-        run()
-    dt = (time.time() - t0) / sample_ops
-    return {"value": 1.0 / dt, "unit": "ops/s", "cores": cores, "kind": "port",
-            "sample": f"{sample_ops} full {opn} ops (N=2^16, l=35, alpha=15) on the CPU oracle, OpenMP over limbs"}
+
+    def median_s(threads):
+        o.set_threads(threads)
+        run()  # warm
+        ts = []
+        for _ in range(runs):
+            t0 = time.perf_counter()
+            run()
+            ts.append(time.perf_counter() - t0)
+        return sorted(ts)[len(ts) // 2]
+    multi, single = median_s(cores), median_s(1)
+    return {"value": 1.0 / multi, "unit": "ops/s", "cores": cores, "kind": "port",
+            "single_thread_value": 1.0 / single,
+            "sample": f"median of {runs} full {opn} ops (N=2^16, l=35, alpha=15) on the CPU oracle after one warm-up: "
+                      f"{cores} threads (OpenMP over limbs) = `value`, 1 thread = `single_thread_value`"}
+
+
+def pick_batch(steps, streams, default):
+    """ops per launch: the largest of 10, 8, 6, 5, 4 that deals the K timed steps evenly over the in-flight instances
+    (K = 20 with 2 x 4 would leave one instance a batch short: 3 + 2 enqueues, the timed region then ends on the longer
+    queue); the default when none does (the remainder then runs through the one-op instance)."""
+    for b in (10, 8, 6, 5, 4):
+        if steps % (b * streams) == 0:
+            return b
+    return default
 
 
 def main():
@@ -75,9 +109,10 @@ def main():
     ap.add_argument("--streams", type=int, default=2,
                     help="independent hmult instances in flight on one GPU (own inputs, HBM pool and HIP stream each); "
                          "the K timed steps are dealt round-robin over them.  1 = one op at a time (latency mode)")
-    ap.add_argument("--batch", type=int, default=4,
+    ap.add_argument("--batch", type=int, default=0,
                     help="independent hmults carried by every launch of an instance (config key `batch`: own inputs, one "
-                         "evaluation key); a step is still ONE hmult, an enqueue advances `batch` steps")
+                         "evaluation key); a step is still ONE hmult, an enqueue advances `batch` steps.  0 = pick one "
+                         "that deals --steps evenly over the instances (pick_batch)")
     ap.add_argument("--op", default=OP, choices=["hmult", "hrotate"],
                     help="hmult = BASELINE.json's metric (default); hrotate = BASELINE configs[3], for information")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -113,9 +148,9 @@ def main():
     # sharded: the ops of a batch share the exchanges around each base conversion; a batch that divides --steps, so that
     # exactly --steps hmults are timed without a second (communicating) instance for the remainder
     if world == 1:
-        batch = args.batch
+        batch = args.batch if args.batch > 0 else pick_batch(args.steps, streams, 4)
     else:   # per-rank launches shrink with the rank count: a proportionally larger batch keeps them (and the exchanges) big
-        target = max(1, min(16, args.batch * world // 2))
+        target = max(1, min(16, (args.batch or 4) * world // 2))
         batch = max(d for d in range(1, target + 1) if args.steps % d == 0)
     opn = args.op
     alg_bytes = HMULT_ALG_BYTES if opn == "hmult" else HROTATE_ALG_BYTES
@@ -130,15 +165,12 @@ def main():
         from homulator_amd import dist as hdist
         transport = "gloo-rehearsal" if rehearsal else os.environ.get("HOMULATOR_TRANSPORT", "rccl")
         if transport == "rccl":
-            try:   # the HIP library's own RCCL communicator: ncclSend/ncclRecv groups on its stream (the product path)
-                hdist.init_rccl(op)
-            except Exception as e:   # reported, never silent: the JSON line names the transport actually used
-                print(f"[bench] rank {rank}: private RCCL communicator failed ({e}); using torch.distributed NCCL staging", file=sys.stderr)
+            # the HIP library's own RCCL communicator: ncclSend/ncclRecv groups on its stream (the product path).
+            # init_rccl agrees on go / no-go BEFORE the collective ncclCommInitRank (every rank enters it or none does)
+            # and again after it; a failure after the GPU call is fatal (no in-process retry).
+            if not hdist.init_rccl(op, device=red_dev):
+                print(f"[bench] rank {rank}: no RCCL unique id could be drawn; using torch.distributed NCCL staging", file=sys.stderr)
                 transport = "torch-nccl-staging"
-        ok = torch.tensor([1 if transport == "rccl" else 0], device=red_dev)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)   # all ranks must agree on the transport
-        if int(ok.item()) == 0 and transport == "rccl":
-            transport = "torch-nccl-staging"
         if transport != "rccl":
             tr = hdist.GlooTransport() if rehearsal else hdist.TorchNcclTransport()
             op.comm_init_external(tr.cfunc)
@@ -158,6 +190,12 @@ def main():
         if tail_op is not None:
             tail_op.sync()
 
+    # untimed: the chip ramps its clocks over the first ~100 ms of load; a 20-step timed region is 5 ms.  Run the same
+    # steps for at least 0.3 s first, then the W warm-up steps the contract asks for.
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < 0.3:
+        run(streams * batch)
+        sync_all()
     run(max(args.warmup, streams * batch))
     if tail_op is not None:
         tail_op.enqueue(1)
@@ -197,6 +235,12 @@ def main():
         sweep_limbs = ELL + ALPHA
         ntt_ns = measure_ntt_sweep(sweep_limbs)
         achieved = NTT_ALG_BYTES * sweep_limbs / ntt_ns  # B/ns = GB/s
+        rin = roofline_inputs()
+        # second ceiling (SURVEY.md §8d "measure and print both"): VALU issue.  One limb-NTT = N/2 * logN butterflies; a
+        # wave executes 64 at a time; `wave_butterfly_ns` is the measured full-chip time per wave-butterfly
+        wb_ns = rin.get("wave_butterfly_ns")
+        valu_floor_ns = wb_ns * BFLY_PER_LIMB_NTT / 64 * sweep_limbs if wb_ns else None
+        hbm_floor_ns = NTT_ALG_BYTES * sweep_limbs / HBM_PEAK_GBS
         out = {
             "metric": "hmult+key-switch ops/sec" if opn == "hmult" else "hrotate+key-switch ops/sec", "value": value, "unit": "ops/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
@@ -204,16 +248,26 @@ def main():
             "config": {"workload": f"{CFG} {opn} L={L} l={ELL} alpha={ALPHA} (N=2^16, beta=3, " + ("full hybrid key switch + rescale)" if opn == "hmult" else "automorphism + full hybrid key switch)"),
                        "parallelism": "single GPU" if world == 1 else f"limbs sharded over {world} GPUs (limb e -> e % {world}); RCCL all-to-all around ModUp/ModDown base conversion + replicate of the rescale residue; {batch} hmults per launch share the exchanges",
                        "launches_per_op": op.launch_count(), "streams": streams, "batch": batch, "transport": transport,
+                       "evk_note": "the ops of a batch share ONE evaluation key: the 157 MB key stream that the algorithmic figure charges per op is read from HBM once per batch, the other readers hit cache",
                        "streams_note": "`streams` instances in flight (own HBM pool / HIP stream each), each carrying `batch` independent hmults per launch (own inputs, one evaluation key); a step is one hmult"},
             "single_stream_ops_per_s": single,
             "stage_us": [[kind, name, round(ns * 1e-3, 2)] for kind, name, ns in stage_rows],
             "exchange_us_per_op": round(sum(ns for kind, _, ns in stage_rows if kind in ("EXCH_IN", "EXCH_OUT", "REPLICATE")) * 1e-3 / (batch if world > 1 else 1), 2),
             "hmult_hbm_gbs_algorithmic": alg_bytes / (ms * 1e-3) / 1e9,
             "hmult_frac_of_hbm_peak": alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "roofline": {"bound": "hbm", "kernel": "forward NTT sweep, 50 limbs = k_ntt_pass<COL> + k_ntt_pass<ROW>",
+            "roofline": {"bound": "valu" if valu_floor_ns and valu_floor_ns > hbm_floor_ns else "hbm",
+                         "kernel": "forward NTT sweep, 50 limbs = k_ntt_pass<COL> + k_ntt_pass<ROW>",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": NTT_SWEEP50_TRAFFIC_BYTES if sweep_limbs == 50 else None, "us_per_launch": ntt_ns * 1e-3,
-                         "algorithmic_bytes_per_launch": NTT_ALG_BYTES * sweep_limbs},
+                         "traffic": rin.get("ntt_sweep50_traffic_bytes") if sweep_limbs == 50 else None, "us_per_launch": ntt_ns * 1e-3,
+                         "algorithmic_bytes_per_launch": NTT_ALG_BYTES * sweep_limbs,
+                         "working_set": "6 rotating buffer pairs, 315 MB: past the 256 MiB Infinity Cache",
+                         "hbm": {"floor_us": hbm_floor_ns * 1e-3, "frac": hbm_floor_ns / ntt_ns},
+                         "valu": None if valu_floor_ns is None else {
+                             "floor_us": valu_floor_ns * 1e-3, "frac": valu_floor_ns / ntt_ns, "unit": "wave-butterflies/ns",
+                             "achieved": BFLY_PER_LIMB_NTT / 64 * sweep_limbs / ntt_ns, "peak": 1.0 / wb_ns,
+                             "source": rin.get("wave_butterfly_source")},
+                         "note": "`achieved`/`peak`/`frac` are the HBM figures of the task's contract; `bound` names the ceiling "
+                                 "with the larger floor for this launch (the 64-bit modular butterflies are integer VALU work)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(opn)

@@ -171,11 +171,13 @@ __global__ void __launch_bounds__(256) k_inner_product(HmIpArgs a) {
 // at 32 inputs) and hipcc left the per-case input arrays in scratch; every problem of a launch has the same n_in.
 template <int N_IN>
 __global__ void __launch_bounds__(HM_BCONV_THREADS) k_bconv(HmBconvArgs a) {
-  const HmBconvProb &p = a.prob[blockIdx.z];
-  const uint32_t t0 = blockIdx.y * HM_BCONV_CHUNK;
+  const auto &p = HM_CONST_PROB(a.prob)[blockIdx.z];
+  const uint32_t t0 = blockIdx.y * a.chunk;
   if (t0 >= p.n_out) return;
-  const uint32_t t1 = min(t0 + HM_BCONV_CHUNK, p.n_out);
-  hm_bconv_thread<N_IN>(p, a.mods, a.logN, blockIdx.x * HM_BCONV_THREADS + threadIdx.x, t0, t1);
+  const uint32_t t1 = min(t0 + a.chunk, p.n_out);
+  const uint32_t x = (blockIdx.x * HM_BCONV_THREADS + threadIdx.x) * HM_BCONV_CPT;
+  if (x >= (1u << a.logN)) return;
+  hm_bconv_thread<N_IN, HM_BCONV_CPT>(p, a.logN, x, t0, t1);
 }
 typedef void (*hm_bconv_kernel)(HmBconvArgs);
 static const hm_bconv_kernel k_bconv_by_n_in[HM_BCONV_MAX_IN + 1] = {
@@ -247,7 +249,8 @@ struct hm_ctx {
   HmTw *d_twist_fwd = nullptr, *d_twist_inv = nullptr;  // [L+K][N/256][3], hm::Params::make_twist
   HmMod *d_mods = nullptr;
   std::map<std::vector<uint32_t>, uint64_t *> bconv_tables;  // key: n_in, in_ids..., out_ids...
-  std::map<std::string, HmNttEntry *> ntt_tables;            // key: the bytes of a launch's entry table
+  std::map<std::string, void *> ntt_tables;                  // launch tables (device_table), key: their bytes
+  bool tables_pinned = false;                                 // a captured graph references the tables: no eviction
   std::string err;
   // multi-GPU
   int rank = 0, world = 1;
@@ -439,6 +442,7 @@ extern "C" hm_status hm_capture_begin(hm_ctx *c) {
   if (!c) return HM_ERR_ARG;
   if (c->ext_fn) return fail(c, HM_ERR_UNSUPPORTED, "hm_capture_begin: an external exchange transport cannot be captured");
   HM_HIP(c, hipSetDevice(c->device));
+  c->tables_pinned = true;  // kernel nodes of the graph keep the device addresses of the launch tables
   HM_HIP(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
   return HM_OK;
 }
@@ -515,23 +519,34 @@ static void launch_ntt(hm_ctx *c, const HmNttArgs &a, bool fusedEpilogue, bool m
   }
 }
 
-// device copy of a launch's entry table, cached by content; uploaded (synchronously) on first use
-static hm_status ntt_table(hm_ctx *c, const std::vector<HmNttEntry> &tab, const HmNttEntry **out) {
-  const std::string key(reinterpret_cast<const char *>(tab.data()), sizeof(HmNttEntry) * tab.size());
+// Device copy of a launch's table (NTT entry constants, base-conversion problem records), cached by content; uploaded
+// (synchronously) on first use.  Tables are never freed while a graph captured from this context may still replay them
+// (hm_capture_begin pins the cache); a miss while the stream is capturing is an error, not a hidden synchronisation.
+static hm_status device_table(hm_ctx *c, const void *data, size_t bytes, const void **out) {
+  const std::string key(static_cast<const char *>(data), bytes);
   auto it = c->ntt_tables.find(key);
   if (it == c->ntt_tables.end()) {
-    if (c->ntt_tables.size() >= 512) {  // callers that never repeat a launch (tests): start over rather than grow without bound
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(c->stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+      return fail(c, HM_ERR_UNSUPPORTED, "a launch table is missing while the stream is capturing: run the plan once before hm_capture_begin");
+    if (c->ntt_tables.size() >= 1024 && !c->tables_pinned) {  // callers that never repeat a launch (tests): start over rather than grow without bound
       HM_HIP(c, hipStreamSynchronize(c->stream));
       for (auto &kv : c->ntt_tables) (void)hipFree(kv.second);
       c->ntt_tables.clear();
     }
-    HmNttEntry *dev = nullptr;
-    HM_HIP(c, hipMalloc(&dev, key.size()));
-    HM_HIP(c, hipMemcpy(dev, tab.data(), key.size(), hipMemcpyHostToDevice));
+    void *dev = nullptr;
+    HM_HIP(c, hipMalloc(&dev, bytes));
+    HM_HIP(c, hipMemcpy(dev, data, bytes, hipMemcpyHostToDevice));
     it = c->ntt_tables.emplace(key, dev).first;
   }
   *out = it->second;
   return HM_OK;
+}
+static hm_status ntt_table(hm_ctx *c, const std::vector<HmNttEntry> &tab, const HmNttEntry **out) {
+  const void *p = nullptr;
+  hm_status st = device_table(c, tab.data(), sizeof(HmNttEntry) * tab.size(), &p);
+  *out = static_cast<const HmNttEntry *>(p);
+  return st;
 }
 
 // operands of the fused forward transform: x = NTT(in [+ mix_k * mix]); out = (minuend - x) * k [+ addend [* addend_k]]
@@ -864,41 +879,58 @@ extern "C" hm_status hm_bconv_batch(hm_ctx *c, const hm_bconv_desc *descs, uint3
           for (uint32_t t = 0; t < d.n_out; ++t) tt[(size_t)t * row + i] = hm_bconv_entry(tb[(size_t)i * d.n_out + t], c->P.modc[d.out_ids[t]]);
         tb.swap(tt);
       }
+      for (uint32_t t = 0; t < d.n_out; ++t) {  // behind the rows: {q, -q^-1} per output (HmQn)
+        tb.push_back(c->P.modc[d.out_ids[t]].q);
+        tb.push_back(c->P.modc[d.out_ids[t]].nqinv);
+      }
       uint64_t *dev = nullptr;
-      HM_HIP(c, hipMalloc(&dev, 8ull * row * d.n_out));
-      HM_HIP(c, hipMemcpy(dev, tb.data(), 8ull * row * d.n_out, hipMemcpyHostToDevice));
+      HM_HIP(c, hipMalloc(&dev, 8ull * tb.size()));
+      HM_HIP(c, hipMemcpy(dev, tb.data(), 8ull * tb.size(), hipMemcpyHostToDevice));
       it = c->bconv_tables.emplace(key, dev).first;
     }
     HmBconvProb &p = probs[pi];
     p.in = d.in; p.out = d.out; p.table = it->second; p.n_in = d.n_in; p.n_out = d.n_out;
+    p.qn = it->second + (size_t)HM_BCONV_ROW(d.n_in) * d.n_out;
     for (uint32_t i = 0; i < d.n_in; ++i) p.in_limb[i] = limb_at(d.in_limbs, i);
     for (uint32_t t = 0; t < d.n_out; ++t) {
       p.out_limb[t] = limb_at(d.out_limbs, t);
-      p.out_mod[t] = d.out_ids[t];
     }
   }
-  // one launch per distinct input-basis size (the digits of a ModUp differ only in the last, shorter digit),
-  // up to HM_BCONV_MAX_PROB problems each
+  // one launch per distinct input-basis size (the digits of a ModUp differ only in the last, shorter digit), up to
+  // HM_BCONV_MAX_PROB problems each; the problem records go into a device table cached by content (plans repeat)
   std::vector<char> done(n_desc, 0);
   for (uint32_t first = 0; first < n_desc; ++first) {
     if (done[first]) continue;
     const uint32_t n_in = probs[first].n_in;
-    HmBconvArgs a;
-    a.mods = c->d_mods; a.logN = logN; a.n_prob = 0;
+    std::vector<HmBconvProb> grp;
     uint32_t max_out = 0;
-    auto launch = [&]() {
-      dim3 grid((1u << logN) / HM_BCONV_THREADS, (max_out + HM_BCONV_CHUNK - 1) / HM_BCONV_CHUNK, a.n_prob);
+    auto launch = [&]() -> hm_status {
+      const void *dtab = nullptr;
+      hm_status st = device_table(c, grp.data(), sizeof(HmBconvProb) * grp.size(), &dtab);
+      if (st) return st;
+      HmBconvArgs a;
+      a.prob = static_cast<const HmBconvProb *>(dtab); a.logN = logN; a.n_prob = (uint32_t)grp.size();
+      // output limbs per block: a block re-reads its N_IN input limbs for every chunk, so the chunk should be as large
+      // as the launch allows while leaving >= ~4 rounds of blocks for the chip (3 blocks of 256 threads per CU)
+      const uint32_t xb = std::max(1u, (1u << logN) / (HM_BCONV_THREADS * HM_BCONV_CPT));
+      const uint32_t want = 3072;
+      uint32_t nchunk = std::max<uint32_t>(1, (want + xb * a.n_prob - 1) / (xb * a.n_prob));
+      nchunk = std::min(nchunk, (max_out + HM_BCONV_CHUNK / 2 - 1) / std::max(1, HM_BCONV_CHUNK / 2));  // chunks of >= 4 outputs
+      nchunk = std::max<uint32_t>(1, nchunk);
+      a.chunk = (max_out + nchunk - 1) / nchunk;
+      dim3 grid(xb, (max_out + a.chunk - 1) / a.chunk, a.n_prob);
       hipLaunchKernelGGL(k_bconv_by_n_in[n_in], grid, dim3(HM_BCONV_THREADS), 0, c->stream, a);
-      a.n_prob = 0; max_out = 0;
+      grp.clear(); max_out = 0;
+      return HM_OK;
     };
     for (uint32_t pi = first; pi < n_desc; ++pi) {
       if (done[pi] || probs[pi].n_in != n_in) continue;
       done[pi] = 1;
-      a.prob[a.n_prob++] = probs[pi];
+      grp.push_back(probs[pi]);
       max_out = std::max(max_out, probs[pi].n_out);
-      if (a.n_prob == HM_BCONV_MAX_PROB) launch();
+      if (grp.size() == HM_BCONV_MAX_PROB) { hm_status st = launch(); if (st) return st; }
     }
-    if (a.n_prob) launch();
+    if (!grp.empty()) { hm_status st = launch(); if (st) return st; }
     HM_HIP(c, hipGetLastError());
   }
   return HM_OK;

@@ -99,29 +99,42 @@ struct HmIpArgs {
 
 // ---- K4 base conversion: out[t][x] = sum_i in[i][x] * table[i][t] mod q_t (device table: hm_bconv_entry form)
 // One launch carries up to HM_BCONV_MAX_PROB independent conversions (the beta digits of a ModUp, the two
-// keys of a ModDown): grid = (N / HM_BCONV_THREADS, output chunks, problems); one coefficient per thread.
+// keys of a ModDown): grid = (N / (HM_BCONV_THREADS * HM_BCONV_CPT), output chunks, problems); two adjacent
+// coefficients per thread (16-byte accesses; every scalar operand feeds two multiply-adds).
 #define HM_BCONV_MAX_IN 32   // parameter set A converts from a 28-limb basis (alpha = 28)
 #define HM_BCONV_MAX_OUT 64
-#define HM_BCONV_MAX_PROB 4
-#define HM_BCONV_CHUNK 8    // output limbs per block (4, 12, 16 and 128-thread blocks measured: same time)
+#define HM_BCONV_MAX_PROB 256  // problems per launch (blockIdx.z); the records live in a device table cached by content
+#ifndef HM_BCONV_CHUNK
+#define HM_BCONV_CHUNK 8    // output limbs per block when the launch is small (hm_bconv_batch raises it for big ones)
+#endif
 #define HM_BCONV_THREADS 256
+#ifndef HM_BCONV_CPT
+#define HM_BCONV_CPT 2       // coefficients per thread
+#endif
 struct HmBconvProb {
   const uint64_t *in;
   uint64_t *out;
   const uint64_t *table;  // device, [n_out][HM_BCONV_ROW(n_in)], entries in hm_bconv_entry form, rows zero-padded
+  const uint64_t *qn;     // device, [n_out] x {q, -q^-1 mod 2^64} of the output moduli (HmQn)
   uint32_t n_in, n_out;
   // 32-bit entries: indexed by the (wave-uniform) output counter, they must be scalar loads from the kernarg
   // segment; 16-bit entries made hipcc emit a VECTOR load per output, and the modulus record load that depends on it
   // was a second serialised global-memory round trip per output (the kernel was latency-bound on these two loads)
   uint32_t in_limb[HM_BCONV_MAX_IN];
   uint32_t out_limb[HM_BCONV_MAX_OUT];
-  uint32_t out_mod[HM_BCONV_MAX_OUT];
 };
 struct HmBconvArgs {
-  const HmMod *mods;
+  const HmBconvProb *prob;  // device, [n_prob]: read with scalar loads (wave-uniform index)
   uint32_t logN, n_prob;
-  HmBconvProb prob[HM_BCONV_MAX_PROB];
+  uint32_t chunk;           // output limbs per block (the host trades input re-reads against blocks in flight)
 };
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const HmBconvProb __attribute__((address_space(4))) *HmConstProb;
+#define HM_CONST_PROB(p) ((HmConstProb)(uintptr_t)(p))
+#else
+typedef const HmBconvProb *HmConstProb;
+#define HM_CONST_PROB(p) (p)
+#endif
 
 // Split-30 MAC: operands are below 2^60, so y = y1 2^30 + y0 and w = w1 2^30 + w0 with 30-bit halves; each
 // of the four partial-product columns y_a w_b stays below 2^64 over 16 terms, so a MAC is four
@@ -185,27 +198,53 @@ HM_HD uint64_t hm_bconv_dot(const uint32_t (&yl)[N_IN], const uint32_t (&yh)[N_I
   return hm_redc_wide(acc, m);
 }
 
-// coefficient x for outputs [t0, t1)
-template <int N_IN>
-HM_HD void hm_bconv_thread(const HmBconvProb &p, const HmMod *mods, uint32_t logN, uint32_t x, uint32_t t0, uint32_t t1) {
+// per-output modulus constants, stored behind the table rows (HmBconvProb::qn): no load depends on another load
+struct HmQn {
+  uint64_t q, nqinv;
+};
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const HmQn __attribute__((address_space(4))) *HmConstQn;
+#define HM_CONST_QN(p) ((HmConstQn)(uintptr_t)(p))
+#else
+typedef const HmQn *HmConstQn;
+#define HM_CONST_QN(p) ((const HmQn *)(p))
+#endif
+
+// CPT coefficients x, x+1, .. (CPT = 2: one 16-byte access per input / output limb) for outputs [t0, t1).  The inputs
+// stay in registers for all outputs of the chunk; a row feeds 4 * N_IN * CPT multiply-adds as scalar operands.
+// (Requesting the NEXT output's row ahead of the products changed nothing: hipcc sinks the loads to the end of the
+// iteration, and the kernel is bound by VALU issue — per output and coefficient 4 * N_IN multiply-adds plus ~50
+// instructions of column recombination and Montgomery reduction — not by the scalar-cache latency.)
+template <int N_IN, int CPT, class PROB>
+HM_HD void hm_bconv_thread(const PROB &p, uint32_t logN, uint32_t x, uint32_t t0, uint32_t t1) {
   const size_t N = (size_t)1 << logN;
   constexpr int NG = (N_IN + 7) / 8;  // 8-entry groups per row
   HmConstRow8 tab = HM_CONST_ROWS(p.table);
-  HmConstMod cmods = HM_CONST_MODS(mods);
-  uint32_t yl[N_IN], yh[N_IN];
+  HmConstQn qn = HM_CONST_QN(p.qn);
+  uint32_t yl[CPT][N_IN], yh[CPT][N_IN];
 #pragma unroll
   for (int i = 0; i < N_IN; ++i) {
-    const uint64_t v = p.in[(size_t)p.in_limb[i] * N + x];
-    yl[i] = (uint32_t)v & 0x3FFFFFFFu;
-    yh[i] = (uint32_t)(v >> 30);
-  }
-  {  // (double-buffering the row in SGPRs gained 3 %: scalar loads return out of order, so the dependent modulus load drains the prefetch)
-    for (uint32_t t = t0; t < t1; ++t) {
-      HmRow8 row[NG];
+    uint64_t v[2] = {0, 0};
+    // uniform limb base + one lane offset: all N_IN loads issue back to back (with a 64-bit address per load hipcc
+    // recycled the registers of loaded data for the next addresses and serialised the loads pairwise)
+    if (CPT == 2) hm_bld2(p.in + (size_t)p.in_limb[i] * N, x << 3, v[0], v[1]);
+    else v[0] = p.in[(size_t)p.in_limb[i] * N + x];
 #pragma unroll
-      for (int g = 0; g < NG; ++g) row[g] = tab[t * NG + g];
-      p.out[(size_t)p.out_limb[t] * N + x] = hm_bconv_dot<N_IN>(yl, yh, row, cmods[p.out_mod[t]].q, cmods[p.out_mod[t]].nqinv);
+    for (int c = 0; c < CPT; ++c) {
+      yl[c][i] = (uint32_t)v[c] & 0x3FFFFFFFu;
+      yh[c][i] = (uint32_t)(v[c] >> 30);
     }
+  }
+  for (uint32_t t = t0; t < t1; ++t) {
+    HmRow8 row[NG];
+    const HmQn m = qn[t];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) row[g] = tab[t * NG + g];
+    uint64_t r[2] = {0, 0};
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) r[c] = hm_bconv_dot<N_IN>(yl[c], yh[c], row, m.q, m.nqinv);
+    if (CPT == 2) hm_bst2(p.out + (size_t)p.out_limb[t] * N, x << 3, r[0], r[1]);
+    else p.out[(size_t)p.out_limb[t] * N + x] = r[0];
   }
 }
 

@@ -129,6 +129,25 @@ HM_HD __amdgpu_buffer_rsrc_t hm_rsrc(const uint64_t *base) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint64_t *>(base), 0, -1, 0x00020000);
 }
 #endif
+// 16 bytes at uniform base + 32-bit lane byte offset (buffer form on the device: one address VGPR for all limbs)
+HM_HD void hm_bld2(const uint64_t *base, uint32_t lane_bytes, uint64_t &v0, uint64_t &v1) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const hm_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(hm_rsrc(base), lane_bytes, 0, 0);
+  v0 = (uint64_t)t.x | ((uint64_t)t.y << 32);
+  v1 = (uint64_t)t.z | ((uint64_t)t.w << 32);
+#else
+  hm_ld2(base + (lane_bytes >> 3), v0, v1);
+#endif
+}
+HM_HD void hm_bst2(uint64_t *base, uint32_t lane_bytes, uint64_t v0, uint64_t v1) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  hm_u32x4 t;
+  t.x = (unsigned)v0; t.y = (unsigned)(v0 >> 32); t.z = (unsigned)v1; t.w = (unsigned)(v1 >> 32);
+  __builtin_amdgcn_raw_buffer_store_b128(t, hm_rsrc(base), lane_bytes, 0, 0);  // soffset stays 0: see hm_gst2
+#else
+  hm_st2(base + (lane_bytes >> 3), v0, v1);
+#endif
+}
 template <class G>
 HM_HD void hm_gld2(const uint64_t *g, uint32_t tile, int tid, int a, uint64_t &v0, uint64_t &v1) {
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -16,11 +16,33 @@ EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t)
                           C.POINTER(C.c_size_t), C.POINTER(C.c_size_t))
 
 
-def init_rccl(op, group=None):
-    """collective over `group`: distribute rank 0's RCCL unique id and create the communicator inside the HIP library"""
-    obj = [host.rccl_unique_id() if dist.get_rank(group) == 0 else None]
+def init_rccl(op, group=None, device="cuda"):
+    """collective over `group`: distribute rank 0's RCCL unique id and create the communicator inside the HIP library.
+
+    Every step that can fail on one rank only is followed by an agreement, so that no rank is ever left inside a
+    collective the others skipped: (1) rank 0 draws the id inside try/except and broadcasts the id OR a failure marker
+    — all ranks return False together (the caller falls back) before any RCCL call; (2) ncclCommInitRank is entered by
+    every rank; its outcome is MIN-reduced, and a failure on any rank after that GPU call raises on ALL ranks (fatal:
+    no in-process retry)."""
+    obj = [None]
+    if dist.get_rank(group) == 0:
+        try:
+            obj[0] = host.rccl_unique_id()
+        except Exception as e:  # noqa: BLE001 - reported through the marker
+            obj[0] = "ERR:" + repr(e)
     dist.broadcast_object_list(obj, src=0, group=group)
-    op.comm_init_rccl(obj[0])
+    if not isinstance(obj[0], (bytes, bytearray)):
+        return False
+    err = None
+    try:
+        op.comm_init_rccl(obj[0])
+    except Exception as e:  # noqa: BLE001
+        err = e
+    ok = torch.tensor([0 if err else 1], device=device)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+    if int(ok.item()) == 0:
+        raise RuntimeError(f"RCCL communicator creation failed on at least one rank (this rank: {err!r})")
+    return True
 
 
 def _hip_runtime():
@@ -112,6 +134,10 @@ class GlooTransport:
                     torch.cuda.synchronize()
             for r, off, nb in recvs:
                 self.h2d(recv_dev + off, r.data_ptr(), nb)
+            if self.staging_device != "cpu":
+                # device-to-device staging copies run on the null stream, the backend's stream is non-blocking: make sure
+                # they have landed before the unpack kernels read the buffer
+                torch.cuda.synchronize()
             self.calls += 1
             return 0
         except Exception as e:  # never let an exception cross the C boundary

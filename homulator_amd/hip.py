@@ -26,6 +26,12 @@ class hm_ntt_fused_desc(C.Structure):
                 ("k", C.c_void_p)]
 
 
+class hm_bconv_desc(C.Structure):
+    _fields_ = [("in_", C.c_void_p), ("in_limbs", C.c_void_p), ("in_ids", C.c_void_p), ("n_in", C.c_uint32),
+                ("out", C.c_void_p), ("out_limbs", C.c_void_p), ("out_ids", C.c_void_p), ("n_out", C.c_uint32),
+                ("log_len", C.c_uint32)]
+
+
 class hm_params(C.Structure):
     _fields_ = [("logN", C.c_uint32), ("L", C.c_uint32), ("K", C.c_uint32), ("device", C.c_int32),
                 ("q", C.c_void_p), ("p", C.c_void_p), ("psi", C.c_void_p)]
@@ -68,6 +74,7 @@ def load():
     L.hm_automorph.argtypes = [vp, vp, vp, vp, vp, u32, u32]
     L.hm_ewe.argtypes = [vp, i32] + [vp] * 11 + [u32, vp]
     L.hm_bconv.argtypes = [vp, vp, vp, vp, u32, vp, vp, vp, u32]
+    L.hm_bconv_batch.argtypes = [vp, C.POINTER(hm_bconv_desc), u32]
     L.hm_bconv_consts.argtypes = [vp, vp, u32, vp, u32, vp, vp]
     L.hm_fill_uniform.argtypes = [vp, vp, vp, vp, u32, u64]
     L.hm_timer_start.argtypes = [vp]
@@ -224,6 +231,16 @@ class Context:
         k3, pol = _u32(out_limbs)
         k4, poi = _u32(out_ids)
         self._ck(self.L.hm_bconv(self.h, src.ptr, pil, pii, len(in_ids), dst.ptr, pol, poi, len(out_ids)))
+
+    def bconv_batch(self, probs, log_len=0):
+        """several conversions in one launch: probs = [(src, in_limbs, in_ids, dst, out_limbs, out_ids), ...]"""
+        keep, descs = [], (hm_bconv_desc * len(probs))()
+        for d, (src, in_limbs, in_ids, dst, out_limbs, out_ids) in zip(descs, probs):
+            arrs = [_u32(in_limbs), _u32(in_ids), _u32(out_limbs), _u32(out_ids)]
+            keep.append(arrs)
+            d.in_, d.in_limbs, d.in_ids, d.n_in = src.ptr, arrs[0][1], arrs[1][1], len(in_ids)
+            d.out, d.out_limbs, d.out_ids, d.n_out, d.log_len = dst.ptr, arrs[2][1], arrs[3][1], len(out_ids), log_len
+        self._ck(self.L.hm_bconv_batch(self.h, descs, len(probs)))
 
     def bconv_consts(self, in_ids, out_ids):
         k1, pii = _u32(in_ids)

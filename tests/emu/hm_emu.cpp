@@ -50,15 +50,18 @@ static void run_ntt(const Emu &e, uint32_t mod, const uint64_t *in, uint64_t *ou
 }
 
 template <int N_IN>
-static void emu_bconv_n(Emu &e, HmBconvProb &p, const std::vector<uint64_t> &tb) {
+static void emu_bconv_n(Emu &e, HmBconvProb &p, const std::vector<uint64_t> &tb, const uint32_t *out_ids) {
   const uint32_t row = HM_BCONV_ROW(p.n_in);
   std::vector<uint64_t> tt((size_t)row * p.n_out, 0);  // device format: [n_out][row], Montgomery form, packed, zero-padded rows
+  std::vector<uint64_t> qn;                            // {q, -q^-1} per output
   for (uint32_t i = 0; i < p.n_in; ++i)
-    for (uint32_t t = 0; t < p.n_out; ++t) tt[(size_t)t * row + i] = hm_bconv_entry(tb[(size_t)i * p.n_out + t], e.P.modc[p.out_mod[t]]);
+    for (uint32_t t = 0; t < p.n_out; ++t) tt[(size_t)t * row + i] = hm_bconv_entry(tb[(size_t)i * p.n_out + t], e.P.modc[out_ids[t]]);
+  for (uint32_t t = 0; t < p.n_out; ++t) { qn.push_back(e.P.modc[out_ids[t]].q); qn.push_back(e.P.modc[out_ids[t]].nqinv); }
   p.table = tt.data();
+  p.qn = qn.data();
   for (uint32_t t0 = 0; t0 < p.n_out; t0 += HM_BCONV_CHUNK) {
     uint32_t t1 = t0 + HM_BCONV_CHUNK < p.n_out ? t0 + HM_BCONV_CHUNK : p.n_out;
-    for (uint32_t x = 0; x < e.P.N; ++x) hm_bconv_thread<N_IN>(p, e.P.modc.data(), e.P.logN, x, t0, t1);
+    for (uint32_t x = 0; x < e.P.N; x += HM_BCONV_CPT) hm_bconv_thread<N_IN, HM_BCONV_CPT>(p, e.P.logN, x, t0, t1);
   }
 }
 
@@ -152,9 +155,9 @@ void emu_bconv(void *h, const uint32_t *in_ids, uint32_t n_in, const uint32_t *o
   HmBconvProb p;
   p.in = in; p.out = out; p.table = tb.data(); p.n_in = n_in; p.n_out = n_out;
   for (uint32_t i = 0; i < n_in; ++i) p.in_limb[i] = i;
-  for (uint32_t t = 0; t < n_out; ++t) { p.out_limb[t] = t; p.out_mod[t] = out_ids[t]; }
+  for (uint32_t t = 0; t < n_out; ++t) p.out_limb[t] = t;
   switch (n_in) {
-#define HM_CASE(n) case n: emu_bconv_n<n>(e, p, tb); break;
+#define HM_CASE(n) case n: emu_bconv_n<n>(e, p, tb, out_ids); break;
     HM_CASE(1) HM_CASE(2) HM_CASE(3) HM_CASE(4) HM_CASE(5) HM_CASE(6) HM_CASE(7) HM_CASE(8)
     HM_CASE(9) HM_CASE(10) HM_CASE(11) HM_CASE(12) HM_CASE(13) HM_CASE(14) HM_CASE(15) HM_CASE(16)
     HM_CASE(17) HM_CASE(18) HM_CASE(19) HM_CASE(20) HM_CASE(21) HM_CASE(22) HM_CASE(23) HM_CASE(24)

@@ -3,7 +3,7 @@ usage: python tools/pmc_op_sum.py <dir> <counter> <ops>"""
 import collections, csv, glob, sys
 d, counter, ops = sys.argv[1], sys.argv[2], float(sys.argv[3])
 tot = collections.defaultdict(float)
-for f in glob.glob(d + "/*/*_counter_collection.csv"):
+for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name'].replace("void ", "")
         if r['Counter_Name'] != counter or k.startswith("k_fill") or k.startswith("__amd"):

@@ -1,7 +1,7 @@
 """Summarise rocprofv3 --pmc counter_collection CSVs: median counter value per kernel."""
 import collections, csv, glob, sys
 for d in sys.argv[1:]:
-    for f in glob.glob(d + "/*/*_counter_collection.csv"):
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         rows = list(csv.DictReader(open(f)))
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in rows:

@@ -7,7 +7,7 @@ import sys
 
 path = sys.argv[1]
 ops = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
-f = glob.glob(path + "/*/*_kernel_trace.csv")[0]
+f = (glob.glob(path + "/**/*kernel_trace.csv", recursive=True))[0]
 rows = list(csv.DictReader(open(f)))
 agg = collections.defaultdict(list)
 for r in rows:
