@@ -153,3 +153,91 @@ class TorchNcclTransport(GlooTransport):
     def __init__(self, group=None):
         self.staging_device = torch.device("cuda", torch.cuda.current_device())
         super().__init__(group, memcpy=_hip_memcpy_d2d())
+
+
+class InProcessGroup:
+    """G ranks as G threads of ONE process on one GPU (every rank its own HIP context / stream / HBM pool): the exchange is
+    a rendezvous of the threads plus device-to-device copies out of each peer's send buffer.  This is how the 8-rank split
+    of BASELINE configs[4] is executed on a one-GPU box (RCCL refuses two ranks per device, and a GPU box admits at most 6
+    processes on its card, so 8 gloo processes are not an option).  `transport(rank)` gives rank `rank`'s hm_exchange_fn."""
+
+    def __init__(self, world):
+        import threading
+        self.world = world
+        self.barrier = threading.Barrier(world)
+        self.posted = [None] * world
+        hip = _hip_runtime()
+        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        hip.hipMemcpy.restype = C.c_int
+        hip.hipDeviceSynchronize.restype = C.c_int
+        self.hip = hip
+        self.calls = [0] * world
+        self.bytes_recv = [0] * world
+        self.failed = False
+        self._fns = [self._make(r) for r in range(world)]
+
+    def transport(self, rank):
+        return self._fns[rank]
+
+    def _make(self, me):
+        def exchange(user, send_dev, send_off, send_bytes, recv_dev, recv_off, recv_bytes):
+            try:
+                W = self.world
+                self.posted[me] = (send_dev or 0, [send_off[p] for p in range(W)], [send_bytes[p] for p in range(W)])
+                self.barrier.wait(timeout=120)          # every rank's send buffer is complete (the caller synchronised its stream)
+                for p in range(W):
+                    nb = recv_bytes[p]
+                    if p == me or not nb:
+                        continue
+                    pdev, poff, pbytes = self.posted[p]
+                    if pbytes[me] != nb:                # both sides must agree on every pair's size
+                        raise RuntimeError(f"rank {me} expects {nb} bytes from rank {p}, which sends {pbytes[me]}")
+                    if self.hip.hipMemcpy(recv_dev + recv_off[p], pdev + poff[me], nb, 3):
+                        raise RuntimeError("hipMemcpy D2D failed")
+                    self.bytes_recv[me] += nb
+                for p in range(W):                       # and nobody may send what the peer does not expect
+                    if p != me and send_bytes[p] and not self.posted[me][2][p] == send_bytes[p]:
+                        raise RuntimeError("inconsistent post")
+                self.hip.hipDeviceSynchronize()
+                self.barrier.wait(timeout=120)          # all copies have landed: send buffers may be reused
+                self.calls[me] += 1
+                return 0
+            except Exception as e:  # noqa: BLE001 - never let an exception cross the C boundary
+                self.failed = True
+                try:
+                    self.barrier.abort()
+                except Exception:  # noqa: BLE001
+                    pass
+                print(f"InProcessGroup rank {me} failed:", repr(e), flush=True)
+                return 1
+        return EXCHANGE_FN(exchange)
+
+
+def run_in_process(world, make_op, body):
+    """run `body(rank, op)` on `world` threads; make_op(rank) builds rank's host.Op (world / rank overrides included).
+    Returns the list of results; raises the first exception of any rank."""
+    import threading
+    grp = InProcessGroup(world)
+    ops, res, err = [None] * world, [None] * world, [None] * world
+    for r in range(world):
+        ops[r] = make_op(r)
+        ops[r].comm_init_external(grp.transport(r))
+
+    def work(r):
+        try:
+            res[r] = body(r, ops[r])
+        except Exception as e:  # noqa: BLE001
+            err[r] = e
+            try:
+                grp.barrier.abort()
+            except Exception:  # noqa: BLE001
+                pass
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for e in err:
+        if e is not None:
+            raise e
+    return ops, res, grp

@@ -7,7 +7,7 @@ import os
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(ROOT, "host", "lib", "libhomulator_host.so")
+LIB_PATH = os.environ.get("HOMULATOR_HOST_LIB") or os.path.join(ROOT, "host", "lib", "libhomulator_host.so")  # override: A/B builds
 CONFIG_DIR = os.path.join(ROOT, "config")
 BACKEND_HIP, BACKEND_COUNT = 0, 1
 SEED = 0x484F4D55
@@ -50,6 +50,11 @@ def load():
         L.hh_chain_op.restype = vp
         L.hh_chain_op.argtypes = [vp, u32]
         L.hh_chain_execute.argtypes = [vp, u32, C.POINTER(C.c_double)]
+        L.hh_chain_enqueue.argtypes = [vp, u32]
+        L.hh_chain_sync.argtypes = [vp]
+        L.hh_op_refill.argtypes = [vp, C.c_char_p, C.c_uint64]
+        L.hh_op_snapshot.argtypes = [vp, C.c_char_p, u32]
+        L.hh_op_snapshot_read.argtypes = [vp, u32, vp]
         L.hh_chain_simulate.argtypes = [vp]
         L.hh_comm_unique_id.argtypes = [vp]
         L.hh_op_comm_init_rccl.argtypes = [vp, vp]
@@ -90,6 +95,21 @@ class Op:
             if not getattr(self, "borrowed", False):
                 self.L.hh_op_destroy(self.h)
             self.h = None
+
+    def refill(self, input_name, seed):
+        """asynchronous: new synthetic data for input ciphertext `input_name` ("ct1" / "ct2"), stream-ordered"""
+        self._ck(self.L.hh_op_refill(self.h, input_name.encode(), C.c_uint64(int(seed))))
+
+    def snapshot(self, name, slot=0):
+        """asynchronous device-side copy of a named buffer as it is at this point of the op's stream"""
+        self._ck(self.L.hh_op_snapshot(self.h, name.encode(), slot))
+
+    def snapshot_read(self, name, slot=0):
+        n = C.c_uint32()
+        self._ck(self.L.hh_op_buffer_limbs(self.h, name.encode(), C.byref(n)))
+        out = np.empty((n.value, self.N), dtype=np.uint64)
+        self._ck(self.L.hh_op_snapshot_read(self.h, slot, out.ctypes.data_as(C.c_void_p)))
+        return out
 
     def bind_input(self, input_name, producer):
         """continuous execution: this op's input ciphertext (\"ct1\" / \"ct2\") is `producer`'s output, kept in HBM"""
@@ -212,6 +232,14 @@ class Chain:
         if self.L.hh_chain_execute(self.h, iters, C.byref(ns)):
             raise HostError(self.L.hh_last_error().decode())
         return ns.value
+
+    def enqueue(self, iters=1):
+        if self.L.hh_chain_enqueue(self.h, iters):
+            raise HostError(self.L.hh_last_error().decode())
+
+    def sync(self):
+        if self.L.hh_chain_sync(self.h):
+            raise HostError(self.L.hh_last_error().decode())
 
     def close(self):
         if self.h:

@@ -74,6 +74,10 @@ public:
   void sync();
   double timedRun(uint32_t iters);      // ns per iteration, device time
   bool readLimbs(const std::vector<AddrType> &addrs, uint64_t *host, uint32_t copy = 0);  // download limbs (N words each) of op `copy` of the batch
+  // asynchronous helpers on the op's stream (tests of the chain ordering, streaming callers):
+  void refill(const std::vector<AddrType> &addrs, uint64_t seed);              // new synthetic input data (all ops of the batch)
+  void snapshot(const std::vector<AddrType> &addrs, uint32_t slot);             // device-side copy of the limbs as they are NOW in stream order
+  bool readSnapshot(uint32_t slot, uint64_t *host);                             // synchronises, then downloads the slot
   uint32_t batch() const { return batch_; }
   size_t launchCount() const { return launches.size(); }
   std::string stageTimes(uint32_t iters);  // one line per launch: "<kind> <stage names> <ns>", each launch timed alone
@@ -95,6 +99,7 @@ private:
   unsigned runCount = 0;
   void *graph = nullptr;  // hm_graph*: the whole plan captured once, replayed by run()
   std::vector<void *> sliceBuffers;
+  std::map<uint32_t, std::pair<uint64_t *, size_t>> snapshots;  // slot -> (device buffer, limbs)
   hm_ctx *ctx = nullptr;
   void *hostParams = nullptr;  // hm::Params: moduli / roots / conversion constants on the host (both backends)
   uint64_t *pool = nullptr;  // all limb-polys, [limb][N]

@@ -6,8 +6,11 @@
 #include "Config.h"
 #include "Instruction.h"
 
+class Arch;
 class InsGen {
 private:
+  Arch *arch_ = nullptr;
+  uint64_t keySeed_ = 0;
   uint32_t batchSize, batchCount;
   std::vector<AddrType> *DataPool = nullptr;
   std::map<AddrType, std::vector<Instruction *>> *DataInsMap = nullptr;
@@ -19,6 +22,13 @@ public:
   void setGlobalDatapPoll(std::vector<AddrType> *pool) { DataPool = pool; }
   void setGlobalDataInsMap(std::map<AddrType, std::vector<Instruction *>> *map) { DataInsMap = map; }
   uint32_t getbatchCount() const { return batchCount; }
+  // What real execution needs and the timing model never did travels with the generator, so that the sub-builders keep
+  // the reference's constructor signatures (include/Operation.h:48-54, 156-162): the backend (moduli and conversion
+  // constants of the context) and the seed of the synthetic evaluation key.
+  void setBackend(Arch *a) { arch_ = a; }
+  Arch *backend() const { return arch_; }
+  void setKeySeed(uint64_t s) { keySeed_ = s; }
+  uint64_t keySeed() const { return keySeed_; }
 
   // ntt == true: forward; false: inverse.  scale (inverse only): extra epilogue constant, 0 = none.
   INSGROUP GenNTT(uint32_t levelId, std::string name, INSGROUP *depInsGroup, bool ntt, AddrType op1AddrStart,

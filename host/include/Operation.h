@@ -34,8 +34,7 @@ private:
 public:
   KeySwitch(std::string labelName, uint32_t maxlevel, uint32_t level, uint32_t alpha,
             const std::vector<AddrType> &inputPolynomialAddress, std::vector<AddrType> *pool,
-            std::map<AddrType, std::vector<Instruction *>> *map, InsGen *insgen, AddrManage *memoryMange, Arch *arch,
-            uint64_t evkSeed);
+            std::map<AddrType, std::vector<Instruction *>> *map, InsGen *insgen, AddrManage *memoryMange);
   std::pair<StageMap, std::vector<std::string>> getInsMap() { return {KeySwicthInsMap, KeySwitchInsMapName}; }
 
   void ModUpINTT();
@@ -85,7 +84,7 @@ private:
 public:
   Rescale(std::string labelName, uint32_t level, const std::vector<AddrType> &inputPolynomialAddress,
           std::vector<AddrType> *pool, std::map<AddrType, std::vector<Instruction *>> *map, InsGen *insgen,
-          AddrManage *memoryMange, Arch *arch);
+          AddrManage *memoryMange);
   void NTTOps();
   void SubOps();
   void MulOps();

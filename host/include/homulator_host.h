@@ -47,6 +47,13 @@ void hh_chain_destroy(hh_chain *c);
 uint32_t hh_chain_size(hh_chain *c);
 hh_op *hh_chain_op(hh_chain *c, uint32_t i);   /* borrowed handle of op i (read buffers, plan); do not destroy */
 int hh_chain_execute(hh_chain *c, uint32_t iters, double *ns_per_pass);
+int hh_chain_enqueue(hh_chain *c, uint32_t iters);            /* asynchronous passes over the chain */
+int hh_chain_sync(hh_chain *c);
+/* stream-ordered helpers (asynchronous): new synthetic data for an input ("ct1", "ct2": .c0 gets `seed`, .c1 `seed` + 1000,
+ * as at construction); device-side snapshot of a named buffer into `slot`; download of a slot (synchronises) */
+int hh_op_refill(hh_op *op, const char *input, uint64_t seed);
+int hh_op_snapshot(hh_op *op, const char *name, uint32_t slot);
+int hh_op_snapshot_read(hh_op *op, uint32_t slot, uint64_t *host);
 int hh_chain_simulate(hh_chain *c);
 /* multi-GPU (overrides "world=W;rank=R" at creation): set the transport before the first execute */
 int hh_comm_unique_id(void *out128);

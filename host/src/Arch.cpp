@@ -39,8 +39,22 @@ Arch::Arch(Config *cfg) : config(cfg) {
   uint32_t b = cfg->getValueOr("backend", BACKEND_HIP);
   if (const char *e = getenv("HOMULATOR_BACKEND")) b = (std::string(e) == "count") ? BACKEND_COUNT : BACKEND_HIP;
   backendKind = b == BACKEND_COUNT ? BACKEND_COUNT : BACKEND_HIP;
-  world_ = std::max<uint32_t>(1, cfg->getValueOr("world", 1));
+  world_ = cfg->getValueOr("world", 0);
   rank_ = cfg->getValueOr("rank", 0);
+  if (world_ == 0) {
+    // no explicit `world` key: one rank per GPU when started by a multi-process launcher (torch.distributed.run, mpirun
+    // wrappers: WORLD_SIZE / RANK / LOCAL_RANK).  The CLI's [cluster] argument doubles as the GPU count:
+    // when it was given on the command line it must agree with the launcher.
+    world_ = 1;
+    const char *ws = getenv("WORLD_SIZE"), *rk = getenv("RANK"), *lr = getenv("LOCAL_RANK");
+    if (ws && atoi(ws) > 1 && b != BACKEND_COUNT) {
+      world_ = (uint32_t)atoi(ws);
+      rank_ = rk ? (uint32_t)atoi(rk) : 0;
+      if (lr && !getenv("HOMULATOR_DEVICE")) cfg->setValue("device", (uint32_t)atoi(lr));
+      if (cfg->getValueOr("cluster_from_argv", 0) && clusterCount != world_)
+        throw std::runtime_error("[cluster] = " + std::to_string(clusterCount) + " GPUs requested, but the launcher started " + std::to_string(world_) + " ranks");
+    }
+  }
   if (rank_ >= world_) throw std::runtime_error("rank must be below world");
   if (world_ & (world_ - 1)) throw std::runtime_error("world must be a power of two");
   useGraph = cfg->getValueOr("graph", 0) != 0;  // measured: no gain on one GPU (the op is GPU-bound: 2 440 vs 2 422 ops/s)
@@ -57,6 +71,8 @@ Arch::~Arch() {
   if (graph) hm_graph_destroy(static_cast<hm_graph *>(graph));
   if (ctx)
     for (void *p : sliceBuffers) hm_free(ctx, p);
+  if (ctx)
+    for (auto &kv : snapshots) hm_free(ctx, kv.second.first);
   if (ctx) {
     if (pool) hm_free(ctx, pool);
     hm_destroy(ctx);
@@ -909,6 +925,9 @@ void Arch::run() {
     if (hm_ewe(ctx, EWE_COPY, b.src->pool, b.srcLimbs.data(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, pool, b.dstLimbs.data(),
                b.mods.data(), (uint32_t)b.dstLimbs.size(), nullptr) != HM_OK)
       throw std::runtime_error(std::string("bound input copy: ") + hm_last_error(ctx));
+    // back edge: the producer's NEXT pass overwrites these limbs (its transforms even use their output as first-pass
+    // scratch), so its stream waits until this copy has read them
+    if (hm_wait_for(b.src->ctx, ctx) != HM_OK) throw std::runtime_error(std::string("hm_wait_for (back edge): ") + hm_last_error(ctx));
   }
   // single GPU: the plan is a fixed sequence of kernels -> captured into a HIP graph on the second run (the first
   // one warms the base-conversion table cache, which allocates) and replayed with one launch afterwards.
@@ -941,6 +960,40 @@ double Arch::timedRun(uint32_t iters) {
   uint64_t ns = 0;
   hm_timer_stop(ctx, &ns);
   return (double)ns / iters;
+}
+
+void Arch::refill(const std::vector<AddrType> &addrs, uint64_t seed) {
+  if (!prepared) prepare();
+  if (backendKind != BACKEND_HIP || addrs.empty()) return;
+  const InputFill *f = nullptr;
+  for (const InputFill &x : fills)
+    if (x.addrs == addrs) f = &x;
+  if (!f) throw std::runtime_error("refill: not an input of this op");
+  for (uint32_t c = 0; c < (f->shared ? 1u : batch_); ++c) {
+    std::vector<uint32_t> limbs;
+    for (AddrType a : addrs) limbs.push_back(limbOf(a) + c * (uint32_t)limbIndex.size());
+    if (hm_fill_uniform(ctx, pool, limbs.data(), f->mods.data(), (uint32_t)limbs.size(), seed + c * kBatchSeedStride) != HM_OK)
+      throw std::runtime_error(std::string("hm_fill_uniform: ") + hm_last_error(ctx));
+  }
+}
+void Arch::snapshot(const std::vector<AddrType> &addrs, uint32_t slot) {
+  if (!prepared) prepare();
+  if (backendKind != BACKEND_HIP) return;
+  auto &sn = snapshots[slot];
+  if (sn.second != addrs.size()) {
+    if (sn.first) hm_free(ctx, sn.first);
+    void *p = nullptr;
+    if (hm_malloc(ctx, addrs.size() * (size_t)n * 8, &p) != HM_OK) throw std::runtime_error(std::string("hm_malloc (snapshot): ") + hm_last_error(ctx));
+    sn = {static_cast<uint64_t *>(p), addrs.size()};
+  }
+  for (size_t i = 0; i < addrs.size(); ++i)
+    if (hm_memcpy_d2d(ctx, sn.first + i * n, pool + (size_t)limbOf(addrs[i]) * n, (size_t)n * 8) != HM_OK)
+      throw std::runtime_error(std::string("hm_memcpy_d2d: ") + hm_last_error(ctx));
+}
+bool Arch::readSnapshot(uint32_t slot, uint64_t *host) {
+  auto it = snapshots.find(slot);
+  if (it == snapshots.end() || backendKind != BACKEND_HIP) return false;
+  return hm_memcpy_d2h(ctx, host, it->second.first, it->second.second * (size_t)n * 8) == HM_OK;
 }
 
 bool Arch::readLimbs(const std::vector<AddrType> &addrs, uint64_t *host, uint32_t copy) {

@@ -13,8 +13,9 @@ static std::string S(uint32_t v) { return std::to_string(v); }
 // =====================================================================================================
 KeySwitch::KeySwitch(std::string labelName, uint32_t maxlevel, uint32_t level, uint32_t alpha,
                      const std::vector<AddrType> &inputPolynomialAddress, std::vector<AddrType> *pool,
-                     std::map<AddrType, std::vector<Instruction *>> *map, InsGen *insgen, AddrManage *memoryMange,
-                     Arch *arch_, uint64_t evkSeed) {
+                     std::map<AddrType, std::vector<Instruction *>> *map, InsGen *insgen, AddrManage *memoryMange) {
+  Arch *arch_ = insgen->backend();             // same signature as upstream (include/Operation.h:48-54): the backend
+  const uint64_t evkSeed = insgen->keySeed();  // and the key seed travel with the generator
   DataInsMap = map;
   DataPool = pool;
   MaxLevel = maxlevel;
@@ -334,7 +335,8 @@ void TensorCompute::computeD2() {  // :701-739
 // =====================================================================================================
 Rescale::Rescale(std::string labelName, uint32_t level, const std::vector<AddrType> &inputPolynomialAddress,
                  std::vector<AddrType> *, std::map<AddrType, std::vector<Instruction *>> *map, InsGen *insgen,
-                 AddrManage *memoryMange, Arch *arch_) {
+                 AddrManage *memoryMange) {
+  Arch *arch_ = insgen->backend();  // upstream's signature (include/Operation.h:156-162)
   DataInsMap = map;
   currentLevel = level;
   insGenPointer = insgen;
@@ -419,6 +421,8 @@ OperationBase::OperationBase(const std::string &op, Config *cfg, Arch *_arch, ui
   seed = cfg->getValueOr("seed", 0x484F4D55u);
   insgener->setGlobalDatapPoll(&Datapool);
   insgener->setGlobalDataInsMap(&DataInsMap);
+  insgener->setBackend(arch);
+  insgener->setKeySeed(seed + 10000);
   arch->bindParams(maxLevel, curLevel, alpha);
   Datapool.push_back(BASEADDRESS);
 }
@@ -539,7 +543,7 @@ HMULT::HMULT(std::string labelName, uint32_t maxLevel, uint32_t currentLevel, ui
   dispatch(tcm.getInsMap());
 
   KeySwitch ksw(labelName, maxLevel, currentLevel, alpha, addrManager->getAddr("TensorD2Out"), &Datapool, &DataInsMap, insgener,
-                addrManager, arch, seed + 10000);
+                addrManager);
   dispatch(ksw.getInsMap());
 
   StageMap hadd;
@@ -559,7 +563,7 @@ HMULT::HMULT(std::string labelName, uint32_t maxLevel, uint32_t currentLevel, ui
 
   for (uint32_t k = 0; k < 2; k++) {
     Rescale res(labelName + "_" + S(k), currentLevel, addrManager->getAddr("HMULTHaddOutput(" + S(k) + ")"), &Datapool, &DataInsMap,
-                insgener, addrManager, arch);
+                insgener, addrManager);
     dispatch(res.getInsMap());
     namedOutputs[k == 0 ? "out.c0" : "out.c1"] = addrManager->getAddr(labelName + "_" + S(k) + "_Rescale_Rescale_MulOut");
   }
@@ -591,7 +595,7 @@ HROTATE::HROTATE(std::string labelName, uint32_t maxLevel, uint32_t currentLevel
   dispatch({autoMap, autoNames});
 
   KeySwitch ksw(labelName, maxLevel, currentLevel, alpha, addrManager->getAddr("AUTOOutput(1)"), &Datapool, &DataInsMap, insgener,
-                addrManager, arch, seed + 10000);
+                addrManager);
   dispatch(ksw.getInsMap());
 
   addrManager->MallocMem("HROTATEOutput(1)", currentLevel);

@@ -143,6 +143,16 @@ uint32_t hh_chain_size(hh_chain *h) { return (uint32_t)h->chain->size(); }
 hh_op *hh_chain_op(hh_chain *h, uint32_t i) { return i < h->views.size() ? h->views[i] : nullptr; }
 int hh_chain_execute(hh_chain *h, uint32_t iters, double *ns) { HH_TRY(double t = h->chain->execute(iters); if (ns) *ns = t) }
 int hh_chain_simulate(hh_chain *h) { HH_TRY(h->chain->simulate()) }
+int hh_chain_enqueue(hh_chain *h, uint32_t iters) { HH_TRY(h->chain->prepare(); for (uint32_t i = 0; i < iters; ++i) h->chain->run()) }
+int hh_chain_sync(hh_chain *h) { HH_TRY(h->chain->sync()) }
+int hh_op_refill(hh_op *h, const char *input, uint64_t seed) {
+  HH_TRY(h->op->prepare(); h->arch->refill(h->op->bufferAddrs(std::string(input) + ".c0"), seed);
+         h->arch->refill(h->op->bufferAddrs(std::string(input) + ".c1"), seed + 1000))
+}
+int hh_op_snapshot(hh_op *h, const char *name, uint32_t slot) { HH_TRY(h->op->prepare(); h->arch->snapshot(h->op->bufferAddrs(name), slot)) }
+int hh_op_snapshot_read(hh_op *h, uint32_t slot, uint64_t *host) {
+  HH_TRY(if (!h->arch->readSnapshot(slot, host)) throw std::runtime_error("no such snapshot"))
+}
 extern "C" int hm_comm_unique_id(void *);
 int hh_comm_unique_id(void *out) { if (hm_comm_unique_id(out)) { g_err = "hm_comm_unique_id failed (is librccl.so available?)"; return 1; } return 0; }
 int hh_op_comm_init_rccl(hh_op *h, const void *id) { HH_TRY(h->arch->commInitRccl(id)) }

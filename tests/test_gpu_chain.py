@@ -84,3 +84,31 @@ def test_bind_input_between_two_ops_and_level_mismatch():
         wrong.bind_input("ct1", a)
     for x in (b, wrong, a):
         x.close()
+
+
+def test_chain_passes_with_changing_inputs_are_ordered_both_ways():
+    """A fast producer (hadd) in front of a slow consumer (hmult), several passes enqueued back to back with NEW producer
+    input before every pass.  The consumer's pass i must see the producer's pass i: producer -> consumer order AND the
+    back edge (the producer's pass i+1 may not overwrite its output before the consumer's copy of pass i has read it).
+    Every pass's consumer output is kept by a stream-ordered device snapshot and compared with the oracle afterwards."""
+    from homulator_amd import host
+    # N = 2^16, 45/35/15: one consumer pass is ~350 us of GPU work against ~100 us of host enqueue time, so the producer's
+    # stream really runs passes ahead of the consumer's (with the small configurations the host is the slower side and
+    # the hazard never opens: the test was checked to FAIL at this size with the back edge removed)
+    logN, L, ell, alpha = 16, 45, 35, 15
+    o = Oracle(logN, L, alpha)
+    o.set_threads(8)
+    chain = host.Chain("config_4.cfg", "hadd,hmult", L, ell, alpha)
+    passes, seeds = 4, [SEED + 7777 * i for i in range(4)]
+    chain.execute(1)                                   # prepared, tables warm
+    for i in range(passes):
+        chain[0].refill("ct1", seeds[i])               # producer input of pass i (stream-ordered after its pass i-1)
+        chain.enqueue(1)
+        chain[1].snapshot("out.c0", slot=i)
+    chain.sync()
+    evk = o.synth_evk(ell, SEED + 31 + 10000)
+    for i in range(passes):
+        mid = o.hadd(ell, o.synth_ct(ell, seeds[i]), o.synth_ct(ell, SEED + 2000))
+        exp = o.hmult(ell, mid, o.synth_ct(ell, SEED + 31 + 2000), evk, rescale=True)
+        assert np.array_equal(chain[1].snapshot_read("out.c0", slot=i), exp[0]), f"pass {i}"
+    chain.close()

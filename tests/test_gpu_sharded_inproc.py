@@ -1,0 +1,90 @@
+"""BASELINE configs[4]: hmult 45/35/15 with the limb-polys sharded over EIGHT ranks, executed for real on the one GPU of
+the test box: 8 ranks = 8 threads of this process (own HIP context, stream and HBM pool each), exchanges through
+homulator_amd.dist.InProcessGroup (device-to-device copies between the ranks' staging buffers).  A GPU box admits at
+most 6 processes on its card, so 8 gloo processes are not an option; the ownership rule (upstream's `limb % cluster`,
+include/Driver.h:158,178), the all-to-all pairs around both base conversions, the replicate of the rescale residue
+and the per-pair byte counts are exactly those of an 8-GPU run — only the wire differs (RCCL over xGMI there).
+Ranks that own NO limb of a list (the 2-limb rescale INTT at 8 ranks) send and receive nothing; both sides of every
+pair must agree on its size (checked by the transport)."""
+import numpy as np
+import pytest
+
+from oracle.homoracle import Oracle
+
+pytestmark = pytest.mark.gpu
+SEED = 0x484F4D55
+
+
+def assemble(ops, name, n_limbs, N, copy=0):
+    full = np.zeros((n_limbs, N), dtype=np.uint64)
+    seen = np.zeros(n_limbs, dtype=int)
+    for op in ops:
+        mine = op.read(name, copy=copy)
+        for l in op.owned(n_limbs):
+            full[l] = mine[l]
+            seen[l] += 1
+    assert (seen == 1).all(), "every limb has exactly one owner"
+    return full
+
+
+@pytest.mark.parametrize("world,cfg,opname,L,ell,alpha,logN,batch", [
+    (8, "config_4.cfg", "hmult", 45, 35, 15, 16, 1),       # BASELINE configs[4]
+    (8, "config_4.cfg", "hrotate", 45, 35, 15, 16, 1),
+    (8, "config_4_N15.cfg", "hmult", 16, 10, 4, 15, 3),    # batched: the ops of a batch share every exchange
+    (4, "config_4_N15.cfg", "hmult", 6, 5, 2, 15, 1),      # fewer limbs than ranks in some lists
+])
+def test_sharded_in_process(world, cfg, opname, L, ell, alpha, logN, batch):
+    from homulator_amd import host
+    from homulator_amd.dist import run_in_process
+
+    def make(r):
+        return host.Op(cfg, opname, L, ell, alpha, rank=r, world=world, overrides={"batch": batch} if batch > 1 else None)
+
+    def body(r, op):
+        op.execute(1)
+        op.execute(1)   # the plan must be re-runnable
+        return True
+
+    ops, res, grp = run_in_process(world, make, body)
+    assert all(res) and not grp.failed
+    assert len(set(grp.calls)) == 1 and grp.calls[0] > 0, grp.calls          # every rank entered every exchange
+    N = 1 << logN
+    n_out = ell - 1 if opname == "hmult" else ell
+    o = Oracle(logN, L, alpha)
+    o.set_threads(8)
+    evk = o.synth_evk(ell, SEED + 10000)
+    for c in range(batch):
+        S = SEED + c * 100000
+        ct1, ct2 = o.synth_ct(ell, S), o.synth_ct(ell, S + 2000)
+        exp = o.hmult(ell, ct1, ct2, evk) if opname == "hmult" else o.hrotate(ell, ct1, 5, evk)
+        assert np.array_equal(assemble(ops, "out.c0", n_out, N, c), exp[0])
+        assert np.array_equal(assemble(ops, "out.c1", n_out, N, c), exp[1])
+    if world == 8 and opname == "hmult" and batch == 1:
+        # every pair of one exchange carries slices of N/8 coefficients; rank 0's ingress per hmult is
+        # 7/8 of (its share of) the exchanged limb-polys: nonzero, identical on the two runs, below the 13.7 MiB bound + replicate
+        runs = 2       # execute(1) twice
+        assert grp.calls[0] % runs == 0 and grp.calls[0] // runs == 5, grp.calls  # 2 all-to-all pairs + 1 replicate per hmult
+        per_op = grp.bytes_recv[0] / runs
+        assert 0 < per_op < 20 * 2 ** 20, per_op
+    for op in ops:
+        op.close()
+
+
+def test_bench_flow_rehearsal_four_ranks():
+    """the driver's multi-GPU bench flow (torch.distributed.run, batch selection, transport agreement, MAX-reduce, one JSON
+    line on rank 0) executed once with 4 ranks on the one GPU over gloo (HOMULATOR_DIST_BACKEND=gloo; 4 + this process
+    stay within the box's 6-process limit — the reason it is not 8)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HOMULATOR_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+                          "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "8", "--warmup", "2"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 4 and d["steps"] == 8 and d["value"] > 0
+    assert d["config"]["transport"] == "gloo-rehearsal" and d["exchange_us_per_op"] > 0
