@@ -42,7 +42,7 @@ def roofline_inputs():
 
 def measure_ntt_sweep(n_limbs, iters=48, sets=6):
     """forward NTT sweep over the extended basis (l + alpha limbs): device time per sweep, HIP events on the
-    backend stream.  One sweep = one hm_ntt call = the two pass kernels k_ntt_pass<COL> + k_ntt_pass<ROW>.
+    backend stream.  One sweep = one hm_ntt call = the two pass kernels k_ntt_col + k_ntt_row.
     The sweeps rotate over `sets` input/output buffer pairs (6 x 2 x 26 MB = 315 MB > the 256 MiB Infinity Cache), so
     that every sweep reads its input from HBM rather than from a cache the previous replay left warm."""
     from homulator_amd import hip
@@ -256,7 +256,7 @@ def main():
             "hmult_hbm_gbs_algorithmic": alg_bytes / (ms * 1e-3) / 1e9,
             "hmult_frac_of_hbm_peak": alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "roofline": {"bound": "valu" if valu_floor_ns and valu_floor_ns > hbm_floor_ns else "hbm",
-                         "kernel": "forward NTT sweep, 50 limbs = k_ntt_pass<COL> + k_ntt_pass<ROW>",
+                         "kernel": "forward NTT sweep, 50 limbs = k_ntt_col + k_ntt_row",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": rin.get("ntt_sweep50_traffic_bytes") if sweep_limbs == 50 else None, "us_per_launch": ntt_ns * 1e-3,
                          "algorithmic_bytes_per_launch": NTT_ALG_BYTES * sweep_limbs,

@@ -85,14 +85,24 @@ __device__ __forceinline__ void hm_ntt_pass_body(const HmNttArgs &a) {
   }
 }
 
+// Minimum waves per SIMD the register allocator must leave room for (HIP's second launch-bound argument; it is ignored
+// when it depends on a template parameter, hence one kernel template per pass).  4 workgroups of 256 threads per CU
+// (36 KiB of LDS each) = 4 waves per SIMD: up to 128 VGPRs.
 #ifndef HM_NTT_MIN_WAVES
-#define HM_NTT_MIN_WAVES 4  // 4 workgroups of 256 threads per CU (36 KiB of LDS each): up to 128 VGPRs
+#define HM_NTT_MIN_WAVES 4
+#endif
+#ifndef HM_NTT_MIN_WAVES_COL
+#define HM_NTT_MIN_WAVES_COL HM_NTT_MIN_WAVES
 #endif
 // MODE 0: first pass / plain hand-off; 1: forward final; 2: inverse final (x scale); 3: forward final with the fused
 // epilogue; 4: forward first pass with the mix prologue
-template <int LOGR, bool STRIDED, bool INV, int MODE>
-__global__ void __launch_bounds__((1 << HM_TL(STRIDED)) / HM_EPT, HM_NTT_MIN_WAVES) k_ntt_pass(HmNttArgs a) {
-  hm_ntt_pass_body<LOGR, STRIDED, INV, MODE>(a);
+template <int LOGR, bool INV, int MODE>
+__global__ void __launch_bounds__((1 << HM_TL_COL) / HM_EPT) __attribute__((amdgpu_waves_per_eu(HM_NTT_MIN_WAVES_COL))) k_ntt_col(HmNttArgs a) {
+  hm_ntt_pass_body<LOGR, true, INV, MODE>(a);
+}
+template <bool INV, int MODE>
+__global__ void __launch_bounds__((1 << HM_TL_ROW) / HM_EPT) __attribute__((amdgpu_waves_per_eu(HM_NTT_MIN_WAVES))) k_ntt_row(HmNttArgs a) {
+  hm_ntt_pass_body<HM_ROW_LOG, false, INV, MODE>(a);
 }
 
 __global__ void __launch_bounds__(256) k_tensor(HmTensorArgs a) {
@@ -509,13 +519,13 @@ static void launch_ntt(hm_ctx *c, const HmNttArgs &a, bool fusedEpilogue, bool m
   const dim3 gridC(a.n_limbs * (c->P.N >> HM_TL_COL)), blockC((1 << HM_TL_COL) / HM_EPT);
   const dim3 gridR(a.n_limbs * (c->P.N >> HM_TL_ROW)), blockR((1 << HM_TL_ROW) / HM_EPT);
   if (!inverse) {
-    if (mixPrologue) hipLaunchKernelGGL((k_ntt_pass<LOG1, true, false, 4>), gridC, blockC, 0, c->stream, a);
-    else hipLaunchKernelGGL((k_ntt_pass<LOG1, true, false, 0>), gridC, blockC, 0, c->stream, a);
-    if (fusedEpilogue) hipLaunchKernelGGL((k_ntt_pass<HM_ROW_LOG, false, false, 3>), gridR, blockR, 0, c->stream, a);
-    else hipLaunchKernelGGL((k_ntt_pass<HM_ROW_LOG, false, false, 1>), gridR, blockR, 0, c->stream, a);
+    if (mixPrologue) hipLaunchKernelGGL((k_ntt_col<LOG1, false, 4>), gridC, blockC, 0, c->stream, a);
+    else hipLaunchKernelGGL((k_ntt_col<LOG1, false, 0>), gridC, blockC, 0, c->stream, a);
+    if (fusedEpilogue) hipLaunchKernelGGL((k_ntt_row<false, 3>), gridR, blockR, 0, c->stream, a);
+    else hipLaunchKernelGGL((k_ntt_row<false, 1>), gridR, blockR, 0, c->stream, a);
   } else {
-    hipLaunchKernelGGL((k_ntt_pass<HM_ROW_LOG, false, true, 0>), gridR, blockR, 0, c->stream, a);
-    hipLaunchKernelGGL((k_ntt_pass<LOG1, true, true, 2>), gridC, blockC, 0, c->stream, a);
+    hipLaunchKernelGGL((k_ntt_row<true, 0>), gridR, blockR, 0, c->stream, a);
+    hipLaunchKernelGGL((k_ntt_col<LOG1, true, 2>), gridC, blockC, 0, c->stream, a);
   }
 }
 

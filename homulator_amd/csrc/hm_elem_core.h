@@ -237,9 +237,15 @@ HM_HD void hm_bconv_thread(const PROB &p, uint32_t logN, uint32_t x, uint32_t t0
   }
   for (uint32_t t = t0; t < t1; ++t) {
     HmRow8 row[NG];
+#if defined(HM_ABL_BCONV_NOTAB)   // timing-only ablation: one table row for every output (no per-output scalar loads)
+    const HmQn m = qn[t0];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) row[g] = tab[t0 * NG + g];
+#else
     const HmQn m = qn[t];
 #pragma unroll
     for (int g = 0; g < NG; ++g) row[g] = tab[t * NG + g];
+#endif
     uint64_t r[2] = {0, 0};
 #pragma unroll
     for (int c = 0; c < CPT; ++c) r[c] = hm_bconv_dot<N_IN>(yl[c], yh[c], row, m.q, m.nqinv);

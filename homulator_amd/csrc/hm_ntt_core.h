@@ -53,9 +53,14 @@
 #ifndef HM_ROW_LOG
 #define HM_ROW_LOG 8  // log2 of the contiguous sub-transform length (pass ROW)
 #endif
-#ifndef HM_TW_IN_LDS
-#define HM_TW_IN_LDS 1  // shared twiddles of the later rounds come from an LDS copy (0: from global memory)
+// shared twiddles of the later rounds come from an LDS copy (0: from global memory), per pass
+#ifndef HM_TW_LDS_COL
+#define HM_TW_LDS_COL 1
 #endif
+#ifndef HM_TW_LDS_ROW
+#define HM_TW_LDS_ROW 1
+#endif
+#define HM_TW_IN_LDS(STRIDED) ((STRIDED) ? HM_TW_LDS_COL : HM_TW_LDS_ROW)
 
 struct HmLimb {  // one limb-poly of an automorphism / fill launch: limb indices into the in/out bases, modulus id
   uint16_t in, out, mod, aux;
@@ -197,7 +202,7 @@ template <int TL, int LOGR, bool STRIDED>
 struct HmLds {
   static constexpr int TILE = 1 << TL, THREADS = TILE / HM_EPT;
   static constexpr int NTW = STRIDED ? (1 << LOGR) : 128;  // staged entries: w[0 .. NTW) of the modulus
-  static constexpr int WORDS = TILE + 2 * NTW;
+  static constexpr int WORDS = TILE + (HM_TW_IN_LDS(STRIDED) ? 2 * NTW : 0);
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -328,9 +333,13 @@ struct HmPass {
   static constexpr int n = HmRounds<LOGR>::n;
   static constexpr int exec(int i) { return INV ? n - 1 - i : i; }
   // the ROW round on the lowest two bits runs with the shared twiddles (data twisted by alpha^(j mod 4))
+#if defined(HM_NO_TWIST)   // ablation: every ROW round with the row's private twiddles (as much twiddle traffic as data)
+  static constexpr int twistRound = -1;
+#else
   static constexpr int twistRound = (!STRIDED && LOGR == 8) ? n - 1 : -1;
+#endif
   static constexpr bool shared(int R) { return STRIDED || R == twistRound; }
-  static constexpr bool fromLds(int R) { return HM_TW_IN_LDS && shared(R) && R != exec(0); }
+  static constexpr bool fromLds(int R) { return HM_TW_IN_LDS(STRIDED) && shared(R) && R != exec(0); }
   static constexpr bool anyLds() { return fromLds(exec(1)) || (n == 3 && fromLds(exec(2))); }
 };
 
