@@ -607,7 +607,10 @@ static hm_status ntt_common(hm_ctx *c, const char *what, const uint64_t *in, con
   }
   // As few launches as the kernel-argument segment allows (HM_NTT_MAX_ENTRIES records), of equal size; the constants
   // of a launch live in a device table cached by content (plans repeat their launches)
-  const uint32_t maxPairs = HM_NTT_MAX_ENTRIES / 2;
+#ifndef HM_NTT_LAUNCH_PAIRS
+#define HM_NTT_LAUNCH_PAIRS (HM_NTT_MAX_ENTRIES / 2)
+#endif
+  const uint32_t maxPairs = HM_NTT_LAUNCH_PAIRS;
   const uint32_t nLaunch = ((uint32_t)pairs.size() + maxPairs - 1) / maxPairs;
   const uint32_t perLaunch = nLaunch ? (((uint32_t)pairs.size() + nLaunch - 1) / nLaunch + 7) / 8 * 8 : 0;  // whole groups of 8 pairs
   for (uint32_t base = 0; base < pairs.size(); base += perLaunch) {
