@@ -195,7 +195,7 @@ HM_HD uint64_t hm_bconv_dot(const uint32_t (&yl)[N_IN], const uint32_t (&yh)[N_I
   HmMod m;
   m.q = q;
   m.nqinv = nqinv;
-  return hm_redc_wide(acc, m);
+  return hm_redc_wide<N_IN>(acc, m);
 }
 
 // per-output modulus constants, stored behind the table rows (HmBconvProb::qn): no load depends on another load

@@ -67,13 +67,19 @@ HM_HD uint64_t hm_barrett_wide(hm_u128 z, const HmMod &m) {
   return hm_barrett(f, m);
 }
 
-// Montgomery reduction of a wide accumulator: z < 2^125 -> z * 2^-64 mod q, fully reduced.  m = z_lo * (-q^-1) makes
-// z + m q divisible by 2^64; the quotient is below 2^61 + q < 5q (q > 2^59).  About half the instructions of
-// hm_barrett_wide; the 2^-64 is absorbed by constants stored as c * 2^64 mod q (base-conversion tables).
+// Montgomery reduction of a wide accumulator: z -> z * 2^-64 mod q, fully reduced.  m = z_lo * (-q^-1) makes
+// z + m q divisible by 2^64.  About half the instructions of hm_barrett_wide; the 2^-64 is absorbed by constants
+// stored as c * 2^64 mod q (base-conversion tables).
+// TERMS = number of products y * w summed into z with y < 2^60 (any input modulus) and w < q: z >> 64 < TERMS * q / 16,
+// i.e. below q for up to 16 terms and below 2q for up to 32; the Montgomery quotient adds less than q + 1: one
+// conditional subtraction for TERMS <= 16, two for <= 32.
+template <int TERMS = 32>
 HM_HD uint64_t hm_redc_wide(hm_u128 z, const HmMod &m) {
+  static_assert(TERMS <= 32, "accumulator bound");
   const uint64_t lo = (uint64_t)z, hi = (uint64_t)(z >> 64);
-  const uint64_t t = hi + hm_mulhi(lo * m.nqinv, m.q) + (lo != 0);  // the low words cancel; they carry iff lo != 0
-  return hm_csub(hm_csub(hm_csub(t, 4 * m.q), 2 * m.q), m.q);
+  uint64_t t = hi + hm_mulhi(lo * m.nqinv, m.q) + (lo != 0);  // the low words cancel; they carry iff lo != 0
+  if (TERMS > 16) t = hm_csub(t, 2 * m.q);
+  return hm_csub(t, m.q);
 }
 
 HM_HD uint64_t hm_addmod(uint64_t a, uint64_t b, uint64_t q) { return hm_csub(a + b, q); }
