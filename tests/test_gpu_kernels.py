@@ -112,6 +112,30 @@ def test_bconv_modup_moddown_shapes(env):
         d.free(); out.free()
 
 
+def test_bconv_batch_many_problems_one_launch(env):
+    """hm_bconv_batch with more problems than the kernel-argument segment used to hold (4): the records travel in a device
+    table, the output chunk is sized by the launch; mixed input-basis sizes split into one launch per size; ragged output
+    counts (not a multiple of any chunk); inputs at q - 1, 0, 1"""
+    ctx, o, _ = env
+    L, K = o.L, o.K
+    shapes = [([0, 1, 2], [3, 4, 5, L, L + 1, L + 2, L + 3][:6 + (i % 2)]) if i % 3 else ([4, 5], [0, 1, 2, 3, L]) for i in range(23)]
+    srcs, dsts, probs, exps = [], [], [], []
+    for i, (in_ids, out_ids) in enumerate(shapes):
+        out_ids = [t for t in out_ids if t < L + K]
+        x = o.fill_uniform(in_ids, 100 + i)
+        for r, m in enumerate(in_ids):
+            x[r, :3] = [o.moduli[m] - 1, 0, 1]
+        d, out = ctx.from_host(x), ctx.alloc(len(out_ids))
+        srcs.append(d); dsts.append(out)
+        probs.append((d, None, in_ids, out, None, out_ids))
+        exps.append(o.bconv_matmul(in_ids, out_ids, x))
+    ctx.bconv_batch(probs)
+    for out, e in zip(dsts, exps):
+        assert np.array_equal(out.download(), e)
+    for b in srcs + dsts:
+        b.free()
+
+
 @pytest.mark.parametrize("rot", [1, 2, 7])
 def test_automorph_eval(env, rot):
     ctx, o, _ = env
