@@ -191,11 +191,21 @@ def main():
             tail_op.sync()
 
     # untimed: the chip ramps its clocks over the first ~100 ms of load; a 20-step timed region is 5 ms.  Run the same
-    # steps for at least 0.3 s first, then the W warm-up steps the contract asks for.
+    # steps for about 0.3 s first, then the W warm-up steps the contract asks for.  Sharded runs MUST do the same number
+    # of passes on every rank (each pass enters the exchanges): rank 0 times a probe pass and broadcasts the count.
+    run(streams * batch)
+    sync_all()
     t_pre = time.perf_counter()
-    while time.perf_counter() - t_pre < 0.3:
+    run(streams * batch)
+    sync_all()
+    n_pre = max(1, min(1000, int(float(os.environ.get("HOMULATOR_PREWARM_S", "0.3")) / max(time.perf_counter() - t_pre, 1e-4))))
+    if dist is not None:
+        cnt = torch.tensor([n_pre], device=red_dev)
+        dist.broadcast(cnt, src=0)
+        n_pre = int(cnt.item())
+    for _ in range(n_pre):
         run(streams * batch)
-        sync_all()
+    sync_all()
     run(max(args.warmup, streams * batch))
     if tail_op is not None:
         tail_op.enqueue(1)
