@@ -48,6 +48,35 @@ def test_ntt_forward_inverse_bit_exact(env):
     d.free(); out.free()
 
 
+@pytest.mark.parametrize("logN", [13, 14, 17])
+def test_ntt_other_ring_sizes(logN):
+    """every COL-pass instantiation (N / 256 = 32, 64, 512 rows: two rounds, three rounds, 8-column tiles) on the GPU: forward,
+    inverse, fused epilogue with mix prologue, with the all-(q-1) worst case of the lazy ranges; 2^15 and 2^16 run above"""
+    from homulator_amd import hip
+    L, K = 3, 2
+    ctx, o = hip.Context(logN, L, K), Oracle(logN, L, K)
+    try:
+        ids = [0, 1, 2, 3, 4, 0, 4]
+        x, mn, ad, mx = (o.fill_uniform(ids, s) for s in (123, 124, 125, 126))
+        x[0, :] = o.moduli[ids[0]] - 1
+        x[1, :4] = [0, o.moduli[ids[1]] - 1, 1, 2]
+        d, out = ctx.from_host(x), ctx.alloc(len(ids))
+        ctx.ntt(d, out, ids)
+        assert np.array_equal(out.download(), o.ntt(ids, x))
+        ctx.ntt(out, out, ids, inverse=True)
+        assert np.array_equal(out.download(), x)
+        k = [o.moduli[m] - 2 - r for r, m in enumerate(ids)]
+        mk = [(kk * 3 + 1) % o.moduli[m] for kk, m in zip(k, ids)]
+        ak = [(kk * 5 + 1) % o.moduli[m] for kk, m in zip(k, ids)]
+        dmn, dad, dmx = ctx.from_host(mn), ctx.from_host(ad), ctx.from_host(mx)
+        ctx.ntt_mix_sub_scale(d, dmn, out, ids, k, addend=dad, addend_k=ak, mix=dmx, mix_k=mk)
+        xin = o.ewe(3, ids, x, None, o.ewe(5, ids, mx, k=mk))
+        exp = o.ewe(3, ids, o.ewe(6, ids, mn, None, o.ntt(ids, xin), k=k), None, o.ewe(5, ids, ad, k=ak))
+        assert np.array_equal(out.download(), exp)
+    finally:
+        ctx.close()
+
+
 def test_ntt_many_limbs_over_one_launch(env):
     ctx, o, _ = env
     ids = [i % (o.L + o.K) for i in range(140)]   # > HM_MAX_LIMBS: exercises the chunked launch
