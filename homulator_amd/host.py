@@ -9,7 +9,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.environ.get("HOMULATOR_HOST_LIB") or os.path.join(ROOT, "host", "lib", "libhomulator_host.so")  # override: A/B builds
 CONFIG_DIR = os.path.join(ROOT, "config")
-BACKEND_HIP, BACKEND_COUNT = 0, 1
+BACKEND_HIP, BACKEND_COUNT, BACKEND_SIM = 0, 1, 2
 SEED = 0x484F4D55
 
 _lib = None
@@ -27,6 +27,8 @@ def load():
         L.hh_last_error.restype = C.c_char_p
         L.hh_op_simulate.argtypes = [vp]
         L.hh_op_execute.argtypes = [vp, u32, C.POINTER(C.c_double)]
+        L.hh_op_sim_run.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
+        L.hh_op_sim_stats.argtypes = [vp, C.c_char_p, u32]
         L.hh_op_enqueue.argtypes = [vp, u32]
         L.hh_op_sync.argtypes = [vp]
         L.hh_op_total_instructions.argtypes = [vp, u64p]
@@ -123,6 +125,16 @@ class Op:
 
     def simulate(self):
         self._ck(self.L.hh_op_simulate(self.h))
+
+    def sim_run(self):
+        """backend = BACKEND_SIM: run the cycle model of the reference accelerator to completion.
+        Returns {"cycles", "retired", "drained", "stats"}: the reference's cycle count and stat block for this op."""
+        cyc, ret, ok = C.c_uint64(), C.c_uint64(), C.c_int()
+        self._ck(self.L.hh_op_sim_run(self.h, C.byref(cyc), C.byref(ret), C.byref(ok)))
+        buf = C.create_string_buffer(1 << 16)
+        self._ck(self.L.hh_op_sim_stats(self.h, buf, len(buf)))
+        stats = {ln.rsplit(" ", 1)[0]: int(ln.rsplit(" ", 1)[1]) for ln in buf.value.decode().splitlines()}
+        return {"cycles": cyc.value, "retired": ret.value, "drained": bool(ok.value), "stats": stats}
 
     def execute(self, iters=1):
         """runs the whole op `iters` times; returns device ns per iteration"""

@@ -6,12 +6,15 @@
 // elapsed DEVICE NANOSECONDS (not cycles), shownStat() prints measured counters in the upstream format.
 // backend = "count" executes nothing (no GPU needed): it only accounts instructions, for the structural
 // parity tests against the compiled reference (tests/golden/structural.json).
+// backend = "sim" keeps what upstream's Arch was: update() advances the build's own cycle model of the reference
+// accelerator (include/SimModel.h) by one cycle, getCycle() returns CYCLES, shownStat() prints the reference's stat block.
 #ifndef HOMULATOR_ARCH_H
 #define HOMULATOR_ARCH_H
 #include "Basic.h"
 #include "Config.h"
 #include "Instruction.h"
 #include "Statistic.h"
+#include "SimModel.h"
 
 struct hm_ctx;
 
@@ -33,7 +36,7 @@ struct InputFill {
 
 class Arch {
 public:
-  enum Backend { BACKEND_HIP = 0, BACKEND_COUNT = 1 };
+  enum Backend { BACKEND_HIP = 0, BACKEND_COUNT = 1, BACKEND_SIM = 2 };
 
   explicit Arch(Config *cfg);
   ~Arch();
@@ -57,6 +60,9 @@ public:
   // constants of a base conversion (host side): qhat_inv[n_in]
   std::vector<uint64_t> bconvScale(const std::vector<uint32_t> &inMods);
   Backend backend() const { return backendKind; }
+  // backend = sim: the literal reference program of the op (host/src/SimProgram.cpp); replaces any earlier one
+  void loadSim(SimProgram &&program);
+  SimModel *simModel() { return sim; }
   hm_ctx *context() { return ctx; }
 
   // ---- the reference's execution surface
@@ -113,6 +119,7 @@ private:
   bool prepared = false;
   unsigned long long completedIns = 0, elapsedNs = 0, algBytes = 0;
   Statistic *stat;
+  SimModel *sim = nullptr;
 
   uint32_t limbOf(AddrType a) const;
   void buildLaunches();

@@ -102,6 +102,8 @@ protected:
   Arch *arch;
   Config *config;
   std::string opName;       // HMULT, HROTATE, ...
+  std::string label;        // constructor label ("test_hmult", ...): part of the rescale buffer names
+  uint32_t maxLevel_, level_, alpha_;
   uint32_t batchSize, N;
   uint64_t seed;
   std::map<std::string, std::vector<AddrType>> namedInputs;   // ct1.c0, ct1.c1, ... for readBuffer
@@ -116,6 +118,9 @@ protected:
 public:
   virtual ~OperationBase();
   bool simulate();   // upstream entry: banner, execute, stat block
+  // backend = sim: run the cycle model to completion without the banner / progress output; false = no instruction retired
+  // for 2000 cycles (upstream's dead-lock exit).  simulate() on the sim backend is this loop plus upstream's stdout.
+  bool simulateCycles(bool verbose = false);
   void prepare();    // issue stages + allocate/fill/fuse (idempotent)
   double execute(uint32_t iters);  // ns per iteration of the whole op (device time)
   std::vector<AddrType> bufferAddrs(const std::string &name) const;  // named buffer (Malloc name, input or output alias)

@@ -12,7 +12,8 @@ extern "C" {
 #endif
 typedef struct hh_op hh_op;
 
-/* op in {hmult, hrotate, hadd, pmult, padd}; backend: 0 = hip, 1 = count (no GPU); fuse: 0/1;
+/* op in {hmult, hrotate, hadd, pmult, padd}; backend: 0 = hip, 1 = count (no GPU), 2 = sim (no GPU: the cycle model of
+ * the reference accelerator, host/include/SimModel.h); fuse: 0/1;
  * extra "key=value" config overrides separated by ';' (may be NULL), e.g. "galois=25;seed=7".
  * quiet != 0 suppresses the constructors' stdout (config echo, Malloc lines). */
 int hh_op_create(hh_op **op, const char *cfg_path, const char *op_name, uint32_t max_level, uint32_t cur_level,
@@ -22,6 +23,11 @@ const char *hh_last_error(void);
 
 int hh_op_simulate(hh_op *op);                              /* upstream entry: prints banner + stat block */
 int hh_op_execute(hh_op *op, uint32_t iters, double *ns_per_iter); /* whole op, device time */
+/* backend = sim: runs the cycle model to completion (silently).  cycles = the reference's "FHE-Sim Total simulated"; retired =
+ * instructions written back; drained = 0 if upstream's dead-lock exit was taken (no instruction retired for 2000 cycles).
+ * hh_op_sim_stats: the reference's stat block as "key value\n" lines, in its order. */
+int hh_op_sim_run(hh_op *op, uint64_t *cycles, uint64_t *retired, int *drained);
+int hh_op_sim_stats(hh_op *op, char *out, uint32_t cap);
 int hh_op_enqueue(hh_op *op, uint32_t iters);               /* asynchronous: no timing, no sync */
 int hh_op_sync(hh_op *op);
 int hh_op_total_instructions(hh_op *op, uint64_t *total);

@@ -37,8 +37,8 @@ Arch::Arch(Config *cfg) : config(cfg) {
   while ((1u << logN) < n) ++logN;
   clusterCount = cfg->getValueOr("cluster", 1);
   uint32_t b = cfg->getValueOr("backend", BACKEND_HIP);
-  if (const char *e = getenv("HOMULATOR_BACKEND")) b = (std::string(e) == "count") ? BACKEND_COUNT : BACKEND_HIP;
-  backendKind = b == BACKEND_COUNT ? BACKEND_COUNT : BACKEND_HIP;
+  if (const char *e = getenv("HOMULATOR_BACKEND")) b = std::string(e) == "count" ? BACKEND_COUNT : std::string(e) == "sim" ? BACKEND_SIM : BACKEND_HIP;
+  backendKind = b == BACKEND_COUNT ? BACKEND_COUNT : b == BACKEND_SIM ? BACKEND_SIM : BACKEND_HIP;
   world_ = cfg->getValueOr("world", 0);
   rank_ = cfg->getValueOr("rank", 0);
   if (world_ == 0) {
@@ -47,7 +47,7 @@ Arch::Arch(Config *cfg) : config(cfg) {
     // when it was given on the command line it must agree with the launcher.
     world_ = 1;
     const char *ws = getenv("WORLD_SIZE"), *rk = getenv("RANK"), *lr = getenv("LOCAL_RANK");
-    if (ws && atoi(ws) > 1 && b != BACKEND_COUNT) {
+    if (ws && atoi(ws) > 1 && b == BACKEND_HIP) {
       world_ = (uint32_t)atoi(ws);
       rank_ = rk ? (uint32_t)atoi(rk) : 0;
       if (lr && !getenv("HOMULATOR_DEVICE")) cfg->setValue("device", (uint32_t)atoi(lr));
@@ -79,6 +79,14 @@ Arch::~Arch() {
   }
   delete static_cast<hm::Params *>(hostParams);
   delete stat;
+  delete sim;
+}
+
+void Arch::loadSim(SimProgram &&program) {
+  if (backendKind != BACKEND_SIM) throw std::runtime_error("loadSim: backend is not sim");
+  delete sim;
+  sim = nullptr;
+  sim = new SimModel(config, std::move(program));
 }
 
 void Arch::commInitRccl(const void *id) {
@@ -889,6 +897,11 @@ void Arch::enqueue(Launch &l) {
 }
 
 void Arch::update() {
+  if (backendKind == BACKEND_SIM) {
+    if (!sim) throw std::runtime_error("sim backend: no program loaded");
+    sim->step();
+    return;
+  }
   if (!prepared) prepare();
   if (nextLaunch >= launches.size()) return;
   Launch &l = *launches[nextLaunch++];
@@ -904,9 +917,9 @@ void Arch::update() {
   completedIns += l.refInstructions;
 }
 
-bool Arch::simulateComplete() { return prepared && nextLaunch >= launches.size(); }
-unsigned long long Arch::getCycle() { return elapsedNs; }
-unsigned long long Arch::getcompletedIns() { return completedIns; }
+bool Arch::simulateComplete() { return sim ? sim->complete() : prepared && nextLaunch >= launches.size(); }
+unsigned long long Arch::getCycle() { return sim ? sim->cycle() : elapsedNs; }
+unsigned long long Arch::getcompletedIns() { return sim ? sim->completedIns() : completedIns; }
 
 void Arch::state() {
   std::cout << "launched " << nextLaunch << " of " << launches.size() << " stages\n";
@@ -914,6 +927,12 @@ void Arch::state() {
 }
 
 void Arch::shownStat() {
+  if (sim) {  // the reference's block: same keys, same order (std::map), same values
+    std::cout << "Start outPut statistic informations:\n";
+    std::cout << "=====================================\n";
+    for (const auto &kv : sim->stats()) std::cout << kv.first << " :\t" << kv.second << "\n";
+    return;
+  }
   stat->setStat("Total_ns", elapsedNs);
   stat->showStat();
 }

@@ -2,6 +2,7 @@
 // reference's src/Operation.cpp, cited per function; the wiring is the mathematically correct one of
 // SURVEY.md Appendix A (upstream only needs shapes, and mislabels several operands: Appendix C).
 #include "Operation.h"
+#include "SimProgram.h"
 
 #include <chrono>
 #include <sstream>
@@ -413,7 +414,7 @@ void Rescale::MulOps() {  // :877-910
 // OperationBase
 // =====================================================================================================
 OperationBase::OperationBase(const std::string &op, Config *cfg, Arch *_arch, uint32_t maxLevel, uint32_t curLevel, uint32_t alpha)
-    : arch(_arch), config(cfg), opName(op) {
+    : arch(_arch), config(cfg), opName(op), maxLevel_(maxLevel), level_(curLevel), alpha_(alpha) {
   insgener = new InsGen(cfg);
   driver = new Driver(cfg);
   batchSize = cfg->getValue("batchSize");
@@ -499,7 +500,62 @@ double OperationBase::execute(uint32_t iters) {
 // reference: HMULT::simulate src/Operation.cpp:1025-1112 (the five simulate() bodies are textual copies).
 // The stdout contract is kept: banner, start time, [progress], completion block, stat
 // block.  There is no per-cycle loop to report on; each update() launches one stage on the GPU.
+// backend = sim: the reference's loop itself (src/Operation.cpp:1046-1087), on the build's own cycle model
+bool OperationBase::simulateCycles(bool verbose) {
+  if (arch->backend() != Arch::BACKEND_SIM) throw std::runtime_error("simulateCycles: backend is not sim");
+  driver->IssueInsFromDramToChip(arch);
+  arch->loadSim(buildSimProgram(opName, label, level_, alpha_, config, *addrManager, namedInputs));
+  const unsigned long long TotalIns = driver->getTotalIns();
+  if (arch->simModel()->totalIns() != TotalIns)
+    throw std::runtime_error("sim backend: literal program has " + std::to_string(arch->simModel()->totalIns()) + " instructions, the stage graph accounts for " + std::to_string(TotalIns));
+  unsigned long long exeInsCycle = 0, traced = ~0ull;
+  const bool trace = getenv("HOMULATOR_SIM_TRACE") != nullptr;  // "<cycle> <retired>" whenever the count moves (oracle/ref_dump.cpp prints the same)
+  time_t periodTime = time(0);
+  while (!arch->simulateComplete()) {
+    driver->IssueDataFromDramToChip();
+    arch->update();
+    const unsigned long long cycle = arch->getCycle();
+    if (trace && arch->getcompletedIns() != traced) {
+      traced = arch->getcompletedIns();
+      std::fprintf(stderr, "%llu %llu\n", cycle, traced);
+    }
+    if (cycle % 2000 == 0) {
+      const unsigned long long exeins = arch->getcompletedIns() - exeInsCycle;
+      if (exeins == 0) {
+        if (verbose) std::cout << "We have executed " << exeins << " instruction(s) in this period!\n";
+        return false;
+      }
+      if (verbose) {
+        std::cout << "\nFHE-Sim running " << cycle << " cycles!\n";
+        std::cout << "We have executed " << arch->getcompletedIns() << " instructions!\n";
+        const unsigned long long remainIns = TotalIns - arch->getcompletedIns();
+        std::cout << "Remaining " << remainIns << " instructions!\n";
+        std::cout << "We have executed " << exeins << " instruction(s) in this period!\n";
+        const time_t nowTime = time(0);
+        const double speed = static_cast<double>(exeins) / (nowTime - periodTime);
+        std::cout << "Estimated time remaining " << static_cast<double>(remainIns) / speed / 60 << " minutes\n";
+        periodTime = nowTime;
+      }
+      exeInsCycle = arch->getcompletedIns();
+    }
+  }
+  return true;
+}
+
 bool OperationBase::simulate() {
+  if (arch->backend() == Arch::BACKEND_SIM) {
+    std::cout << "\n\nWelcome! Start simulating " << opName << "!\n\n";
+    time_t t0 = time(0);
+    std::cout << "Start time: " << ctime(&t0) << std::endl;
+    simulateCycles(true);
+    time_t t1 = time(0);
+    std::cout << "\n\nCompleted Simulate!\n";
+    std::cout << "FHE-Sim Total simulated\t" << arch->getCycle() << " cycles!\n\n";
+    std::cout << "End time: " << ctime(&t1) << std::endl;
+    std::cout << "The simulator total cost\t" << static_cast<double>(t1 - t0) / 60 << " Minutes!\n";
+    arch->shownStat();
+    return true;
+  }
   driver->IssueInsFromDramToChip(arch);
   const unsigned long long TotalIns = driver->getTotalIns();
   std::cout << "\n\nWelcome! Start simulating " << opName << "!\n\n";
@@ -532,6 +588,7 @@ bool OperationBase::simulate() {
 // reference: HMULT::HMULT :913-1023.  Wiring: KS(d2); out0 = d0 + ks0; out1 = d1 + ks1 (Appendix C item 1)
 HMULT::HMULT(std::string labelName, uint32_t maxLevel, uint32_t currentLevel, uint32_t alpha, Config *cfg, Arch *_arch)
     : OperationBase("HMULT", cfg, _arch, maxLevel, currentLevel, alpha) {
+  label = labelName;
   c1 = new Ciphertext(currentLevel, N, Datapool, batchSize);
   c2 = new Ciphertext(currentLevel, N, Datapool, batchSize);
   inputCiphertext("ct1", c1, seed);
@@ -574,6 +631,7 @@ HMULT::HMULT(std::string labelName, uint32_t maxLevel, uint32_t currentLevel, ui
 // (Appendix C item 2).  The Galois element is the config key `galois` (default 5 = rotation by one slot).
 HROTATE::HROTATE(std::string labelName, uint32_t maxLevel, uint32_t currentLevel, uint32_t alpha, Config *cfg, Arch *_arch)
     : OperationBase("HROTATE", cfg, _arch, maxLevel, currentLevel, alpha) {
+  label = labelName;
   ciph = new Ciphertext(currentLevel, N, Datapool, batchSize);
   inputCiphertext("ct1", ciph, seed);
   addrManager = new AddrManage(Datapool.back() + 1, batchSize);
@@ -613,6 +671,7 @@ HROTATE::HROTATE(std::string labelName, uint32_t maxLevel, uint32_t currentLevel
 // reference: HADD::HADD :1114-1176
 HADD::HADD(std::string labelName, uint32_t maxLevel, uint32_t currentLevel, uint32_t alpha, Config *cfg, Arch *_arch)
     : OperationBase("HADD", cfg, _arch, maxLevel, currentLevel, alpha) {
+  label = labelName;
   c1 = new Ciphertext(currentLevel, N, Datapool, batchSize);
   c2 = new Ciphertext(currentLevel, N, Datapool, batchSize);
   inputCiphertext("ct1", c1, seed);
@@ -635,6 +694,7 @@ HADD::HADD(std::string labelName, uint32_t maxLevel, uint32_t currentLevel, uint
 // reference: PMULT::PMULT :1460-1523
 PMULT::PMULT(std::string labelName, uint32_t maxLevel, uint32_t currentLevel, uint32_t alpha, Config *cfg, Arch *_arch)
     : OperationBase("PMULT", cfg, _arch, maxLevel, currentLevel, alpha) {
+  label = labelName;
   ctx = new Ciphertext(currentLevel, N, Datapool, batchSize);
   ptx = new Plaintext(currentLevel, N, Datapool, batchSize);
   inputCiphertext("ct1", ctx, seed);
@@ -657,6 +717,7 @@ PMULT::PMULT(std::string labelName, uint32_t maxLevel, uint32_t currentLevel, ui
 // reference: PADD::PADD :1625-1680 (upstream adds the plaintext to both components; only c0 takes it)
 PADD::PADD(std::string labelName, uint32_t maxLevel, uint32_t currentLevel, uint32_t alpha, Config *cfg, Arch *_arch)
     : OperationBase("PADD", cfg, _arch, maxLevel, currentLevel, alpha) {
+  label = labelName;
   ctx = new Ciphertext(currentLevel, N, Datapool, batchSize);
   ptx = new Plaintext(currentLevel, N, Datapool, batchSize);
   inputCiphertext("ct1", ctx, seed);

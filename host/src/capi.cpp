@@ -70,6 +70,15 @@ void hh_op_destroy(hh_op *h) {
   delete h;
 }
 int hh_op_simulate(hh_op *h) { HH_TRY(h->op->simulate()) }
+int hh_op_sim_run(hh_op *h, uint64_t *cycles, uint64_t *retired, int *drained) {
+  HH_TRY(const bool ok = h->op->simulateCycles(false); if (cycles) *cycles = h->arch->getCycle(); if (retired) *retired = h->arch->getcompletedIns();
+         if (drained) *drained = ok ? 1 : 0)
+}
+int hh_op_sim_stats(hh_op *h, char *out, uint32_t cap) {
+  HH_TRY(if (!h->arch->simModel()) throw std::runtime_error("no cycle model: backend is not sim, or hh_op_sim_run was not called");
+         std::string s; for (const auto &kv : h->arch->simModel()->stats()) s += kv.first + " " + std::to_string(kv.second) + "\n";
+         if (s.size() + 1 > cap) throw std::runtime_error("buffer too small"); std::memcpy(out, s.c_str(), s.size() + 1))
+}
 int hh_op_execute(hh_op *h, uint32_t iters, double *ns) { HH_TRY(double t = h->op->execute(iters); if (ns) *ns = t) }
 int hh_op_enqueue(hh_op *h, uint32_t iters) { HH_TRY(h->op->prepare(); for (uint32_t i = 0; i < iters; ++i) h->arch->run()) }
 int hh_op_sync(hh_op *h) { HH_TRY(h->arch->sync()) }

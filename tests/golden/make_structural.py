@@ -7,6 +7,15 @@ The fixture is DATA: per (cfg, op, L, l, alpha) the `Malloc <name> from <a> to <
 instruction count (executed + remaining of the first progress block, = Driver::getTotalIns(),
 include/Driver.h:370), the simulated cycle count (src/Operation.cpp:1095) and the stat block keys.
 Also the usage / unknown-op messages and exit codes of bench_test/bench_micro24.cpp:5-52.
+
+Every complete point is run twice: stock, and with MALLOC_PERTURB_=85 (`cycles_clean`, `stats_clean`).  The reference's
+scoreboard reads operands 1 and 2 of every instruction (include/recodeboard.h:33-46), which single-operand NTT / AUTO
+instructions do not have (include/Instruction.h:59-74): those reads return whatever the allocator left behind, sometimes
+a live line address, and then stall the instruction (seen with oracle/ref_dump.cpp probe: hrotate 16 10 4, cluster 3,
+AUTO batch 124 waits 7 cycles on the stale out-address of batch 88).  With glibc's MALLOC_PERTURB_ the stale bytes can no
+longer look like an address; the stock and the perturbed run agree everywhere except where that accident happens
+(hrotate 8 8 8: 9956 vs 9748 cycles; four counters of hrotate 16 10 4).  The `sim` backend is held to the clean numbers.
+`sim_points` are extra cycle-model points (other cluster counts through argv[6], N = 2^16, uneven digits).
 """
 import json, os, re, subprocess, sys, time
 
@@ -27,10 +36,26 @@ POINTS = [  # (cfg, op, L, l, alpha, run_to_completion)
 ]
 
 
-def run_point(cfg, op, L, l, a, complete):
+SIM_POINTS = [  # (cfg, op, L, l, alpha, cluster or None)
+    ("config_4_N15.cfg", "hmult", 12, 9, 4, None), ("config_4_N15.cfg", "hrotate", 12, 9, 4, 2),
+    ("config_4_N15.cfg", "hmult", 6, 4, 2, 8), ("config_4_N15.cfg", "hmult", 6, 5, 3, 1),
+    ("config_4_N15.cfg", "hrotate", 6, 5, 3, 8), ("config_4_N15.cfg", "pmult", 4, 3, 2, 3),
+    ("config_4_N15.cfg", "hadd", 4, 3, 2, 2), ("config_4_N15.cfg", "padd", 6, 6, 2, None),
+    ("config_4.cfg", "hmult", 4, 2, 2, None), ("config_4.cfg", "hrotate", 4, 3, 2, None),
+    ("config_4.cfg", "hmult", 6, 4, 2, 2),
+]
+
+
+def run_point(cfg, op, L, l, a, complete, cluster=None, perturb=None):
     cmd = ["stdbuf", "-oL", REF_BIN, os.path.join(REF_CFG, cfg), op, str(L), str(l), str(a)]
+    if cluster is not None:
+        cmd.append(str(cluster))
+    env = dict(os.environ)
+    env.pop("MALLOC_PERTURB_", None)
+    if perturb is not None:
+        env["MALLOC_PERTURB_"] = str(perturb)
     t0 = time.time()
-    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env)
     lines = []
     for line in p.stdout:
         lines.append(line.rstrip("\n"))
@@ -40,6 +65,8 @@ def run_point(cfg, op, L, l, a, complete):
     p.wait()
     out = "\n".join(lines)
     rec = {"cfg": cfg, "op": op, "L": L, "l": l, "alpha": a, "complete": complete}
+    if cluster is not None:
+        rec["cluster"] = cluster
     rec["malloc"] = [ln for ln in lines if ln.startswith("Malloc ")]
     ex = re.search(r"We have executed (\d+) instructions!\nRemaining (\d+) instructions!", out)
     rec["total_instructions"] = int(ex.group(1)) + int(ex.group(2)) if ex else None
@@ -66,8 +93,20 @@ def main():
            "points": []}
     for pt in POINTS:
         rec = run_point(*pt)
-        print(pt, "->", rec["total_instructions"], rec["cycles"], f"{rec['wall_s']}s", flush=True)
+        if pt[5]:
+            clean = run_point(*pt, perturb=85)
+            rec["cycles_clean"], rec["stats_clean"] = clean["cycles"], clean["stats"]
+        print(pt, "->", rec["total_instructions"], rec["cycles"], rec.get("cycles_clean"), f"{rec['wall_s']}s", flush=True)
         out["points"].append(rec)
+    out["sim_points"] = []
+    for cfg, op, L, l, a, cluster in SIM_POINTS:
+        rec = run_point(cfg, op, L, l, a, True, cluster=cluster)
+        clean = run_point(cfg, op, L, l, a, True, cluster=cluster, perturb=85)
+        rec = {k: rec[k] for k in ("cfg", "op", "L", "l", "alpha", "total_instructions", "cycles", "stats", "wall_s")}
+        rec["cluster"] = cluster
+        rec["cycles_clean"], rec["stats_clean"] = clean["cycles"], clean["stats"]
+        print((cfg, op, L, l, a, cluster), "->", rec["total_instructions"], rec["cycles"], rec["cycles_clean"], f"{rec['wall_s']}s", flush=True)
+        out["sim_points"].append(rec)
     # CLI contract
     r = subprocess.run([REF_BIN], capture_output=True, text=True)
     out["usage"] = {"stderr": r.stderr, "stdout": r.stdout, "rc": r.returncode}

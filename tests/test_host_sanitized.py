@@ -52,6 +52,31 @@ def test_host_layer_under_asan_ubsan():
     assert "plans built" in out.stdout and "runtime error" not in out.stderr and "AddressSanitizer" not in out.stderr, out.stderr[-4000:]
 
 
+SIM_SCRIPT = r"""
+import sys
+sys.path.insert(0, %r)
+from homulator_amd import host
+want = {("hmult", 4, 3, 2, None): 4775, ("hrotate", 6, 4, 2, None): 3455, ("hadd", 16, 10, 4, None): 1296, ("hmult", 6, 4, 2, 8): 4487, ("pmult", 4, 3, 2, 3): 400}
+for (opn, L, ell, alpha, cluster), cycles in want.items():
+    op = host.Op("config_4_N15.cfg", opn, L, ell, alpha, backend=host.BACKEND_SIM, overrides={"cluster": cluster} if cluster else None)
+    r = op.sim_run()
+    assert r["drained"] and r["cycles"] == cycles, (opn, L, ell, alpha, cluster, r["cycles"])
+    op.close()
+print("sanitized cycle model: %%d points" %% len(want))
+""" % ROOT
+
+
+def test_cycle_model_under_asan_ubsan():
+    """backend = sim (host/src/SimModel.cpp, SimProgram.cpp): dense address-indexed arrays, ring-buffer pipelines and queue cursors,
+    run under the sanitizers on points whose cycle counts the compiled reference fixes"""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "host"), "asan"], stdout=subprocess.DEVNULL)
+    env = _asan_env(HOMULATOR_HOST_LIB=os.path.join(ROOT, "host", "lib", "libhomulator_host_asan.so"))
+    env.pop("HOMULATOR_BACKEND", None)
+    out = subprocess.run([sys.executable, "-c", SIM_SCRIPT], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-6000:]
+    assert "5 points" in out.stdout and "runtime error" not in out.stderr and "AddressSanitizer" not in out.stderr, out.stderr[-4000:]
+
+
 ORACLE_SCRIPT = r"""
 import sys
 sys.path.insert(0, %r)
