@@ -281,6 +281,15 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(opn)
+        try:  # the reference's own answer for the same command line, from the build's cycle model (backend = sim): host only
+            t0 = time.time()
+            sim_op = host.Op(CFG, opn, L, ELL, ALPHA, backend=host.BACKEND_SIM)
+            sim = sim_op.sim_run()
+            sim_op.close()
+            out["reference_model"] = {"cycles": sim["cycles"], "instructions": sim["retired"], "drained": sim["drained"], "host_seconds": round(time.time() - t0, 2),
+                                      "note": "simulated accelerator of the .cfg (4 clusters): what the reference simulator prints for this op; not a GPU measurement"}
+        except Exception as e:  # never let the side figure take the bench line down
+            out["reference_model"] = {"error": str(e)[:200]}
     for o in ops:
         o.close()
     if tail_op is not None:

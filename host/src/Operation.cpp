@@ -797,6 +797,12 @@ double OpChain::execute(uint32_t iters) {
   return std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t0).count() / (iters ? iters : 1);
 }
 bool OpChain::simulate() {
+  if (!archs.empty() && archs[0]->backend() == Arch::BACKEND_SIM) {  // the reference cannot chain: every op is simulated on its own
+    unsigned long long cycles = 0;
+    for (size_t i = 0; i < ops.size(); ++i) { ops[i]->simulate(); cycles += archs[i]->getCycle(); }
+    std::cout << "\nChain of " << ops.size() << " operations, simulated one by one: " << cycles << " cycles in total\n";
+    return true;
+  }
   prepare();
   for (auto *o : ops) o->simulate();
   const double ns = execute(20);
