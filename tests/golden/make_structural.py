@@ -16,6 +16,8 @@ AUTO batch 124 waits 7 cycles on the stale out-address of batch 88).  With glibc
 longer look like an address; the stock and the perturbed run agree everywhere except where that accident happens
 (hrotate 8 8 8: 9956 vs 9748 cycles; four counters of hrotate 16 10 4).  The `sim` backend is held to the clean numbers.
 `sim_points` are extra cycle-model points (other cluster counts through argv[6], N = 2^16, uneven digits).
+`slow_points` (parameter set A at levels 10 / 12 / 20 / 28: 17 to 55 minutes of reference time EACH, clean run only) are
+regenerated only with `--slow`; a normal run keeps the entries the file already has.
 """
 import json, os, re, subprocess, sys, time
 
@@ -86,9 +88,15 @@ def run_point(cfg, op, L, l, a, complete, cluster=None, perturb=None):
     return rec
 
 
+SLOW_POINTS = [("config_4_N15.cfg", "hmult", 28, 10, 28), ("config_4_N15.cfg", "hrotate", 28, 12, 28),
+               ("config_4_N15.cfg", "hrotate", 28, 20, 28), ("config_4_N15.cfg", "hmult", 28, 28, 28)]
+
+
 def main():
     if not os.path.exists(REF_BIN):
         sys.exit("build the reference first: make -C oracle ref")
+    path = os.path.join(os.path.dirname(__file__), "structural.json")
+    previous = json.load(open(path)) if os.path.exists(path) else {}
     out = {"generated_by": "tests/golden/make_structural.py", "reference_build": "g++ -std=c++17 -O2 (oracle/Makefile: ref)",
            "points": []}
     for pt in POINTS:
@@ -112,7 +120,16 @@ def main():
     out["usage"] = {"stderr": r.stderr, "stdout": r.stdout, "rc": r.returncode}
     r = subprocess.run([REF_BIN, os.path.join(REF_CFG, "config_4_N15.cfg"), "bogus", "4", "2", "2"], capture_output=True, text=True)
     out["unknown_op"] = {"stdout_tail": r.stdout.splitlines()[-1], "rc": r.returncode}
-    with open(os.path.join(os.path.dirname(__file__), "structural.json"), "w") as f:
+    if "--slow" in sys.argv:
+        out["slow_points"] = []
+        for cfg, op, L, l, a in SLOW_POINTS:
+            clean = run_point(cfg, op, L, l, a, True, perturb=85)
+            out["slow_points"].append({"cfg": cfg, "op": op, "L": L, "l": l, "alpha": a, "cluster": None, "total_instructions": clean["total_instructions"],
+                                       "cycles_clean": clean["cycles"], "stats_clean": clean["stats"], "reference_minutes": round(clean["wall_s"] / 60)})
+            print((cfg, op, L, l, a), "->", clean["cycles"], f"{clean['wall_s']}s", flush=True)
+    else:
+        out["slow_points"] = previous.get("slow_points", [])
+    with open(path, "w") as f:
         json.dump(out, f, indent=1)
 
 
