@@ -27,6 +27,7 @@ def load():
         L.hh_last_error.restype = C.c_char_p
         L.hh_op_simulate.argtypes = [vp]
         L.hh_op_execute.argtypes = [vp, u32, C.POINTER(C.c_double)]
+        L.hh_op_write_buffer.argtypes = [vp, C.c_char_p, u32, vp]
         L.hh_op_sim_run.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
         L.hh_op_sim_stats.argtypes = [vp, C.c_char_p, u32]
         L.hh_op_enqueue.argtypes = [vp, u32]
@@ -125,6 +126,15 @@ class Op:
 
     def simulate(self):
         self._ck(self.L.hh_op_simulate(self.h))
+
+    def write(self, name, data, copy=0):
+        """upload real data ([n_limbs][N] uint64, fully reduced, evaluation form) into a named input / key buffer"""
+        n = C.c_uint32()
+        self._ck(self.L.hh_op_buffer_limbs(self.h, name.encode(), C.byref(n)))
+        a = np.ascontiguousarray(data, dtype=np.uint64)
+        if a.shape != (n.value, self.N):
+            raise HostError(f"{name}: expected shape {(n.value, self.N)}, got {a.shape}")
+        self._ck(self.L.hh_op_write_buffer(self.h, name.encode(), copy, a.ctypes.data_as(C.c_void_p)))
 
     def sim_run(self):
         """backend = BACKEND_SIM: run the cycle model of the reference accelerator to completion.

@@ -80,6 +80,7 @@ public:
   void sync();
   double timedRun(uint32_t iters);      // ns per iteration, device time
   bool readLimbs(const std::vector<AddrType> &addrs, uint64_t *host, uint32_t copy = 0);  // download limbs (N words each) of op `copy` of the batch
+  bool writeLimbs(const std::vector<AddrType> &addrs, const uint64_t *host, uint32_t copy = 0);  // upload limbs (real ciphertexts / keys); shared key limbs live in copy 0
   // asynchronous helpers on the op's stream (tests of the chain ordering, streaming callers):
   void refill(const std::vector<AddrType> &addrs, uint64_t seed);              // new synthetic input data (all ops of the batch)
   void snapshot(const std::vector<AddrType> &addrs, uint32_t slot);             // device-side copy of the limbs as they are NOW in stream order

@@ -125,6 +125,7 @@ public:
   double execute(uint32_t iters);  // ns per iteration of the whole op (device time)
   std::vector<AddrType> bufferAddrs(const std::string &name) const;  // named buffer (Malloc name, input or output alias)
   bool readBuffer(const std::string &name, uint64_t *host, uint32_t copy = 0);  // copy: op of the batch (config key `batch`)
+  bool writeBuffer(const std::string &name, const uint64_t *host, uint32_t copy = 0);  // real data for an input / key buffer ([limbs][N], fully reduced)
   unsigned long long totalInstructions();
   Arch *getArch() { return arch; }
   std::vector<std::string> bufferNames() const;

@@ -39,6 +39,9 @@ int hh_op_buffer_names(hh_op *op, char *out, uint32_t cap); /* '\n'-separated */
 uint32_t hh_op_N(hh_op *op);
 /* overrides "batch=B": every launch carries B independent ops (own inputs: fill seeds + copy * 100000; shared evaluation key) */
 int hh_op_read_buffer_copy(hh_op *op, const char *name, uint32_t copy, uint64_t *host);
+/* real data in: overwrite a named input / key buffer ([n_limbs][N] words, fully reduced, evaluation form) of op `copy` of the batch; the
+ * evaluation-key limbs ("IP_Key<k>_<j>", shared by the batch) live in copy 0.  Prepares the op if needed; synchronises. */
+int hh_op_write_buffer(hh_op *op, const char *name, uint32_t copy, const uint64_t *host);
 uint32_t hh_op_batch(hh_op *op);
 int hh_op_plan(hh_op *op, char *out, uint32_t cap);          /* launch plan, one line per launch */
 int hh_op_stage_times(hh_op *op, uint32_t iters, char *out, uint32_t cap); /* "<kind> <stages> <ns>" per launch, each timed alone */

@@ -1015,6 +1015,14 @@ bool Arch::readSnapshot(uint32_t slot, uint64_t *host) {
   return hm_memcpy_d2h(ctx, host, it->second.first, it->second.second * (size_t)n * 8) == HM_OK;
 }
 
+// real data in: overwrites limb-polys (inputs, evaluation-key limbs) after prepare(); stream-ordered after everything enqueued so far
+bool Arch::writeLimbs(const std::vector<AddrType> &addrs, const uint64_t *host, uint32_t copy) {
+  if (backendKind != BACKEND_HIP || !pool || copy >= batch_) return false;
+  sync();
+  for (size_t i = 0; i < addrs.size(); ++i)
+    if (hm_memcpy_h2d(ctx, pool + ((size_t)limbOf(addrs[i]) + (size_t)copy * limbIndex.size()) * n, host + i * n, (size_t)n * 8) != HM_OK) return false;
+  return true;
+}
 bool Arch::readLimbs(const std::vector<AddrType> &addrs, uint64_t *host, uint32_t copy) {
   if (backendKind != BACKEND_HIP || !pool || copy >= batch_) return false;
   for (size_t i = 0; i < addrs.size(); ++i)

@@ -472,6 +472,7 @@ std::vector<std::string> OperationBase::bufferNames() const {
   return v;
 }
 bool OperationBase::readBuffer(const std::string &name, uint64_t *host, uint32_t copy) { return arch->readLimbs(bufferAddrs(name), host, copy); }
+bool OperationBase::writeBuffer(const std::string &name, const uint64_t *host, uint32_t copy) { prepare(); return arch->writeLimbs(bufferAddrs(name), host, copy); }
 unsigned long long OperationBase::totalInstructions() { prepare(); return driver->getTotalIns(); }
 void OperationBase::bindInput(const std::string &input, OperationBase *producer) {
   for (const char *part : {".c0", ".c1"}) {

@@ -96,6 +96,9 @@ int hh_op_buffer_names(hh_op *h, char *out, uint32_t cap) {
 int hh_op_read_buffer_copy(hh_op *h, const char *name, uint32_t copy, uint64_t *host) {
   HH_TRY(if (!h->op->readBuffer(name, host, copy)) throw std::runtime_error("buffer not readable (count backend, not prepared, or copy >= batch)"))
 }
+int hh_op_write_buffer(hh_op *h, const char *name, uint32_t copy, const uint64_t *host) {
+  HH_TRY(if (!h->op->writeBuffer(name, host, copy)) throw std::runtime_error("buffer not writable (not the hip backend, or copy >= batch)"))
+}
 uint32_t hh_op_batch(hh_op *h) { return h->arch->batch(); }
 uint32_t hh_op_N(hh_op *h) { return h->arch->N(); }
 int hh_op_plan(hh_op *h, char *out, uint32_t cap) {
