@@ -92,3 +92,31 @@ def test_hrotate_on_uploaded_ciphertext_decrypts_to_the_rotation(toy):
     got, _ = toy.decrypt(out, ELL)
     exp = toy.automorph(m, g)
     assert max(abs(int(a) - int(b)) for a, b in zip(got, exp)) < 1 << 16  # measured: 2^11 against a signal of 2^40
+
+
+def test_chain_on_real_data_multiplies_then_rotates(toy):
+    """continuous execution on real data: hmult (relinearisation key) -> hrotate (rotation key), the ciphertext never leaves HBM;
+    the result decrypts to sigma_5(m1 m2 / q_last)"""
+    o = toy.o
+    n, g = o.N, 5
+    s2 = negacyclic_small(np.array([int(x) for x in toy.s]), np.array([int(x) for x in toy.s])).astype(object)
+    relin = toy.evk_at_level(toy.gen_evk(s2), ELL)
+    rot = toy.evk_at_level(toy.gen_evk(toy.automorph(toy.s, g)), ELL - 1)
+    a1, a2 = toy.rng.integers(-50, 50, n), toy.rng.integers(-50, 50, n)
+    ct1 = toy.encrypt(a1.astype(object) * (1 << 40), ELL)
+    ct2 = toy.encrypt(a2.astype(object) * (1 << 40), ELL)
+    chain = host.Chain("config_4_N15.cfg", "hmult,hrotate", L, ELL, ALPHA, overrides=dict(OV, galois=g))
+    for name, data in (("ct1.c0", ct1[0]), ("ct1.c1", ct1[1]), ("ct2.c0", ct2[0]), ("ct2.c1", ct2[1])):
+        chain[0].write(name, data)
+    upload_keys(chain[0], relin)
+    upload_keys(chain[1], rot)
+    chain.execute(1)
+    out = np.stack([chain[1].read("out.c0"), chain[1].read("out.c1")])
+    chain.close()
+    exp_ct = o.hrotate(ELL - 1, o.hmult(ELL, ct1, ct2, relin, rescale=True), g, rot)
+    assert np.array_equal(out[0], exp_ct[0]) and np.array_equal(out[1], exp_ct[1])
+    got, _ = toy.decrypt(out, ELL - 1)
+    ql = o.moduli[ELL - 1]
+    exp = toy.automorph(negacyclic_small(a1, a2).astype(object) * (1 << 80), g)
+    err = max(abs(int(x) * ql - int(e)) for x, e in zip(got, exp))
+    assert err < ql << 14, err.bit_length()
