@@ -53,6 +53,9 @@ public:
   unsigned long long totalIns() const { return total_; }
   // the stat block in the reference's key set, order and (32-bit, first-increment-stores-1) arithmetic
   std::map<std::string, uint32_t> stats() const;
+  // what is stuck where (printed at upstream's dead-lock exit instead of its Arch::state dump): per cluster the instructions still
+  // queued per unit, in flight per unit, free scratchpad lines, FIFO fills and DRAM lines not yet fetched
+  std::string describe() const;
 
 private:
   struct Impl;

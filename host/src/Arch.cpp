@@ -922,6 +922,7 @@ unsigned long long Arch::getCycle() { return sim ? sim->cycle() : elapsedNs; }
 unsigned long long Arch::getcompletedIns() { return sim ? sim->completedIns() : completedIns; }
 
 void Arch::state() {
+  if (sim) { std::cout << sim->describe(); return; }
   std::cout << "launched " << nextLaunch << " of " << launches.size() << " stages\n";
   if (nextLaunch < launches.size()) std::cout << "next: " << launches[nextLaunch]->name << "\n";
 }

@@ -523,7 +523,11 @@ bool OperationBase::simulateCycles(bool verbose) {
     if (cycle % 2000 == 0) {
       const unsigned long long exeins = arch->getcompletedIns() - exeInsCycle;
       if (exeins == 0) {
-        if (verbose) std::cout << "We have executed " << exeins << " instruction(s) in this period!\n";
+        if (verbose) {
+          std::cout << "We have executed " << exeins << " instruction(s) in this period!\n";
+          arch->state();
+          std::cout << "\n";
+        }
         return false;
       }
       if (verbose) {

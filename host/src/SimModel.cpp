@@ -449,3 +449,20 @@ std::map<std::string, uint32_t> SimModel::stats() const {
   put("NoC_Mem_Chip", m->stNoC);
   return out;
 }
+
+std::string SimModel::describe() const {
+  std::string out;
+  for (uint32_t c = 0; c < m->C; c++) {
+    const Cluster &k = m->cl[c];
+    size_t convLeft = 0, convFlight = 0;
+    for (const Slot &s : k.conv) { convLeft = std::max(convLeft, m->prog.bconv[c].size() - s.cursor); convFlight += s.inflight.size() - s.inflightHead; }
+    out += "cluster " + std::to_string(c) + ": queued EWE " + std::to_string(m->prog.ewe[c].size() - k.eweCursor) + " NTT " +
+           std::to_string(m->prog.ntt[c].size() - k.nttCursor) + " AUTO " + std::to_string(m->prog.aut[c].size() - k.autoCursor) +
+           " BCONV groups " + std::to_string(convLeft) + "; in flight EWE " + std::to_string(k.flightEWE) + " NTT " + std::to_string(k.flightNTT) +
+           " AUTO " + std::to_string(k.flightAUTO) + " BCONV " + std::to_string(convFlight) + "; free scratchpad lines " + std::to_string(k.freeLines) +
+           "; FIFOs units " + std::to_string(k.fromUnits.size()) + "/" + std::to_string(m->depthUnits) + " NoC " + std::to_string(k.fromNoC.size()) + "/" +
+           std::to_string(m->depthNoC) + " DRAM " + std::to_string(k.fromDram.size()) + "/" + std::to_string(m->depthDram) + "; DRAM lines to fetch " +
+           std::to_string(m->prog.dram[c].size() - k.dramCursor) + "\n";
+  }
+  return out;
+}
