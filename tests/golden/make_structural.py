@@ -17,7 +17,7 @@ longer look like an address; the stock and the perturbed run agree everywhere ex
 (hrotate 8 8 8: 9956 vs 9748 cycles; four counters of hrotate 16 10 4).  The `sim` backend is held to the clean numbers.
 `sim_points` are extra cycle-model points (other cluster counts through argv[6], N = 2^16, uneven digits).
 `slow_points` (parameter set A at levels 10 / 12 / 20 / 28: 17 to 55 minutes of reference time EACH, and the headline
-configuration `config_4.cfg hrotate 45 35 15`: 149 minutes; clean run only) are
+configurations `config_4.cfg hrotate / hmult 45 35 15`: 149 and 198 minutes; clean run only) are
 regenerated only with `--slow`; a normal run keeps the entries the file already has.
 """
 import json, os, re, subprocess, sys, time
@@ -91,7 +91,7 @@ def run_point(cfg, op, L, l, a, complete, cluster=None, perturb=None):
 
 SLOW_POINTS = [("config_4_N15.cfg", "hmult", 28, 10, 28), ("config_4_N15.cfg", "hrotate", 28, 12, 28),
                ("config_4_N15.cfg", "hrotate", 28, 20, 28), ("config_4_N15.cfg", "hmult", 28, 28, 28),
-               ("config_4.cfg", "hrotate", 45, 35, 15)]  # BASELINE config #4 at full size: 149 minutes of reference time
+               ("config_4.cfg", "hrotate", 45, 35, 15), ("config_4.cfg", "hmult", 45, 35, 15)]  # BASELINE configs #4 / #3 at full size: 149 and 198 minutes
 
 
 def main():
