@@ -287,7 +287,7 @@ def main():
             sim = sim_op.sim_run()
             sim_op.close()
             out["reference_model"] = {"cycles": sim["cycles"], "instructions": sim["retired"], "drained": sim["drained"], "host_seconds": round(time.time() - t0, 2),
-                                      "note": "simulated accelerator of the .cfg (4 clusters): what the reference simulator prints for this op; not a GPU measurement"}
+                                      "note": "simulated accelerator of the .cfg (4 clusters): what the reference simulator prints for this op (its own run of this configuration took 3 h 18 min and gave the same cycles and counters: tests/golden/structural.json slow_points); not a GPU measurement"}
         except Exception as e:  # never let the side figure take the bench line down
             out["reference_model"] = {"error": str(e)[:200]}
     for o in ops:
