@@ -233,6 +233,8 @@ def main():
         single = args.steps / (time.perf_counter() - t1)
     # per-launch device time of one op, each launch bracketed by its own event pair (collective when sharded)
     stage_rows = (tail_op if tail_op is not None else op).stage_times(5)   # sharded: of one batch
+    # the same at the launch shape of the timed region (batch ops per launch), for the in-op roofline figure
+    batched_rows = ops[0].stage_times(3) if world == 1 and batch > 1 else None
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -276,6 +278,13 @@ def main():
                              "floor_us": valu_floor_ns * 1e-3, "frac": valu_floor_ns / ntt_ns, "unit": "wave-butterflies/ns",
                              "achieved": BFLY_PER_LIMB_NTT / 64 * sweep_limbs / ntt_ns, "peak": 1.0 / wb_ns,
                              "source": rin.get("wave_butterfly_source")},
+                         "in_op": None if not batched_rows else (lambda ns, limbs: {
+                             "kernel": "the ModUp forward transforms as the timed region launches them (k_ntt_col + k_ntt_row), timed alone with HIP events on the op's stream",
+                             "limbs_per_launch_group": limbs, "us": ns * 1e-3, "us_per_limb": ns * 1e-3 / limbs,
+                             "achieved": NTT_ALG_BYTES * limbs / ns, "frac": NTT_ALG_BYTES * limbs / ns / HBM_PEAK_GBS,
+                             "valu_frac": None if not wb_ns else wb_ns * BFLY_PER_LIMB_NTT / 64 * limbs / ns})(
+                             [r[2] for r in batched_rows if r[0] == "NTT"][0],
+                             sum(ELL + ALPHA - min(ALPHA, ELL - j * ALPHA) for j in range(-(-ELL // ALPHA))) * batch),  # sum over digits of (E - d_j) = 115 limbs per op
                          "note": "`achieved`/`peak`/`frac` are the HBM figures of the task's contract; `bound` names the ceiling "
                                  "with the larger floor for this launch (the 64-bit modular butterflies are integer VALU work)"},
         }
