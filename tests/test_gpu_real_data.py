@@ -120,3 +120,22 @@ def test_chain_on_real_data_multiplies_then_rotates(toy):
     exp = toy.automorph(negacyclic_small(a1, a2).astype(object) * (1 << 80), g)
     err = max(abs(int(x) * ql - int(e)) for x, e in zip(got, exp))
     assert err < ql << 14, err.bit_length()
+
+
+def test_uploads_address_the_ops_of_a_batch(toy):
+    """batch = 2: copy 0 and copy 1 carry different uploaded ciphertexts, share the uploaded key (copy 0), and each equals the oracle"""
+    o = toy.o
+    s2 = negacyclic_small(np.array([int(x) for x in toy.s]), np.array([int(x) for x in toy.s])).astype(object)
+    evk = toy.evk_at_level(toy.gen_evk(s2), ELL)
+    cts = [(toy.encrypt((toy.rng.integers(-9, 9, o.N).astype(object) * (1 << 40)), ELL), toy.encrypt((toy.rng.integers(-9, 9, o.N).astype(object) * (1 << 40)), ELL))
+           for _ in range(2)]
+    op = host.Op("config_4_N15.cfg", "hmult", L, ELL, ALPHA, overrides=dict(OV, batch=2))
+    for c, (a, b) in enumerate(cts):
+        for name, data in (("ct1.c0", a[0]), ("ct1.c1", a[1]), ("ct2.c0", b[0]), ("ct2.c1", b[1])):
+            op.write(name, data, copy=c)
+    upload_keys(op, evk)
+    op.execute(1)
+    for c, (a, b) in enumerate(cts):
+        exp = o.hmult(ELL, a, b, evk, rescale=True)
+        assert np.array_equal(op.read("out.c0", copy=c), exp[0]) and np.array_equal(op.read("out.c1", copy=c), exp[1]), c
+    op.close()
