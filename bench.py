@@ -265,6 +265,8 @@ def main():
             "single_stream_ops_per_s": single,
             "stage_us": [[kind, name, round(ns * 1e-3, 2)] for kind, name, ns in stage_rows],
             "exchange_us_per_op": round(sum(ns for kind, _, ns in stage_rows if kind in ("EXCH_IN", "EXCH_OUT", "REPLICATE")) * 1e-3 / (batch if world > 1 else 1), 2),
+            "exchange_overlap": {"hidden_us_per_op": 0.0, "exposed_us_per_op": round(sum(ns for kind, _, ns in stage_rows if kind in ("EXCH_IN", "EXCH_OUT", "REPLICATE")) * 1e-3 / (batch if world > 1 else 1), 2),
+                                 "note": "the exchanges run on the op's own stream between the stages that produce and consume them: nothing is hidden behind compute yet (DESIGN.md section 7)"},
             "hmult_hbm_gbs_algorithmic": alg_bytes / (ms * 1e-3) / 1e9,
             "hmult_frac_of_hbm_peak": alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "roofline": {"bound": "valu" if valu_floor_ns and valu_floor_ns > hbm_floor_ns else "hbm",
