@@ -288,7 +288,13 @@ static const char *rccl_load() {
   if (g_rccl.h) return nullptr;
   // prefer an RCCL that is already mapped into the process (PyTorch ships and loads its own librccl.so): paging in a
   // second ~0.5 GB copy took minutes on a cold box
-  void *h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
+  // HOMULATOR_RCCL_LIB: another build of RCCL, or the test double of tests/mock_rccl (ranks as threads on one GPU)
+  void *h = nullptr;
+  if (const char *path = getenv("HOMULATOR_RCCL_LIB")) {
+    h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+    if (!h) return "HOMULATOR_RCCL_LIB could not be loaded";
+  }
+  if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
   if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
   if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
   if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
