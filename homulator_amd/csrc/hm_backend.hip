@@ -222,13 +222,22 @@ struct HmAutoArgs {
   uint32_t logN, n_limbs, g;
   HmLimb limb[HM_MAX_LIMBS];
 };
+// 1024 outputs per workgroup, four per thread 256 apart: a wave's 64 consecutive outputs come from ONE aligned block of 64 inputs
+// (the permutation is affine in the natural index and both sides are stored bit-reversed), so every read touches whole lines;
+// the four gathers of a thread are in flight together (13.4 against 17.0 us per hrotate at batch 10: 5.5 TB/s)
 __global__ void __launch_bounds__(256) k_automorph(HmAutoArgs a) {
   const uint32_t N = 1u << a.logN;
-  const uint32_t per_limb = N / 256;
-  uint32_t entry = blockIdx.x / per_limb;
-  uint32_t i = (blockIdx.x % per_limb) * 256 + threadIdx.x;
+  const uint32_t per_limb = N / 1024;
+  const uint32_t entry = blockIdx.x / per_limb;
+  const uint32_t i0 = (blockIdx.x % per_limb) * 1024 + threadIdx.x;
   const HmLimb lb = a.limb[entry];
-  a.out[(size_t)lb.out * N + i] = a.in[(size_t)lb.in * N + hm_auto_src(i, a.g, a.logN)];
+  const uint64_t *in = a.in + (size_t)lb.in * N;
+  uint64_t v[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = in[hm_auto_src(i0 + 256 * k, a.g, a.logN)];
+  uint64_t *out = a.out + (size_t)lb.out * N + i0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) out[256 * k] = v[k];
 }
 
 struct HmFillArgs {
@@ -748,7 +757,7 @@ extern "C" hm_status hm_automorph(hm_ctx *c, const uint64_t *in, const uint32_t 
     a.in = in; a.out = out; a.logN = c->P.logN; a.n_limbs = cnt; a.g = galois;
     for (uint32_t i = 0; i < cnt; ++i)
       a.limb[i] = HmLimb{(uint16_t)limb_at(in_limbs, base + i), (uint16_t)limb_at(out_limbs, base + i), 0, 0};
-    hipLaunchKernelGGL(k_automorph, dim3(cnt * (c->P.N / 256)), dim3(256), 0, c->stream, a);
+    hipLaunchKernelGGL(k_automorph, dim3(cnt * (c->P.N / 1024)), dim3(256), 0, c->stream, a);
     HM_HIP(c, hipGetLastError());
   }
   return HM_OK;
