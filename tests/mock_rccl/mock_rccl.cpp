@@ -4,14 +4,15 @@
 // RCCL code path — hm_comm_unique_id, the collective hm_comm_init_rccl, the grouped ncclSend / ncclRecv of every exchange with
 // their counts, datatype, peers and streams — executes exactly as on a node.  Only the wire differs: a send is matched with
 // the peer's receive by a rendezvous of the threads and copied device to device.
-// What a real run would turn into a HANG is an ERROR here: a receive nobody sends to, a send nobody receives, a size the two
-// sides disagree on, a peer out of range, ranks entering a different number of groups (rendezvous time-out).
+// What a real run would turn into a HANG is an ERROR here (after a 45 s time-out): a receive nobody sends to, a send nobody
+// receives; a size the two sides disagree on and a peer out of range are reported at once.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -19,23 +20,15 @@
 #include <vector>
 
 namespace {
-struct Post { int peer; const void *ptr; size_t bytes; bool taken; };
+// one FIFO of posted sends per (source, destination) pair of a communicator: a send is posted without blocking, the receiver
+// copies and acknowledges it; nobody else takes part (no global barrier: like RCCL, ranks only meet the peers they exchange with)
+struct Post { const void *ptr; size_t bytes; unsigned long seq; };
 struct Group {
   int world = 0, attached = 0;
   std::mutex m;
   std::condition_variable cv;
-  int arrived = 0;
-  unsigned long generation = 0;
-  bool failed = false;
-  std::vector<std::vector<Post>> sends;  // [rank]
-  // returns false on time-out or if any rank flagged a failure
-  bool barrier() {
-    std::unique_lock<std::mutex> lk(m);
-    const unsigned long gen = generation;
-    if (++arrived == world) { arrived = 0; generation++; cv.notify_all(); return !failed; }
-    if (!cv.wait_for(lk, std::chrono::seconds(60), [&] { return generation != gen; })) { failed = true; cv.notify_all(); return false; }
-    return !failed;
-  }
+  std::vector<std::vector<Post>> box;         // [src * world + dst]: posted, not yet received
+  std::vector<unsigned long> posted, acked;   // [src * world + dst]: counters
 };
 struct Comm { Group *g; int rank; };
 struct Op { bool send; void *ptr; size_t bytes; int peer; Comm *comm; hipStream_t stream; };
@@ -47,7 +40,8 @@ std::atomic<long> g_group_calls{0}, g_bytes{0}, g_errors{0};
 thread_local int t_depth = 0;
 thread_local std::vector<Op> t_ops;
 thread_local std::string t_error;
-thread_local void *t_last_comm = nullptr;  // a group without operations still takes part in the rendezvous (one communicator per thread here)
+static std::chrono::seconds timeout_s() { const char *e = getenv("MOCK_RCCL_TIMEOUT_S"); return std::chrono::seconds(e ? atoi(e) : 45); }
+const auto TIMEOUT = timeout_s();
 
 size_t type_size(ncclDataType_t t) {
   switch (t) {
@@ -68,47 +62,58 @@ ncclResult_t run_group() {
   std::vector<Op> ops;
   ops.swap(t_ops);
   g_group_calls++;
-  Comm *c = ops.empty() ? static_cast<Comm *>(t_last_comm) : ops[0].comm;
-  if (!c) return ncclSuccess;
-  const hipStream_t stream = ops.empty() ? nullptr : ops[0].stream;
+  if (ops.empty()) return ncclSuccess;   // an empty group is a no-op, as over RCCL
+  Comm *c = ops[0].comm;
+  Group *g = c->g;
+  const int W = g->world, me = c->rank;
   for (const Op &o : ops) {
     if (o.comm != c) return fail("one group mixes communicators");
     if (o.stream != ops[0].stream) return fail("one group mixes streams");
-    if (o.peer < 0 || o.peer >= c->g->world) return fail("peer " + std::to_string(o.peer) + " out of range");
+    if (o.peer < 0 || o.peer >= W) return fail("peer " + std::to_string(o.peer) + " out of range");
   }
-  Group *g = c->g;
-  if (!ops.empty() && hipStreamSynchronize(stream) != hipSuccess) return fail("hipStreamSynchronize failed");
+  if (hipStreamSynchronize(ops[0].stream) != hipSuccess) return fail("hipStreamSynchronize failed");  // the double is synchronous
+  std::vector<std::pair<int, unsigned long>> mine;  // (destination, sequence number) of my sends
   {
     std::lock_guard<std::mutex> lk(g->m);
-    g->sends[c->rank].clear();
     for (const Op &o : ops)
-      if (o.send) g->sends[c->rank].push_back({o.peer, o.ptr, o.bytes, false});
+      if (o.send) {
+        const size_t slot = (size_t)me * W + o.peer;
+        g->box[slot].push_back({o.ptr, o.bytes, ++g->posted[slot]});
+        mine.emplace_back(o.peer, g->posted[slot]);
+      }
+    g->cv.notify_all();
   }
   std::string problem;
-  if (!g->barrier()) problem = "rendezvous failed before the copies (a rank did not enter this exchange, or failed)";
-  if (problem.empty())
-    for (const Op &o : ops) {
-      if (o.send) continue;
-      Post *match = nullptr;
-      {
-        std::lock_guard<std::mutex> lk(g->m);
-        for (Post &p : g->sends[o.peer])
-          if (p.peer == c->rank && !p.taken) { match = &p; p.taken = true; break; }
+  for (const Op &o : ops) {
+    if (o.send) continue;
+    const size_t slot = (size_t)o.peer * W + me;
+    Post p{};
+    {
+      std::unique_lock<std::mutex> lk(g->m);
+      if (!g->cv.wait_for(lk, TIMEOUT, [&] { return !g->box[slot].empty(); })) {
+        problem = "rank " + std::to_string(me) + " receives from rank " + std::to_string(o.peer) + ", which sends nothing to it: a hang over RCCL";
+        break;
       }
-      if (!match) { problem = "rank " + std::to_string(c->rank) + " receives from rank " + std::to_string(o.peer) + ", which sends nothing to it: a hang over RCCL"; break; }
-      if (match->bytes != o.bytes) { problem = "rank " + std::to_string(c->rank) + " expects " + std::to_string(o.bytes) + " bytes from rank " + std::to_string(o.peer) + ", which sends " + std::to_string(match->bytes); break; }
-      if (hipMemcpy(o.ptr, match->ptr, o.bytes, hipMemcpyDeviceToDevice) != hipSuccess) { problem = "hipMemcpy failed"; break; }
-      g_bytes += (long)o.bytes;
+      p = g->box[slot].front();
+      g->box[slot].erase(g->box[slot].begin());
     }
-  if (!problem.empty()) { std::lock_guard<std::mutex> lk(g->m); g->failed = true; }
-  (void)hipDeviceSynchronize();
-  const bool ok = g->barrier();
-  if (problem.empty() && ok) {
-    std::lock_guard<std::mutex> lk(g->m);
-    for (const Post &p : g->sends[c->rank])
-      if (!p.taken) { problem = "rank " + std::to_string(c->rank) + " sends " + std::to_string(p.bytes) + " bytes to rank " + std::to_string(p.peer) + ", which does not receive them: a hang over RCCL"; g->failed = true; break; }
+    if (p.bytes != o.bytes) problem = "rank " + std::to_string(me) + " expects " + std::to_string(o.bytes) + " bytes from rank " + std::to_string(o.peer) + ", which sends " + std::to_string(p.bytes);
+    else if (hipMemcpy(o.ptr, p.ptr, o.bytes, hipMemcpyDeviceToDevice) != hipSuccess) problem = "hipMemcpy failed";
+    else g_bytes += (long)o.bytes;
+    {
+      std::lock_guard<std::mutex> lk(g->m);
+      g->acked[slot] = p.seq;   // also after a failed check: the sender must not wait for ever
+      g->cv.notify_all();
+    }
+    if (!problem.empty()) break;
   }
-  if (!g->barrier() && problem.empty()) problem = "another rank failed in this exchange";
+  (void)hipDeviceSynchronize();
+  for (const auto &s : mine) {   // my send buffers may be reused only when the receivers have copied them
+    const size_t slot = (size_t)me * W + s.first;
+    std::unique_lock<std::mutex> lk(g->m);
+    if (!g->cv.wait_for(lk, TIMEOUT, [&] { return g->acked[slot] >= s.second; }) && problem.empty())
+      problem = "rank " + std::to_string(me) + " sends to rank " + std::to_string(s.first) + ", which does not receive: a hang over RCCL";
+  }
   if (!problem.empty()) return fail(problem);
   return ncclSuccess;
 }
@@ -130,7 +135,7 @@ ncclResult_t ncclCommInitRank(ncclComm_t *out, int world, ncclUniqueId id, int r
   {
     std::lock_guard<std::mutex> lk(g_registry_lock);
     Group *&slot = g_groups[std::string(id.internal, sizeof id.internal)];
-    if (!slot) { slot = new Group; slot->world = world; slot->sends.resize(world); }
+    if (!slot) { slot = new Group; slot->world = world; slot->box.resize((size_t)world * world); slot->posted.assign((size_t)world * world, 0); slot->acked.assign((size_t)world * world, 0); }
     g = slot;
   }
   {
@@ -141,9 +146,7 @@ ncclResult_t ncclCommInitRank(ncclComm_t *out, int world, ncclUniqueId id, int r
     if (!g->cv.wait_for(lk, std::chrono::seconds(60), [&] { return g->attached >= g->world; }))   // collective, like the real call
       return fail("ncclCommInitRank: only " + std::to_string(g->attached) + " of " + std::to_string(world) + " ranks arrived");
   }
-  Comm *made = new Comm{g, rank};
-  t_last_comm = made;
-  *out = reinterpret_cast<ncclComm_t>(made);
+  *out = reinterpret_cast<ncclComm_t>(new Comm{g, rank});
   return ncclSuccess;
 }
 ncclResult_t ncclCommDestroy(ncclComm_t comm) {
