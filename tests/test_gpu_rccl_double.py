@@ -107,3 +107,48 @@ assert res[1][0] == 0, res          # an empty group is a no-op, as over RCCL
 ''' % lib
     r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=300, env=dict(os.environ, MOCK_RCCL_TIMEOUT_S="3"))
     assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-2000:]
+
+
+TWO_COMMS = r"""
+import sys, threading
+sys.path.insert(0, %(root)r)
+import numpy as np
+from homulator_amd import host
+from oracle.homoracle import Oracle
+world, cfg, L, ell, alpha, logN = 4, "config_4_N15.cfg", 16, 10, 4, 15
+uids = [host.rccl_unique_id(), host.rccl_unique_id()]
+ops = [[host.Op(cfg, "hmult", L, ell, alpha, rank=r, world=world, overrides={"seed": host.SEED + 7 * i}) for i in range(2)] for r in range(world)]
+err = [None] * world
+def work(r):
+    try:
+        for i in range(2): ops[r][i].comm_init_rccl(uids[i])       # communicator i of every rank, created in the same order
+        for _ in range(3):
+            for i in range(2): ops[r][i].enqueue(1)                 # A, B, A, B, ...: the order every rank uses
+        for i in range(2): ops[r][i].sync()
+    except Exception as e:
+        err[r] = e
+th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+[t.start() for t in th]; [t.join() for t in th]
+for e in err:
+    if e is not None: raise e
+o = Oracle(logN, L, alpha); o.set_threads(8)
+for i in range(2):
+    S = host.SEED + 7 * i
+    exp = o.hmult(ell, o.synth_ct(ell, S), o.synth_ct(ell, S + 2000), o.synth_evk(ell, S + 10000))
+    for name, want in (("out.c0", exp[0]), ("out.c1", exp[1])):
+        full = np.zeros((ell - 1, 1 << logN), dtype=np.uint64)
+        for r in range(world):
+            mine = ops[r][i].read(name)
+            for l in ops[r][i].owned(ell - 1): full[l] = mine[l]
+        assert np.array_equal(full, want), (i, name)
+print("two communicators per rank: ok")
+"""
+
+
+def test_two_sharded_instances_per_rank_with_a_communicator_each():
+    """the opt-in overlap mode of the bench (--sharded-streams 2): every rank drives two sharded instances, each with its own RCCL
+    communicator and stream, enqueued alternately; through the double, 4 ranks, three passes each, both instances bit-exact"""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "mock_rccl")], stdout=subprocess.DEVNULL)
+    lib = os.path.join(ROOT, "tests", "mock_rccl", "libmockrccl.so")
+    r = subprocess.run([sys.executable, "-c", TWO_COMMS % {"root": ROOT}], env=dict(os.environ, HOMULATOR_RCCL_LIB=lib), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "two communicators per rank: ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]

@@ -88,3 +88,23 @@ def test_bench_flow_rehearsal_four_ranks():
     d = json.loads(line)
     assert d["n_gpus"] == 4 and d["steps"] == 8 and d["value"] > 0
     assert d["config"]["transport"] == "gloo-rehearsal" and d["exchange_us_per_op"] > 0
+    assert d["exchange_overlap"]["instances_in_flight"] == 1 and d["exchange_overlap"]["hidden_us_per_op"] == 0.0
+
+
+def test_bench_flow_rehearsal_two_sharded_instances():
+    """--sharded-streams 2 (opt-in): two sharded instances per rank, a transport each, enqueued alternately in the same order on every
+    rank; 2 ranks over gloo.  The bench line carries the hidden / exposed estimate."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HOMULATOR_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29537", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "2", "--sharded-streams", "2"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["streams"] == 2
+    ov = d["exchange_overlap"]
+    assert ov["instances_in_flight"] == 2 and ov["hidden_us_per_op"] >= 0 and abs(ov["hidden_us_per_op"] + ov["exposed_us_per_op"] - d["exchange_us_per_op"]) < 0.05
