@@ -1,7 +1,8 @@
 """Differential test of the `sim` backend against the compiled, unmodified reference (oracle/_ref/ForgeHomulator.run, build
 container only): random operations, levels, cluster counts AND random timing / sizing constants in the .cfg, comparing the
 cycle count and every counter of the stat block.  The reference runs with MALLOC_PERTURB_ set (see
-tests/golden/make_structural.py for why).  usage: python tools/sim_diff.py [points] [seed] [jobs]"""
+tests/golden/make_structural.py for why); `--stock` runs it as it is, which shows how often its uninitialised scoreboard operands
+change a result.  usage: python tools/sim_diff.py [points] [seed] [jobs] [--stock]"""
 import os
 import random
 import subprocess
@@ -58,7 +59,11 @@ def one(args):
         path = f.name
     argv = [path, op, str(L), str(level), str(alpha)] + ([str(cluster)] if cluster else [])
     try:
-        ref = subprocess.run([REF] + argv, capture_output=True, text=True, env=dict(os.environ, MALLOC_PERTURB_="85"), timeout=900)
+        renv = dict(os.environ)
+        renv.pop("MALLOC_PERTURB_", None)
+        if not STOCK:
+            renv["MALLOC_PERTURB_"] = "85"
+        ref = subprocess.run([REF] + argv, capture_output=True, text=True, env=renv, timeout=900)
         mine = subprocess.run([CLI] + argv, capture_output=True, text=True, env=dict(os.environ, HOMULATOR_BACKEND="sim"), timeout=900)
     except subprocess.TimeoutExpired:
         return idx, "timeout", argv, cfg
@@ -75,6 +80,11 @@ def one(args):
         return idx, "ok", argv[1:], delta
     diff = {k: (rs.get(k), ms.get(k)) for k in set(rs) | set(ms) if rs.get(k) != ms.get(k)}
     return idx, f"DIFF cycles ref={rc} mine={mc} counters={dict(list(diff.items())[:6])} {mine.stderr[-300:]}", argv[1:], delta
+
+
+STOCK = "--stock" in sys.argv   # compare with the reference as it is (its uninitialised scoreboard operands included): how often do they matter?
+if STOCK:
+    sys.argv.remove("--stock")
 
 
 def main():
