@@ -1,9 +1,10 @@
 #!/bin/bash
-# timing-only ablation builds of the HIP backend into build_variants/ (git-ignored; travels with gpurun):
+# A/B and timing-only ablation builds of the HIP backend into ab_builds/ (git-ignored; the .so files travel with gpurun, the
+# objects stay in /tmp; delete a variant when its question is answered: every file here is pushed with every lease):
 #   tools/ablate.sh <name> "<extra hipcc flags>"     e.g.  tools/ablate.sh nocompute "-DHM_ABL_NOCOMPUTE"
-# use with HOMULATOR_HIP_LIB=build_variants/libhm_<name>.so python tools/ntt_scale.py
+# use with HOMULATOR_HIP_LIB=ab_builds/libhm_<name>.so python tools/ntt_ab.py
 set -e
 cd "$(dirname "$0")/../homulator_amd/csrc"
-mkdir -p ../../build_variants
-make OUT=../../build_variants/libhm_$1.so OBJ=../../build_variants/obj_$1 EXTRA="$2" >/dev/null
-echo "built build_variants/libhm_$1.so"
+mkdir -p ../../ab_builds
+make OUT=../../ab_builds/libhm_$1.so OBJ=/tmp/hm_ab_obj_$1 EXTRA="$2" >/dev/null
+echo "built ab_builds/libhm_$1.so"
