@@ -25,29 +25,25 @@
 
 // XCD-aware block -> (limb entry, tile) map.  Blocks are dealt round-robin over the 8 XCDs, so blocks b and
 // b+8 share an L2.  All tiles of one limb-poly get the same b % 8, and both passes of a transform use the
-// same map, so the second pass finds the first pass's output in that XCD's L2.  Entries come in PAIRS
-// (e, e+8 inside a group of 16) that the host fills with two limb-polys of the SAME modulus whenever the
-// launch has them (the two keys of a ModDown, two digits of a ModUp, c0/c1 of a rescale): the pair's blocks
-// for one tile sit in adjacent dispatch slots of one XCD, so the second one finds the row twiddles (1 MiB per
-// limb-NTT, as much as the data) in L2 instead of fetching them from HBM again.
-__device__ __forceinline__ bool hm_block_map(uint32_t tiles_per_limb, uint32_t n_entries, uint32_t &entry, uint32_t &tile) {
+// same map.  Entries come in GROUPS of G = 2^logG (e, e+8, .., e+8(G-1) inside a block of 8G) that the host fills with
+// limb-polys of the SAME modulus whenever the launch has them (the two keys of a ModDown, the digits of a ModUp, c0/c1 of
+// a rescale, the ops of a batch): the group's blocks for one tile sit in adjacent dispatch slots of one XCD, so all but
+// the first find the row twiddles (0.27 MB per limb-NTT, a quarter of the data) in L2 instead of fetching them again.
+__device__ __forceinline__ bool hm_block_map(uint32_t tiles_per_limb, uint32_t n_entries, uint32_t logG, uint32_t &entry, uint32_t &tile) {
   const uint32_t b = blockIdx.x, xcd = b & 7u, slot = b >> 3;
-  const uint32_t pair = slot / (2u * tiles_per_limb), within = slot % (2u * tiles_per_limb);
-  tile = within >> 1;
-  entry = pair * 16u + (within & 1u) * 8u + xcd;
+  const uint32_t per = tiles_per_limb << logG;
+  const uint32_t grp = slot / per, within = slot % per;
+  tile = within >> logG;
+  entry = grp * (8u << logG) + (within & ((1u << logG) - 1u)) * 8u + xcd;
   return entry < n_entries;
 }
 
-template <int LOGR, bool STRIDED, bool INV, int MODE>
-__device__ __forceinline__ void hm_ntt_pass_body(const HmNttArgs &a) {
+// One pass of a transform over tile `tile` of limb-poly `entry`, in the workgroup's LDS buffer.
+template <int LOGR, bool STRIDED, bool INV, int MODE, int LDAUX = 0, int STAUX = 0, int EPICH = HM_EPI_CHUNK>
+__device__ __forceinline__ void hm_ntt_pass_run(const HmNttArgs &a, uint64_t *lds, uint32_t entry, uint32_t tile, int tid) {
   constexpr int TL = HM_TL(STRIDED);
-  __shared__ __attribute__((aligned(16))) uint64_t lds[HmLds<TL, LOGR, STRIDED>::WORDS];
-  uint32_t entry, tile;
-  if (!hm_block_map(1u << (a.logN - TL), a.n_limbs, entry, tile)) return;
-  const int tid = threadIdx.x;
   const HmLimb lb = a.limb[entry];
   const uint32_t mod = lb.mod;
-  if (mod == HM_NTT_NONE) return;
   const size_t N = (size_t)1 << a.logN;
   const uint64_t q = a.mods[mod].q;
   const HmTw *twl = a.tw + (size_t)mod * N;
@@ -61,28 +57,42 @@ __device__ __forceinline__ void hm_ntt_pass_body(const HmNttArgs &a) {
 
   HmTw sc = {0, 0};
   HmEpi ep = hm_epi_none();
-  if constexpr (MODE == 2) sc = a.entry[entry].sc;
+  // the per-limb constants are wave-uniform: read through the scalar cache into SGPRs (as a plain global pointer hipcc
+  // loaded them with vector loads and kept 12-16 VGPRs of uniform values alive through the whole pass)
+  typedef const HmNttEntry __attribute__((address_space(4))) *ConstEntry;
+  const ConstEntry entries = (ConstEntry)(uintptr_t)a.entry;
+  if constexpr (MODE == 2) { sc.w = entries[entry].sc.w; sc.ws = entries[entry].sc.ws; }
   if constexpr (MODE == 3) {
-    const HmNttEntry &en = a.entry[entry];
-    sc = en.sc;
+    const auto &en = entries[entry];
+    sc.w = en.sc.w; sc.ws = en.sc.ws;
     ep.a = a.minuend + (size_t)lb.aux * N;
     ep.d = a.addend && en.alimb != HM_NTT_NONE ? a.addend + (size_t)en.alimb * N : nullptr;  // per limb-poly
-    ep.dk = en.ak;
+    ep.dk.w = en.ak.w; ep.dk.ws = en.ak.ws;
   }
   if constexpr (MODE == 4) {
-    const HmNttEntry &en = a.entry[entry];
+    const auto &en = entries[entry];
     ep.b = a.mix + (size_t)en.mixlimb * N;
-    ep.bk = en.mixk;
+    ep.bk.w = en.mixk.w; ep.bk.ws = en.mixk.ws;
   }
   HmNttState st;
-  hm_ntt_phase<TL, LOGR, STRIDED, INV, MODE, 0>(st, tid, lds, src, dst, tile, twl, twt, s0, prefix0, q, sc, ep);
-  hm_ntt_phase<TL, LOGR, STRIDED, INV, MODE, 1>(st, tid, lds, src, dst, tile, twl, twt, s0, prefix0, q, sc, ep);
+  hm_ntt_phase<TL, LOGR, STRIDED, INV, MODE, 0, LDAUX, STAUX, EPICH>(st, tid, lds, src, dst, tile, twl, twt, s0, prefix0, q, sc, ep);
+  hm_ntt_phase<TL, LOGR, STRIDED, INV, MODE, 1, LDAUX, STAUX, EPICH>(st, tid, lds, src, dst, tile, twl, twt, s0, prefix0, q, sc, ep);
   __syncthreads();
-  hm_ntt_phase<TL, LOGR, STRIDED, INV, MODE, 2>(st, tid, lds, src, dst, tile, twl, twt, s0, prefix0, q, sc, ep);
+  hm_ntt_phase<TL, LOGR, STRIDED, INV, MODE, 2, LDAUX, STAUX, EPICH>(st, tid, lds, src, dst, tile, twl, twt, s0, prefix0, q, sc, ep);
   if constexpr (HmRounds<LOGR>::n == 3) {
     __syncthreads();
-    hm_ntt_phase<TL, LOGR, STRIDED, INV, MODE, 3>(st, tid, lds, src, dst, tile, twl, twt, s0, prefix0, q, sc, ep);
+    hm_ntt_phase<TL, LOGR, STRIDED, INV, MODE, 3, LDAUX, STAUX, EPICH>(st, tid, lds, src, dst, tile, twl, twt, s0, prefix0, q, sc, ep);
   }
+}
+
+template <int LOGR, bool STRIDED, bool INV, int MODE>
+__device__ __forceinline__ void hm_ntt_pass_body(const HmNttArgs &a) {
+  constexpr int TL = HM_TL(STRIDED);
+  __shared__ __attribute__((aligned(16))) uint64_t lds[HmLds<TL, LOGR, STRIDED>::WORDS];
+  uint32_t entry, tile;
+  if (!hm_block_map(1u << (a.logN - TL), a.n_limbs, a.logG, entry, tile)) return;
+  if (a.limb[entry].mod == HM_NTT_NONE) return;
+  hm_ntt_pass_run<LOGR, STRIDED, INV, MODE>(a, lds, entry, tile, threadIdx.x);
 }
 
 // Minimum waves per SIMD the register allocator must leave room for (HIP's second launch-bound argument; it is ignored
@@ -103,6 +113,122 @@ __global__ void __launch_bounds__((1 << HM_TL_COL) / HM_EPT) __attribute__((amdg
 template <bool INV, int MODE>
 __global__ void __launch_bounds__((1 << HM_TL_ROW) / HM_EPT) __attribute__((amdgpu_waves_per_eu(HM_NTT_MIN_WAVES))) k_ntt_row(HmNttArgs a) {
   hm_ntt_pass_body<HM_ROW_LOG, false, INV, MODE>(a);
+}
+
+// ---- both passes of a transform in ONE launch (opt-in: hm_set_option "ntt_fused"; measured, not the default) ------------
+// Built to keep the hand-off between the passes in the XCD's L2: the workgroups of one limb-poly (N / 4096 of them, all dealt
+// to one XCD by hm_block_map) run the first pass on their tile, store the hand-off, meet at a per-limb counter and run the
+// second pass on what the others stored.  What the MI355X does with it (profiles/r03_fused_ntt.txt): WRITE_SIZE and
+// FETCH_SIZE of the 50-limb sweep are the SAME as for two kernels (51.2 MB written, 65 MB fetched) with plain stores and
+// plain, sc1 or nt loads alike — the L2 writes every store through to the fabric and a later load of the line by another CU
+// of the XCD misses (no write-allocate), so a hand-off through global memory costs two fabric crossings however it is
+// synchronised; and the rendezvous makes it slower (0.82-0.95 us per limb-NTT against 0.48-0.52): the workgroups of a
+// limb-poly start whenever slots free up, and the first ones hold their slots idle until the last one has arrived.
+// Kept as a tested code path (tests/test_gpu_ntt_fused.py) because the rendezvous is placement-independent and reusable.
+//
+// Correct for ANY placement: every workgroup adds its XCC id (HW_REG_XCC_ID) to the counter word; if the limb's workgroups
+// turn out to sit on several XCDs (hipcc / the dispatcher promise nothing), all of them take the agent-scope path instead:
+// release (L2 write-back), a second rendezvous, acquire — slow, still right.  The rendezvous needs the limb's workgroups
+// co-resident: they are neighbours in dispatch order (consecutive slots of one XCD hold a group of limb-polys), so with
+// workgroups dispatched in order the oldest unfinished limb of an XCD is always fully dispatched; the spin is bounded all
+// the same, and a timeout is reported through the context (hm_sync fails) instead of hanging the GPU.
+struct HmNttSync {
+  unsigned long long arrive[HM_NTT_MAX_ENTRIES];   // bits 0..7 arrivals, 6 bits per XCD above: arrivals from that XCD
+  unsigned long long arrive2[HM_NTT_MAX_ENTRIES];  // second rendezvous of the agent-scope path
+  unsigned done[HM_NTT_MAX_ENTRIES];               // workgroups that left the limb-poly: the last one zeroes its three words
+  unsigned stats[4];                               // [0] limb-polys that took the agent-scope path (diagnostic)
+};
+#define HM_SPIN_LIMIT (1u << 22)
+#ifndef HM_OPAQUE_TID2
+#define HM_OPAQUE_TID2 1
+#endif
+#ifndef HM_FUSED_IN_AUX
+#define HM_FUSED_IN_AUX 0    // cache policy of the first pass's input loads (2 = nt)
+#endif
+#ifndef HM_FUSED_OUT_AUX
+#define HM_FUSED_OUT_AUX 0   // cache policy of the second pass's output stores (2 = nt)
+#endif
+#ifndef HM_FUSED_MID_AUX
+#define HM_FUSED_MID_AUX 16  // the hand-off loads: sc1
+#endif
+__device__ __forceinline__ unsigned hm_xcc_id() {
+  unsigned v;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(v));
+  return v & 7u;
+}
+// all `members` workgroups of limb-poly `entry` have stored their hand-off.  Returns true if they all run on this XCD.
+__device__ __forceinline__ bool hm_limb_rendezvous(HmNttSync *ws, unsigned *err, uint32_t entry, uint32_t members, uint32_t *lds_flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave: its stores have reached L2
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned xcc = hm_xcc_id();
+    __hip_atomic_fetch_add(&ws->arrive[entry], 1ull | (1ull << (8 + 6 * xcc)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long v;
+    unsigned spins = 0;
+    while (((v = __hip_atomic_load(&ws->arrive[entry], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0xFFull) < members) {
+      __builtin_amdgcn_s_sleep(4);
+      if (++spins > HM_SPIN_LIMIT) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+    }
+    *lds_flag = ((v >> (8 + 6 * xcc)) & 0x3Full) == members;
+  }
+  __syncthreads();
+  return *lds_flag != 0;
+}
+// the agent-scope path: make the hand-off visible to every XCD
+__device__ __forceinline__ void hm_limb_publish_everywhere(HmNttSync *ws, unsigned *err, uint32_t entry, uint32_t members) {
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_fetch_add(&ws->arrive2[entry], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned spins = 0;
+    while (__hip_atomic_load(&ws->arrive2[entry], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < members) {
+      __builtin_amdgcn_s_sleep(4);
+      if (++spins > HM_SPIN_LIMIT) { __hip_atomic_store(err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+}
+// leave the limb-poly: the last workgroup out zeroes the words for the next launch (everybody has finished polling)
+__device__ __forceinline__ void hm_limb_leave(HmNttSync *ws, uint32_t entry, uint32_t members, bool slow) {
+  if (threadIdx.x == 0) {
+    if (__hip_atomic_fetch_add(&ws->done[entry], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1) {
+      __hip_atomic_store(&ws->arrive[entry], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&ws->arrive2[entry], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&ws->done[entry], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (slow) __hip_atomic_fetch_add(&ws->stats[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+struct HmNttFusedArgs {
+  HmNttSync *ws;
+  unsigned *err;   // host-visible word: 0 = fine, 1 / 2 = a rendezvous timed out
+};
+// MODE_A: first pass (0, or 4 = mix prologue); MODE_B: last pass (1 forward, 3 fused epilogue, 2 inverse)
+template <int LOG1, bool INV, int MODE_A, int MODE_B>
+__global__ void __launch_bounds__((1 << HM_TL_ROW) / HM_EPT) __attribute__((amdgpu_waves_per_eu(HM_NTT_MIN_WAVES))) k_ntt_fused(HmNttArgs a, HmNttFusedArgs f) {
+  static_assert(HM_TL_COL == HM_TL_ROW, "the one-launch transform keeps a workgroup on tile t of both passes");
+  constexpr int TL = HM_TL_ROW;
+  constexpr int W1 = HmLds<TL, LOG1, true>::WORDS, W2 = HmLds<TL, HM_ROW_LOG, false>::WORDS;
+  __shared__ __attribute__((aligned(16))) uint64_t lds[(W1 > W2 ? W1 : W2) + 2];
+  uint32_t entry, tile;
+  const uint32_t members = 1u << (a.logN - TL);
+  if (!hm_block_map(members, a.n_limbs, a.logG, entry, tile)) return;
+  if (a.limb[entry].mod == HM_NTT_NONE) return;
+  uint32_t *flag = reinterpret_cast<uint32_t *>(lds + (W1 > W2 ? W1 : W2));
+  if (!INV) hm_ntt_pass_run<LOG1, true, false, MODE_A, HM_FUSED_IN_AUX, 0>(a, lds, entry, tile, threadIdx.x);
+  else hm_ntt_pass_run<HM_ROW_LOG, false, true, MODE_A, HM_FUSED_IN_AUX, 0>(a, lds, entry, tile, threadIdx.x);
+  const bool same = hm_limb_rendezvous(f.ws, f.err, entry, members, flag);
+  if (!same) hm_limb_publish_everywhere(f.ws, f.err, entry, members);
+  // a thread id the compiler cannot connect with the first pass's: otherwise lane offsets of the second pass are computed
+  // up front and kept (spilled) through the first
+  int tid2 = threadIdx.x;
+  if (HM_OPAQUE_TID2) asm volatile("" : "+v"(tid2));
+  __builtin_assume(tid2 >= 0 && tid2 < (1 << HM_TL_ROW) / HM_EPT);
+  if (!INV) hm_ntt_pass_run<HM_ROW_LOG, false, false, MODE_B, HM_FUSED_MID_AUX, HM_FUSED_OUT_AUX, 1>(a, lds, entry, tile, tid2);
+  else hm_ntt_pass_run<LOG1, true, true, MODE_B, HM_FUSED_MID_AUX, HM_FUSED_OUT_AUX>(a, lds, entry, tile, tid2);
+  hm_limb_leave(f.ws, entry, members, !same);
 }
 
 __global__ void __launch_bounds__(256) k_tensor(HmTensorArgs a) {
@@ -271,6 +397,10 @@ struct hm_ctx {
   std::map<std::string, void *> ntt_tables;                  // launch tables (device_table), key: their bytes
   bool tables_pinned = false;                                 // a captured graph references the tables: no eviction
   std::string err;
+  // one-launch transforms (k_ntt_fused): rendezvous words in HBM, a host-visible error word, and the switch
+  HmNttSync *ntt_ws = nullptr;
+  unsigned *err_host = nullptr, *err_dev = nullptr;
+  bool fused_ntt = false;  // measured slower and no lighter on HBM: opt-in
   // multi-GPU
   int rank = 0, world = 1;
   ncclComm_t comm = nullptr;
@@ -377,6 +507,12 @@ extern "C" hm_status hm_create(hm_ctx **out, const hm_params *p) {
     HM_HIP(nullptr, hipMemcpy(cc->d_tw_inv + (size_t)m * N, tmp.data(), sizeof(HmTw) * N, hipMemcpyHostToDevice));
   }
   HM_HIP(nullptr, hipMemcpy(cc->d_mods, cc->P.modc.data(), sizeof(HmMod) * M, hipMemcpyHostToDevice));
+  HM_HIP(nullptr, hipMalloc(&cc->ntt_ws, sizeof(HmNttSync)));
+  HM_HIP(nullptr, hipMemset(cc->ntt_ws, 0, sizeof(HmNttSync)));
+  HM_HIP(nullptr, hipHostMalloc(reinterpret_cast<void **>(&cc->err_host), 64, hipHostMallocMapped));
+  memset(cc->err_host, 0, 64);
+  HM_HIP(nullptr, hipHostGetDevicePointer(reinterpret_cast<void **>(&cc->err_dev), cc->err_host, 0));
+  if (const char *e = getenv("HOMULATOR_NTT_FUSED")) cc->fused_ntt = std::string(e) != "0";
   *out = c.release();
   return HM_OK;
 }
@@ -395,6 +531,8 @@ extern "C" void hm_destroy(hm_ctx *c) {
   (void)hipFree(c->d_twist_fwd);
   (void)hipFree(c->d_twist_inv);
   (void)hipFree(c->d_mods);
+  (void)hipFree(c->ntt_ws);
+  (void)hipHostFree(c->err_host);
   (void)hipEventDestroy(c->ev0);
   (void)hipEventDestroy(c->ev1);
   if (c->ev_done) (void)hipEventDestroy(c->ev_done);
@@ -442,10 +580,23 @@ extern "C" hm_status hm_memcpy_d2d(hm_ctx *c, void *dst, const void *src, size_t
   HM_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->stream));
   return HM_OK;
 }
+// a rendezvous of a one-launch transform timed out (the limb's workgroups were never co-resident): the outputs of that
+// launch are invalid.  Reported at the next synchronisation; the context falls back to two-kernel transforms.
+static hm_status check_device_error(hm_ctx *c) {
+  if (c->err_host && *c->err_host) {
+    const unsigned code = *c->err_host;
+    *c->err_host = 0;
+    c->fused_ntt = false;
+    (void)hipMemsetAsync(c->ntt_ws, 0, sizeof(HmNttSync), c->stream);
+    (void)hipStreamSynchronize(c->stream);
+    return fail(c, HM_ERR_HIP, "one-launch transform: rendezvous %u timed out (workgroups of a limb-poly not co-resident); results of the last launches are invalid, the context now uses two-kernel transforms", code);
+  }
+  return HM_OK;
+}
 extern "C" hm_status hm_sync(hm_ctx *c) {
   if (!c) return HM_ERR_ARG;
   HM_HIP(c, hipStreamSynchronize(c->stream));
-  return HM_OK;
+  return check_device_error(c);
 }
 extern "C" void *hm_stream(hm_ctx *c) { return c ? (void *)c->stream : nullptr; }
 extern "C" hm_status hm_wait_for(hm_ctx *c, hm_ctx *producer) {
@@ -457,6 +608,23 @@ extern "C" hm_status hm_wait_for(hm_ctx *c, hm_ctx *producer) {
   HM_HIP(c, hipEventRecord(producer->ev_done, producer->stream));
   HM_HIP(c, hipStreamWaitEvent(c->stream, producer->ev_done, 0));
   return HM_OK;
+}
+
+extern "C" hm_status hm_set_option(hm_ctx *c, const char *name, uint64_t value) {
+  if (!c || !name) return HM_ERR_ARG;
+  if (!strcmp(name, "ntt_fused")) { c->fused_ntt = value != 0; return HM_OK; }
+  return fail(c, HM_ERR_ARG, "hm_set_option: unknown option %s", name);
+}
+extern "C" hm_status hm_get_counter(hm_ctx *c, const char *name, uint64_t *value) {
+  if (!c || !name || !value) return HM_ERR_ARG;
+  if (!strcmp(name, "ntt_cross_xcd")) {
+    HM_HIP(c, hipStreamSynchronize(c->stream));
+    unsigned v = 0;
+    HM_HIP(c, hipMemcpy(&v, &c->ntt_ws->stats[0], sizeof v, hipMemcpyDeviceToHost));
+    *value = v;
+    return check_device_error(c);
+  }
+  return fail(c, HM_ERR_ARG, "hm_get_counter: unknown counter %s", name);
 }
 
 struct hm_graph {
@@ -505,6 +673,7 @@ extern "C" hm_status hm_timer_stop(hm_ctx *c, uint64_t *ns) {
   if (!c || !ns) return HM_ERR_ARG;
   HM_HIP(c, hipEventRecord(c->ev1, c->stream));
   HM_HIP(c, hipEventSynchronize(c->ev1));
+  if (hm_status st = check_device_error(c)) return st;
   float ms = 0;
   HM_HIP(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
   *ns = (uint64_t)((double)ms * 1e6);
@@ -533,6 +702,14 @@ static void launch_ntt(hm_ctx *c, const HmNttArgs &a, bool fusedEpilogue, bool m
   // n_limbs = entries, a multiple of 16 (pairs x 8 XCDs); one workgroup per tile of each pass
   const dim3 gridC(a.n_limbs * (c->P.N >> HM_TL_COL)), blockC((1 << HM_TL_COL) / HM_EPT);
   const dim3 gridR(a.n_limbs * (c->P.N >> HM_TL_ROW)), blockR((1 << HM_TL_ROW) / HM_EPT);
+  if (c->fused_ntt) {   // both passes in one launch, hand-off through the XCD's L2
+    const HmNttFusedArgs f = {c->ntt_ws, c->err_dev};
+    if (inverse) hipLaunchKernelGGL((k_ntt_fused<LOG1, true, 0, 2>), gridR, blockR, 0, c->stream, a, f);
+    else if (mixPrologue) hipLaunchKernelGGL((k_ntt_fused<LOG1, false, 4, 3>), gridR, blockR, 0, c->stream, a, f);
+    else if (fusedEpilogue) hipLaunchKernelGGL((k_ntt_fused<LOG1, false, 0, 3>), gridR, blockR, 0, c->stream, a, f);
+    else hipLaunchKernelGGL((k_ntt_fused<LOG1, false, 0, 1>), gridR, blockR, 0, c->stream, a, f);
+    return;
+  }
   if (!inverse) {
     if (mixPrologue) hipLaunchKernelGGL((k_ntt_col<LOG1, false, 4>), gridC, blockC, 0, c->stream, a);
     else hipLaunchKernelGGL((k_ntt_col<LOG1, false, 0>), gridC, blockC, 0, c->stream, a);
@@ -606,40 +783,56 @@ static hm_status ntt_common(hm_ctx *c, const char *what, const uint64_t *in, con
     if (f.addend_k && f.addend_k[g] == 0) return fail(c, HM_ERR_ARG, "%s: addend_k[%u] is zero (pass addend = NULL instead)", what, g);
   }
   HM_HIP(c, hipSetDevice(c->device));
-  // pair up limb-polys that share a modulus (see hm_block_map), then the leftovers with each other
-  std::vector<std::pair<int, int>> pairs;  // indices into the caller's lists, -1 = empty
+  // group limb-polys that share a modulus (see hm_block_map): G = the largest of 8, 4, 2 for which at least 7 of 8 limb-polys
+  // of the call fall into full same-modulus groups (a batch of 10 ops x 2 keys has 20 limb-polys per modulus, a 50-limb sweep
+  // of the extended basis one: G = 2 then costs nothing); leftovers of a modulus share groups with other leftovers
+  std::map<uint32_t, std::vector<int>> byMod;
+  for (uint32_t i = 0; i < n; ++i) byMod[mod_ids[i]].push_back((int)i);
+  uint32_t logG = 1;
+#ifndef HM_NTT_MAX_LOGG
+#define HM_NTT_MAX_LOGG 3
+#endif
+  for (uint32_t lg = HM_NTT_MAX_LOGG; lg >= 2; --lg) {
+    size_t full = 0;
+    for (auto &kv : byMod) full += kv.second.size() >> lg << lg;
+    if (full * 8 >= (size_t)n * 7 && n >= (64u << lg)) { logG = lg; break; }
+  }
+  const uint32_t G = 1u << logG;
+  std::vector<std::vector<int>> groups;  // indices into the caller's lists, -1 = empty
   {
-    std::map<uint32_t, std::vector<int>> byMod;
-    for (uint32_t i = 0; i < n; ++i) byMod[mod_ids[i]].push_back((int)i);
-    std::vector<int> singles;
+    std::vector<int> rest;
     for (auto &kv : byMod) {
       auto &v = kv.second;
       size_t i = 0;
-      for (; i + 1 < v.size(); i += 2) pairs.emplace_back(v[i], v[i + 1]);
-      if (i < v.size()) singles.push_back(v[i]);
+      for (; i + G <= v.size(); i += G) groups.emplace_back(v.begin() + i, v.begin() + i + G);
+      rest.insert(rest.end(), v.begin() + i, v.end());   // leftovers of one modulus stay adjacent: they still share among themselves
     }
-    for (size_t i = 0; i < singles.size(); i += 2) pairs.emplace_back(singles[i], i + 1 < singles.size() ? singles[i + 1] : -1);
+    for (size_t i = 0; i < rest.size(); i += G) {
+      std::vector<int> g(rest.begin() + i, rest.begin() + std::min(rest.size(), i + G));
+      g.resize(G, -1);
+      groups.push_back(g);
+    }
   }
   // As few launches as the kernel-argument segment allows (HM_NTT_MAX_ENTRIES records), of equal size; the constants
   // of a launch live in a device table cached by content (plans repeat their launches)
-#ifndef HM_NTT_LAUNCH_PAIRS
-#define HM_NTT_LAUNCH_PAIRS (HM_NTT_MAX_ENTRIES / 2)
+#ifndef HM_NTT_LAUNCH_ENTRIES
+#define HM_NTT_LAUNCH_ENTRIES HM_NTT_MAX_ENTRIES
 #endif
-  const uint32_t maxPairs = HM_NTT_LAUNCH_PAIRS;
-  const uint32_t nLaunch = ((uint32_t)pairs.size() + maxPairs - 1) / maxPairs;
-  const uint32_t perLaunch = nLaunch ? (((uint32_t)pairs.size() + nLaunch - 1) / nLaunch + 7) / 8 * 8 : 0;  // whole groups of 8 pairs
-  for (uint32_t base = 0; base < pairs.size(); base += perLaunch) {
-    const uint32_t np = std::min<uint32_t>(perLaunch, (uint32_t)pairs.size() - base);
-    const uint32_t cnt = ((np + 7) / 8) * 16;  // entries: groups of 8 pairs = 16 entries
+  const uint32_t maxGroups = HM_NTT_LAUNCH_ENTRIES / G / 8 * 8;   // whole blocks of 8 groups (one per XCD)
+  const uint32_t nLaunch = ((uint32_t)groups.size() + maxGroups - 1) / maxGroups;
+  const uint32_t perLaunch = nLaunch ? (((uint32_t)groups.size() + nLaunch - 1) / nLaunch + 7) / 8 * 8 : 0;
+  for (uint32_t base = 0; base < groups.size(); base += perLaunch) {
+    const uint32_t ng = std::min<uint32_t>(perLaunch, (uint32_t)groups.size() - base);
+    const uint32_t cnt = ((ng + 7) / 8) * 8 * G;  // entries: blocks of 8 groups = 8G entries
     std::vector<HmNttEntry> tab(cnt);
     memset(tab.data(), 0, sizeof(HmNttEntry) * cnt);
     HmNttArgs a;
     for (uint32_t e = 0; e < cnt; ++e) a.limb[e] = HmLimb{0, 0, (uint16_t)HM_NTT_NONE, 0};
-    for (uint32_t kk = 0; kk < np; ++kk) {
-      for (int which = 0; which < 2; ++which) {
-        const int gi = which ? pairs[base + kk].second : pairs[base + kk].first;
+    for (uint32_t kk = 0; kk < ng; ++kk) {
+      for (uint32_t which = 0; which < G; ++which) {
+        const int gi = groups[base + kk][which];
         if (gi < 0) continue;
-        const uint32_t g = (uint32_t)gi, e = (kk / 8) * 16 + which * 8 + (kk % 8), m = mod_ids[g];
+        const uint32_t g = (uint32_t)gi, e = (kk / 8) * 8 * G + which * 8 + (kk % 8), m = mod_ids[g];
         const uint64_t q = c->P.mod[m];
         HmNttEntry &t = tab[e];
         a.limb[e] = HmLimb{(uint16_t)limb_at(in_limbs, g), (uint16_t)limb_at(out_limbs, g), (uint16_t)m, 0};
@@ -669,7 +862,7 @@ static hm_status ntt_common(hm_ctx *c, const char *what, const uint64_t *in, con
     a.mods = c->d_mods;
     a.entry = dtab;
     a.minuend = f.minuend; a.addend = f.addend; a.mix = f.mix;
-    a.logN = c->P.logN; a.n_limbs = cnt;
+    a.logN = c->P.logN; a.n_limbs = cnt; a.logG = logG;
     const bool mixPro = fused && f.mix;
     switch (c->P.logN - HM_ROW_LOG) {
     case 5: launch_ntt<5>(c, a, fused, mixPro, inverse); break;

@@ -61,6 +61,15 @@
 #define HM_TW_LDS_ROW 1
 #endif
 #define HM_TW_IN_LDS(STRIDED) ((STRIDED) ? HM_TW_LDS_COL : HM_TW_LDS_ROW)
+#ifndef HM_EPI_CHUNK
+#define HM_EPI_CHUNK 2
+#endif
+#ifndef HM_EPI_FENCE
+#define HM_EPI_FENCE 1
+#endif
+#ifndef HM_LATE_TW1
+#define HM_LATE_TW1 1  // inverse ROW pass: second round's twiddles requested after the first round's butterflies (see hm_ntt_phase)
+#endif
 
 struct HmLimb {  // one limb-poly of an automorphism / fill launch: limb indices into the in/out bases, modulus id
   uint16_t in, out, mod, aux;
@@ -93,7 +102,8 @@ struct HmNttArgs {
   const HmNttEntry *entry;                // [n_limbs], device
   const uint64_t *minuend, *addend, *mix; // bases of the MODE 3 / MODE 4 operands (addend may be null)
   uint32_t logN;
-  uint32_t n_limbs;    // entries, a multiple of 16 (pairs x 8 XCDs, see hm_block_map)
+  uint32_t n_limbs;    // entries, a multiple of 8 G (groups x 8 XCDs, see hm_block_map)
+  uint32_t logG;       // log2 of the same-modulus group size G (1 .. 3)
   // what a workgroup needs before it can issue its first load rides in the kernel arguments (a dependent read of the
   // device table at workgroup start cost 5 % on the whole op): in / out limbs, modulus id (HM_NTT_NONE: empty slot) and,
   // in aux, the MODE 3 minuend limb
@@ -153,17 +163,20 @@ HM_HD void hm_bst2(uint64_t *base, uint32_t lane_bytes, uint64_t v0, uint64_t v1
   hm_st2(base + (lane_bytes >> 3), v0, v1);
 #endif
 }
-template <class G>
+// AUX = cache-policy bits of the buffer instruction (gfx950: 1 = sc0, 2 = nt, 16 = sc1).  The second pass of the one-launch
+// transform reads the first pass's hand-off with sc1 loads: they bypass this CU's vector L1 (never refreshed by another CU's
+// stores) and are served by the XCD's L2, where the producing workgroups' plain stores left the lines.
+template <class G, int AUX = 0>
 HM_HD void hm_gld2(const uint64_t *g, uint32_t tile, int tid, int a, uint64_t &v0, uint64_t &v1) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  const hm_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(hm_rsrc(g), G::gthr(tid, a) << 3, G::guni(tile, a) << 3, 0);
+  const hm_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(hm_rsrc(g), G::gthr(tid, a) << 3, G::guni(tile, a) << 3, AUX);
   v0 = (uint64_t)t.x | ((uint64_t)t.y << 32);
   v1 = (uint64_t)t.z | ((uint64_t)t.w << 32);
 #else
   hm_ld2(g + G::guni(tile, a) + G::gthr(tid, a), v0, v1);
 #endif
 }
-template <class G>
+template <class G, int AUX = 0>
 HM_HD void hm_gst2(uint64_t *g, uint32_t tile, int tid, int a, uint64_t v0, uint64_t v1) {
 #if defined(__HIP_DEVICE_COMPILE__)
   hm_u32x4 t;
@@ -172,7 +185,7 @@ HM_HD void hm_gst2(uint64_t *g, uint32_t tile, int tid, int a, uint64_t v0, uint
   // registers, stored the new values for the lanes read last on gfx950 (hipcc only guards the immediate-soffset form of
   // this hazard: seen as 16 wrong coefficients in random tiles, different ones every run).  The uniform part goes into
   // the descriptor's base instead (two scalar adds).
-  __builtin_amdgcn_raw_buffer_store_b128(t, hm_rsrc(g + G::guni(tile, a)), G::gthr(tid, a) << 3, 0, 0);
+  __builtin_amdgcn_raw_buffer_store_b128(t, hm_rsrc(g + G::guni(tile, a)), G::gthr(tid, a) << 3, 0, AUX);
 #else
   hm_st2(g + G::guni(tile, a) + G::gthr(tid, a), v0, v1);
 #endif
@@ -391,7 +404,7 @@ HM_HD void hm_ph_stage_tw(int tid, uint64_t *lds, const HmTw *twl) {
   }
 }
 
-template <int TL, int LOGR, bool STRIDED, int R>
+template <int TL, int LOGR, bool STRIDED, int R, int AUX = 0>
 HM_HD void hm_ph_load_global(HmNttState &st, int tid, const uint64_t *g, uint32_t tile) {
   using G = HmRound<TL, LOGR, STRIDED, R>;
 #pragma unroll
@@ -401,12 +414,12 @@ HM_HD void hm_ph_load_global(HmNttState &st, int tid, const uint64_t *g, uint32_
 #if defined(HM_ABL_NOMEM)   // timing-only ablation build (tools/ablate.sh): no data traffic
     st.v[i0] = (uint64_t)G::gidx(tile, x, c) * 0x9E3779B97F4A7C15ull >> 5; st.v[i1] = st.v[i0] ^ 0x5555;
 #else
-    hm_gld2<G>(g, tile, tid, a, st.v[i0], st.v[i1]);
+    hm_gld2<G, AUX>(g, tile, tid, a, st.v[i0], st.v[i1]);
 #endif
   }
 }
 // MODE 4: the same with the linear prologue x = in + k * mix (both reduced; x reduced)
-template <int TL, int LOGR, bool STRIDED, int R>
+template <int TL, int LOGR, bool STRIDED, int R, int AUX = 0>
 HM_HD void hm_ph_load_global_mix(HmNttState &st, int tid, const uint64_t *g, uint32_t tile, uint64_t q, HmEpi ep) {
   using G = HmRound<TL, LOGR, STRIDED, R>;
 #pragma unroll
@@ -414,8 +427,8 @@ HM_HD void hm_ph_load_global_mix(HmNttState &st, int tid, const uint64_t *g, uin
     int i0, i1, x, c;
     G::unit(tid, a, i0, i1, x, c);
     uint64_t p0, p1, b0, b1;
-    hm_gld2<G>(g, tile, tid, a, p0, p1);
-    hm_gld2<G>(ep.b, tile, tid, a, b0, b1);
+    hm_gld2<G, AUX>(g, tile, tid, a, p0, p1);
+    hm_gld2<G, AUX>(ep.b, tile, tid, a, b0, b1);
     st.v[i0] = hm_addmod(p0, hm_shoup(b0, ep.bk.w, ep.bk.ws, q), q);
     st.v[i1] = hm_addmod(p1, hm_shoup(b1, ep.bk.w, ep.bk.ws, q), q);
   }
@@ -434,17 +447,18 @@ HM_HD uint64_t hm_epilogue(uint64_t a, uint64_t va, uint64_t vd, uint64_t q, HmT
   }
   return a;
 }
-template <int TL, int LOGR, bool STRIDED, int R, int MODE>
+template <int TL, int LOGR, bool STRIDED, int R, int MODE, int AUX = 0, int CH = HM_EPI_CHUNK>
 HM_HD void hm_ph_store_global(const HmNttState &st, int tid, uint64_t *g, uint32_t tile, uint64_t q, HmTw sc, HmEpi ep) {
   using G = HmRound<TL, LOGR, STRIDED, R>;
   // MODE 3: the epilogue operands are requested two units at a time, right before they are used (with a scheduling
   // fence in between): prefetching all of them before the last round costs 32 registers
+  // CH = units per chunk: 2 in the two-kernel transform, 1 inside the one-launch transform (whose second pass has less room)
 #pragma unroll
-  for (int a2 = 0; a2 < HM_UNITS; a2 += 2) {
+  for (int a2 = 0; a2 < HM_UNITS; a2 += CH) {
     uint64_t ea[4] = {0, 0, 0, 0}, ed[4] = {0, 0, 0, 0};
     if (MODE == 3) {
 #pragma unroll
-      for (int k = 0; k < 2; ++k) {
+      for (int k = 0; k < CH; ++k) {
         int i0, i1, x, c;
         G::unit(tid, a2 + k, i0, i1, x, c);
         hm_gld2<G>(ep.a, tile, tid, a2 + k, ea[2 * k], ea[2 * k + 1]);
@@ -452,13 +466,13 @@ HM_HD void hm_ph_store_global(const HmNttState &st, int tid, uint64_t *g, uint32
       }
     }
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < CH; ++k) {
       int i0, i1, x, c;
       G::unit(tid, a2 + k, i0, i1, x, c);
 #if defined(HM_ABL_NOMEM)
       if (st.v[i0] == 0x123456789ull)   // never true in practice: keeps the values alive without the store traffic
 #endif
-      hm_gst2<G>(g, tile, tid, a2 + k, hm_epilogue<MODE>(st.v[i0], ea[2 * k], ed[2 * k], q, sc, ep),
+      hm_gst2<G, AUX>(g, tile, tid, a2 + k, hm_epilogue<MODE>(st.v[i0], ea[2 * k], ed[2 * k], q, sc, ep),
                  hm_epilogue<MODE>(st.v[i1], ea[2 * k + 1], ed[2 * k + 1], q, sc, ep));
     }
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -536,7 +550,8 @@ HM_HD void hm_ph_twist(HmNttState &st, uint64_t q) {
 //   P2: tw[r2] (if global), tw[r1] (if LDS), LDS -> v, compute r1, then (2 rounds) v -> global  or  v -> LDS | barrier
 //   P3: tw[r2] (if LDS), LDS -> v, compute r2, v -> global
 // twl = table of the modulus; twist_tile = twist constants of the tile's first row (ROW pass)
-template <int TL, int LOGR, bool STRIDED, bool INV, int MODE, int PHASE>
+// LDAUX / STAUX: cache-policy bits of the pass's data loads / stores (hm_gld2)
+template <int TL, int LOGR, bool STRIDED, bool INV, int MODE, int PHASE, int LDAUX = 0, int STAUX = 0, int EPICH = HM_EPI_CHUNK>
 HM_HD void hm_ntt_phase(HmNttState &st, int tid, uint64_t *lds, const uint64_t *src, uint64_t *dst, uint32_t tile,
                         const HmTw *twl, const HmTw *twist_tile, uint32_t s0, uint32_t prefix0, uint64_t q, HmTw sc, HmEpi ep) {
   using PS = HmPass<LOGR, STRIDED, INV>;
@@ -544,16 +559,27 @@ HM_HD void hm_ntt_phase(HmNttState &st, int tid, uint64_t *lds, const uint64_t *
   constexpr int r0 = PS::exec(0), r1 = PS::exec(1), r2 = n == 3 ? PS::exec(2) : PS::exec(1);  // r2 only when n == 3
   constexpr int TWR = PS::twistRound;
   const HmTw *ltw = reinterpret_cast<const HmTw *>(lds + (1 << TL));
+  // register pressure: the inverse ROW pass has 120 registers of loads in flight in its first phase (data, the first
+  // round's shared twiddles, the twist constants and the NEXT round's private twiddles); inside the one-launch transform
+  // that no longer fits 128.  The next round's twiddles are then requested after the first round's butterflies instead
+  // (they still have the LDS exchange and the barrier to arrive in).
+  constexpr bool LATE_TW1 = INV && !STRIDED && HM_LATE_TW1;
   if (PHASE == 0) {
     if (PS::anyLds()) hm_ph_stage_tw<TL, LOGR, STRIDED>(tid, lds, twl);
     hm_ph_load_tw<TL, LOGR, STRIDED, r0, PS::shared(r0)>(st, tid, twl, s0, prefix0);
-    if (MODE == 4) hm_ph_load_global_mix<TL, LOGR, STRIDED, r0>(st, tid, src, tile, q, ep);
-    else hm_ph_load_global<TL, LOGR, STRIDED, r0>(st, tid, src, tile);
+    if (MODE == 4) hm_ph_load_global_mix<TL, LOGR, STRIDED, r0, LDAUX>(st, tid, src, tile, q, ep);
+    else hm_ph_load_global<TL, LOGR, STRIDED, r0, LDAUX>(st, tid, src, tile);
     if (TWR >= 0 && (INV || n == 2)) hm_ph_load_twist<TL, LOGR, STRIDED, (TWR >= 0 ? TWR : 0)>(st, tid, twist_tile);
-    if (!PS::fromLds(r1)) hm_ph_load_tw<TL, LOGR, STRIDED, r1, PS::shared(r1)>(st, tid, twl, s0, prefix0);
+    if (!PS::fromLds(r1) && !LATE_TW1) hm_ph_load_tw<TL, LOGR, STRIDED, r1, PS::shared(r1)>(st, tid, twl, s0, prefix0);
   } else if (PHASE == 1) {
     hm_ph_compute<TL, LOGR, STRIDED, r0, INV>(st, q);
     if (INV && r0 == TWR) hm_ph_twist(st, q);
+    if (!PS::fromLds(r1) && LATE_TW1) {
+#if defined(__HIP_DEVICE_COMPILE__)
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      hm_ph_load_tw<TL, LOGR, STRIDED, r1, PS::shared(r1)>(st, tid, twl, s0, prefix0);
+    }
     hm_ph_store_lds<TL, LOGR, STRIDED, r0>(st, tid, lds);
   } else if (PHASE == 2) {
     if (n == 3 && !PS::fromLds(r2)) hm_ph_load_tw<TL, LOGR, STRIDED, r2, PS::shared(r2)>(st, tid, twl, s0, prefix0);
@@ -563,14 +589,26 @@ HM_HD void hm_ntt_phase(HmNttState &st, int tid, uint64_t *lds, const uint64_t *
     if (!INV && n == 2 && r1 == TWR) hm_ph_twist(st, q);
     hm_ph_compute<TL, LOGR, STRIDED, r1, INV>(st, q);
     if (n == 3) hm_ph_store_lds<TL, LOGR, STRIDED, r1>(st, tid, lds);
-    else hm_ph_store_global<TL, LOGR, STRIDED, r1, MODE>(st, tid, dst, tile, q, sc, ep);
+    else hm_ph_store_global<TL, LOGR, STRIDED, r1, MODE, STAUX, EPICH>(st, tid, dst, tile, q, sc, ep);
   } else if (PHASE == 3) {
     if (n == 3) {
-      if (PS::fromLds(r2)) hm_ph_load_tw<TL, LOGR, STRIDED, r2, PS::shared(r2)>(st, tid, ltw, s0, prefix0);
+      // fused epilogue (MODE 3): the twist constants are dead before the last round's twiddles are read from LDS (the
+      // other order keeps 12 more registers alive and spilled inside the one-launch transform)
+      constexpr bool TWIST_FIRST = MODE == 3 && !INV && r2 == TWR && PS::fromLds(r2);
+      if (PS::fromLds(r2) && !TWIST_FIRST) hm_ph_load_tw<TL, LOGR, STRIDED, r2, PS::shared(r2)>(st, tid, ltw, s0, prefix0);
       hm_ph_load_lds<TL, LOGR, STRIDED, r2>(st, tid, lds);
       if (!INV && r2 == TWR) hm_ph_twist(st, q);
+      if (TWIST_FIRST) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        hm_ph_load_tw<TL, LOGR, STRIDED, r2, PS::shared(r2)>(st, tid, ltw, s0, prefix0);
+      }
       hm_ph_compute<TL, LOGR, STRIDED, r2, INV>(st, q);
-      hm_ph_store_global<TL, LOGR, STRIDED, r2, MODE>(st, tid, dst, tile, q, sc, ep);
+#if defined(__HIP_DEVICE_COMPILE__)
+      if (TWIST_FIRST && HM_EPI_FENCE) __builtin_amdgcn_sched_barrier(0);   // the epilogue's operand loads start after the last butterflies
+#endif
+      hm_ph_store_global<TL, LOGR, STRIDED, r2, MODE, STAUX, EPICH>(st, tid, dst, tile, q, sc, ep);
     }
   }
 }

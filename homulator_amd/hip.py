@@ -16,6 +16,7 @@ SYMBOLS = [
     "hm_memcpy_h2d", "hm_memcpy_d2h", "hm_memcpy_d2d", "hm_sync", "hm_stream", "hm_wait_for", "hm_ntt", "hm_ntt_sub_scale", "hm_ntt_mix_sub_scale", "hm_tensor", "hm_inner_product", "hm_automorph", "hm_ewe",
     "hm_bconv", "hm_bconv_batch", "hm_bconv_consts", "hm_fill_uniform", "hm_timer_start", "hm_timer_stop", "hm_comm_unique_id", "hm_comm_init_rccl", "hm_comm_init_external",
     "hm_capture_begin", "hm_capture_end", "hm_graph_launch", "hm_graph_destroy", "hm_comm_info", "hm_slice_rows", "hm_limbs_to_slices", "hm_slices_to_limbs", "hm_replicate_limbs",
+    "hm_set_option", "hm_get_counter",
 ]
 
 
@@ -77,6 +78,8 @@ def load():
     L.hm_bconv_batch.argtypes = [vp, C.POINTER(hm_bconv_desc), u32]
     L.hm_bconv_consts.argtypes = [vp, vp, u32, vp, u32, vp, vp]
     L.hm_fill_uniform.argtypes = [vp, vp, vp, vp, u32, u64]
+    L.hm_set_option.argtypes = [vp, C.c_char_p, u64]
+    L.hm_get_counter.argtypes = [vp, C.c_char_p, C.POINTER(u64)]
     L.hm_timer_start.argtypes = [vp]
     L.hm_timer_stop.argtypes = [vp, C.POINTER(u64)]
     _lib = L
@@ -255,6 +258,14 @@ class Context:
         k1, pol = _u32(out_limbs)
         k2, pm = _u32(mod_ids)
         self._ck(self.L.hm_fill_uniform(self.h, dst.ptr, pol, pm, len(mod_ids), int(seed) & (2 ** 64 - 1)))
+
+    def set_option(self, name, value):
+        self._ck(self.L.hm_set_option(self.h, name.encode(), int(value)))
+
+    def counter(self, name):
+        v = C.c_uint64()
+        self._ck(self.L.hm_get_counter(self.h, name.encode(), C.byref(v)))
+        return v.value
 
     def timer_start(self):
         self._ck(self.L.hm_timer_start(self.h))

@@ -207,6 +207,17 @@ hm_status hm_capture_end(hm_ctx *ctx, hm_graph **graph);
 hm_status hm_graph_launch(hm_ctx *ctx, hm_graph *graph);
 void hm_graph_destroy(hm_graph *graph);
 
+/* Execution options of a context (A/B measurements, tests; every option has a working default):
+ *   "ntt_fused"  0 (default): two kernels per transform; 1: both passes of a transform in ONE launch behind a per-limb
+ *                rendezvous (measured slower on MI355X and no lighter on HBM: the L2 writes through and does not
+ *                allocate on a store).  Env HOMULATOR_NTT_FUSED sets the default.
+ * Counters:
+ *   "ntt_cross_xcd"  limb-polys whose workgroups were NOT all placed on one XCD and took the agent-scope hand-off
+ *                    (slow, still correct); expected 0 under the dispatcher's observed round-robin placement.
+ * No reference counterpart: the reference's Arch has no tunables besides the .cfg keys (src/Arch.cpp:8-168). */
+hm_status hm_set_option(hm_ctx *ctx, const char *name, uint64_t value);
+hm_status hm_get_counter(hm_ctx *ctx, const char *name, uint64_t *value); /* synchronises */
+
 /* Timing on the context's stream (replaces Arch::getCycle include/Arch.h:271: elapsed device time in
  * nanoseconds instead of simulated cycles). */
 hm_status hm_timer_start(hm_ctx *ctx);

@@ -1,0 +1,114 @@
+"""GPU parity of the one-launch transform (k_ntt_fused: both passes in one kernel, the hand-off between them through the XCD's
+L2 behind a per-limb rendezvous) against the two-kernel transform and the CPU oracle, bit for bit.  Covers what the
+rendezvous can get wrong: more limb-polys than the chip holds at once (workgroups of later limbs start while earlier ones
+wait), repeated launches (the rendezvous words reset themselves), in-place transforms, two contexts sharing the chip
+(uneven load), every ring size (2 .. 32 workgroups per limb-poly) and the fused prologue / epilogue variants."""
+import numpy as np
+import pytest
+
+from oracle.homoracle import Oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _ctx(logN, L, K):
+    from homulator_amd import hip
+    return hip.Context(logN, L, K), Oracle(logN, L, K)
+
+
+@pytest.mark.parametrize("logN", [13, 14, 15, 16, 17])
+def test_fused_equals_two_kernel_and_oracle(logN):
+    ctx, o = _ctx(logN, 4, 2)
+    try:
+        ids = [0, 1, 2, 3, 4, 5, 0, 5, 3]
+        x = o.fill_uniform(ids, 77)
+        x[0, :] = o.moduli[ids[0]] - 1          # worst case of the lazy ranges
+        x[1, :3] = [0, 1, o.moduli[ids[1]] - 1]
+        d, a, b = ctx.from_host(x), ctx.alloc(len(ids)), ctx.alloc(len(ids))
+        exp = o.ntt(ids, x)
+        for inverse in (False, True):
+            src = x if not inverse else exp
+            dsrc = ctx.from_host(src)
+            ctx.set_option("ntt_fused", 1)
+            ctx.ntt(dsrc, a, ids, inverse=inverse)
+            ctx.set_option("ntt_fused", 0)
+            ctx.ntt(dsrc, b, ids, inverse=inverse)
+            A, B = a.download(), b.download()
+            assert np.array_equal(A, B)
+            assert np.array_equal(A, o.ntt(ids, src, inverse=inverse))
+            dsrc.free()
+        # merged ModDown + rescale form: mix prologue + sub-scale-add epilogue
+        mn, ad, mx = (o.fill_uniform(ids, s) for s in (124, 125, 126))
+        k = [o.moduli[m] - 2 - r for r, m in enumerate(ids)]
+        mk = [(kk * 3 + 1) % o.moduli[m] for kk, m in zip(k, ids)]
+        ak = [(kk * 5 + 1) % o.moduli[m] for kk, m in zip(k, ids)]
+        dmn, dad, dmx = ctx.from_host(mn), ctx.from_host(ad), ctx.from_host(mx)
+        xin = o.ewe(3, ids, x, None, o.ewe(5, ids, mx, k=mk))
+        exp3 = o.ewe(3, ids, o.ewe(6, ids, mn, None, o.ntt(ids, xin), k=k), None, o.ewe(5, ids, ad, k=ak))
+        for fused in (1, 0):
+            ctx.set_option("ntt_fused", fused)
+            ctx.ntt_mix_sub_scale(d, dmn, a, ids, k, addend=dad, addend_k=ak, mix=dmx, mix_k=mk)
+            assert np.array_equal(a.download(), exp3)
+            ctx.ntt_sub_scale(d, dmn, a, ids, k)
+            assert np.array_equal(a.download(), o.ewe(6, ids, mn, None, o.ntt(ids, x), k=k))
+        assert ctx.counter("ntt_cross_xcd") == 0, "a limb-poly's workgroups were spread over several XCDs (slow path taken: correct, but unexpected)"
+    finally:
+        ctx.close()
+
+
+def test_more_limbs_than_the_chip_holds_repeated_and_in_place():
+    """700 limb-polys of N = 2^16 = 11 200 workgroups on 1 024 slots: later limbs start while earlier ones sit in their rendezvous;
+    three launches back to back reuse the same rendezvous words; then the inverse in place brings the input back."""
+    ctx, o = _ctx(16, 6, 3)
+    try:
+        n = 700
+        ids = [(i * 7) % 9 for i in range(n)]
+        src = ctx.alloc(n)
+        ctx.fill_uniform(src, ids, 4242)
+        x = src.download()
+        out, ref = ctx.alloc(n), ctx.alloc(n)
+        ctx.set_option("ntt_fused", 0)
+        ctx.ntt(src, ref, ids)
+        R = ref.download()
+        ctx.set_option("ntt_fused", 1)
+        for _ in range(3):
+            ctx.ntt(src, out, ids)
+        assert np.array_equal(out.download(), R)
+        ctx.ntt(out, out, ids, inverse=True)
+        assert np.array_equal(out.download(), x)
+        # a sample of limbs against the oracle (the two-kernel path is compared with it in test_gpu_kernels.py)
+        pick = [0, 1, 350, 699]
+        assert np.array_equal(R[pick], o.ntt([ids[i] for i in pick], x[pick]))
+        assert ctx.counter("ntt_cross_xcd") == 0
+    finally:
+        ctx.close()
+
+
+def test_two_contexts_share_the_chip():
+    """uneven load: two contexts (own stream each) enqueue one-launch transforms of different sizes alternately; every output is
+    checked against the two-kernel result"""
+    from homulator_amd import hip
+    c1, c2 = hip.Context(16, 6, 3), hip.Context(16, 6, 3)
+    try:
+        jobs = []
+        for c, n, seed in ((c1, 50, 1), (c2, 130, 2), (c1, 9, 3), (c2, 50, 4), (c1, 260, 5), (c2, 3, 6)):
+            ids = [(i * 5 + seed) % 9 for i in range(n)]
+            s, f, r = c.alloc(n), c.alloc(n), c.alloc(n)
+            c.fill_uniform(s, ids, 900 + seed)
+            jobs.append((c, ids, s, f, r))
+        for c in (c1, c2):
+            c.sync()
+        for c in (c1, c2):
+            c.set_option("ntt_fused", 1)
+        for rep in range(4):
+            for c, ids, s, f, r in jobs:
+                c.ntt(s, f, ids)
+        for c in (c1, c2):
+            c.sync()
+            c.set_option("ntt_fused", 0)
+        for c, ids, s, f, r in jobs:
+            c.ntt(s, r, ids)
+        for c, ids, s, f, r in jobs:
+            assert np.array_equal(f.download(), r.download())
+    finally:
+        c1.close(); c2.close()
