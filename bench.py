@@ -305,7 +305,7 @@ def main():
                              "limbs_per_launch_group": limbs, "us": ns * 1e-3, "us_per_limb": ns * 1e-3 / limbs,
                              "achieved": NTT_ALG_BYTES * limbs / ns, "frac": NTT_ALG_BYTES * limbs / ns / HBM_PEAK_GBS,
                              "valu_frac": None if not wb_ns else wb_ns * BFLY_PER_LIMB_NTT / 64 * limbs / ns})(
-                             [r[2] for r in batched_rows if r[0] == "NTT"][0],
+                             ([r[2] for r in batched_rows if r[0] == "NTT"] or [float("nan")])[0],
                              sum(ELL + ALPHA - min(ALPHA, ELL - j * ALPHA) for j in range(-(-ELL // ALPHA))) * batch),  # sum over digits of (E - d_j) = 115 limbs per op
                          "note": "`achieved`/`peak`/`frac` are the HBM figures of the task's contract; `bound` names the ceiling "
                                  "with the larger floor for this launch (the 64-bit modular butterflies are integer VALU work)"},
@@ -318,7 +318,7 @@ def main():
             sim = sim_op.sim_run()
             sim_op.close()
             out["reference_model"] = {"cycles": sim["cycles"], "instructions": sim["retired"], "drained": sim["drained"], "host_seconds": round(time.time() - t0, 2),
-                                      "note": "simulated accelerator of the .cfg (4 clusters): what the reference simulator prints for this op (its own run of this configuration took 3 h 18 min and gave the same cycles and counters: tests/golden/structural.json slow_points); not a GPU measurement"}
+                                      "note": "simulated accelerator of the .cfg (4 clusters): what the reference simulator prints for this op (the reference's own run of this configuration with MALLOC_PERTURB_ set — its clean run: it reads uninitialised scoreboard operands, include/recodeboard.h:33-46 — took 3 h 18 min and gave the same cycles and counters: tests/golden/structural.json slow_points" + ("" if opn == "hmult" else "; for hrotate the stock binary can differ in a few counters for that reason") + "); not a GPU measurement"}
         except Exception as e:  # never let the side figure take the bench line down
             out["reference_model"] = {"error": str(e)[:200]}
     for o in ops:

@@ -231,6 +231,110 @@ __global__ void __launch_bounds__((1 << HM_TL_ROW) / HM_EPT) __attribute__((amdg
   hm_limb_leave(f.ws, entry, members, !same);
 }
 
+// ---- K1 x K5: last transform pass x evaluation key, both keys, all digits of one extended limb in one workgroup ---------
+#define HM_NIP_MAX_TERMS 4
+#define HM_NIP_MAX_OUT 2
+#define HM_NIP_MAX_LIMBS 4096   // per launch: the records live in a device table (cached by content), read through the scalar cache
+struct HmNipLimb {                       // 32 bytes
+  uint16_t x[HM_NIP_MAX_TERMS];          // per digit: limb of the first pass's hand-off (transformed digit) or of the evaluation-form operand
+  uint16_t y[HM_NIP_MAX_OUT][HM_NIP_MAX_TERMS];
+  uint16_t out[HM_NIP_MAX_OUT];
+  uint16_t mod;                          // HM_NTT_NONE: empty slot
+  uint16_t coeff_mask;                   // bit j: digit j goes through the transform (its x limb is relative to `hand`)
+};
+struct HmNipArgs {
+  const uint64_t *hand;   // first-pass hand-off (written by k_ntt_col just before)
+  const uint64_t *x;      // evaluation-form operands (a digit's own limbs)
+  const uint64_t *y;      // evaluation key
+  uint64_t *out;
+  const HmTw *tw, *twist;
+  const HmMod *mods;
+  uint32_t logN, n_limbs, logG, n_terms;
+  const HmNipLimb *limb;  // device, [n_limbs]
+};
+typedef const HmNipLimb __attribute__((address_space(4))) *HmConstNipLimb;
+#ifndef HM_NIP_WAVES
+#define HM_NIP_WAVES 3   // 64 accumulator registers on top of the pass: 168 VGPRs, three workgroups per CU
+#endif
+#ifndef HM_NIP_WIDE
+#define HM_NIP_WIDE 0      // 1: 128-bit accumulators, one reduction per output (128 registers: HM_NIP_WAVES = 2)
+#endif
+#ifndef HM_NIP_PREFETCH
+#define HM_NIP_PREFETCH 0  // 1: all key words of a digit requested before its transform (needs HM_NIP_WAVES = 2: 64 more registers)
+#endif
+#ifndef HM_NIP_MAC_CH
+#define HM_NIP_MAC_CH 1   // access units of key words in flight per multiply-accumulate step
+#endif
+template <int OUTS>
+__global__ void __launch_bounds__((1 << HM_TL_ROW) / HM_EPT) __attribute__((amdgpu_waves_per_eu(HM_NIP_WAVES))) k_ntt_row_ip(HmNipArgs a) {
+  constexpr int TL = HM_TL_ROW, LOGR = HM_ROW_LOG, R2 = HmRounds<LOGR>::n - 1;
+  __shared__ __attribute__((aligned(16))) uint64_t lds[HmLds<TL, LOGR, false>::WORDS];
+  uint32_t entry, tile;
+  if (!hm_block_map(1u << (a.logN - TL), a.n_limbs, a.logG, entry, tile)) return;
+  const HmConstNipLimb rec = (HmConstNipLimb)(uintptr_t)a.limb + entry;
+  const uint32_t mod = rec->mod;
+  if (mod == HM_NTT_NONE) return;
+  const size_t N = (size_t)1 << a.logN;
+  const HmMod m = HM_CONST_MODS(a.mods)[mod];
+  const HmTw *twl = a.tw + (size_t)mod * N;
+  const uint32_t s0 = a.logN - LOGR, prefix0 = tile << (TL - LOGR);
+  const HmTw *twt = a.twist + ((size_t)mod * (N >> LOGR) + prefix0) * 3;
+  const uint32_t mask = rec->coeff_mask;
+#if HM_NIP_WIDE
+  typedef hm_u128 Acc;
+#else
+  typedef uint64_t Acc;
+#endif
+  Acc acc[OUTS][HM_EPT];
+#pragma unroll
+  for (int k = 0; k < OUTS; ++k)
+#pragma unroll
+    for (int i = 0; i < HM_EPT; ++i) acc[k][i] = 0;
+#pragma unroll 1
+  for (uint32_t j = 0; j < a.n_terms; ++j) {
+    HmNttState st;
+    // a thread id the compiler cannot see through: otherwise the ~60 lane offsets of the pass are hoisted out of the digit
+    // loop as loop invariants and live (spilled) beside the accumulators
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    __builtin_assume(tid >= 0 && tid < (1 << HM_TL_ROW) / HM_EPT);
+    const uint32_t xl = rec->x[j];
+    const uint64_t *y[OUTS];
+#pragma unroll
+    for (int k = 0; k < OUTS; ++k) y[k] = a.y + (size_t)rec->y[k][j] * N;
+#if HM_NIP_PREFETCH
+    uint64_t e[OUTS][HM_EPT];
+    hm_ph_key_load<TL, LOGR, R2, OUTS>(e, tid, y, tile);
+#endif
+    if (mask & (1u << j)) {   // wave-uniform
+      const uint64_t *src = a.hand + (size_t)xl * N;
+      const HmTw sc = {0, 0};
+      const HmEpi ep = hm_epi_none();
+      if (j) __syncthreads();   // the previous digit's last round has read the tile
+      hm_ntt_phase<TL, LOGR, false, false, 5, 0>(st, tid, lds, src, nullptr, tile, twl, twt, s0, prefix0, m.q, sc, ep);
+      hm_ntt_phase<TL, LOGR, false, false, 5, 1>(st, tid, lds, src, nullptr, tile, twl, twt, s0, prefix0, m.q, sc, ep);
+      __syncthreads();
+      hm_ntt_phase<TL, LOGR, false, false, 5, 2>(st, tid, lds, src, nullptr, tile, twl, twt, s0, prefix0, m.q, sc, ep);
+      __syncthreads();
+      hm_ntt_phase<TL, LOGR, false, false, 5, 3>(st, tid, lds, src, nullptr, tile, twl, twt, s0, prefix0, m.q, sc, ep);
+#if HM_NIP_WIDE
+      hm_ph_below_2q(st, m.q);
+#endif
+    } else {
+      hm_ph_load_global<TL, LOGR, false, R2>(st, tid, a.x + (size_t)xl * N, tile);
+    }
+#if HM_NIP_PREFETCH
+    hm_ph_mac_regs<OUTS, Acc>(st, acc, e, m);
+#else
+    hm_ph_mac<TL, LOGR, R2, OUTS, HM_NIP_MAC_CH, Acc>(st, acc, tid, y, tile, m);
+#endif
+  }
+  uint64_t *out[OUTS];
+#pragma unroll
+  for (int k = 0; k < OUTS; ++k) out[k] = a.out + (size_t)rec->out[k] * N;
+  hm_ph_mac_store<TL, LOGR, R2, OUTS, Acc>(acc, threadIdx.x, out, tile, m);
+}
+
 __global__ void __launch_bounds__(256) k_tensor(HmTensorArgs a) {
   const uint32_t N = 1u << a.logN;
   const uint32_t per_limb = N / 512;
@@ -395,7 +499,8 @@ struct hm_ctx {
   HmMod *d_mods = nullptr;
   std::map<std::vector<uint32_t>, uint64_t *> bconv_tables;  // key: n_in, in_ids..., out_ids...
   std::map<std::string, void *> ntt_tables;                  // launch tables (device_table), key: their bytes
-  bool tables_pinned = false;                                 // a captured graph references the tables: no eviction
+  int live_graphs = 0;                                        // captured graphs that reference the tables: no eviction while > 0
+  bool capturing = false;
   std::string err;
   // one-launch transforms (k_ntt_fused): rendezvous words in HBM, a host-visible error word, and the switch
   HmNttSync *ntt_ws = nullptr;
@@ -630,18 +735,21 @@ extern "C" hm_status hm_get_counter(hm_ctx *c, const char *name, uint64_t *value
 struct hm_graph {
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
+  hm_ctx *owner = nullptr;   // its kernel nodes keep device addresses of the owner's launch tables: destroy graphs before their context
 };
 extern "C" hm_status hm_capture_begin(hm_ctx *c) {
   if (!c) return HM_ERR_ARG;
   if (c->ext_fn) return fail(c, HM_ERR_UNSUPPORTED, "hm_capture_begin: an external exchange transport cannot be captured");
   HM_HIP(c, hipSetDevice(c->device));
-  c->tables_pinned = true;  // kernel nodes of the graph keep the device addresses of the launch tables
-  HM_HIP(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+  c->capturing = true;  // kernel nodes of the graph keep the device addresses of the launch tables
+  hipError_t e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal);
+  if (e != hipSuccess) { c->capturing = false; return fail(c, HM_ERR_HIP, "hipStreamBeginCapture: %s", hipGetErrorString(e)); }
   return HM_OK;
 }
 extern "C" hm_status hm_capture_end(hm_ctx *c, hm_graph **out) {
   if (!c || !out) return HM_ERR_ARG;
   hm_graph *g = new hm_graph;
+  c->capturing = false;
   hipError_t e = hipStreamEndCapture(c->stream, &g->graph);
   if (e == hipSuccess) e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
   if (e != hipSuccess) {
@@ -649,6 +757,8 @@ extern "C" hm_status hm_capture_end(hm_ctx *c, hm_graph **out) {
     delete g;
     return fail(c, HM_ERR_HIP, "hm_capture_end: %s", hipGetErrorString(e));
   }
+  g->owner = c;
+  c->live_graphs++;   // the launch-table cache is pinned while this graph lives (released in hm_graph_destroy)
   *out = g;
   return HM_OK;
 }
@@ -659,6 +769,7 @@ extern "C" hm_status hm_graph_launch(hm_ctx *c, hm_graph *g) {
 }
 extern "C" void hm_graph_destroy(hm_graph *g) {
   if (!g) return;
+  if (g->owner && g->owner->live_graphs > 0) g->owner->live_graphs--;
   (void)hipGraphExecDestroy(g->exec);
   (void)hipGraphDestroy(g->graph);
   delete g;
@@ -698,10 +809,14 @@ static hm_status check_mods(hm_ctx *c, const char *what, const uint32_t *m, uint
 }
 
 template <int LOG1>
-static void launch_ntt(hm_ctx *c, const HmNttArgs &a, bool fusedEpilogue, bool mixPrologue, bool inverse) {
+static void launch_ntt(hm_ctx *c, const HmNttArgs &a, bool fusedEpilogue, bool mixPrologue, bool inverse, bool firstPassOnly) {
   // n_limbs = entries, a multiple of 16 (pairs x 8 XCDs); one workgroup per tile of each pass
   const dim3 gridC(a.n_limbs * (c->P.N >> HM_TL_COL)), blockC((1 << HM_TL_COL) / HM_EPT);
   const dim3 gridR(a.n_limbs * (c->P.N >> HM_TL_ROW)), blockR((1 << HM_TL_ROW) / HM_EPT);
+  if (firstPassOnly) {  // forward COL pass alone: hm_ntt_inner_product runs the ROW pass inside its own kernel
+    hipLaunchKernelGGL((k_ntt_col<LOG1, false, 0>), gridC, blockC, 0, c->stream, a);
+    return;
+  }
   if (c->fused_ntt) {   // both passes in one launch, hand-off through the XCD's L2
     const HmNttFusedArgs f = {c->ntt_ws, c->err_dev};
     if (inverse) hipLaunchKernelGGL((k_ntt_fused<LOG1, true, 0, 2>), gridR, blockR, 0, c->stream, a, f);
@@ -731,7 +846,7 @@ static hm_status device_table(hm_ctx *c, const void *data, size_t bytes, const v
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(c->stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
       return fail(c, HM_ERR_UNSUPPORTED, "a launch table is missing while the stream is capturing: run the plan once before hm_capture_begin");
-    if (c->ntt_tables.size() >= 1024 && !c->tables_pinned) {  // callers that never repeat a launch (tests): start over rather than grow without bound
+    if (c->ntt_tables.size() >= 1024 && c->live_graphs == 0 && !c->capturing) {  // callers that never repeat a launch (tests): start over rather than grow without bound
       HM_HIP(c, hipStreamSynchronize(c->stream));
       for (auto &kv : c->ntt_tables) (void)hipFree(kv.second);
       c->ntt_tables.clear();
@@ -761,6 +876,7 @@ struct NttFused {
   const uint64_t *mix = nullptr;
   const uint32_t *mix_limbs = nullptr;
   const uint64_t *mix_k = nullptr;
+  bool firstPassOnly = false;   // forward transform: run the COL pass only (the hand-off stays in `out`)
 };
 
 // common body of hm_ntt / hm_ntt_sub_scale / hm_ntt_mix_sub_scale.  `k`: inverse -> optional extra scale; fused forward ->
@@ -865,11 +981,11 @@ static hm_status ntt_common(hm_ctx *c, const char *what, const uint64_t *in, con
     a.logN = c->P.logN; a.n_limbs = cnt; a.logG = logG;
     const bool mixPro = fused && f.mix;
     switch (c->P.logN - HM_ROW_LOG) {
-    case 5: launch_ntt<5>(c, a, fused, mixPro, inverse); break;
-    case 6: launch_ntt<6>(c, a, fused, mixPro, inverse); break;
-    case 7: launch_ntt<7>(c, a, fused, mixPro, inverse); break;
-    case 8: launch_ntt<8>(c, a, fused, mixPro, inverse); break;
-    case 9: launch_ntt<9>(c, a, fused, mixPro, inverse); break;
+    case 5: launch_ntt<5>(c, a, fused, mixPro, inverse, f.firstPassOnly); break;
+    case 6: launch_ntt<6>(c, a, fused, mixPro, inverse, f.firstPassOnly); break;
+    case 7: launch_ntt<7>(c, a, fused, mixPro, inverse, f.firstPassOnly); break;
+    case 8: launch_ntt<8>(c, a, fused, mixPro, inverse, f.firstPassOnly); break;
+    case 9: launch_ntt<9>(c, a, fused, mixPro, inverse, f.firstPassOnly); break;
     default: return fail(c, HM_ERR_UNSUPPORTED, "%s: logN %u", what, c->P.logN);
     }
     HM_HIP(c, hipGetLastError());
@@ -1045,6 +1161,100 @@ extern "C" hm_status hm_inner_product(hm_ctx *c, const uint64_t *x, const uint32
     case 31: launch_ip<3, 1>(c, a); break; case 32: launch_ip<3, 2>(c, a); break;
     case 41: launch_ip<4, 1>(c, a); break; case 42: launch_ip<4, 2>(c, a); break;
     }
+    HM_HIP(c, hipGetLastError());
+  }
+  return HM_OK;
+}
+
+
+// K1 x K5: out[i][k] = sum_j X_j[i] * y[i][k][j] with X_j[i] = NTT(x[i][j]) for the digits that go through
+// the transform (x_is_coeff) and x[i][j] itself for a digit's own limbs.  Two launches: the COL pass of every transformed
+// (limb, digit) into `hand`, then k_ntt_row_ip: ROW pass, product with both keys, accumulation over the digits in registers.
+extern "C" hm_status hm_ntt_inner_product(hm_ctx *c, const hm_ntt_ip_desc *d) {
+  if (!c) return HM_ERR_ARG;
+  if (!d || !d->x || !d->x_limbs || !d->x_is_coeff || !d->y || !d->y_limbs || !d->out || !d->out_limbs || !d->mod_ids)
+    return fail(c, HM_ERR_ARG, "hm_ntt_inner_product: null argument");
+  const uint32_t n = d->n, T = d->n_terms, K = d->n_out;
+  if (T == 0 || T > HM_NIP_MAX_TERMS || K == 0 || K > HM_NIP_MAX_OUT)
+    return fail(c, HM_ERR_ARG, "hm_ntt_inner_product: n_terms in [1,%d], n_out in [1,%d]", HM_NIP_MAX_TERMS, HM_NIP_MAX_OUT);
+  hm_status st;
+  if ((st = check_limbs(c, "hm_ntt_inner_product", d->x_limbs, n * T)) || (st = check_limbs(c, "hm_ntt_inner_product", d->y_limbs, n * T * K)) ||
+      (st = check_limbs(c, "hm_ntt_inner_product", d->out_limbs, n * K)) || (st = check_mods(c, "hm_ntt_inner_product", d->mod_ids, n)))
+    return st;
+  // 1. first pass of every transformed (limb, digit): x -> hand
+  std::vector<uint32_t> cin, chand, cmod;
+  for (uint32_t i = 0; i < n; ++i)
+    for (uint32_t j = 0; j < T; ++j)
+      if (d->x_is_coeff[i * T + j]) {
+        if (!d->hand || !d->hand_limbs) return fail(c, HM_ERR_ARG, "hm_ntt_inner_product: transformed digits need the hand-off buffer");
+        if (d->hand_limbs[i * T + j] > 0xFFFFu) return fail(c, HM_ERR_ARG, "hm_ntt_inner_product: limb index exceeds 65535");
+        cin.push_back(d->x_limbs[i * T + j]); chand.push_back(d->hand_limbs[i * T + j]); cmod.push_back(d->mod_ids[i]);
+      }
+  if (!cin.empty()) {
+    NttFused f;
+    f.firstPassOnly = true;
+    if ((st = ntt_common(c, "hm_ntt_inner_product", d->x, cin.data(), d->hand, chand.data(), cmod.data(), (uint32_t)cin.size(), 0, nullptr, f))) return st;
+  }
+  HM_HIP(c, hipSetDevice(c->device));
+  // 2. same-modulus groups (the ops of a batch bring one limb-poly per modulus each: they share the row twiddles AND the key)
+  std::map<uint32_t, std::vector<uint32_t>> byMod;
+  for (uint32_t i = 0; i < n; ++i) byMod[d->mod_ids[i]].push_back(i);
+  uint32_t logG = 0;
+  for (uint32_t lg = 3; lg >= 1; --lg) {
+    size_t full = 0;
+    for (auto &kv : byMod) full += kv.second.size() >> lg << lg;
+    if (full * 8 >= (size_t)n * 7 && n >= (8u << lg)) { logG = lg; break; }
+  }
+  const uint32_t G = 1u << logG;
+  std::vector<std::vector<int>> groups;
+  {
+    std::vector<int> rest;
+    for (auto &kv : byMod) {
+      auto &v = kv.second;
+      size_t i = 0;
+      for (; i + G <= v.size(); i += G) groups.emplace_back(v.begin() + i, v.begin() + i + G);
+      rest.insert(rest.end(), v.begin() + i, v.end());
+    }
+    for (size_t i = 0; i < rest.size(); i += G) {
+      std::vector<int> g(rest.begin() + i, rest.begin() + std::min(rest.size(), i + G));
+      g.resize(G, -1);
+      groups.push_back(g);
+    }
+  }
+  const uint32_t maxGroups = HM_NIP_MAX_LIMBS / G / 8 * 8;
+  const uint32_t nLaunch = ((uint32_t)groups.size() + maxGroups - 1) / maxGroups;
+  const uint32_t perLaunch = nLaunch ? (((uint32_t)groups.size() + nLaunch - 1) / nLaunch + 7) / 8 * 8 : 0;
+  for (uint32_t base = 0; base < groups.size(); base += perLaunch) {
+    const uint32_t ng = std::min<uint32_t>(perLaunch, (uint32_t)groups.size() - base);
+    const uint32_t cnt = ((ng + 7) / 8) * 8 * G;
+    HmNipArgs a;
+    std::vector<HmNipLimb> recs(cnt);
+    memset(recs.data(), 0, sizeof(HmNipLimb) * cnt);
+    for (uint32_t e = 0; e < cnt; ++e) recs[e].mod = (uint16_t)HM_NTT_NONE;
+    for (uint32_t kk = 0; kk < ng; ++kk)
+      for (uint32_t which = 0; which < G; ++which) {
+        const int gi = groups[base + kk][which];
+        if (gi < 0) continue;
+        const uint32_t i = (uint32_t)gi, e = (kk / 8) * 8 * G + which * 8 + (kk % 8);
+        HmNipLimb &l = recs[e];
+        l.mod = (uint16_t)d->mod_ids[i];
+        for (uint32_t j = 0; j < T; ++j) {
+          const bool tr = d->x_is_coeff[i * T + j] != 0;
+          l.x[j] = (uint16_t)(tr ? d->hand_limbs[i * T + j] : d->x_limbs[i * T + j]);
+          if (tr) l.coeff_mask |= (uint16_t)(1u << j);
+          for (uint32_t k = 0; k < K; ++k) l.y[k][j] = (uint16_t)d->y_limbs[(i * K + k) * T + j];
+        }
+        for (uint32_t k = 0; k < K; ++k) l.out[k] = (uint16_t)d->out_limbs[i * K + k];
+      }
+    const void *dtab = nullptr;
+    if ((st = device_table(c, recs.data(), sizeof(HmNipLimb) * cnt, &dtab))) return st;
+    a.limb = static_cast<const HmNipLimb *>(dtab);
+    a.hand = d->hand; a.x = d->x; a.y = d->y; a.out = d->out;
+    a.tw = c->d_tw_fwd; a.twist = c->d_twist_fwd; a.mods = c->d_mods;
+    a.logN = c->P.logN; a.n_limbs = cnt; a.logG = logG; a.n_terms = T;
+    const dim3 grid(cnt * (c->P.N >> HM_TL_ROW)), block((1 << HM_TL_ROW) / HM_EPT);
+    if (K == 1) hipLaunchKernelGGL((k_ntt_row_ip<1>), grid, block, 0, c->stream, a);
+    else hipLaunchKernelGGL((k_ntt_row_ip<2>), grid, block, 0, c->stream, a);
     HM_HIP(c, hipGetLastError());
   }
   return HM_OK;

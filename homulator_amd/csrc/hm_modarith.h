@@ -59,6 +59,15 @@ HM_HD uint64_t hm_barrett(hm_u128 z, const HmMod &m) {
   return hm_csub(r, m.q);
 }
 HM_HD uint64_t hm_mulmod(uint64_t a, uint64_t b, const HmMod &m) { return hm_barrett((hm_u128)a * b, m); }
+// the same without the final conditional subtractions: z mod q + {0, q, 2q}, in [0, 3q) — for sums that are reduced once at the end
+HM_HD uint64_t hm_barrett_lazy(hm_u128 z, const HmMod &m) {
+  const uint64_t zh = (uint64_t)(z >> m.sh);
+  return (uint64_t)z - hm_mulhi(zh, m.mu) * m.q;
+}
+// [0, 16q) -> [0, q)   (q < 2^60)
+HM_HD uint64_t hm_reduce16(uint64_t x, uint64_t q) {
+  return hm_csub(hm_csub(hm_csub(hm_csub(x, 8 * q), 4 * q), 2 * q), q);
+}
 
 // full 128-bit accumulator (base conversion: up to 16 products of 2^2k): fold the top word first.
 HM_HD uint64_t hm_barrett_wide(hm_u128 z, const HmMod &m) {

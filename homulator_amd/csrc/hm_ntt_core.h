@@ -434,6 +434,8 @@ HM_HD void hm_ph_load_global_mix(HmNttState &st, int tid, const uint64_t *g, uin
   }
 }
 
+// MODE 5 (ROW pass of the fused transform x key inner product): the last pass keeps its results in registers (lazy, below 8q)
+// and stores nothing; hm_ph_mac consumes them.
 // the epilogue of one coefficient.  MODE 0 / 4: store as is (lazy values, hand-off between the two passes; 4 = first
 // pass with the mix prologue); 1: forward final, reduce [0,8q) -> [0,q); 2: inverse final, multiply by the per-limb
 // constant and reduce to [0,q); 3: forward final fused with out = (minuend - x) * k [+ addend [* ak]]
@@ -563,7 +565,7 @@ HM_HD void hm_ntt_phase(HmNttState &st, int tid, uint64_t *lds, const uint64_t *
   // round's shared twiddles, the twist constants and the NEXT round's private twiddles); inside the one-launch transform
   // that no longer fits 128.  The next round's twiddles are then requested after the first round's butterflies instead
   // (they still have the LDS exchange and the barrier to arrive in).
-  constexpr bool LATE_TW1 = INV && !STRIDED && HM_LATE_TW1;
+  constexpr bool LATE_TW1 = ((INV && HM_LATE_TW1) || MODE == 5) && !STRIDED;   // MODE 5: 64 accumulator registers are live beside the pass
   if (PHASE == 0) {
     if (PS::anyLds()) hm_ph_stage_tw<TL, LOGR, STRIDED>(tid, lds, twl);
     hm_ph_load_tw<TL, LOGR, STRIDED, r0, PS::shared(r0)>(st, tid, twl, s0, prefix0);
@@ -594,7 +596,7 @@ HM_HD void hm_ntt_phase(HmNttState &st, int tid, uint64_t *lds, const uint64_t *
     if (n == 3) {
       // fused epilogue (MODE 3): the twist constants are dead before the last round's twiddles are read from LDS (the
       // other order keeps 12 more registers alive and spilled inside the one-launch transform)
-      constexpr bool TWIST_FIRST = MODE == 3 && !INV && r2 == TWR && PS::fromLds(r2);
+      constexpr bool TWIST_FIRST = (MODE == 3 || MODE == 5) && !INV && r2 == TWR && PS::fromLds(r2);
       if (PS::fromLds(r2) && !TWIST_FIRST) hm_ph_load_tw<TL, LOGR, STRIDED, r2, PS::shared(r2)>(st, tid, ltw, s0, prefix0);
       hm_ph_load_lds<TL, LOGR, STRIDED, r2>(st, tid, lds);
       if (!INV && r2 == TWR) hm_ph_twist(st, q);
@@ -605,10 +607,92 @@ HM_HD void hm_ntt_phase(HmNttState &st, int tid, uint64_t *lds, const uint64_t *
         hm_ph_load_tw<TL, LOGR, STRIDED, r2, PS::shared(r2)>(st, tid, ltw, s0, prefix0);
       }
       hm_ph_compute<TL, LOGR, STRIDED, r2, INV>(st, q);
+      if (MODE == 5) return;
 #if defined(__HIP_DEVICE_COMPILE__)
       if (TWIST_FIRST && HM_EPI_FENCE) __builtin_amdgcn_sched_barrier(0);   // the epilogue's operand loads start after the last butterflies
 #endif
       hm_ph_store_global<TL, LOGR, STRIDED, r2, MODE, STAUX, EPICH>(st, tid, dst, tile, q, sc, ep);
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K1 x K5: the transform's last pass multiplied into the evaluation key (the reference's HPIP unit as a fused NTT-epilogue x
+// evk MAC: HPIP src/Components.cpp:571-668, InsGen::GenHPIP src/InsGen.cpp:356-406, KeySwitch::InnerProduceOperation
+// src/Operation.cpp:294-414).  After the ROW pass of digit j (MODE 5) a thread holds 16 coefficients of ext_j in the layout
+// of the pass's last round; hm_ph_mac adds ext_j * evk_{j,k} for both keys to the thread's accumulators, which live in
+// registers across the digits: the extended digit never exists in HBM.  Accumulators are lazy: every product is reduced
+// to [0, 3q) (hm_barrett_lazy; x may be any value below 8q), up to 4 terms stay below 12q < 2^64; hm_ph_mac_store reduces once.
+// ---------------------------------------------------------------------------------------------------
+// Accumulator forms: uint64_t — every product reduced to [0, 3q) before it is added (about 40 instructions per product, 64
+// registers for both keys); hm_u128 — the raw 128-bit products are summed (12 instructions per product: x < 2q and y < q keep 4
+// terms below 2^123 once x is brought below 2q) and reduced once per output by hm_barrett, at the price of 128 accumulator
+// registers (two waves per SIMD).
+HM_HD void hm_mac_add(uint64_t &acc, uint64_t x, uint64_t y, const HmMod &m) { acc += hm_barrett_lazy((hm_u128)x * y, m); }
+HM_HD void hm_mac_add(hm_u128 &acc, uint64_t x, uint64_t y, const HmMod &) { acc += (hm_u128)x * y; }
+HM_HD uint64_t hm_mac_final(uint64_t acc, const HmMod &m) { return hm_reduce16(acc, m.q); }
+HM_HD uint64_t hm_mac_final(hm_u128 acc, const HmMod &m) { return hm_barrett(acc, m); }   // 4 terms x (x < 2q) x (y < q) < 2^123
+// [0, 8q) -> [0, 2q): the wide accumulators take transform outputs below 2q, so that the sum stays inside hm_barrett's range
+HM_HD void hm_ph_below_2q(HmNttState &st, uint64_t q) {
+  const HmBflyMod m = hm_bfly_mod(q);
+#pragma unroll
+  for (int i = 0; i < HM_EPT; ++i) st.v[i] = hm_csub_neg(hm_csub_neg(st.v[i], m.nq4), m.z - 2 * q);
+}
+template <int TL, int LOGR, int R, int OUTS, int CH = 2, class ACC = uint64_t>
+HM_HD void hm_ph_mac(const HmNttState &st, ACC (&acc)[OUTS][HM_EPT], int tid, const uint64_t *const (&y)[OUTS], uint32_t tile, const HmMod &m) {
+  using G = HmRound<TL, LOGR, false, R>;
+#pragma unroll
+  for (int a2 = 0; a2 < HM_UNITS; a2 += CH) {
+    uint64_t e[OUTS][2 * CH];
+#pragma unroll
+    for (int k = 0; k < OUTS; ++k)
+#pragma unroll
+      for (int c = 0; c < CH; ++c) hm_gld2<G>(y[k], tile, tid, a2 + c, e[k][2 * c], e[k][2 * c + 1]);
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      int i0, i1, x, cc;
+      G::unit(tid, a2 + c, i0, i1, x, cc);
+#pragma unroll
+      for (int k = 0; k < OUTS; ++k) {
+        hm_mac_add(acc[k][i0], st.v[i0], e[k][2 * c], m);
+        hm_mac_add(acc[k][i1], st.v[i1], e[k][2 * c + 1], m);
+      }
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+  }
+}
+// the same with the key words already in registers (requested before the digit's transform by hm_ph_key_load: two waves per
+// SIMD leave room for them, and their latency hides behind the butterflies)
+template <int TL, int LOGR, int R, int OUTS>
+HM_HD void hm_ph_key_load(uint64_t (&e)[OUTS][HM_EPT], int tid, const uint64_t *const (&y)[OUTS], uint32_t tile) {
+  using G = HmRound<TL, LOGR, false, R>;
+#pragma unroll
+  for (int k = 0; k < OUTS; ++k)
+#pragma unroll
+    for (int a = 0; a < HM_UNITS; ++a) {
+      int i0, i1, x, c;
+      G::unit(tid, a, i0, i1, x, c);
+      hm_gld2<G>(y[k], tile, tid, a, e[k][i0], e[k][i1]);
+    }
+}
+template <int OUTS, class ACC>
+HM_HD void hm_ph_mac_regs(const HmNttState &st, ACC (&acc)[OUTS][HM_EPT], const uint64_t (&e)[OUTS][HM_EPT], const HmMod &m) {
+#pragma unroll
+  for (int k = 0; k < OUTS; ++k)
+#pragma unroll
+    for (int i = 0; i < HM_EPT; ++i) hm_mac_add(acc[k][i], st.v[i], e[k][i], m);
+}
+template <int TL, int LOGR, int R, int OUTS, class ACC>
+HM_HD void hm_ph_mac_store(const ACC (&acc)[OUTS][HM_EPT], int tid, uint64_t *const (&out)[OUTS], uint32_t tile, const HmMod &m) {
+  using G = HmRound<TL, LOGR, false, R>;
+#pragma unroll
+  for (int k = 0; k < OUTS; ++k)
+#pragma unroll
+    for (int a = 0; a < HM_UNITS; ++a) {
+      int i0, i1, x, c;
+      G::unit(tid, a, i0, i1, x, c);
+      hm_gst2<G>(out[k], tile, tid, a, hm_mac_final(acc[k][i0], m), hm_mac_final(acc[k][i1], m));
+    }
 }

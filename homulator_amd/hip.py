@@ -16,7 +16,7 @@ SYMBOLS = [
     "hm_memcpy_h2d", "hm_memcpy_d2h", "hm_memcpy_d2d", "hm_sync", "hm_stream", "hm_wait_for", "hm_ntt", "hm_ntt_sub_scale", "hm_ntt_mix_sub_scale", "hm_tensor", "hm_inner_product", "hm_automorph", "hm_ewe",
     "hm_bconv", "hm_bconv_batch", "hm_bconv_consts", "hm_fill_uniform", "hm_timer_start", "hm_timer_stop", "hm_comm_unique_id", "hm_comm_init_rccl", "hm_comm_init_external",
     "hm_capture_begin", "hm_capture_end", "hm_graph_launch", "hm_graph_destroy", "hm_comm_info", "hm_slice_rows", "hm_limbs_to_slices", "hm_slices_to_limbs", "hm_replicate_limbs",
-    "hm_set_option", "hm_get_counter",
+    "hm_set_option", "hm_get_counter", "hm_ntt_inner_product",
 ]
 
 
@@ -25,6 +25,12 @@ class hm_ntt_fused_desc(C.Structure):
                 ("minuend", C.c_void_p), ("minuend_limbs", C.c_void_p), ("addend", C.c_void_p), ("addend_limbs", C.c_void_p),
                 ("addend_k", C.c_void_p), ("out", C.c_void_p), ("out_limbs", C.c_void_p), ("mod_ids", C.c_void_p), ("n", C.c_uint32),
                 ("k", C.c_void_p)]
+
+
+class hm_ntt_ip_desc(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("x_limbs", C.c_void_p), ("x_is_coeff", C.c_void_p), ("hand", C.c_void_p), ("hand_limbs", C.c_void_p),
+                ("y", C.c_void_p), ("y_limbs", C.c_void_p), ("out", C.c_void_p), ("out_limbs", C.c_void_p), ("mod_ids", C.c_void_p),
+                ("n", C.c_uint32), ("n_terms", C.c_uint32), ("n_out", C.c_uint32)]
 
 
 class hm_bconv_desc(C.Structure):
@@ -78,6 +84,7 @@ def load():
     L.hm_bconv_batch.argtypes = [vp, C.POINTER(hm_bconv_desc), u32]
     L.hm_bconv_consts.argtypes = [vp, vp, u32, vp, u32, vp, vp]
     L.hm_fill_uniform.argtypes = [vp, vp, vp, vp, u32, u64]
+    L.hm_ntt_inner_product.argtypes = [vp, C.POINTER(hm_ntt_ip_desc)]
     L.hm_set_option.argtypes = [vp, C.c_char_p, u64]
     L.hm_get_counter.argtypes = [vp, C.c_char_p, C.POINTER(u64)]
     L.hm_timer_start.argtypes = [vp]
@@ -215,6 +222,14 @@ class Context:
         keep = [_u32(v) for v in (x_limbs, y_limbs, out_limbs, mod_ids)]
         self._ck(self.L.hm_inner_product(self.h, x.ptr, keep[0][1], y.ptr, keep[1][1], out.ptr, keep[2][1], keep[3][1], len(mod_ids),
                                          n_terms, n_out))
+
+    def ntt_inner_product(self, x, x_limbs, x_is_coeff, hand, hand_limbs, y, y_limbs, out, out_limbs, mod_ids, n_terms, n_out):
+        """out[i][k] = sum_j (NTT(x[i][j]) if x_is_coeff[i][j] else x[i][j]) * y[i][k][j]: the HPIP unit as a fused NTT-epilogue x key MAC"""
+        keep = [_u32(v) for v in (x_limbs, hand_limbs, y_limbs, out_limbs, mod_ids)]
+        flags = np.ascontiguousarray(np.asarray(x_is_coeff, dtype=np.uint8))
+        d = hm_ntt_ip_desc(x.ptr, keep[0][1], flags.ctypes.data_as(C.c_void_p), None if hand is None else hand.ptr, keep[1][1], y.ptr, keep[2][1],
+                           out.ptr, keep[3][1], keep[4][1], len(mod_ids), n_terms, n_out)
+        self._ck(self.L.hm_ntt_inner_product(self.h, C.byref(d)))
 
     def automorph(self, src, dst, n, galois, in_limbs=None, out_limbs=None):
         k1, pi = _u32(in_limbs)

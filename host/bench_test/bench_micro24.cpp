@@ -3,6 +3,7 @@
 #include "Arch.h"
 #include "Basic.h"
 #include "Operation.h"
+#include "RcclRendezvous.h"
 
 #include <sys/stat.h>
 #include <unistd.h>
@@ -14,30 +15,18 @@ extern "C" int hm_comm_unique_id(void *out128);
 
 // [cluster] doubles as the GPU count: `torchrun --nproc-per-node 8 ./Homulator.run <cfg> hmult 45 35 15 8` (or
 // any launcher that sets WORLD_SIZE / RANK / LOCAL_RANK) runs ONE op sharded over the ranks.  The 128-byte RCCL id goes
-// from rank 0 to the others through a file (HOMULATOR_RCCL_ID_FILE, default /tmp/homulator_rccl_<MASTER_PORT>.id): the CLI
-// has no other channel between its processes.  Files older than this process are leftovers of earlier runs and ignored.
-static void rcclRendezvous(Arch *arch) {
-  const char *envp = getenv("HOMULATOR_RCCL_ID_FILE"), *port = getenv("MASTER_PORT");
-  const std::string path = envp ? envp : std::string("/tmp/homulator_rccl_") + (port ? port : "0") + ".id";
-  const time_t started = time(nullptr) - 5;
-  char id[128];
+// from rank 0 to the others through a file whose name is unique to the run (RcclRendezvous.h).
+static void rcclRendezvous(Arch *arch, const std::string &path) {
+  char id[hrv::kIdBytes];
   if (arch->rank() == 0) {
     if (hm_comm_unique_id(id)) throw std::runtime_error("hm_comm_unique_id failed (is librccl.so available?)");
-    const std::string tmp = path + ".tmp";
-    { std::ofstream f(tmp, std::ios::binary); f.write(id, sizeof id); }
-    if (rename(tmp.c_str(), path.c_str())) throw std::runtime_error("cannot publish the RCCL id at " + path);
+    hrv::publish(path, id);
   } else {
-    for (int waited = 0;; ++waited) {
-      struct stat st;
-      if (stat(path.c_str(), &st) == 0 && st.st_size == (off_t)sizeof id && st.st_mtime >= started) {
-        std::ifstream f(path, std::ios::binary);
-        if (f.read(id, sizeof id)) break;
-      }
-      if (waited > 1200) throw std::runtime_error("no RCCL id from rank 0 at " + path + " after 120 s");
-      std::this_thread::sleep_for(std::chrono::milliseconds(100));
-    }
+    const char *t = getenv("HOMULATOR_RCCL_ID_TIMEOUT_S");
+    hrv::fetch(path, id, (t ? (unsigned)atoi(t) : 600u) * 1000u);
   }
-  arch->commInitRccl(id);
+  arch->commInitRccl(id);   // collective: when it returns, every rank has read the file
+  if (arch->rank() == 0) hrv::removeStale(path);
 }
 
 int main(int argc, char *argv[]) {
@@ -54,6 +43,13 @@ int main(int argc, char *argv[]) {
   if (argc > 6) {
     config->setValue("cluster", std::atoi(argv[6]));
     config->setValue("cluster_from_argv", 1);
+  }
+  // only the CLI infers its rank from a launcher's environment (WORLD_SIZE / RANK / LOCAL_RANK); library users say world / rank
+  config->setValue("launcher_env", 1);
+  const std::string idFile = hrv::idPath();
+  if (const char *ws = getenv("WORLD_SIZE")) {   // rank 0 of a launcher run: a leftover of an aborted run with this name goes first
+    const char *rk = getenv("RANK");
+    if (atoi(ws) > 1 && (!rk || atoi(rk) == 0)) hrv::removeStale(idFile);
   }
 
   if (ops.find(',') != std::string::npos) {  // build extension: "hmult,hrotate,hadd" = a chain with the ciphertext resident in HBM
@@ -74,23 +70,23 @@ int main(int argc, char *argv[]) {
   }
   if (ops == "hmult") {
     HMULT *hmult = new HMULT("test_hmult", maxlevel, currentlevel, alpha, config, arch);
-    if (arch->world() > 1) rcclRendezvous(arch);
+    if (arch->world() > 1) rcclRendezvous(arch, idFile);
     hmult->simulate();
   } else if (ops == "hrotate") {
     HROTATE *hrotate = new HROTATE("test_hrotate", maxlevel, currentlevel, alpha, config, arch);
-    if (arch->world() > 1) rcclRendezvous(arch);
+    if (arch->world() > 1) rcclRendezvous(arch, idFile);
     hrotate->simulate();
   } else if (ops == "hadd") {
     HADD *hadd = new HADD("test_hadd", maxlevel, currentlevel, alpha, config, arch);
-    if (arch->world() > 1) rcclRendezvous(arch);
+    if (arch->world() > 1) rcclRendezvous(arch, idFile);
     hadd->simulate();
   } else if (ops == "pmult") {
     PMULT *pmult = new PMULT("test_pmult", maxlevel, currentlevel, alpha, config, arch);
-    if (arch->world() > 1) rcclRendezvous(arch);
+    if (arch->world() > 1) rcclRendezvous(arch, idFile);
     pmult->simulate();
   } else if (ops == "padd") {
     PADD *padd = new PADD("test_ADD", maxlevel, currentlevel, alpha, config, arch);
-    if (arch->world() > 1) rcclRendezvous(arch);
+    if (arch->world() > 1) rcclRendezvous(arch, idFile);
     padd->simulate();
   } else {
     std::cout << "Error operation requirement, please double confirm!\n";

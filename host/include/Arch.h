@@ -17,6 +17,8 @@
 #include "SimModel.h"
 
 struct hm_ctx;
+class DataMap;        // upstream's use-count map (include/mem.h:12-109) and per-cluster memory controller (:465-651): the cycle
+class MemController;  // model's types, kept as opaque names so that upstream-shaped callers compile; never instantiated here
 
 // one dispatched stage: all limb-level instructions of one stage key, in limb order
 struct Stage {
@@ -66,7 +68,16 @@ public:
   hm_ctx *context() { return ctx; }
 
   // ---- the reference's execution surface
-  void issueIns(uint32_t cluster, const std::string &unit, const Stage &stage);  // include/Arch.h:276-277
+  // upstream's two issue entry points, upstream's signatures (include/Arch.h:234-237, src/Arch.cpp:1000-1017): one instruction
+  // group for a unit of a cluster / for MAC port (h, w) of the BCONV or HPIP array.  Each group joins the plan as a stage of its
+  // own (stages of equal kind and dependency depth are coalesced into one launch anyway).  Upstream's Driver issues every BCONV /
+  // HPIP group to ALL ports (include/Driver.h:307-320): the replicas (h, w) != (0, 0) are accounted, not executed again.
+  void issueIns(uint32_t index, const std::string &name, std::vector<Instruction *> &insg);
+  void issueIns(uint32_t index, uint32_t h, uint32_t w, std::vector<Instruction *> &insg, bool hpip);
+  void setDataMap(DataMap *) {}                                   // include/Arch.h:165: the functional backends track no use counts
+  std::vector<MemController *> getMemController() { return {}; }  // :244
+  // the build's own form: a whole stage at once (what host/include/Driver.h issues)
+  void issueIns(uint32_t cluster, const std::string &unit, const Stage &stage);
   void update();                // launch the next queued stage (src/Arch.cpp:912-929 advanced one cycle)
   bool simulateComplete();      // include/Arch.h:246-269
   unsigned long long getCycle();         // elapsed device time in ns
@@ -98,6 +109,7 @@ private:
   Config *config;
   Backend backendKind;
   bool fuse;
+  bool fuseHpip = true;   // config key fuse_hpip: the ModUp transforms' last pass runs inside the inner-product kernel
   uint32_t n = 0, logN = 0, clusterCount = 1;
   uint32_t maxLevel_ = 0, curLevel_ = 0, world_ = 1, rank_ = 0;
   uint32_t batch_ = 1;  // config key `batch`: independent ops (own inputs, shared evaluation key) carried by every launch

@@ -21,6 +21,7 @@ public:
     auto it = configMap.find(key);
     return it == configMap.end() ? dflt : it->second;
   }
+  bool hasKey(const std::string &key) const { return configMap.count(key) != 0; }
   void setValue(std::string name, uint32_t count) { configMap[name] = count; }
 };
 #endif

@@ -25,8 +25,26 @@ public:
     bconvw = cfg->getValue("bconv_num_width");
   }
 
-  // Input: [level] -> instruction group of that limb.  Throws like upstream on an empty stage
-  // (include/Driver.h:72-74) or an op kind no unit executes (:100-104).
+  // ---- upstream's entry point, upstream's signature (include/Driver.h:71): map[level][batch] = instruction group.
+  // Upstream routes each 256-coefficient group to a cluster FIFO (include/Driver.h:155-246); here a STAGE is the unit of
+  // dispatch (one GPU launch covers all limbs x all N), so the per-batch groups of a level are coalesced: the instructions of
+  // batch 0 are the stage's limb records and the records of the other batches add their upstream-instruction counts to them.
+  // The build's own generators emit one record per limb (map[level].size() == 1).  Throws like upstream on an empty stage
+  // (:72-74) or an op kind no unit executes (:100-104).
+  void dispatchInstructions(const std::vector<std::vector<INSGROUP>> &map) { dispatchInstructions(std::string(), map); }
+  void dispatchInstructions(const std::string &stageName, const std::vector<std::vector<INSGROUP>> &map) {
+    if (map.empty() || map[0].empty() || map[0][0].empty()) throw std::runtime_error("Empty instruction map provided.");
+    std::vector<INSGROUP> perLimb;
+    for (const auto &level : map) {
+      if (level.empty()) continue;
+      INSGROUP g = level[0];
+      for (size_t b = 1; b < level.size(); ++b)
+        for (size_t k = 0; k < level[b].size() && k < g.size(); ++k) g[k]->refInstructions += level[b][k]->refInstructions;
+      perLimb.push_back(std::move(g));
+    }
+    dispatchInstructions(stageName, perLimb);
+  }
+  // the compact form the build's Operation classes use: map[level] = the limb's record(s), plus the stage key
   void dispatchInstructions(const std::string &stageName, const std::vector<INSGROUP> &map) {
     if (map.empty() || map[0].empty()) throw std::runtime_error("Empty instruction map provided.");
     const std::string &opName = map[0][0]->GetOpName();
@@ -54,8 +72,9 @@ public:
     }
     pending.clear();
   }
-  // operands are resident in HBM from the start: nothing to feed (upstream: DRAM -> scratchpad lines)
-  void IssueDataFromDramToChip() {}
+  // upstream's signature (include/Driver.h:327-340: one group of DRAM lines per cluster and call goes to the scratchpad).
+  // Operands are resident in HBM from the start and the sim backend feeds its own model (SimModel::step), so nothing moves here.
+  void IssueDataFromDramToChip(std::vector<MemController *> memC) { (void)memC; }
   unsigned long long getTotalIns() const { return totalIns; }
   uint32_t getCluster() const { return cluster; }
 };

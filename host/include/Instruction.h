@@ -42,6 +42,11 @@ public:
   // fused inner product (ops == IP): out_k = sum_j ipX[j] * ipY[k][j]; out_0 = OutputOperand, out_1 = extraOutputs[0]
   std::vector<AddrType> ipX;
   std::vector<std::vector<AddrType>> ipY;
+  // fused NTT-epilogue x key MAC (Arch::fusePasses (7)): digit j with ipCoeff[j] set is still in coefficient
+  // form at ipSrc[j] and goes through the forward transform inside the inner-product kernel; ipX[j] (the buffer the separate
+  // transform would have written: NTTOut_beta(j)) then only serves as the scratch of its first pass
+  std::vector<AddrType> ipSrc;
+  std::vector<uint8_t> ipCoeff;
   std::vector<Instruction *> depsInsList;
 
   Instruction(std::string name, ins_ops op, uint32_t level) : ops(op), Name(std::move(name)), level_id(level) {}

@@ -68,6 +68,12 @@ int hh_chain_simulate(hh_chain *c);
 int hh_comm_unique_id(void *out128);
 int hh_op_comm_init_rccl(hh_op *op, const void *unique_id128);
 int hh_op_comm_init_external(hh_op *op, void *exchange_fn, void *user); /* hm_exchange_fn of homulator_hip.h */
+/* the CLI's rendezvous file for the RCCL unique id (host/include/RcclRendezvous.h), exposed for its tests: the run-unique path for
+ * the current environment, publish (atomic), fetch (waits up to timeout_ms), remove */
+int hh_rccl_id_path(char *out, uint32_t cap);
+int hh_rccl_id_publish(const char *path, const void *id128);
+int hh_rccl_id_fetch(const char *path, void *id128, uint32_t timeout_ms);
+int hh_rccl_id_remove(const char *path);
 #ifdef __cplusplus
 }
 #endif

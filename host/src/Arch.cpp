@@ -10,7 +10,8 @@
 
 // one C-ABI call, with its argument arrays prebuilt so that run() is a tight loop of calls
 struct Arch::Launch {
-  enum Kind { L_NTT, L_INTT, L_EWE, L_BCONV, L_AUTO, L_NTT_SUBSCALE, L_TENSOR, L_EXCH_IN, L_EXCH_OUT, L_REPLICATE, L_IP } kind;
+  enum Kind { L_NTT, L_INTT, L_EWE, L_BCONV, L_AUTO, L_NTT_SUBSCALE, L_TENSOR, L_EXCH_IN, L_EXCH_OUT, L_REPLICATE, L_IP, L_NTT_IP } kind;
+  std::vector<uint8_t> ipCoeff;   // L_NTT_IP: per (limb, digit) 1 = transformed inside the kernel (a = source, c = first-pass scratch)
   uint32_t ipTerms = 0, ipOuts = 0;
   std::string name;
   std::string statKey;
@@ -47,10 +48,12 @@ Arch::Arch(Config *cfg) : config(cfg) {
     // when it was given on the command line it must agree with the launcher.
     world_ = 1;
     const char *ws = getenv("WORLD_SIZE"), *rk = getenv("RANK"), *lr = getenv("LOCAL_RANK");
-    if (ws && atoi(ws) > 1 && b == BACKEND_HIP) {
+    // ... and only for the CLI (it sets `launcher_env`): a library user who builds an op inside a torchrun job without saying
+    // `world` gets a plain one-GPU op on the device they asked for, not a silently sharded one on LOCAL_RANK
+    if (ws && atoi(ws) > 1 && b == BACKEND_HIP && cfg->getValueOr("launcher_env", 0)) {
       world_ = (uint32_t)atoi(ws);
       rank_ = rk ? (uint32_t)atoi(rk) : 0;
-      if (lr && !getenv("HOMULATOR_DEVICE")) cfg->setValue("device", (uint32_t)atoi(lr));
+      if (lr && !getenv("HOMULATOR_DEVICE") && !cfg->hasKey("device")) cfg->setValue("device", (uint32_t)atoi(lr));
       if (cfg->getValueOr("cluster_from_argv", 0) && clusterCount != world_)
         throw std::runtime_error("[cluster] = " + std::to_string(clusterCount) + " GPUs requested, but the launcher started " + std::to_string(world_) + " ranks");
     }
@@ -63,6 +66,11 @@ Arch::Arch(Config *cfg) : config(cfg) {
   if (const char *e = getenv("HOMULATOR_BATCH")) batch_ = std::max(1, atoi(e));
   fuse = cfg->getValueOr("fuse", 1) != 0;
   if (const char *e = getenv("HOMULATOR_FUSE")) fuse = std::string(e) != "0";
+  // the HPIP unit as a fused NTT-epilogue x evaluation-key MAC.  Upstream switches its HPIP unit with
+  // `hasHPIPU` (src/Arch.cpp:10; 0 in the shipped files, where the inner product runs on the EWE); that key keeps describing
+  // the SIMULATED machine (backend = sim).  On the GPU the fused kernel is a scheduling decision of the backend: `fuse_hpip`.
+  fuseHpip = cfg->getValueOr("fuse_hpip", 1) != 0;
+  if (const char *e = getenv("HOMULATOR_FUSE_HPIP")) fuseHpip = std::string(e) != "0";
   stat = new Statistic();
 }
 
@@ -150,6 +158,18 @@ void Arch::bindInput(const std::vector<AddrType> &dst, Arch *src, const std::vec
 void Arch::issueIns(uint32_t, const std::string &, const Stage &stage) {
   if (prepared) throw std::runtime_error("issueIns after prepare()");
   stages.push_back(stage);
+}
+void Arch::issueIns(uint32_t index, const std::string &name, std::vector<Instruction *> &insg) {
+  if (insg.empty()) return;
+  Stage st;
+  st.name = name + "_" + std::to_string(stages.size());
+  st.kind = insg[0]->ops;
+  st.ins = insg;
+  st.cluster0 = index;
+  issueIns(index, name, st);
+}
+void Arch::issueIns(uint32_t index, uint32_t h, uint32_t w, std::vector<Instruction *> &insg, bool hpip) {
+  if (h == 0 && w == 0) issueIns(index, hpip ? "HPIP" : "BCONV", insg);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -406,6 +426,42 @@ void Arch::fusePasses(std::vector<Stage> &st) {
       byX.erase(partner);
     }
   }
+  // (7) HPIP as SURVEY.md 8f-2 specifies it: a forward transform whose only reader is an inner-product record moves INTO that
+  //     record (ModUp_NTT_(j) + InnerProOut: src/Operation.cpp:190-414).  The kernel runs the digit's ROW pass and multiplies
+  //     its registers into both keys' accumulators; the extended digit (NTTOut_beta(j)) is never written or read back — its
+  //     buffer only serves the first pass as scratch.
+  if (fuseHpip) {
+    std::map<AddrType, std::vector<Instruction *>> readers;
+    for (auto &s : st)
+      for (Instruction *i : s.ins) {
+        if (dead.count(i)) continue;
+        if (i->ops == IP && !i->ipX.empty()) {
+          for (AddrType x : i->ipX) readers[x].push_back(i);
+          for (auto &y : i->ipY) for (AddrType yy : y) readers[yy].push_back(i);
+        } else {
+          for (AddrType a : operands(i)) readers[a].push_back(i);
+          if (i->fusedSubScale) { readers[i->fMinuend].push_back(i); if (i->fAddend) readers[i->fAddend].push_back(i); if (i->fMix) readers[i->fMix].push_back(i); }
+        }
+      }
+    for (auto &s : st)
+      for (Instruction *ip : s.ins) {
+        if (ip->ops != IP || ip->ipX.empty() || dead.count(ip)) continue;
+        ip->ipSrc = ip->ipX;
+        ip->ipCoeff.assign(ip->ipX.size(), 0);
+        for (size_t j = 0; j < ip->ipX.size(); ++j) {
+          auto p = producer.find(ip->ipX[j]);
+          if (p == producer.end()) continue;
+          Instruction *t = p->second;
+          if (t->ops != NTT || t->passthrough || t->fusedSubScale || dead.count(t) || t->mod_id != ip->mod_id) continue;
+          auto &rd = readers[ip->ipX[j]];
+          if (rd.size() != 1 || rd[0] != ip) continue;
+          ip->ipSrc[j] = t->operandList[0];
+          ip->ipCoeff[j] = 1;
+          ip->refInstructions += t->refInstructions;
+          dead.insert(t);
+        }
+      }
+  }
   // drop dead instructions and empty stages; upstream instructions of eliminated pass-through records are
   // accounted on the first surviving instruction so that the retired total still matches getTotalIns()
   unsigned long long orphan = 0;
@@ -440,7 +496,8 @@ void Arch::buildLaunches() {
   for (const Stage &s : st) {
     size_t first = parts.size();
     for (Instruction *i : s.ins) {
-      int key = i->ops == IP && !i->ipX.empty() ? 300 + (int)i->ipX.size() * 10 + (int)i->ipY.size() : i->fusedTensor ? 200 : i->fusedSubScale ? (i->fMix ? 203 : 201) : i->ops == MULT ? 100 + i->opcode : (i->ops == NTT && i->passthrough) ? 100 + EWE_COPY : i->ops == AUTO ? 1000 + (int)i->galois : (int)i->ops;
+      const bool nip = i->ops == IP && std::find(i->ipCoeff.begin(), i->ipCoeff.end(), 1) != i->ipCoeff.end();
+      int key = nip ? 400 + (int)i->ipX.size() * 10 + (int)i->ipY.size() : i->ops == IP && !i->ipX.empty() ? 300 + (int)i->ipX.size() * 10 + (int)i->ipY.size() : i->fusedTensor ? 200 : i->fusedSubScale ? (i->fMix ? 203 : 201) : i->ops == MULT ? 100 + i->opcode : (i->ops == NTT && i->passthrough) ? 100 + EWE_COPY : i->ops == AUTO ? 1000 + (int)i->galois : (int)i->ops;
       size_t p = first;
       for (; p < parts.size(); ++p)
         if (parts[p].key == key) break;
@@ -455,7 +512,7 @@ void Arch::buildLaunches() {
   auto reads = [&](Instruction *i) {
     std::vector<AddrType> v;
     if (i->ops == IP && !i->ipX.empty()) {
-      v = i->ipX;
+      v = i->ipSrc.empty() ? i->ipX : i->ipSrc;
       for (auto &y : i->ipY) v.insert(v.end(), y.begin(), y.end());
       return v;
     }
@@ -468,6 +525,8 @@ void Arch::buildLaunches() {
   auto writes = [&](Instruction *i) {
     std::vector<AddrType> v = {i->OutputOperand};
     v.insert(v.end(), i->extraOutputs.begin(), i->extraOutputs.end());
+    for (size_t j = 0; j < i->ipCoeff.size(); ++j)
+      if (i->ipCoeff[j]) v.push_back(i->ipX[j]);   // first-pass scratch of a digit transformed inside the inner product
     return v;
   };
   std::map<AddrType, int> writerDepth, readerDepth;
@@ -548,7 +607,24 @@ void Arch::buildLaunches() {
       size_t count = 0;
       for (const Part *g : group)
         for (Instruction *i : g->ins) { L->refInstructions += i->refInstructions * (i->ops == BCONV_STEP2 ? bconvPorts : 1ull); ++count; }
-      if (f->ops == IP && !f->ipX.empty()) {
+      if (f->ops == IP && std::find(f->ipCoeff.begin(), f->ipCoeff.end(), 1) != f->ipCoeff.end()) {
+        L->kind = Launch::L_NTT_IP; L->statKey = "NTT";
+        L->ipTerms = (uint32_t)f->ipX.size(); L->ipOuts = (uint32_t)f->ipY.size();
+        unsigned long long lp = 0;
+        for (const Part *g : group)
+          for (Instruction *i : g->ins) {
+            for (size_t j = 0; j < i->ipX.size(); ++j) {
+              L->a.push_back(limbOf(i->ipSrc[j])); L->c.push_back(limbOf(i->ipX[j])); L->ipCoeff.push_back(i->ipCoeff[j]);
+              lp += i->ipCoeff[j] ? 3 : 1;       // transformed digit: source read, hand-off written and read; own limb: read
+            }
+            for (auto &y : i->ipY) for (AddrType yy : y) L->b.push_back(limbOf(yy));
+            L->out.push_back(limbOf(i->OutputOperand));
+            for (AddrType o : i->extraOutputs) L->out.push_back(limbOf(o));
+            L->mods.push_back(i->mod_id);
+            lp += (unsigned long long)L->ipTerms * L->ipOuts + L->ipOuts;
+          }
+        L->bytes = lp * LP;
+      } else if (f->ops == IP && !f->ipX.empty()) {
         L->kind = Launch::L_IP; L->statKey = "EWE";
         L->ipTerms = (uint32_t)f->ipX.size(); L->ipOuts = (uint32_t)f->ipY.size();
         for (const Part *g : group)
@@ -713,7 +789,7 @@ void Arch::replicateForBatch() {
       l->bytes *= batch_;
       continue;
     }
-    if (l->kind == Launch::L_IP) {
+    if (l->kind == Launch::L_IP || l->kind == Launch::L_NTT_IP) {
       // entry e: ipTerms x limbs, ipTerms * ipOuts y limbs, ipOuts outputs.  Entry-major order (entry e of every op
       // side by side): the ops share the key limbs, so the second and later readers of a key chunk find it in L2
       auto inter = [&](std::vector<uint32_t> &v, size_t width, bool isLimb) {
@@ -728,6 +804,12 @@ void Arch::replicateForBatch() {
         v.swap(o);
       };
       inter(l->a, l->ipTerms, true); inter(l->b, (size_t)l->ipTerms * l->ipOuts, true); inter(l->out, l->ipOuts, true); inter(l->mods, 1, false);
+      if (l->kind == Launch::L_NTT_IP) {
+        inter(l->c, l->ipTerms, true);
+        std::vector<uint32_t> f(l->ipCoeff.begin(), l->ipCoeff.end());
+        inter(f, l->ipTerms, false);
+        l->ipCoeff.assign(f.begin(), f.end());
+      }
     } else {
       rep(l->a, true); rep(l->b, true); rep(l->c, true); rep(l->d, true);
       rep(l->out, true); rep(l->out1, true); rep(l->out2, true); rep(l->mods, false);
@@ -802,7 +884,7 @@ void Arch::prepare() {
   hm_sync(ctx);
 }
 
-static const char *const kLaunchKindNames[] = {"NTT", "INTT", "EWE", "BCONV", "AUTO", "NTT_SUBSCALE", "TENSOR", "EXCH_IN", "EXCH_OUT", "REPLICATE", "IP"};
+static const char *const kLaunchKindNames[] = {"NTT", "INTT", "EWE", "BCONV", "AUTO", "NTT_SUBSCALE", "TENSOR", "EXCH_IN", "EXCH_OUT", "REPLICATE", "IP", "NTT_IP"};
 
 // Per-launch device time (SURVEY.md §8d "per-stage hipEvent times", exchange time at N > 1): every launch of the plan
 // bracketed by its own event pair, in plan order so that the data dependencies (and, sharded, the collectives) line up.
@@ -830,7 +912,7 @@ std::string Arch::planText() const {
   for (const Launch *l : launches) {
     size_t cnt = l->out.size();
     if (l->kind == Launch::L_BCONV) { cnt = 0; for (auto &q : l->probs) cnt += q.out.size(); }
-    if (l->kind == Launch::L_IP) cnt = l->mods.size();
+    if (l->kind == Launch::L_IP || l->kind == Launch::L_NTT_IP) cnt = l->mods.size();
     out += std::string(names[l->kind]) + " " + l->name + " n=" + std::to_string(cnt) + " ref=" + std::to_string(l->refInstructions);
     if (!l->exLimbs.empty()) {
       out += " limbs=";
@@ -866,6 +948,12 @@ void Arch::enqueue(Launch &l) {
   case Launch::L_IP:
     st = hm_inner_product(ctx, pool, l.a.data(), pool, l.b.data(), pool, l.out.data(), l.mods.data(), (uint32_t)l.mods.size(), l.ipTerms, l.ipOuts);
     break;
+  case Launch::L_NTT_IP: {
+    hm_ntt_ip_desc d = {pool, l.a.data(), l.ipCoeff.data(), pool, l.c.data(), pool, l.b.data(), pool, l.out.data(), l.mods.data(),
+                        (uint32_t)l.mods.size(), l.ipTerms, l.ipOuts};
+    st = hm_ntt_inner_product(ctx, &d);
+    break;
+  }
   case Launch::L_TENSOR:
     st = hm_tensor(ctx, pool, l.a.data(), pool, l.b.data(), pool, l.c.data(), pool, l.d.data(), pool, l.out.data(), pool, l.out1.data(), pool,
                    l.out2.data(), l.mods.data(), cnt);

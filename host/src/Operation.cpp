@@ -513,7 +513,7 @@ bool OperationBase::simulateCycles(bool verbose) {
   const bool trace = getenv("HOMULATOR_SIM_TRACE") != nullptr;  // "<cycle> <retired>" whenever the count moves (oracle/ref_dump.cpp prints the same)
   time_t periodTime = time(0);
   while (!arch->simulateComplete()) {
-    driver->IssueDataFromDramToChip();
+    driver->IssueDataFromDramToChip(arch->getMemController());
     arch->update();
     const unsigned long long cycle = arch->getCycle();
     if (trace && arch->getcompletedIns() != traced) {
@@ -570,7 +570,7 @@ bool OperationBase::simulate() {
   arch->run();   // untimed warm-up of the whole plan (first-use table uploads, code-object loads); the plan is idempotent
   arch->sync();
   while (!arch->simulateComplete()) {
-    driver->IssueDataFromDramToChip();
+    driver->IssueDataFromDramToChip(arch->getMemController());
     arch->update();
   }
   arch->sync();

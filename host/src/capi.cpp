@@ -5,6 +5,7 @@
 #include <sstream>
 
 #include "Operation.h"
+#include "RcclRendezvous.h"
 
 struct hh_op {
   Config *cfg = nullptr;
@@ -169,3 +170,13 @@ extern "C" int hm_comm_unique_id(void *);
 int hh_comm_unique_id(void *out) { if (hm_comm_unique_id(out)) { g_err = "hm_comm_unique_id failed (is librccl.so available?)"; return 1; } return 0; }
 int hh_op_comm_init_rccl(hh_op *h, const void *id) { HH_TRY(h->arch->commInitRccl(id)) }
 int hh_op_comm_init_external(hh_op *h, void *fn, void *user) { HH_TRY(h->arch->commInitExternal(fn, user)) }
+
+int hh_rccl_id_path(char *out, uint32_t cap) {
+  const std::string p = hrv::idPath();
+  if (!out || p.size() + 1 > cap) { g_err = "buffer too small"; return 1; }
+  memcpy(out, p.c_str(), p.size() + 1);
+  return 0;
+}
+int hh_rccl_id_publish(const char *path, const void *id128) { HH_TRY(hrv::publish(path, static_cast<const char *>(id128))); }
+int hh_rccl_id_fetch(const char *path, void *id128, uint32_t timeout_ms) { HH_TRY(hrv::fetch(path, static_cast<char *>(id128), timeout_ms)); }
+int hh_rccl_id_remove(const char *path) { HH_TRY(hrv::removeStale(path)); }

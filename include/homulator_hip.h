@@ -139,6 +139,26 @@ hm_status hm_inner_product(hm_ctx *ctx, const uint64_t *x, const uint32_t *x_lim
                            const uint32_t *y_limbs, uint64_t *out, const uint32_t *out_limbs,
                            const uint32_t *mod_ids, uint32_t n, uint32_t n_terms, uint32_t n_out);
 
+/* K1 x K5 — the HPIP unit as a fused NTT-epilogue x evaluation-key MAC: for extended limb i,
+ *     out[i][k] = sum_{j < n_terms} X_j[i] * y[i][k][j],   X_j[i] = NTT(x[i][j]) if x_is_coeff[i][j] else x[i][j]
+ * i.e. ModUp_NTT_(j) + InnerProOut_(.)_Key<k> of src/Operation.cpp:190-414 in one call: per extended limb the n_terms forward
+ * transforms run back to back and both keys accumulate in registers, so the extended digits (NTTOut_beta(j)) are never
+ * written to HBM or read back.  Replaces issueIns(cluster, h, w, group, hpip = true) include/Arch.h:277 for
+ * InsGen::GenHPIP (src/InsGen.cpp:356-406) together with the NTT stage that feeds it (HPIP: src/Components.cpp:571-668).
+ * Row-major lists: x_limbs / x_is_coeff / hand_limbs [i * n_terms + j], y_limbs [(i * n_out + k) * n_terms + j],
+ * out_limbs [i * n_out + k].  x_is_coeff[i][j] != 0: x[i][j] is in coefficient form (a converted limb) and is transformed;
+ * hand + hand_limbs[i][j] * N is N words of scratch for its first pass (contents undefined afterwards); 0: x[i][j] is already
+ * in evaluation form (a digit's own limbs).  `out` must not alias x, hand or y.  Bit-identical to hm_ntt + hm_inner_product. */
+typedef struct hm_ntt_ip_desc {
+  const uint64_t *x;    const uint32_t *x_limbs;   const uint8_t *x_is_coeff;
+  uint64_t *hand;       const uint32_t *hand_limbs;
+  const uint64_t *y;    const uint32_t *y_limbs;
+  uint64_t *out;        const uint32_t *out_limbs;
+  const uint32_t *mod_ids;
+  uint32_t n, n_terms, n_out;
+} hm_ntt_ip_desc;
+hm_status hm_ntt_inner_product(hm_ctx *ctx, const hm_ntt_ip_desc *desc);
+
 /* K4 — fast base conversion, matrix step: out_t = sum_i in_i * [Q_D / q_i]_t mod t for the input
  * basis in_ids (n_in <= 32) and output basis out_ids (n_out <= 64).  `in` must already hold
  * y_i = x_i * [(Q_D/q_i)^-1]_{q_i} (hm_ntt's scale or HM_OP_MUL_CONST with hm_bconv_consts).

@@ -286,3 +286,47 @@ def test_inner_product_one_pass(env, terms, outs):
         assert np.array_equal(got[k * n:(k + 1) * n], exp), (k, terms)
     for b_ in (xb, yb, out):
         b_.free()
+
+
+@pytest.mark.parametrize("terms,outs", [(1, 1), (1, 2), (2, 2), (3, 2), (4, 2), (3, 1)])
+def test_ntt_inner_product_fused(env, terms, outs):
+    """K1 x K5 (the HPIP unit): out[i][k] = sum_j X_j[i] * y[i][k][j] with X_j = NTT(x_j) for the digits that are
+    transformed and x_j itself for a digit's own (evaluation-form) limbs, against the oracle's NTT + MAC chain.  Limbs with a
+    mix of transformed / own digits, worst-case operands (q - 1), duplicate moduli (same-modulus groups), more limbs than one
+    launch carries."""
+    ctx, o, _ = env
+    M = o.L + o.K
+    ids = [(i * 5 + 1) % M for i in range(37)] + [0, 0, 0, 0, M - 1, M - 1]
+    n = len(ids)
+    X = [o.fill_uniform(ids, 10 + j) for j in range(terms)]
+    Y = [[o.fill_uniform(ids, 100 + 10 * k + j) for j in range(terms)] for k in range(outs)]
+    for r, m in enumerate(ids[:6]):
+        for j in range(terms):
+            X[j][r, :] = o.moduli[m] - 1          # worst case of the lazy ranges through the transform and the MAC
+            for k in range(outs):
+                Y[k][j][r, :3] = o.moduli[m] - 1
+    coeff = [[(i + j) % 3 != 0 for j in range(terms)] for i in range(n)]   # which digits go through the transform
+    coeff[1] = [True] * terms
+    coeff[2] = [False] * terms
+    xb = ctx.from_host(np.concatenate(X))
+    yb = ctx.from_host(np.concatenate([Y[k][j] for k in range(outs) for j in range(terms)]))
+    hand, out = ctx.alloc(n * terms), ctx.alloc(n * outs)
+    xl = [j * n + i for i in range(n) for j in range(terms)]
+    yl = [(k * terms + j) * n + i for i in range(n) for k in range(outs) for j in range(terms)]
+    ol = [k * n + i for i in range(n) for k in range(outs)]
+    ctx.ntt_inner_product(xb, xl, [c for row in coeff for c in row], hand, xl, yb, yl, out, ol, ids, terms, outs)
+    got = out.download()
+    XE = []
+    for j in range(terms):
+        t = o.ntt(ids, X[j])
+        for i in range(n):
+            if not coeff[i][j]:
+                t[i] = X[j][i]
+        XE.append(t)
+    for k in range(outs):
+        exp = o.ewe(0, ids, XE[0], Y[k][0])
+        for j in range(1, terms):
+            exp = o.ewe(2, ids, XE[j], Y[k][j], exp)
+        assert np.array_equal(got[k * n:(k + 1) * n], exp), (k, terms)
+    for b_ in (xb, yb, out, hand):
+        b_.free()
