@@ -24,6 +24,7 @@ LP = (1 << LOGN) * 8                       # one limb-poly, bytes
 HMULT_ALG_BYTES = 1_102_577_664            # 2 103 LP
 HROTATE_ALG_BYTES = 883_425_280            # 1 685 LP
 NTT_ALG_BYTES = 2 * LP                     # per limb-NTT
+EVK_BYTES = 2 * 3 * 50 * LP                # evaluation key of configs[2]: 2 beta E = 300 limb-polys = 157 286 400 B
 HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md
 BFLY_PER_LIMB_NTT = (1 << LOGN) // 2 * LOGN  # butterflies of one limb-NTT: N/2 per stage, logN stages
 
@@ -40,6 +41,45 @@ def roofline_inputs():
         return {}
 
 
+def _warm(ctx, launch, seconds=0.25):
+    """the same launches, untimed, for a quarter of a second: the chip ramps its clocks over the first ~100 ms of load (the timed
+    region of the op gets the same treatment in main())"""
+    t0, i = time.perf_counter(), 0
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(8):
+            launch(i)
+            i += 1
+        ctx.sync()
+
+
+def measure_ntt_inop(batch, iters=12, sets=2):
+    """the ModUp forward transforms at the launch shape of the timed region: the 115 converted limb-polys of each of `batch` ops
+    (sum over digits of E - d_j, same-modulus limb-polys of the ops and digits side by side) in ONE hm_ntt call, timed alone
+    with HIP events on the backend's stream; rotating over two buffer pairs.  Returns (ns per call, limb-polys per call)."""
+    from homulator_amd import hip
+    ctx = hip.Context(LOGN, L, ALPHA)
+    ext = ctx.ext_ids(ELL)
+    ids = []
+    for j in range(-(-ELL // ALPHA)):
+        own = set(range(j * ALPHA, min(ELL, (j + 1) * ALPHA)))
+        ids += [m for t, m in enumerate(ext) if t not in own]
+    ids = ids * batch
+    n = len(ids)
+    bufs = [(ctx.alloc(n), ctx.alloc(n)) for _ in range(sets)]
+    for i, (a, _) in enumerate(bufs):
+        ctx.fill_uniform(a, ids, 1 + i)
+    _warm(ctx, lambda i: ctx.ntt(*bufs[i % sets], ids))
+    ctx.timer_start()
+    for i in range(iters):
+        a, b = bufs[i % sets]
+        ctx.ntt(a, b, ids)
+    ns = ctx.timer_stop() / iters
+    for a, b in bufs:
+        a.free(); b.free()
+    ctx.close()
+    return ns, n
+
+
 def measure_ntt_sweep(n_limbs, iters=48, sets=6):
     """forward NTT sweep over the extended basis (l + alpha limbs): device time per sweep, HIP events on the
     backend stream.  One sweep = one hm_ntt call = the two pass kernels k_ntt_col + k_ntt_row.
@@ -51,9 +91,7 @@ def measure_ntt_sweep(n_limbs, iters=48, sets=6):
     bufs = [(ctx.alloc(n_limbs), ctx.alloc(n_limbs)) for _ in range(sets)]
     for i, (a, _) in enumerate(bufs):
         ctx.fill_uniform(a, ids, 1 + i)
-    for a, b in bufs:
-        ctx.ntt(a, b, ids)
-    ctx.sync()
+    _warm(ctx, lambda i: ctx.ntt(*bufs[i % sets], ids))
     ctx.timer_start()
     for i in range(iters):
         a, b = bufs[i % sets]
@@ -91,28 +129,32 @@ def cpu_baseline(opn="hmult", runs=5):
                       f"{cores} threads (OpenMP over limbs) = `value`, 1 thread = `single_thread_value`"}
 
 
-def exchange_overlap(stage_rows, ops_per_launch, us_per_step, instances):
-    """hidden / exposed exchange time per op.  The stage rows time every launch ALONE; with one instance in flight nothing overlaps
-    (exposed = the exchange time).  With two sharded instances (--sharded-streams 2) the part of the step time that the compute
-    stages alone do not explain is what stayed exposed."""
+def exchange_overlap(stage_rows, ops_per_launch, us_per_step, instances, pipelined):
+    """hidden / exposed exchange time per op.  The stage rows time every launch ALONE (an exchange launch together with the wait for
+    its own mark).  What the compute launches alone do not explain of the step time is the exposed exchange time; the rest of the
+    exchange time ran beside compute: with per-digit pipelined exchanges (the default when sharded: digit j+1's all-to-all on the
+    context's exchange stream while digit j converts and transforms) already inside ONE instance, with --sharded-streams 2 also across
+    instances.  One instance without pipelining hides nothing by construction."""
     ex = sum(ns for kind, _, ns in stage_rows if kind in ("EXCH_IN", "EXCH_OUT", "REPLICATE")) * 1e-3 / ops_per_launch
     comp = sum(ns for kind, _, ns in stage_rows if kind not in ("EXCH_IN", "EXCH_OUT", "REPLICATE")) * 1e-3 / ops_per_launch
-    if instances <= 1:
-        return {"hidden_us_per_op": 0.0, "exposed_us_per_op": round(ex, 2), "instances_in_flight": 1,
-                "note": "one sharded instance: the exchanges run on the op's own stream between the stages that produce and consume them, nothing is hidden (DESIGN.md section 7)"}
+    n_coll = sum(1 for kind, _, _ in stage_rows if kind in ("EXCH_IN", "EXCH_OUT", "REPLICATE"))
+    if instances <= 1 and not pipelined:
+        return {"hidden_us_per_op": 0.0, "exposed_us_per_op": round(ex, 2), "instances_in_flight": 1, "pipelined_per_digit": False, "collectives_per_launch": n_coll,
+                "note": "one sharded instance, bulk-synchronous exchanges on the op's own stream: nothing is hidden (DESIGN.md section 7)"}
     exposed = min(ex, max(0.0, us_per_step - comp))
     return {"hidden_us_per_op": round(ex - exposed, 2), "exposed_us_per_op": round(exposed, 2), "instances_in_flight": instances,
-            "note": "estimate: step time minus the compute stages timed alone = exposed exchange time; each instance has its own communicator and stream"}
+            "pipelined_per_digit": bool(pipelined), "collectives_per_launch": n_coll,
+            "note": "estimate: step time minus the compute launches timed alone = exposed exchange time; exchanges run on the context's exchange stream, ordered against compute by marks"}
 
 
-def pick_batch(steps, streams, default):
-    """ops per launch: the largest of 10, 8, 6, 5, 4 that deals the K timed steps evenly over the in-flight instances
-    (K = 20 with 2 x 4 would leave one instance a batch short: 3 + 2 enqueues, the timed region then ends on the longer
-    queue); the default when none does (the remainder then runs through the one-op instance)."""
-    for b in (10, 8, 6, 5, 4):
-        if steps % (b * streams) == 0:
-            return b
-    return default
+DEFAULT_BATCH = 10
+
+
+def pick_batch(steps, streams, default=DEFAULT_BATCH):
+    """ops per launch: a FIXED default (10), whatever --steps is; only when K is too small to give every in-flight instance one
+    full launch is the batch cut to K // streams.  Steps that do not fill a launch run through the one-op instance, so exactly K
+    hmults are timed.  (Round 2 searched for a batch that divides K: the reported rate then hinged on --steps.)"""
+    return max(1, min(default, steps // max(1, streams)))
 
 
 def main():
@@ -127,8 +169,8 @@ def main():
                          "the K timed steps are dealt round-robin over them.  1 = one op at a time (latency mode)")
     ap.add_argument("--batch", type=int, default=0,
                     help="independent hmults carried by every launch of an instance (config key `batch`: own inputs, one "
-                         "evaluation key); a step is still ONE hmult, an enqueue advances `batch` steps.  0 = pick one "
-                         "that deals --steps evenly over the instances (pick_batch)")
+                         "evaluation key); a step is still ONE hmult, an enqueue advances `batch` steps.  0 = the fixed "
+                         "default of 10 (pick_batch)")
     ap.add_argument("--op", default=OP, choices=["hmult", "hrotate"],
                     help="hmult = BASELINE.json's metric (default); hrotate = BASELINE configs[3], for information")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -166,7 +208,7 @@ def main():
     # sharded: the ops of a batch share the exchanges around each base conversion; a batch that divides --steps, so that
     # exactly --steps hmults are timed without a second (communicating) instance for the remainder
     if world == 1:
-        batch = args.batch if args.batch > 0 else pick_batch(args.steps, streams, 4)
+        batch = args.batch if args.batch > 0 else pick_batch(args.steps, streams)
     else:   # per-rank launches shrink with the rank count: a proportionally larger batch keeps them (and the exchanges) big
         target = max(1, min(16, (args.batch or 4) * world // 2))
         batch = max(d for d in range(1, target + 1) if args.steps % d == 0)
@@ -243,6 +285,16 @@ def main():
     sync_all()
     barrier()
     dt = time.perf_counter() - t0
+    # the same steady state over ten launches per instance (information: the contract's K = 20 is one launch per instance)
+    sustained = None
+    if world == 1:
+        n_sus = 10 * streams * batch
+        barrier()
+        t1 = time.perf_counter()
+        run(n_sus)
+        sync_all()
+        barrier()
+        sustained = n_sus / (time.perf_counter() - t1)
     single = None
     if world == 1 and (streams > 1 or batch > 1):   # latency mode beside it: one op at a time
         lat_op = tail_op if tail_op is not None else op
@@ -254,8 +306,7 @@ def main():
         single = args.steps / (time.perf_counter() - t1)
     # per-launch device time of one op, each launch bracketed by its own event pair (collective when sharded)
     stage_rows = (tail_op if tail_op is not None else op).stage_times(5)   # sharded: of one batch
-    # the same at the launch shape of the timed region (batch ops per launch), for the in-op roofline figure
-    batched_rows = ops[0].stage_times(3) if world == 1 and batch > 1 else None
+    batched_rows = ops[0].stage_times(3) if world == 1 and batch > 1 else None   # per launch of `batch` ops
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -267,6 +318,7 @@ def main():
         value = args.steps / dt   # whole-job rate: the N GPUs complete `steps` sharded hmults together
         sweep_limbs = ELL + ALPHA
         ntt_ns = measure_ntt_sweep(sweep_limbs)
+        inop_ns, inop_limbs = measure_ntt_inop(batch) if world == 1 else (None, None)
         achieved = NTT_ALG_BYTES * sweep_limbs / ntt_ns  # B/ns = GB/s
         rin = roofline_inputs()
         # second ceiling (SURVEY.md §8d "measure and print both"): VALU issue.  One limb-NTT = N/2 * logN butterflies; a
@@ -279,17 +331,32 @@ def main():
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": f"{CFG} {opn} L={L} l={ELL} alpha={ALPHA} (N=2^16, beta=3, " + ("full hybrid key switch + rescale)" if opn == "hmult" else "automorphism + full hybrid key switch)"),
-                       "parallelism": "single GPU" if world == 1 else f"limbs sharded over {world} GPUs (limb e -> e % {world}); RCCL all-to-all around ModUp/ModDown base conversion + replicate of the rescale residue; {batch} hmults per launch share the exchanges",
+                       "parallelism": "single GPU" if world == 1 else f"limbs sharded over {world} GPUs (limb e -> e % {world}); RCCL all-to-all around every digit's ModUp conversion and around the ModDown conversion (2 beta + 2 per key switch, digit j+1's exchange on the exchange stream beside digit j's conversion and transform) + replicate of the rescale residue; {batch} hmults per launch share the exchanges",
                        "launches_per_op": op.launch_count(), "streams": streams, "batch": batch, "transport": transport,
                        "evk_note": "the ops of a batch share ONE evaluation key: the 157 MB key stream that the algorithmic figure charges per op is read from HBM once per batch, the other readers hit cache",
                        "streams_note": "`streams` instances in flight (own HBM pool / HIP stream each), each carrying `batch` independent hmults per launch (own inputs, one evaluation key); a step is one hmult"},
             "single_stream_ops_per_s": single,
+            "sustained_ops_per_s": sustained,
+            "launches_in_timed_region_per_instance": args.steps // (batch * streams),
             "stage_us": [[kind, name, round(ns * 1e-3, 2)] for kind, name, ns in stage_rows],
+            "stage_us_per_op_batched": None if not batched_rows else [[kind, name, round(ns * 1e-3 / batch, 2)] for kind, name, ns in batched_rows],
             "exchange_us_per_op": round(sum(ns for kind, _, ns in stage_rows if kind in ("EXCH_IN", "EXCH_OUT", "REPLICATE")) * 1e-3 / (batch if world > 1 else 1), 2),
-            "exchange_overlap": exchange_overlap(stage_rows, batch if world > 1 else 1, ms * 1e3, streams if world > 1 else 1),
+            "exchange_overlap": exchange_overlap(stage_rows, batch if world > 1 else 1, ms * 1e3, streams if world > 1 else 1,
+                                                 world > 1 and os.environ.get("HOMULATOR_PIPELINE_DIGITS", "1") != "0"),
             "hmult_hbm_gbs_algorithmic": alg_bytes / (ms * 1e-3) / 1e9,
             "hmult_frac_of_hbm_peak": alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "roofline": {"bound": "valu" if valu_floor_ns and valu_floor_ns > hbm_floor_ns else "hbm",
+            # the same with the evaluation key (2 beta E = 300 limb-polys) charged ONCE per launch of `batch` ops instead of once per
+            # op: what the algorithmic figure describes when the ops of a launch share their key, as they do here
+            "hmult_alg_bytes_evk_once": alg_bytes - EVK_BYTES * (1 - 1 / batch),
+            "hmult_frac_evk_once": (alg_bytes - EVK_BYTES * (1 - 1 / batch)) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            # what the chip moved: FETCH_SIZE x 2 + WRITE_SIZE of one op at the timed region's launch shape (profiler run, not this run)
+            "measured_hbm": None if opn != "hmult" or not rin.get("whole_op_bytes") or rin.get("whole_op_batch") != batch or rin.get("whole_op_instances") != streams else {
+                "bytes_per_op": rin["whole_op_bytes"], "tb_per_s": rin["whole_op_bytes"] / (ms * 1e-3) / 1e12,
+                "frac_of_peak": rin["whole_op_bytes"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "batch": rin["whole_op_batch"], "instances": rin["whole_op_instances"], "source": rin.get("whole_op_source"),
+                "note": "bytes from the committed rocprofv3 counter passes of the same launch shape, time from this run"},
+            "roofline": {"bound": "hbm",
+                         "binding_ceiling": "valu" if valu_floor_ns and valu_floor_ns > hbm_floor_ns else "hbm",
                          "kernel": "forward NTT sweep, 50 limbs = k_ntt_col + k_ntt_row",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": rin.get("ntt_sweep50_traffic_bytes") if sweep_limbs == 50 else None, "us_per_launch": ntt_ns * 1e-3,
@@ -300,14 +367,17 @@ def main():
                              "floor_us": valu_floor_ns * 1e-3, "frac": valu_floor_ns / ntt_ns, "unit": "wave-butterflies/ns",
                              "achieved": BFLY_PER_LIMB_NTT / 64 * sweep_limbs / ntt_ns, "peak": 1.0 / wb_ns,
                              "source": rin.get("wave_butterfly_source")},
-                         "in_op": None if not batched_rows else (lambda ns, limbs: {
-                             "kernel": "the ModUp forward transforms as the timed region launches them (k_ntt_col + k_ntt_row), timed alone with HIP events on the op's stream",
-                             "limbs_per_launch_group": limbs, "us": ns * 1e-3, "us_per_limb": ns * 1e-3 / limbs,
-                             "achieved": NTT_ALG_BYTES * limbs / ns, "frac": NTT_ALG_BYTES * limbs / ns / HBM_PEAK_GBS,
-                             "valu_frac": None if not wb_ns else wb_ns * BFLY_PER_LIMB_NTT / 64 * limbs / ns})(
-                             ([r[2] for r in batched_rows if r[0] == "NTT"] or [float("nan")])[0],
-                             sum(ELL + ALPHA - min(ALPHA, ELL - j * ALPHA) for j in range(-(-ELL // ALPHA))) * batch),  # sum over digits of (E - d_j) = 115 limbs per op
-                         "note": "`achieved`/`peak`/`frac` are the HBM figures of the task's contract; `bound` names the ceiling "
+                         "in_op": None if not inop_ns else {
+                             "kernel": "the ModUp forward transforms of one launch of the timed region (115 limb-polys per op x batch) as ONE hm_ntt call = k_ntt_col + k_ntt_row, timed alone with HIP events on the backend's stream",
+                             "limbs_per_launch_group": inop_limbs, "us": inop_ns * 1e-3, "us_per_limb": inop_ns * 1e-3 / inop_limbs,
+                             "achieved": NTT_ALG_BYTES * inop_limbs / inop_ns, "frac": NTT_ALG_BYTES * inop_limbs / inop_ns / HBM_PEAK_GBS,
+                             "valu_frac": None if not wb_ns else wb_ns * BFLY_PER_LIMB_NTT / 64 * inop_limbs / inop_ns},
+                         "real_traffic": {
+                             "floor_bytes_per_limb_ntt": 4 * LP,
+                             "note": "a limb-poly (512 KiB) does not fit one CU's LDS (160 KiB), so a transform is two passes through global memory; the MI355X L2 writes "
+                                     "every store through and does not allocate on it (profiles/r03_fused_ntt.txt), so the hand-off crosses the fabric twice: 4 limb-polys "
+                                     "per limb-NTT + row twiddles is the floor of `traffic`, twice the algorithmic figure"},
+                         "note": "`achieved`/`peak`/`frac`/`bound` are the HBM figures of the task's contract; `binding_ceiling` names the ceiling "
                                  "with the larger floor for this launch (the 64-bit modular butterflies are integer VALU work)"},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -513,7 +513,23 @@ struct hm_ctx {
   void *ext_user = nullptr;
   uint64_t *stage_send = nullptr, *stage_recv = nullptr;
   size_t stage_words = 0;
+  // exchange / compute overlap inside one op: the exchanges run on a stream of their own (hm_exchange_stream), ordered against the
+  // compute stream by marks (events)
+  hipStream_t xstream = nullptr;
+  bool xasync = false;
+  hipEvent_t xdep = nullptr;
+  std::vector<hipEvent_t> xmarks;
 };
+// the stream an exchange runs on; with the exchange stream on, it first waits for everything enqueued on the compute stream so far
+static hm_status exchange_stream_begin(hm_ctx *c, hipStream_t *S) {
+  *S = c->stream;
+  if (!c->xasync) return HM_OK;
+  hipError_t e = hipEventRecord(c->xdep, c->stream);
+  if (e == hipSuccess) e = hipStreamWaitEvent(c->xstream, c->xdep, 0);
+  if (e != hipSuccess) { c->err = std::string("exchange stream: ") + hipGetErrorString(e); return HM_ERR_HIP; }
+  *S = c->xstream;
+  return HM_OK;
+}
 
 // RCCL is loaded lazily so that the library itself never depends on it being present
 struct RcclApi {
@@ -638,6 +654,9 @@ extern "C" void hm_destroy(hm_ctx *c) {
   (void)hipFree(c->d_mods);
   (void)hipFree(c->ntt_ws);
   (void)hipHostFree(c->err_host);
+  if (c->xstream) { (void)hipStreamSynchronize(c->xstream); (void)hipStreamDestroy(c->xstream); }
+  if (c->xdep) (void)hipEventDestroy(c->xdep);
+  for (hipEvent_t e : c->xmarks) (void)hipEventDestroy(e);
   (void)hipEventDestroy(c->ev0);
   (void)hipEventDestroy(c->ev1);
   if (c->ev_done) (void)hipEventDestroy(c->ev_done);
@@ -701,7 +720,39 @@ static hm_status check_device_error(hm_ctx *c) {
 extern "C" hm_status hm_sync(hm_ctx *c) {
   if (!c) return HM_ERR_ARG;
   HM_HIP(c, hipStreamSynchronize(c->stream));
+  if (c->xstream) HM_HIP(c, hipStreamSynchronize(c->xstream));
   return check_device_error(c);
+}
+extern "C" hm_status hm_exchange_stream(hm_ctx *c, int enable) {
+  if (!c) return HM_ERR_ARG;
+  HM_HIP(c, hipSetDevice(c->device));
+  if (enable && !c->xstream) {
+    HM_HIP(c, hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking));
+    HM_HIP(c, hipEventCreateWithFlags(&c->xdep, hipEventDisableTiming));
+  }
+  if (!enable && c->xasync) {   // leaving the mode: the compute stream continues behind everything the exchange stream holds
+    HM_HIP(c, hipEventRecord(c->xdep, c->xstream));
+    HM_HIP(c, hipStreamWaitEvent(c->stream, c->xdep, 0));
+  }
+  c->xasync = enable != 0;
+  return HM_OK;
+}
+extern "C" hm_status hm_exchange_mark(hm_ctx *c, uint32_t slot) {
+  if (!c || slot >= 256) return HM_ERR_ARG;
+  HM_HIP(c, hipSetDevice(c->device));
+  while (c->xmarks.size() <= slot) {
+    hipEvent_t e;
+    HM_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    c->xmarks.push_back(e);
+  }
+  HM_HIP(c, hipEventRecord(c->xmarks[slot], c->xasync ? c->xstream : c->stream));
+  return HM_OK;
+}
+extern "C" hm_status hm_exchange_wait(hm_ctx *c, uint32_t slot) {
+  if (!c) return HM_ERR_ARG;
+  if (slot >= c->xmarks.size()) return fail(c, HM_ERR_ARG, "hm_exchange_wait: mark %u was never set", slot);
+  HM_HIP(c, hipStreamWaitEvent(c->stream, c->xmarks[slot], 0));
+  return HM_OK;
 }
 extern "C" void *hm_stream(hm_ctx *c) { return c ? (void *)c->stream : nullptr; }
 extern "C" hm_status hm_wait_for(hm_ctx *c, hm_ctx *producer) {
@@ -1426,6 +1477,7 @@ extern "C" hm_status hm_slice_rows(const uint32_t *owners, uint32_t n, uint32_t 
 static hm_status ensure_stage(hm_ctx *c, size_t words) {
   if (c->stage_words >= words) return HM_OK;
   HM_HIP(c, hipStreamSynchronize(c->stream));
+  if (c->xstream) HM_HIP(c, hipStreamSynchronize(c->xstream));
   (void)hipFree(c->stage_send);
   (void)hipFree(c->stage_recv);
   c->stage_send = c->stage_recv = nullptr;
@@ -1434,26 +1486,26 @@ static hm_status ensure_stage(hm_ctx *c, size_t words) {
   c->stage_words = words;
   return HM_OK;
 }
-static hm_status chunk_copy(hm_ctx *c, const uint64_t *src, uint64_t *dst, uint32_t len, const std::vector<uint32_t> &so,
+static hm_status chunk_copy(hm_ctx *c, hipStream_t S, const uint64_t *src, uint64_t *dst, uint32_t len, const std::vector<uint32_t> &so,
                             const std::vector<uint32_t> &dof) {
   for (size_t base = 0; base < so.size(); base += HM_MAX_CHUNKS / 2) {
     const uint32_t cnt = (uint32_t)std::min<size_t>(HM_MAX_CHUNKS / 2, so.size() - base);
     HmChunkArgs a;
     a.src = src; a.dst = dst; a.len = len; a.n_chunks = cnt;
     for (uint32_t i = 0; i < cnt; ++i) { a.src_off[i] = so[base + i]; a.dst_off[i] = dof[base + i]; }
-    hipLaunchKernelGGL(k_chunk_copy, dim3(cnt * (len / 512)), dim3(256), 0, c->stream, a);
+    hipLaunchKernelGGL(k_chunk_copy, dim3(cnt * (len / 512)), dim3(256), 0, S, a);
     HM_HIP(c, hipGetLastError());
   }
   return HM_OK;
 }
 // the exchange itself: per peer p, send_bytes[p] bytes at send + send_off[p] go to rank p and recv_bytes[p] bytes
 // from rank p land at recv + recv_off[p].  Nothing is sent to self (callers place their own part directly).
-static hm_status all_to_all(hm_ctx *c, const uint64_t *send, std::vector<size_t> send_off, std::vector<size_t> send_bytes,
+static hm_status all_to_all(hm_ctx *c, hipStream_t S, const uint64_t *send, std::vector<size_t> send_off, std::vector<size_t> send_bytes,
                             uint64_t *recv, std::vector<size_t> recv_off, std::vector<size_t> recv_bytes) {
   if (c->world == 1) return HM_OK;
   send_bytes[c->rank] = recv_bytes[c->rank] = 0;
   if (c->ext_fn) {
-    HM_HIP(c, hipStreamSynchronize(c->stream));
+    HM_HIP(c, hipStreamSynchronize(S));   // the external transports move the bytes on the host's clock
     if (c->ext_fn(c->ext_user, send, send_off.data(), send_bytes.data(), recv, recv_off.data(), recv_bytes.data()))
       return fail(c, HM_ERR_COMM, "external exchange failed");
     return HM_OK;
@@ -1461,8 +1513,8 @@ static hm_status all_to_all(hm_ctx *c, const uint64_t *send, std::vector<size_t>
   if (!c->comm) return fail(c, HM_ERR_COMM, "no communicator: call hm_comm_init_rccl first");
   ncclResult_t r = g_rccl.GroupStart();
   for (int p = 0; p < c->world && r == ncclSuccess; ++p) {
-    if (send_bytes[p]) r = g_rccl.Send((const char *)send + send_off[p], send_bytes[p] / 8, ncclUint64, p, c->comm, c->stream);
-    if (recv_bytes[p] && r == ncclSuccess) r = g_rccl.Recv((char *)recv + recv_off[p], recv_bytes[p] / 8, ncclUint64, p, c->comm, c->stream);
+    if (send_bytes[p]) r = g_rccl.Send((const char *)send + send_off[p], send_bytes[p] / 8, ncclUint64, p, c->comm, S);
+    if (recv_bytes[p] && r == ncclSuccess) r = g_rccl.Recv((char *)recv + recv_off[p], recv_bytes[p] / 8, ncclUint64, p, c->comm, S);
   }
   ncclResult_t e = g_rccl.GroupEnd();
   if (r == ncclSuccess) r = e;
@@ -1505,10 +1557,12 @@ extern "C" hm_status hm_limbs_to_slices(hm_ctx *c, const uint64_t *buf, const ui
       ++j;
     }
   }
-  if ((st = chunk_copy(c, buf, slices, len, so_self, do_self))) return st;
-  if ((st = chunk_copy(c, buf, c->stage_send, len, so, dof))) return st;
+  hipStream_t S;
+  if ((st = exchange_stream_begin(c, &S))) return st;
+  if ((st = chunk_copy(c, S, buf, slices, len, so_self, do_self))) return st;
+  if ((st = chunk_copy(c, S, buf, c->stage_send, len, so, dof))) return st;
   // a rank's own rows must not be overwritten by the receive: recv_off[me] block is skipped by all_to_all
-  return all_to_all(c, c->stage_send, send_off, send_bytes, slices, recv_off, recv_bytes);
+  return all_to_all(c, S, c->stage_send, send_off, send_bytes, slices, recv_off, recv_bytes);
 }
 
 extern "C" hm_status hm_slices_to_limbs(hm_ctx *c, const uint64_t *slices, uint64_t *buf, const uint32_t *limbs,
@@ -1535,7 +1589,9 @@ extern "C" hm_status hm_slices_to_limbs(hm_ctx *c, const uint64_t *slices, uint6
     recv_bytes[p] = p == me ? 0 : (size_t)mine * len * 8;
     ro_acc += recv_bytes[p];
   }
-  if ((st = all_to_all(c, slices, send_off, send_bytes, c->stage_recv, recv_off, recv_bytes))) return st;
+  hipStream_t S;
+  if ((st = exchange_stream_begin(c, &S))) return st;
+  if ((st = all_to_all(c, S, slices, send_off, send_bytes, c->stage_recv, recv_off, recv_bytes))) return st;
   std::vector<uint32_t> so, dof, so_self, do_self;
   for (uint32_t p = 0; p < W; ++p) {
     uint32_t j = 0;
@@ -1546,8 +1602,8 @@ extern "C" hm_status hm_slices_to_limbs(hm_ctx *c, const uint64_t *slices, uint6
       ++j;
     }
   }
-  if ((st = chunk_copy(c, slices, buf, len, so_self, do_self))) return st;
-  return chunk_copy(c, c->stage_recv, buf, len, so, dof);
+  if ((st = chunk_copy(c, S, slices, buf, len, so_self, do_self))) return st;
+  return chunk_copy(c, S, c->stage_recv, buf, len, so, dof);
 }
 
 extern "C" hm_status hm_replicate_limbs(hm_ctx *c, uint64_t *buf, const uint32_t *limbs, const uint32_t *owners, uint32_t n) {
@@ -1576,8 +1632,10 @@ extern "C" hm_status hm_replicate_limbs(hm_ctx *c, uint64_t *buf, const uint32_t
   uint32_t j = 0;
   for (uint32_t i = 0; i < n; ++i)
     if (owners[i] == me) { so.push_back(limbs[i]); dof.push_back(j++); }
-  if ((st = chunk_copy(c, buf, c->stage_send, N, so, dof))) return st;
-  if ((st = all_to_all(c, c->stage_send, send_off, send_bytes, c->stage_recv, recv_off, recv_bytes))) return st;
+  hipStream_t S;
+  if ((st = exchange_stream_begin(c, &S))) return st;
+  if ((st = chunk_copy(c, S, buf, c->stage_send, N, so, dof))) return st;
+  if ((st = all_to_all(c, S, c->stage_send, send_off, send_bytes, c->stage_recv, recv_off, recv_bytes))) return st;
   so.clear(); dof.clear();
   for (uint32_t p = 0; p < W; ++p) {
     if (p == me) continue;
@@ -1585,7 +1643,7 @@ extern "C" hm_status hm_replicate_limbs(hm_ctx *c, uint64_t *buf, const uint32_t
     for (uint32_t i = 0; i < n; ++i)
       if (owners[i] == p) { so.push_back((uint32_t)(recv_off[p] / 8 / N) + k++); dof.push_back(limbs[i]); }
   }
-  return chunk_copy(c, c->stage_recv, buf, N, so, dof);
+  return chunk_copy(c, S, c->stage_recv, buf, N, so, dof);
 }
 
 extern "C" hm_status hm_fill_uniform(hm_ctx *c, uint64_t *out, const uint32_t *out_limbs, const uint32_t *mod_ids,

@@ -109,6 +109,7 @@ private:
   Config *config;
   Backend backendKind;
   bool fuse;
+  bool pipelineDigits = false;  // sharded: per-digit exchanges on the exchange stream (config key pipeline_digits, default 1 when world > 1)
   bool fuseHpip = true;   // config key fuse_hpip: the ModUp transforms' last pass runs inside the inner-product kernel
   uint32_t n = 0, logN = 0, clusterCount = 1;
   uint32_t maxLevel_ = 0, curLevel_ = 0, world_ = 1, rank_ = 0;

@@ -11,6 +11,9 @@
 // one C-ABI call, with its argument arrays prebuilt so that run() is a tight loop of calls
 struct Arch::Launch {
   enum Kind { L_NTT, L_INTT, L_EWE, L_BCONV, L_AUTO, L_NTT_SUBSCALE, L_TENSOR, L_EXCH_IN, L_EXCH_OUT, L_REPLICATE, L_IP, L_NTT_IP } kind;
+  Launch *xin = nullptr, *xout = nullptr;   // sharded BCONV: the exchange launches around it (they share its slice buffers)
+  int recordSlot = -1;            // exchange launches of a pipelined sharded plan: the mark set behind them (hm_exchange_mark)
+  std::vector<int> waitSlots;     // marks the compute stream waits for before this launch (hm_exchange_wait)
   std::vector<uint8_t> ipCoeff;   // L_NTT_IP: per (limb, digit) 1 = transformed inside the kernel (a = source, c = first-pass scratch)
   uint32_t ipTerms = 0, ipOuts = 0;
   std::string name;
@@ -71,6 +74,12 @@ Arch::Arch(Config *cfg) : config(cfg) {
   // the SIMULATED machine (backend = sim).  On the GPU the fused kernel is a scheduling decision of the backend: `fuse_hpip`.
   fuseHpip = cfg->getValueOr("fuse_hpip", 1) != 0;
   if (const char *e = getenv("HOMULATOR_FUSE_HPIP")) fuseHpip = std::string(e) != "0";
+  // sharded runs: the exchanges of digit j+1 run on the context's exchange stream while digit j converts and transforms (SURVEY.md 7:
+  // 2 beta + 2 all-to-alls per key switch instead of 4, same order on every rank).  The per-digit transforms must then stay separate
+  // launches, so the fused NTT x key kernel (which needs all digits) is not used.
+  pipelineDigits = world_ > 1 && cfg->getValueOr("pipeline_digits", 1) != 0;
+  if (const char *e = getenv("HOMULATOR_PIPELINE_DIGITS")) pipelineDigits = world_ > 1 && std::string(e) != "0";
+  if (pipelineDigits) fuseHpip = false;
   stat = new Statistic();
 }
 
@@ -559,6 +568,8 @@ void Arch::buildLaunches() {
   }
   const uint32_t logLen = logN - (uint32_t)__builtin_ctz(world_);
   // ---- 3. coalesce and emit, level by level
+  std::map<AddrType, int> slotOfAddr;   // pipelined sharded plan: the exchange mark behind which an address is valid on this rank
+  int nextSlot = 0;
   int maxDepth = 0;
   for (const Part &p : parts) maxDepth = std::max(maxDepth, p.depth);
   for (int d = 0; d <= maxDepth; ++d) {
@@ -588,6 +599,11 @@ void Arch::buildLaunches() {
           R->kind = Launch::L_REPLICATE; R->statKey = "XCHG"; R->name = "replicate";
           for (AddrType a : need) { R->exLimbs.push_back(limbOf(a)); R->exOwners.push_back(ownerOfAddr[a]); }
           R->bytes = LP * need.size();
+          if (pipelineDigits) {
+            for (AddrType a : need) { auto it = slotOfAddr.find(a); if (it != slotOfAddr.end() && std::find(R->waitSlots.begin(), R->waitSlots.end(), it->second) == R->waitSlots.end()) R->waitSlots.push_back(it->second); }
+            R->recordSlot = nextSlot++;
+            for (AddrType a : need) slotOfAddr[a] = R->recordSlot;
+          }
           launches.push_back(R);
         }
         // (b) keep the instructions whose modulus this rank owns
@@ -602,7 +618,35 @@ void Arch::buildLaunches() {
         if (group.empty()) continue;
         f = group[0]->ins[0];
       }
+      // pipelined sharded plan: parts that depend on different exchanges (digit j's transforms read what exchange XO_j delivered)
+      // become launches of their own, each waiting for its own mark; the conversions are split by input basis (= by digit; the two
+      // keys of a ModDown share theirs and stay together).  Exchange-in launches of all digits are issued first.
+      std::vector<std::vector<const Part *>> subgroups;
+      auto slotsOf = [&](const Part *g) {
+        std::set<int> ss;
+        for (Instruction *i : g->ins)
+          for (AddrType a : reads(i)) { auto it = slotOfAddr.find(a); if (it != slotOfAddr.end()) ss.insert(it->second); }
+        return ss;
+      };
+      if (pipelineDigits) {
+        std::vector<std::set<int>> sigs;
+        std::vector<std::vector<uint32_t>> bases;
+        for (const Part *g : group) {
+          const std::set<int> sg = slotsOf(g);
+          const std::vector<uint32_t> bs = f->ops == BCONV_STEP2 ? g->ins[0]->inMods : std::vector<uint32_t>();
+          size_t k = 0;
+          for (; k < subgroups.size(); ++k) if (sigs[k] == sg && bases[k] == bs) break;
+          if (k == subgroups.size()) { subgroups.emplace_back(); sigs.push_back(sg); bases.push_back(bs); }
+          subgroups[k].push_back(g);
+        }
+      } else subgroups.push_back(group);
+      std::vector<Launch *> front, back;
+      for (const std::vector<const Part *> &subgroup : subgroups) {
+      const std::vector<const Part *> &group = subgroup;
+      f = group[0]->ins[0];
       Launch *L = new Launch;
+      if (pipelineDigits)
+        for (const Part *g : group) for (int sl : slotsOf(g)) if (std::find(L->waitSlots.begin(), L->waitSlots.end(), sl) == L->waitSlots.end()) L->waitSlots.push_back(sl);
       for (const Part *g : group) L->name += (L->name.empty() ? "" : "+") + g->name;
       size_t count = 0;
       for (const Part *g : group)
@@ -748,10 +792,19 @@ void Arch::buildLaunches() {
           XI->bytes = LP * XI->exLimbs.size() / world_;
           XO->bytes = LP * XO->exLimbs.size() / world_;
           L->bytes /= world_;
-          launches.push_back(XI);
+          if (pipelineDigits) {
+            XI->waitSlots = L->waitSlots;   // (its inputs come from the compute stream; marks matter only if an exchange produced them)
+            XI->recordSlot = nextSlot++;
+            L->waitSlots = {XI->recordSlot};
+            XO->recordSlot = nextSlot++;
+            for (const Part *g : group)
+              for (Instruction *i : g->ins) slotOfAddr[i->OutputOperand] = XO->recordSlot;
+          }
+          L->xin = XI; L->xout = XO;
+          (pipelineDigits ? front : back).push_back(XI);
           algBytes += L->bytes;
-          launches.push_back(L);
-          launches.push_back(XO);
+          back.push_back(L);
+          back.push_back(XO);
           continue;
         }
       } else {
@@ -759,7 +812,10 @@ void Arch::buildLaunches() {
         throw std::runtime_error("no unit executes op " + f->GetOpName());
       }
       algBytes += L->bytes;
-      launches.push_back(L);
+      back.push_back(L);
+      }  // subgroups
+      launches.insert(launches.end(), front.begin(), front.end());
+      launches.insert(launches.end(), back.begin(), back.end());
     }
   }
 }
@@ -851,9 +907,10 @@ void Arch::prepare() {
   pool = static_cast<uint64_t *>(p);
   if (world_ > 1) {
     if (!commReady) throw std::runtime_error("world > 1 but no transport was set (commInitRccl / commInitExternal)");
-    for (size_t i = 0; i + 2 < launches.size() + 0; ++i) {
-      if (launches[i]->kind != Launch::L_EXCH_IN) continue;
-      Launch *xi = launches[i], *bc = launches[i + 1], *xo = launches[i + 2];
+    if (pipelineDigits && hm_exchange_stream(ctx, 1) != HM_OK) throw std::runtime_error(std::string("hm_exchange_stream: ") + hm_last_error(ctx));
+    for (Launch *bc : launches) {
+      if (bc->kind != Launch::L_BCONV || !bc->xin) continue;
+      Launch *xi = bc->xin, *xo = bc->xout;
       void *si = nullptr, *so = nullptr;
       if (hm_malloc(ctx, (size_t)xi->exLimbs.size() * (n / world_) * 8, &si) != HM_OK || hm_malloc(ctx, (size_t)xo->exLimbs.size() * (n / world_) * 8, &so) != HM_OK)
         throw std::runtime_error(std::string("hm_malloc (slices): ") + hm_last_error(ctx));
@@ -896,6 +953,7 @@ std::string Arch::stageTimes(uint32_t iters) {
     for (size_t i = 0; i < launches.size(); ++i) {
       hm_timer_start(ctx);
       enqueue(*launches[i]);
+      if (launches[i]->recordSlot >= 0) hm_exchange_wait(ctx, (uint32_t)launches[i]->recordSlot);   // timed alone: the compute stream's timer covers the exchange
       uint64_t ns = 0;
       hm_timer_stop(ctx, &ns);
       total[i] += ns;
@@ -914,6 +972,8 @@ std::string Arch::planText() const {
     if (l->kind == Launch::L_BCONV) { cnt = 0; for (auto &q : l->probs) cnt += q.out.size(); }
     if (l->kind == Launch::L_IP || l->kind == Launch::L_NTT_IP) cnt = l->mods.size();
     out += std::string(names[l->kind]) + " " + l->name + " n=" + std::to_string(cnt) + " ref=" + std::to_string(l->refInstructions);
+    if (l->recordSlot >= 0) out += " mark=" + std::to_string(l->recordSlot);
+    if (!l->waitSlots.empty()) { out += " wait="; for (int w : l->waitSlots) out += std::to_string(w) + ","; }
     if (!l->exLimbs.empty()) {
       out += " limbs=";
       for (size_t i = 0; i < l->exLimbs.size(); ++i) out += std::to_string(l->exLimbs[i]) + ":" + std::to_string(l->exOwners[i]) + ",";
@@ -925,6 +985,8 @@ std::string Arch::planText() const {
 
 void Arch::enqueue(Launch &l) {
   hm_status st = HM_OK;
+  for (int sl : l.waitSlots)
+    if (hm_exchange_wait(ctx, (uint32_t)sl) != HM_OK) throw std::runtime_error("stage " + l.name + ": " + hm_last_error(ctx));
   const uint32_t cnt = (uint32_t)l.out.size();
   std::vector<hm_bconv_desc> descs;
   switch (l.kind) {
@@ -981,6 +1043,7 @@ void Arch::enqueue(Launch &l) {
     st = hm_bconv_batch(ctx, descs.data(), (uint32_t)descs.size());
     break;
   }
+  if (st == HM_OK && l.recordSlot >= 0) st = hm_exchange_mark(ctx, (uint32_t)l.recordSlot);
   if (st != HM_OK) throw std::runtime_error("stage " + l.name + ": " + hm_last_error(ctx));
 }
 
@@ -996,6 +1059,7 @@ void Arch::update() {
   if (backendKind == BACKEND_HIP) {
     hm_timer_start(ctx);
     enqueue(l);
+    if (l.recordSlot >= 0) hm_exchange_wait(ctx, (uint32_t)l.recordSlot);
     uint64_t ns = 0;
     hm_timer_stop(ctx, &ns);
     elapsedNs += ns;

@@ -207,6 +207,17 @@ hm_status hm_limbs_to_slices(hm_ctx *ctx, const uint64_t *buf, const uint32_t *l
 hm_status hm_slices_to_limbs(hm_ctx *ctx, const uint64_t *slices, uint64_t *buf, const uint32_t *limbs,
                              const uint32_t *owners, uint32_t n);
 
+/* Exchange / compute overlap inside ONE op ("overlap digit j+1's exchange with digit j's NTT"; upstream's digit loop
+ * src/Operation.cpp:31-35, its only communication src/mem.cpp:78-100).  hm_exchange_stream(ctx, 1): from now on the three exchange
+ * calls below run on a second stream of the context — each starts once everything enqueued on the compute stream BEFORE the call
+ * has finished, and the compute stream does not wait for it.  hm_exchange_mark(ctx, slot) marks the end of the exchanges issued
+ * so far; hm_exchange_wait(ctx, slot) makes the compute stream wait for that mark (slot < 256).  Exchanges keep their issue order
+ * among themselves (one stream, one staging buffer), so every rank still enters the collectives in the same order.  With an
+ * external transport the exchange stream is synchronised on the host inside the call (correct, no overlap). */
+hm_status hm_exchange_stream(hm_ctx *ctx, int enable);
+hm_status hm_exchange_mark(hm_ctx *ctx, uint32_t slot);
+hm_status hm_exchange_wait(hm_ctx *ctx, uint32_t slot);
+
 /* every rank ends up with a full copy of the n limbs (owner -> everybody).  The one place the hmult path needs
  * it is the rescale: r = INTT(x_last) lives on one rank and every other limb's NTT reads it (src/Operation.cpp:
  * 806-822). */

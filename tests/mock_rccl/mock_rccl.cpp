@@ -98,7 +98,10 @@ ncclResult_t run_group() {
       g->box[slot].erase(g->box[slot].begin());
     }
     if (p.bytes != o.bytes) problem = "rank " + std::to_string(me) + " expects " + std::to_string(o.bytes) + " bytes from rank " + std::to_string(o.peer) + ", which sends " + std::to_string(p.bytes);
-    else if (hipMemcpy(o.ptr, p.ptr, o.bytes, hipMemcpyDeviceToDevice) != hipSuccess) problem = "hipMemcpy failed";
+    // a device-to-device hipMemcpy may return before the copy has run: the sender is told only when the bytes have really left its
+    // buffer (with per-digit pipelined exchanges its next exchange packs into the same staging buffer right away; round 3 saw one run
+    // in ten corrupted by acknowledging too early)
+    else if (hipMemcpy(o.ptr, p.ptr, o.bytes, hipMemcpyDeviceToDevice) != hipSuccess || hipDeviceSynchronize() != hipSuccess) problem = "hipMemcpy failed";
     else g_bytes += (long)o.bytes;
     {
       std::lock_guard<std::mutex> lk(g->m);

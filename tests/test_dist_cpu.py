@@ -39,11 +39,15 @@ def test_gloo_transport_world2():
 
 
 @pytest.mark.parametrize("opname", ["hmult", "hrotate"])
+@pytest.mark.parametrize("pipeline", [1, 0])
 @pytest.mark.parametrize("world,batch", [(2, 1), (4, 1), (8, 1), (2, 4), (8, 16)])
-def test_sharded_plans_are_collectively_consistent(opname, world, batch):
+def test_sharded_plans_are_collectively_consistent(opname, world, batch, pipeline):
+    """pipeline = 1 (default when sharded): per-digit exchanges, 2 beta + 2 all-to-alls per key switch, every launch behind an
+    exchange waits for that exchange's mark only; pipeline = 0: one all-to-all pair per base-conversion stage"""
     from homulator_amd import host
     L, ell, alpha = 45, 35, 15
-    ov = {"batch": batch} if batch > 1 else None
+    beta = -(-ell // alpha)
+    ov = {"pipeline_digits": pipeline, "fuse_hpip": 0 if pipeline else 1, **({"batch": batch} if batch > 1 else {})}
     single = host.Op("config_4.cfg", opname, L, ell, alpha, backend=host.BACKEND_COUNT, overrides=ov)
     total_ref = sum(int(re.search(r"ref=(\d+)", ln).group(1)) for ln in single.plan())
     plans = []
@@ -55,7 +59,23 @@ def test_sharded_plans_are_collectively_consistent(opname, world, batch):
     assert all(c == coll[0] for c in coll)
     n_bconv = sum(1 for ln in plans[0] if ln.startswith("BCONV"))
     assert sum(1 for ln in coll[0] if ln.startswith("EXCH_IN")) == n_bconv == sum(1 for ln in coll[0] if ln.startswith("EXCH_OUT"))
-    assert n_bconv == 2   # one all-to-all pair for ModUp (all digits), one for ModDown (both keys): SURVEY §8e
+    # one all-to-all pair for ModUp (all digits) and one for ModDown (both keys), or 2 beta + 2 pipelined per digit
+    assert n_bconv == (beta + 1 if pipeline else 2)
+    if pipeline:   # marks: every exchange sets one, in issue order; a conversion waits for its own exchange-in, a transform for its digit's exchange-out
+        marks = [int(re.search(r"mark=(\d+)", ln).group(1)) for ln in plans[0] if " mark=" in ln]
+        assert sorted(marks) == list(range(len(marks)))
+        xin = {re.match(r"EXCH_IN (\S+):", ln).group(1): int(re.search(r"mark=(\d+)", ln).group(1)) for ln in plans[0] if ln.startswith("EXCH_IN")}
+        xout = {re.match(r"EXCH_OUT (\S+):", ln).group(1): int(re.search(r"mark=(\d+)", ln).group(1)) for ln in plans[0] if ln.startswith("EXCH_OUT")}
+        for ln in plans[0]:
+            if ln.startswith("BCONV"):
+                assert re.search(r"wait=([\d,]+)", ln).group(1).strip(",") == str(xin[ln.split()[1]])
+        for j in range(beta):
+            for pl in plans:
+                for ln in pl:
+                    if ln.startswith(f"NTT ModUp_NTT_({j})"):
+                        assert re.search(r"wait=([\d,]+)", ln).group(1).strip(",") == str(xout[f"ModUp_BCONV_({j})"])
+        first_bconv = next(i for i, ln in enumerate(plans[0]) if ln.startswith("BCONV"))
+        assert sum(1 for ln in plans[0][:first_bconv] if ln.startswith("EXCH_IN")) == beta   # all digits' exchange-in are in flight before the first conversion
     if opname == "hmult":
         assert sum(1 for ln in coll[0] if ln.startswith("REPLICATE")) == 1   # rescale's r
     # owners follow limb % world on the exchanged limbs, and the element-wise work is partitioned exactly
@@ -64,10 +84,10 @@ def test_sharded_plans_are_collectively_consistent(opname, world, batch):
         n = 0
         for ln in pl:
             kind = ln.split()[0]
-            if kind in ("NTT", "INTT", "EWE", "AUTO", "NTT_SUBSCALE", "TENSOR"):
+            if kind in ("NTT", "INTT", "EWE", "AUTO", "NTT_SUBSCALE", "TENSOR", "IP", "NTT_IP"):
                 n += int(re.search(r" n=(\d+)", ln).group(1))
         per_rank.append(n)
-    n_single = sum(int(re.search(r" n=(\d+)", ln).group(1)) for ln in single.plan() if ln.split()[0] in ("NTT", "INTT", "EWE", "AUTO", "NTT_SUBSCALE", "TENSOR"))
+    n_single = sum(int(re.search(r" n=(\d+)", ln).group(1)) for ln in single.plan() if ln.split()[0] in ("NTT", "INTT", "EWE", "AUTO", "NTT_SUBSCALE", "TENSOR", "IP", "NTT_IP"))
     assert sum(per_rank) == n_single
     assert max(per_rank) - min(per_rank) <= 12 * batch   # balanced up to the remainder limbs of each stage
     assert total_ref > 0

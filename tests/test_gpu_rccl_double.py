@@ -74,8 +74,9 @@ def test_rccl_code_path_with_many_ranks(case):
     assert "errors 0" in r.stdout, r.stdout
     world = case[0]
     if world == 8 and case[2] == "hmult":
-        # 2 runs x (4 all-to-alls + 1 replicate) x 8 ranks = 80 groups; every rank enters every one, also the ranks that own nothing of a list
-        assert "groups 80 " in r.stdout, r.stdout
+        # per-digit pipelined exchanges (default when sharded): 2 runs x (2 beta + 2 = 8 all-to-alls + 1 replicate) x 8 ranks = 144
+        # groups; every rank enters every one, also the ranks that own nothing of a list
+        assert "groups 144 " in r.stdout, r.stdout
 
 
 def test_the_double_reports_what_would_hang():

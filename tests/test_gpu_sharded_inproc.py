@@ -63,7 +63,7 @@ def test_sharded_in_process(world, cfg, opname, L, ell, alpha, logN, batch):
         # every pair of one exchange carries slices of N/8 coefficients; rank 0's ingress per hmult is
         # 7/8 of (its share of) the exchanged limb-polys: nonzero, identical on the two runs, below the 13.7 MiB bound + replicate
         runs = 2       # execute(1) twice
-        assert grp.calls[0] % runs == 0 and grp.calls[0] // runs == 5, grp.calls  # 2 all-to-all pairs + 1 replicate per hmult
+        assert grp.calls[0] % runs == 0 and grp.calls[0] // runs == 9, grp.calls  # per-digit pipelined: 2 beta + 2 = 8 all-to-alls + 1 replicate per hmult
         per_op = grp.bytes_recv[0] / runs
         assert 0 < per_op < 20 * 2 ** 20, per_op
     for op in ops:
@@ -88,7 +88,9 @@ def test_bench_flow_rehearsal_four_ranks():
     d = json.loads(line)
     assert d["n_gpus"] == 4 and d["steps"] == 8 and d["value"] > 0
     assert d["config"]["transport"] == "gloo-rehearsal" and d["exchange_us_per_op"] > 0
-    assert d["exchange_overlap"]["instances_in_flight"] == 1 and d["exchange_overlap"]["hidden_us_per_op"] == 0.0
+    ov = d["exchange_overlap"]   # over gloo the exchanges are host-synchronous: whatever the estimate calls hidden is noise, the sum is the exchange time
+    assert ov["instances_in_flight"] == 1 and ov["pipelined_per_digit"] and ov["hidden_us_per_op"] >= 0.0
+    assert abs(ov["hidden_us_per_op"] + ov["exposed_us_per_op"] - d["exchange_us_per_op"]) < 0.05
 
 
 def test_bench_flow_rehearsal_two_sharded_instances():

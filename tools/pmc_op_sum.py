@@ -11,5 +11,5 @@ for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         tot[k.split("(")[0][:40]] += float(r['Counter_Value'])
 s = sum(tot.values())
 for k, v in sorted(tot.items(), key=lambda kv: -kv[1]):
-    print(f"{k:42s} {v / ops:12.0f} KiB per op")
-print(f"{counter} total {s / ops:.0f} KiB per op = {s / ops * 1024 / 1e6:.1f} MB")
+    print(f"{k:42s} {v / ops:12.0f} " + ("KiB per op" if counter.endswith("SIZE") else "per op"))
+print(f"{counter} total {s / ops:.0f} KiB per op = {s / ops * 1024 / 1e6:.1f} MB" if counter.endswith("SIZE") else f"{counter} total {s / ops:.0f} per op")

@@ -1,9 +1,13 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence of a round on the GPU box (run through gpurun from the repo root):
-#   tools/profile_round.sh r02      -> gpurun_out/prof_r02/*  (copy the summaries into profiles/ afterwards)
+#   tools/profile_round.sh r03      -> gpurun_out/prof_r03/*  (copy the summaries into profiles/ afterwards, then
+#   python tools/make_roofline_inputs.py gpurun_out/prof_r03 r03)
 # Counters go in their own runs with --kernel-trace only (one --pmc set per pass); the program goes directly after `--`.
+# Every figure of the bench line that comes from a profiler is derived from THIS run; the whole-op passes use the timed
+# region's launch shape (batch 10, 2 instances), the sweep passes the same 6 rotating buffer pairs as bench.py.
 set -e
-R=${1:-r02}
+R=${1:-r03}
+BATCH=${BATCH:-10}; INST=${INST:-2}; ROUNDS=${ROUNDS:-3}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$R
 mkdir -p $OUT
@@ -26,9 +30,13 @@ for set in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ
   rocprofv3 --pmc $set --kernel-trace -d $OUT/ntt128_$i -o p --output-format csv -- python3 $ROOT/tools/pmc_ntt.py > $OUT/ntt128_$i.log 2>&1 || true
 done
 python3 $ROOT/tools/pmc_summary.py $OUT/ntt128_1 $OUT/ntt128_2 $OUT/ntt128_3 $OUT/ntt128_4 $OUT/ntt128_5 > $OUT/${R}_pmc_ntt128.txt 2>&1 || true
-# 4. whole-op HBM bytes
-for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace -d $OUT/op_$c -o p --output-format csv -- python3 $ROOT/tools/pmc_op.py hmult 4 > $OUT/op_$c.log 2>&1 || true
+# 4. whole-op HBM bytes and issue counters at the timed region's launch shape
+for c in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+  n=$(echo $c | cut -d' ' -f1)
+  rocprofv3 --pmc $c --kernel-trace -d $OUT/op_$n -o p --output-format csv -- python3 $ROOT/tools/pmc_op.py hmult $ROUNDS $BATCH $INST > $OUT/op_$n.log 2>&1 || true
 done
-(python3 $ROOT/tools/pmc_op_sum.py $OUT/op_FETCH_SIZE FETCH_SIZE 4; python3 $ROOT/tools/pmc_op_sum.py $OUT/op_WRITE_SIZE WRITE_SIZE 4) > $OUT/${R}_pmc_whole_op.txt 2>&1 || true
+OPS=$((ROUNDS * BATCH * INST))
+(echo "# hmult 45/35/15, shape: batch $BATCH x instances $INST, $ROUNDS rounds = $OPS ops; KiB per op"
+ python3 $ROOT/tools/pmc_op_sum.py $OUT/op_FETCH_SIZE FETCH_SIZE $OPS; python3 $ROOT/tools/pmc_op_sum.py $OUT/op_WRITE_SIZE WRITE_SIZE $OPS
+ python3 $ROOT/tools/pmc_op_sum.py $OUT/op_SQ_INSTS_VALU SQ_INSTS_VALU $OPS) > $OUT/${R}_pmc_whole_op.txt 2>&1 || true
 ls $OUT | head -50
