@@ -1,7 +1,10 @@
 // Arch.cpp — execution backend: turns queued stages into GPU launches through the C ABI.
 #include "Arch.h"
 
+#include <algorithm>
 #include <chrono>
+#include <fstream>
+#include <iterator>
 #include <cstring>
 #include <set>
 
@@ -1087,6 +1090,29 @@ void Arch::shownStat() {
     return;
   }
   stat->setStat("Total_ns", elapsedNs);
+  // measured HBM bytes of the op from the profiler ("rocprof HBM counters in the same key : value block"; upstream's
+  // HBM_(c) / MEM_(c) counters, src/mem.cpp:68-69,105-107).  A process cannot read its own rocprofv3 counters: the figures come from
+  // the counter file a profiling pass left (profiles/roofline_inputs.json, written by tools/make_roofline_inputs.py), named by
+  // HOMULATOR_COUNTER_FILE, and are printed only if that file describes this launch shape (hmult at N = 2^16 with this batch).
+  if (const char *path = getenv("HOMULATOR_COUNTER_FILE")) {
+    std::ifstream f(path);
+    std::string text((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    auto num = [&](const std::string &key, double &v) {
+      size_t p = text.find("\"" + key + "\"");
+      if (p == std::string::npos) return false;
+      p = text.find(':', p);
+      if (p == std::string::npos) return false;
+      v = atof(text.c_str() + p + 1);
+      return true;
+    };
+    double fetch = 0, write = 0, b = 0;
+    if (num("whole_op_fetch_kib", fetch) && num("whole_op_write_kib", write) && num("whole_op_batch", b) && (uint32_t)b == batch_ && n == 65536 && maxLevel_ == 45 && curLevel_ == 35 &&
+        std::any_of(launches.begin(), launches.end(), [](const Launch *l) { return l->kind == Launch::L_TENSOR; })) {
+      stat->setStat("HBM_fetch_KiB_per_op", (unsigned long long)(2 * fetch));   // FETCH_SIZE counts 64 B per 128-B request on gfx950
+      stat->setStat("HBM_write_KiB_per_op", (unsigned long long)write);
+      stat->setStat("HBM_bytes_per_op", (unsigned long long)((2 * fetch + write) * 1024));
+    }
+  }
   stat->showStat();
 }
 
