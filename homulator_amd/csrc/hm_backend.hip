@@ -39,7 +39,22 @@ __device__ __forceinline__ bool hm_block_map(uint32_t tiles_per_limb, uint32_t n
 }
 
 // One pass of a transform over tile `tile` of limb-poly `entry`, in the workgroup's LDS buffer.
-template <int LOGR, bool STRIDED, bool INV, int MODE, int LDAUX = 0, int STAUX = 0, int EPICH = HM_EPI_CHUNK>
+// the two geometries of the passes (hm_ntt_core.h)
+struct Geo16 {
+  static constexpr int EPT = 16;
+  typedef hm16::HmNttState State;
+  template <int TL, int LOGR, bool STRIDED> static constexpr int ldsWords() { return hm16::HmLds<TL, LOGR, STRIDED>::WORDS; }
+  template <int TL, int LOGR, bool STRIDED, bool INV, int MODE, int LDAUX, int STAUX, int EPICH, class... A>
+  static __device__ __forceinline__ void phases(A &&...a) { hm16::hm_ntt_pass_phases<TL, LOGR, STRIDED, INV, MODE, LDAUX, STAUX, EPICH>(a...); }
+};
+struct Geo8 {
+  static constexpr int EPT = 8;
+  typedef hm8::HmNttState State;
+  template <int TL, int LOGR, bool STRIDED> static constexpr int ldsWords() { return hm8::HmLds<TL, LOGR, STRIDED>::WORDS; }
+  template <int TL, int LOGR, bool STRIDED, bool INV, int MODE, int LDAUX, int STAUX, int EPICH, class... A>
+  static __device__ __forceinline__ void phases(A &&...a) { hm8::hm_ntt_pass_phases<TL, LOGR, STRIDED, INV, MODE, LDAUX, STAUX, EPICH>(a...); }
+};
+template <int LOGR, bool STRIDED, bool INV, int MODE, int LDAUX = 0, int STAUX = 0, int EPICH = HM_EPI_CHUNK, class GEO = Geo16>
 __device__ __forceinline__ void hm_ntt_pass_run(const HmNttArgs &a, uint64_t *lds, uint32_t entry, uint32_t tile, int tid) {
   constexpr int TL = HM_TL(STRIDED);
   const HmLimb lb = a.limb[entry];
@@ -74,25 +89,18 @@ __device__ __forceinline__ void hm_ntt_pass_run(const HmNttArgs &a, uint64_t *ld
     ep.b = a.mix + (size_t)en.mixlimb * N;
     ep.bk.w = en.mixk.w; ep.bk.ws = en.mixk.ws;
   }
-  HmNttState st;
-  hm_ntt_phase<TL, LOGR, STRIDED, INV, MODE, 0, LDAUX, STAUX, EPICH>(st, tid, lds, src, dst, tile, twl, twt, s0, prefix0, q, sc, ep);
-  hm_ntt_phase<TL, LOGR, STRIDED, INV, MODE, 1, LDAUX, STAUX, EPICH>(st, tid, lds, src, dst, tile, twl, twt, s0, prefix0, q, sc, ep);
-  __syncthreads();
-  hm_ntt_phase<TL, LOGR, STRIDED, INV, MODE, 2, LDAUX, STAUX, EPICH>(st, tid, lds, src, dst, tile, twl, twt, s0, prefix0, q, sc, ep);
-  if constexpr (HmRounds<LOGR>::n == 3) {
-    __syncthreads();
-    hm_ntt_phase<TL, LOGR, STRIDED, INV, MODE, 3, LDAUX, STAUX, EPICH>(st, tid, lds, src, dst, tile, twl, twt, s0, prefix0, q, sc, ep);
-  }
+  typename GEO::State st;
+  GEO::template phases<TL, LOGR, STRIDED, INV, MODE, LDAUX, STAUX, EPICH>(st, tid, lds, src, dst, tile, twl, twt, s0, prefix0, q, sc, ep, [] { __syncthreads(); });
 }
 
-template <int LOGR, bool STRIDED, bool INV, int MODE>
+template <int LOGR, bool STRIDED, bool INV, int MODE, class GEO = Geo16>
 __device__ __forceinline__ void hm_ntt_pass_body(const HmNttArgs &a) {
   constexpr int TL = HM_TL(STRIDED);
-  __shared__ __attribute__((aligned(16))) uint64_t lds[HmLds<TL, LOGR, STRIDED>::WORDS];
+  __shared__ __attribute__((aligned(16))) uint64_t lds[GEO::template ldsWords<TL, LOGR, STRIDED>()];
   uint32_t entry, tile;
   if (!hm_block_map(1u << (a.logN - TL), a.n_limbs, a.logG, entry, tile)) return;
   if (a.limb[entry].mod == HM_NTT_NONE) return;
-  hm_ntt_pass_run<LOGR, STRIDED, INV, MODE>(a, lds, entry, tile, threadIdx.x);
+  hm_ntt_pass_run<LOGR, STRIDED, INV, MODE, 0, 0, HM_EPI_CHUNK, GEO>(a, lds, entry, tile, threadIdx.x);
 }
 
 // Minimum waves per SIMD the register allocator must leave room for (HIP's second launch-bound argument; it is ignored
@@ -113,6 +121,18 @@ __global__ void __launch_bounds__((1 << HM_TL_COL) / HM_EPT) __attribute__((amdg
 template <bool INV, int MODE>
 __global__ void __launch_bounds__((1 << HM_TL_ROW) / HM_EPT) __attribute__((amdgpu_waves_per_eu(HM_NTT_MIN_WAVES))) k_ntt_row(HmNttArgs a) {
   hm_ntt_pass_body<HM_ROW_LOG, false, INV, MODE>(a);
+}
+
+// The small-launch geometry: 512-thread workgroups, 8 coefficients per thread (hm8), N = 2^16.  A launch of up to ~128 limb-polys
+// is ONE round of workgroups, so its time is the latency of one workgroup's pass; here every wave does half the serial work and the
+// launch brings twice the waves (a single op's stages, the 50-limb sweep of the extended basis, a sharded run's per-rank launches).
+template <bool INV, int MODE>
+__global__ void __launch_bounds__((1 << HM_TL_COL) / 8) k_ntt_col8(HmNttArgs a) {
+  hm_ntt_pass_body<8, true, INV, MODE, Geo8>(a);
+}
+template <bool INV, int MODE>
+__global__ void __launch_bounds__((1 << HM_TL_ROW) / 8) k_ntt_row8(HmNttArgs a) {
+  hm_ntt_pass_body<HM_ROW_LOG, false, INV, MODE, Geo8>(a);
 }
 
 // ---- both passes of a transform in ONE launch (opt-in: hm_set_option "ntt_fused"; measured, not the default) ------------
@@ -311,12 +331,7 @@ __global__ void __launch_bounds__((1 << HM_TL_ROW) / HM_EPT) __attribute__((amdg
       const HmTw sc = {0, 0};
       const HmEpi ep = hm_epi_none();
       if (j) __syncthreads();   // the previous digit's last round has read the tile
-      hm_ntt_phase<TL, LOGR, false, false, 5, 0>(st, tid, lds, src, nullptr, tile, twl, twt, s0, prefix0, m.q, sc, ep);
-      hm_ntt_phase<TL, LOGR, false, false, 5, 1>(st, tid, lds, src, nullptr, tile, twl, twt, s0, prefix0, m.q, sc, ep);
-      __syncthreads();
-      hm_ntt_phase<TL, LOGR, false, false, 5, 2>(st, tid, lds, src, nullptr, tile, twl, twt, s0, prefix0, m.q, sc, ep);
-      __syncthreads();
-      hm_ntt_phase<TL, LOGR, false, false, 5, 3>(st, tid, lds, src, nullptr, tile, twl, twt, s0, prefix0, m.q, sc, ep);
+      hm_ntt_pass_phases<TL, LOGR, false, false, 5>(st, tid, lds, src, nullptr, tile, twl, twt, s0, prefix0, m.q, sc, ep, [] { __syncthreads(); });
 #if HM_NIP_WIDE
       hm_ph_below_2q(st, m.q);
 #endif
@@ -505,6 +520,8 @@ struct hm_ctx {
   // one-launch transforms (k_ntt_fused): rendezvous words in HBM, a host-visible error word, and the switch
   HmNttSync *ntt_ws = nullptr;
   unsigned *err_host = nullptr, *err_dev = nullptr;
+  bool small_ept8 = true;      // launches of at most small_limbs entries use the 8-coefficient geometry (N = 2^16)
+  uint32_t small_limbs = 64;   // measured (tools/ntt_small_ab.py): 2-3 us per launch faster up to ~64 entries, equal at 115, slower from 128
   bool fused_ntt = false;  // measured slower and no lighter on HBM: opt-in
   // multi-GPU
   int rank = 0, world = 1;
@@ -634,6 +651,7 @@ extern "C" hm_status hm_create(hm_ctx **out, const hm_params *p) {
   memset(cc->err_host, 0, 64);
   HM_HIP(nullptr, hipHostGetDevicePointer(reinterpret_cast<void **>(&cc->err_dev), cc->err_host, 0));
   if (const char *e = getenv("HOMULATOR_NTT_FUSED")) cc->fused_ntt = std::string(e) != "0";
+  if (const char *e = getenv("HOMULATOR_NTT_SMALL_LIMBS")) { cc->small_limbs = (uint32_t)atoi(e); cc->small_ept8 = cc->small_limbs != 0; }
   *out = c.release();
   return HM_OK;
 }
@@ -769,6 +787,7 @@ extern "C" hm_status hm_wait_for(hm_ctx *c, hm_ctx *producer) {
 extern "C" hm_status hm_set_option(hm_ctx *c, const char *name, uint64_t value) {
   if (!c || !name) return HM_ERR_ARG;
   if (!strcmp(name, "ntt_fused")) { c->fused_ntt = value != 0; return HM_OK; }
+  if (!strcmp(name, "ntt_small_limbs")) { c->small_ept8 = value != 0; c->small_limbs = (uint32_t)value; return HM_OK; }
   return fail(c, HM_ERR_ARG, "hm_set_option: unknown option %s", name);
 }
 extern "C" hm_status hm_get_counter(hm_ctx *c, const char *name, uint64_t *value) {
@@ -864,6 +883,22 @@ static void launch_ntt(hm_ctx *c, const HmNttArgs &a, bool fusedEpilogue, bool m
   // n_limbs = entries, a multiple of 16 (pairs x 8 XCDs); one workgroup per tile of each pass
   const dim3 gridC(a.n_limbs * (c->P.N >> HM_TL_COL)), blockC((1 << HM_TL_COL) / HM_EPT);
   const dim3 gridR(a.n_limbs * (c->P.N >> HM_TL_ROW)), blockR((1 << HM_TL_ROW) / HM_EPT);
+  // small launches (one round of workgroups on the chip): the 8-coefficient geometry halves the serial work per wave
+  if constexpr (LOG1 == 8) {
+    if (c->small_ept8 && !firstPassOnly && !c->fused_ntt && a.n_limbs <= c->small_limbs) {
+      const dim3 grid8(a.n_limbs * (c->P.N >> HM_TL_ROW)), block8((1 << HM_TL_ROW) / 8);
+      if (!inverse) {
+        if (mixPrologue) hipLaunchKernelGGL((k_ntt_col8<false, 4>), grid8, block8, 0, c->stream, a);
+        else hipLaunchKernelGGL((k_ntt_col8<false, 0>), grid8, block8, 0, c->stream, a);
+        if (fusedEpilogue) hipLaunchKernelGGL((k_ntt_row8<false, 3>), grid8, block8, 0, c->stream, a);
+        else hipLaunchKernelGGL((k_ntt_row8<false, 1>), grid8, block8, 0, c->stream, a);
+      } else {
+        hipLaunchKernelGGL((k_ntt_row8<true, 0>), grid8, block8, 0, c->stream, a);
+        hipLaunchKernelGGL((k_ntt_col8<true, 2>), grid8, block8, 0, c->stream, a);
+      }
+      return;
+    }
+  }
   if (firstPassOnly) {  // forward COL pass alone: hm_ntt_inner_product runs the ROW pass inside its own kernel
     hipLaunchKernelGGL((k_ntt_col<LOG1, false, 0>), gridC, blockC, 0, c->stream, a);
     return;

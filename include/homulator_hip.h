@@ -242,6 +242,8 @@ void hm_graph_destroy(hm_graph *graph);
  *   "ntt_fused"  0 (default): two kernels per transform; 1: both passes of a transform in ONE launch behind a per-limb
  *                rendezvous (measured slower on MI355X and no lighter on HBM: the L2 writes through and does not
  *                allocate on a store).  Env HOMULATOR_NTT_FUSED sets the default.
+ *   "ntt_small_limbs"  transform launches of at most this many limb-poly entries (default 64, N = 2^16) use the small-launch
+ *                geometry (512-thread workgroups, 8 coefficients per thread); 0 switches it off.  Env HOMULATOR_NTT_SMALL_LIMBS.
  * Counters:
  *   "ntt_cross_xcd"  limb-polys whose workgroups were NOT all placed on one XCD and took the agent-scope hand-off
  *                    (slow, still correct); expected 0 under the dispatcher's observed round-robin placement.

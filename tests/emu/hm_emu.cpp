@@ -16,36 +16,56 @@ struct Emu {
   std::vector<std::vector<HmTw>> fwd, inv, twf, twi;
 };
 
-template <int LOGR, bool STRIDED, bool INV, int MODE>
+// the two geometries of the passes (hm_ntt_core.h): 16 coefficients per thread (hm16) and 8 (hm8, N = 2^16 only)
+struct G16 {
+  typedef hm16::HmNttState State;
+  static constexpr int EPT = 16;
+  template <int LOGR> static constexpr int rounds() { return hm16::HmRounds<LOGR>::n; }
+  template <int TL, int LOGR, bool STRIDED> static constexpr int ldsWords() { return hm16::HmLds<TL, LOGR, STRIDED>::WORDS; }
+  template <int TL, int LOGR, bool STRIDED, bool INV, int MODE, int P, class... A> static void phase(A &&...a) { hm16::hm_ntt_phase<TL, LOGR, STRIDED, INV, MODE, P>(a...); }
+};
+struct G8 {
+  typedef hm8::HmNttState State;
+  static constexpr int EPT = 8;
+  template <int LOGR> static constexpr int rounds() { return hm8::HmRounds<LOGR>::n; }
+  template <int TL, int LOGR, bool STRIDED> static constexpr int ldsWords() { return hm8::HmLds<TL, LOGR, STRIDED>::WORDS; }
+  template <int TL, int LOGR, bool STRIDED, bool INV, int MODE, int P, class... A> static void phase(A &&...a) { hm8::hm_ntt_phase<TL, LOGR, STRIDED, INV, MODE, P>(a...); }
+};
+
+// phase P of every thread of the workgroup, then phase P + 1, ... (a barrier on the GPU = the end of a phase loop here)
+template <class G, int TL, int LOGR, bool STRIDED, bool INV, int MODE, int P>
+static void run_phases(std::vector<typename G::State> &st, uint64_t *lds, const uint64_t *src, uint64_t *dst, uint32_t tile, const HmTw *twl,
+                       const HmTw *twt, uint32_t s0, uint32_t prefix0, uint64_t q, HmTw sc, HmEpi ep) {
+  for (int t = 0; t < (int)st.size(); ++t) G::template phase<TL, LOGR, STRIDED, INV, MODE, P>(st[t], t, lds, src, dst, tile, twl, twt, s0, prefix0, q, sc, ep);
+  if constexpr (P < G::template rounds<LOGR>()) run_phases<G, TL, LOGR, STRIDED, INV, MODE, P + 1>(st, lds, src, dst, tile, twl, twt, s0, prefix0, q, sc, ep);
+}
+
+template <class G, int LOGR, bool STRIDED, bool INV, int MODE>
 static void run_pass(const Emu &e, uint32_t mod, const uint64_t *src, uint64_t *dst, HmTw sc, HmEpi ep = hm_epi_none()) {
-  constexpr int TL = HM_TL(STRIDED), THREADS = (1 << TL) / HM_EPT;
+  constexpr int TL = HM_TL(STRIDED), THREADS = (1 << TL) / G::EPT;
   const uint32_t tiles = e.P.N >> TL;
   const uint64_t q = e.P.mod[mod];
   const HmTw *twl = (INV ? e.inv : e.fwd)[mod].data();
   const uint32_t s0 = STRIDED ? 0u : (e.P.logN - HM_ROW_LOG);
-  std::vector<uint64_t> lds(HmLds<TL, LOGR, STRIDED>::WORDS);
-  std::vector<HmNttState> st(THREADS);
+  std::vector<uint64_t> lds(G::template ldsWords<TL, LOGR, STRIDED>());
+  std::vector<typename G::State> st(THREADS);
   const HmTw *twist = (INV ? e.twi : e.twf)[mod].data();
   // a pass may run in place (src == dst): every thread reads its elements before any thread writes its own
   for (uint32_t tile = 0; tile < tiles; ++tile) {
     const uint32_t prefix0 = STRIDED ? 0u : (tile << (TL - LOGR));
     const HmTw *twt = twist + (size_t)prefix0 * 3;
-    for (int t = 0; t < THREADS; ++t) hm_ntt_phase<TL, LOGR, STRIDED, INV, MODE, 0>(st[t], t, lds.data(), src, dst, tile, twl, twt, s0, prefix0, q, sc, ep);
-    for (int t = 0; t < THREADS; ++t) hm_ntt_phase<TL, LOGR, STRIDED, INV, MODE, 1>(st[t], t, lds.data(), src, dst, tile, twl, twt, s0, prefix0, q, sc, ep);
-    for (int t = 0; t < THREADS; ++t) hm_ntt_phase<TL, LOGR, STRIDED, INV, MODE, 2>(st[t], t, lds.data(), src, dst, tile, twl, twt, s0, prefix0, q, sc, ep);
-    if (HmRounds<LOGR>::n == 3)
-      for (int t = 0; t < THREADS; ++t) hm_ntt_phase<TL, LOGR, STRIDED, INV, MODE, 3>(st[t], t, lds.data(), src, dst, tile, twl, twt, s0, prefix0, q, sc, ep);
+    run_phases<G, TL, LOGR, STRIDED, INV, MODE, 0>(st, lds.data(), src, dst, tile, twl, twt, s0, prefix0, q, sc, ep);
   }
 }
 
-template <int LOG1>
+template <class G, int LOG1>
 static void run_ntt(const Emu &e, uint32_t mod, const uint64_t *in, uint64_t *out, int inverse, HmTw sc) {
   if (!inverse) {
-    run_pass<LOG1, true, false, 0>(e, mod, in, out, sc);
-    run_pass<HM_ROW_LOG, false, false, 1>(e, mod, out, out, sc);
+    run_pass<G, LOG1, true, false, 0>(e, mod, in, out, sc);
+    run_pass<G, HM_ROW_LOG, false, false, 1>(e, mod, out, out, sc);
   } else {
-    run_pass<HM_ROW_LOG, false, true, 0>(e, mod, in, out, sc);
-    run_pass<LOG1, true, true, 2>(e, mod, out, out, sc);
+    run_pass<G, HM_ROW_LOG, false, true, 0>(e, mod, in, out, sc);
+    run_pass<G, LOG1, true, true, 2>(e, mod, out, out, sc);
   }
 }
 
@@ -90,11 +110,11 @@ int emu_ntt(void *h, uint32_t mod, const uint64_t *in, uint64_t *out, int invers
   if (has_scale) k = hm::mulmod(k, scale, q);
   HmTw sc = {k, hm::shoup(k, q)};
   switch (e.P.logN - HM_ROW_LOG) {
-  case 5: run_ntt<5>(e, mod, in, out, inverse, sc); break;
-  case 6: run_ntt<6>(e, mod, in, out, inverse, sc); break;
-  case 7: run_ntt<7>(e, mod, in, out, inverse, sc); break;
-  case 8: run_ntt<8>(e, mod, in, out, inverse, sc); break;
-  case 9: run_ntt<9>(e, mod, in, out, inverse, sc); break;
+  case 5: run_ntt<G16, 5>(e, mod, in, out, inverse, sc); break;
+  case 6: run_ntt<G16, 6>(e, mod, in, out, inverse, sc); break;
+  case 7: run_ntt<G16, 7>(e, mod, in, out, inverse, sc); break;
+  case 8: run_ntt<G16, 8>(e, mod, in, out, inverse, sc); break;
+  case 9: run_ntt<G16, 9>(e, mod, in, out, inverse, sc); break;
   default: return 1;
   }
   return 0;
@@ -111,12 +131,35 @@ int emu_ntt_sub_scale(void *h, uint32_t mod, const uint64_t *in, const uint64_t 
   if (addend_k) ep.dk = HmTw{addend_k, hm::shoup(addend_k, q)};
   if (mix) { ep.b = mix; ep.bk = HmTw{mix_k, hm::shoup(mix_k, q)}; }
   switch (e.P.logN - HM_ROW_LOG) {
-#define HM_CASE(n) case n: if (mix) run_pass<n, true, false, 4>(e, mod, in, out, sc, ep); else run_pass<n, true, false, 0>(e, mod, in, out, sc); break;
+#define HM_CASE(n) case n: if (mix) run_pass<G16, n, true, false, 4>(e, mod, in, out, sc, ep); else run_pass<G16, n, true, false, 0>(e, mod, in, out, sc); break;
     HM_CASE(5) HM_CASE(6) HM_CASE(7) HM_CASE(8) HM_CASE(9)
 #undef HM_CASE
   default: return 1;
   }
-  run_pass<HM_ROW_LOG, false, false, 3>(e, mod, out, out, sc, ep);
+  run_pass<G16, HM_ROW_LOG, false, false, 3>(e, mod, out, out, sc, ep);
+  return 0;
+}
+// the 8-coefficient geometry (hm8: 512-thread workgroups, radix-4 rounds), N = 2^16 only
+int emu_ntt8(void *h, uint32_t mod, const uint64_t *in, uint64_t *out, int inverse, uint64_t scale, int has_scale) {
+  Emu &e = *(Emu *)h;
+  if (e.P.logN != 16) return 1;
+  uint64_t q = e.P.mod[mod], k = e.P.modc[mod].ninv;
+  if (has_scale) k = hm::mulmod(k, scale, q);
+  run_ntt<G8, 8>(e, mod, in, out, inverse, HmTw{k, hm::shoup(k, q)});
+  return 0;
+}
+int emu_ntt_sub_scale8(void *h, uint32_t mod, const uint64_t *in, const uint64_t *minuend, const uint64_t *addend, uint64_t *out,
+                       uint64_t k, const uint64_t *mix, uint64_t mix_k, uint64_t addend_k) {
+  Emu &e = *(Emu *)h;
+  if (e.P.logN != 16) return 1;
+  const uint64_t q = e.P.mod[mod];
+  HmTw sc = {k, hm::shoup(k, q)};
+  HmEpi ep = hm_epi_none();
+  ep.a = minuend; ep.d = addend;
+  if (addend_k) ep.dk = HmTw{addend_k, hm::shoup(addend_k, q)};
+  if (mix) { ep.b = mix; ep.bk = HmTw{mix_k, hm::shoup(mix_k, q)}; }
+  if (mix) run_pass<G8, 8, true, false, 4>(e, mod, in, out, sc, ep); else run_pass<G8, 8, true, false, 0>(e, mod, in, out, sc);
+  run_pass<G8, HM_ROW_LOG, false, false, 3>(e, mod, out, out, sc, ep);
   return 0;
 }
 void emu_tensor(void *h, uint32_t mod, const uint64_t *a, const uint64_t *b, const uint64_t *c, const uint64_t *d, uint64_t *o0,

@@ -188,3 +188,48 @@ def test_emu_bconv_widest_accumulator(emu):
         assert np.array_equal(out, o.bconv_matmul(in_ids, out_ids, x))
     finally:
         emu.emu_destroy(h)
+
+
+def test_emu_ntt_eight_coefficients_per_thread(emu):
+    """the small-launch geometry (hm8: 512-thread workgroups, 8 coefficients per thread, four radix-4 rounds per pass) on the
+    CPU emulator at N = 2^16: forward, inverse (in place, fused scale), the all-(q-1) worst case of the lazy ranges, and the
+    merged ModDown + rescale form (mix prologue + sub-scale-add epilogue)"""
+    emu.emu_ntt8.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_int]
+    emu.emu_ntt_sub_scale8.argtypes = [C.c_void_p, C.c_uint32] + [C.c_void_p] * 4 + [C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64]
+    logN, L, K = 16, 3, 2
+    o = Oracle(logN, L, K)
+    h = emu.emu_create(logN, L, K)
+    try:
+        for m in (0, L + K - 1):
+            x = o.fill_uniform([m], 42 + m)[0]
+            x[0], x[1], x[-1] = 0, o.moduli[m] - 1, o.moduli[m] - 1
+            out = np.empty_like(x)
+            assert emu.emu_ntt8(h, m, p(x), p(out), 0, 0, 0) == 0
+            exp = o.ntt([m], x[None])[0]
+            assert np.array_equal(out, exp), f"forward mod={m}"
+            back = np.empty_like(x)
+            assert emu.emu_ntt8(h, m, p(out), p(back), 1, 0, 0) == 0
+            assert np.array_equal(back, x), f"inverse mod={m}"
+            k = o.moduli[m] - 12345
+            buf = out.copy()
+            emu.emu_ntt8(h, m, p(buf), p(buf), 1, k, 1)
+            assert np.array_equal(buf, o.ewe(5, [m], x[None], k=[k])[0])
+        m = 1
+        worst = np.full(1 << logN, o.moduli[m] - 1, dtype=np.uint64)
+        out = np.empty_like(worst)
+        emu.emu_ntt8(h, m, p(worst), p(out), 0, 0, 0)
+        assert np.array_equal(out, o.ntt([m], worst[None])[0])
+        emu.emu_ntt8(h, m, p(out), p(out), 1, 0, 0)
+        assert np.array_equal(out, worst)
+        x, mn, ad, mx = (o.fill_uniform([m], s)[0] for s in (1, 2, 3, 4))
+        q = o.moduli[m]
+        k, mk, ak = q - 2, q - 77, q - 5
+        out = np.empty_like(x)
+        assert emu.emu_ntt_sub_scale8(h, m, p(x), p(mn), p(ad), p(out), k, p(mx), mk, ak) == 0
+        xin = o.ewe(3, [m], x[None], None, o.ewe(5, [m], mx[None], k=[mk]))
+        exp = o.ewe(3, [m], o.ewe(6, [m], mn[None], None, o.ntt([m], xin), k=[k]), None, o.ewe(5, [m], ad[None], k=[ak]))[0]
+        assert np.array_equal(out, exp)
+        assert emu.emu_ntt_sub_scale8(h, m, p(x), p(mn), None, p(out), k, None, 0, 0) == 0
+        assert np.array_equal(out, o.ewe(6, [m], mn[None], None, o.ntt([m], x[None]), k=[k])[0])
+    finally:
+        emu.emu_destroy(h)

@@ -112,3 +112,45 @@ def test_two_contexts_share_the_chip():
             assert np.array_equal(f.download(), r.download())
     finally:
         c1.close(); c2.close()
+
+
+def test_small_launch_geometry_equals_wide_and_oracle():
+    """launches of up to 128 limb-polys at N = 2^16 run in the 8-coefficient geometry (k_ntt_col8 / k_ntt_row8: 512-thread
+    workgroups, four radix-4 rounds per pass); the same calls with the geometry switched off (hm_set_option ntt_small_limbs 0)
+    and the oracle must agree bit for bit: forward, inverse in place with a scale, fused epilogue with and without the mix
+    prologue, worst-case operands, 1 .. 128 limb-polys"""
+    ctx, o = _ctx(16, 6, 3)
+    try:
+        for n in (1, 9, 50, 128):
+            ids = [(i * 5 + 2) % 9 for i in range(n)]
+            x = o.fill_uniform(ids, 31 + n)
+            x[0, :] = o.moduli[ids[0]] - 1
+            d, a, b = ctx.from_host(x), ctx.alloc(n), ctx.alloc(n)
+            mn, ad, mx = (ctx.alloc(n) for _ in range(3))
+            for buf, s in ((mn, 5), (ad, 6), (mx, 7)):
+                ctx.fill_uniform(buf, ids, s)
+            k = [o.moduli[m] - 2 - r for r, m in enumerate(ids)]
+            mk = [(kk * 3 + 1) % o.moduli[m] for kk, m in zip(k, ids)]
+            ak = [(kk * 5 + 1) % o.moduli[m] for kk, m in zip(k, ids)]
+            res = {}
+            for small in (128, 0):
+                ctx.set_option("ntt_small_limbs", small)
+                ctx.ntt(d, a, ids)
+                fwd = a.download()
+                ctx.ntt(a, a, ids, inverse=True, scale=k)
+                inv = a.download()
+                ctx.ntt_sub_scale(d, mn, b, ids, k)
+                f3 = b.download()
+                ctx.ntt_mix_sub_scale(d, mn, b, ids, k, addend=ad, addend_k=ak, mix=mx, mix_k=mk)
+                f43 = b.download()
+                res[small] = (fwd, inv, f3, f43)
+            for u, v in zip(res[128], res[0]):
+                assert np.array_equal(u, v)
+            if n <= 50:
+                assert np.array_equal(res[128][0], o.ntt(ids, x))
+                assert np.array_equal(res[128][1], o.ewe(5, ids, x, k=k))
+            for buf in (d, a, b, mn, ad, mx):
+                buf.free()
+        ctx.set_option("ntt_small_limbs", 128)
+    finally:
+        ctx.close()
