@@ -350,6 +350,79 @@ __global__ void __launch_bounds__((1 << HM_TL_ROW) / HM_EPT) __attribute__((amdg
   hm_ph_mac_store<TL, LOGR, R2, OUTS, Acc>(acc, threadIdx.x, out, tile, m);
 }
 
+// ---- base conversion fused into the first pass of the transform that consumes it (round 3) --------------------------------
+// The COL workgroup of (conversion p, output limb o, column tile t) computes its 4096 coefficients of output o from the N_IN input
+// tiles (the workgroups of the same (p, t) for the other outputs sit in neighbouring dispatch slots of one XCD and find the inputs in
+// L2), then runs the COL pass on them: the converted limb-poly never exists in HBM, only the first pass's hand-off does.
+struct HmBcolProb {
+  const uint64_t *in;
+  const uint64_t *table, *qn;
+  uint32_t n_in, n_out;
+  uint32_t in_limb[HM_BCONV_MAX_IN];
+  uint32_t out_limb[HM_BCONV_MAX_OUT];   // where the hand-off of output o goes (limb of `out`)
+  uint32_t out_mod[HM_BCONV_MAX_OUT];    // its modulus id (shared twiddles)
+};
+struct HmBcolArgs {
+  const HmBcolProb *prob;   // device
+  uint64_t *out;
+  const HmTw *tw;
+  uint32_t logN, n_prob, max_out;
+};
+template <int N_IN>
+__global__ void __launch_bounds__((1 << HM_TL_COL) / HM_EPT) __attribute__((amdgpu_waves_per_eu(HM_NTT_MIN_WAVES))) k_bconv_col(HmBcolArgs a) {
+  constexpr int TL = HM_TL_COL, LOG1 = 8;
+  using PS = HmPass<LOG1, true, false>;
+  using G0 = HmRound<TL, LOG1, true, PS::exec(0)>;
+  __shared__ __attribute__((aligned(16))) uint64_t lds[HmLds<TL, LOG1, true>::WORDS];
+  // blocks b, b + 8 share an XCD; inside an XCD: (conversion, tile) pairs, each with its max_out outputs in consecutive slots
+  const uint32_t b = blockIdx.x, xcd = b & 7u, slot = b >> 3;
+  const uint32_t pair = (slot / a.max_out) * 8u + xcd, o = slot % a.max_out;
+  const uint32_t tiles = 1u << (a.logN - TL);
+  const uint32_t pi = pair / tiles, tile = pair % tiles;
+  if (pi >= a.n_prob) return;
+  const auto &p = HM_CONST_PROB_T(HmBcolProb, a.prob)[pi];
+  if (o >= p.n_out) return;
+  const int tid = threadIdx.x;
+  const size_t N = (size_t)1 << a.logN;
+  constexpr int NG = (N_IN + 7) / 8;
+  HmRow8 row[NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) row[g] = HM_CONST_ROWS(p.table)[o * NG + g];
+  const HmQn m = HM_CONST_QN(p.qn)[o];
+  const HmTw *twl = a.tw + (size_t)p.out_mod[o] * N;
+  hm_ph_stage_tw<TL, LOG1, true>(tid, lds, twl);   // every round reads its shared twiddles from LDS (after the barrier below)
+  HmNttState st;
+#pragma unroll
+  for (int u = 0; u < HM_UNITS; ++u) {
+    int i0, i1, x, c;
+    G0::unit(tid, u, i0, i1, x, c);
+    uint32_t yl[2][N_IN], yh[2][N_IN];
+#pragma unroll
+    for (int i = 0; i < N_IN; ++i) {
+      uint64_t v0, v1;
+      hm_gld2<G0>(p.in + (size_t)p.in_limb[i] * N, tile, tid, u, v0, v1);
+      yl[0][i] = (uint32_t)v0 & 0x3FFFFFFFu; yh[0][i] = (uint32_t)(v0 >> 30);
+      yl[1][i] = (uint32_t)v1 & 0x3FFFFFFFu; yh[1][i] = (uint32_t)(v1 >> 30);
+    }
+    st.v[i0] = hm_bconv_dot<N_IN>(yl[0], yh[0], row, m.q, m.nqinv);
+    st.v[i1] = hm_bconv_dot<N_IN>(yl[1], yh[1], row, m.q, m.nqinv);
+    __builtin_amdgcn_sched_barrier(0);   // one unit's loads in flight at a time (15 x 16 bytes per lane)
+  }
+  __syncthreads();
+  const HmTw *ltw = reinterpret_cast<const HmTw *>(lds + (1 << TL));
+  constexpr int r0 = PS::exec(0);
+  hm_ph_load_tw<TL, LOG1, true, r0, true>(st, tid, ltw, 0, 0);
+  hm_ph_compute<TL, LOG1, true, r0, false>(st, m.q);
+  hm_ph_store_lds<TL, LOG1, true, r0>(st, tid, lds);
+  __syncthreads();
+  uint64_t *dst = a.out + (size_t)p.out_limb[o] * N;
+  const HmTw sc = {0, 0};
+  const HmEpi ep = hm_epi_none();
+  hm_ntt_phase<TL, LOG1, true, false, 0, 2>(st, tid, lds, nullptr, dst, tile, twl, nullptr, 0, 0, m.q, sc, ep);
+  __syncthreads();
+  hm_ntt_phase<TL, LOG1, true, false, 0, 3>(st, tid, lds, nullptr, dst, tile, twl, nullptr, 0, 0, m.q, sc, ep);
+}
+
 __global__ void __launch_bounds__(256) k_tensor(HmTensorArgs a) {
   const uint32_t N = 1u << a.logN;
   const uint32_t per_limb = N / 512;
@@ -1253,6 +1326,7 @@ extern "C" hm_status hm_inner_product(hm_ctx *c, const uint64_t *x, const uint32
 }
 
 
+static hm_status bconv_col_launch(hm_ctx *c, const hm_bconv_desc *descs, uint32_t n_desc);
 // K1 x K5: out[i][k] = sum_j X_j[i] * y[i][k][j] with X_j[i] = NTT(x[i][j]) for the digits that go through
 // the transform (x_is_coeff) and x[i][j] itself for a digit's own limbs.  Two launches: the COL pass of every transformed
 // (limb, digit) into `hand`, then k_ntt_row_ip: ROW pass, product with both keys, accumulation over the digits in registers.
@@ -1267,11 +1341,17 @@ extern "C" hm_status hm_ntt_inner_product(hm_ctx *c, const hm_ntt_ip_desc *d) {
   if ((st = check_limbs(c, "hm_ntt_inner_product", d->x_limbs, n * T)) || (st = check_limbs(c, "hm_ntt_inner_product", d->y_limbs, n * T * K)) ||
       (st = check_limbs(c, "hm_ntt_inner_product", d->out_limbs, n * K)) || (st = check_mods(c, "hm_ntt_inner_product", d->mod_ids, n)))
     return st;
-  // 1. first pass of every transformed (limb, digit): x -> hand
+  // 1. first pass of every transformed (limb, digit): x -> hand; or conversion + first pass in one kernel: conv -> hand
+  if (d->n_conv) {
+    if (!d->conv || !d->hand) return fail(c, HM_ERR_ARG, "hm_ntt_inner_product: conversions need their descriptors and the hand-off buffer");
+    for (uint32_t k = 0; k < d->n_conv; ++k)
+      if (d->conv[k].out != d->hand) return fail(c, HM_ERR_ARG, "hm_ntt_inner_product: conv[%u].out must be the hand-off buffer", k);
+    if ((st = bconv_col_launch(c, d->conv, d->n_conv))) return st;
+  }
   std::vector<uint32_t> cin, chand, cmod;
   for (uint32_t i = 0; i < n; ++i)
     for (uint32_t j = 0; j < T; ++j)
-      if (d->x_is_coeff[i * T + j]) {
+      if (d->x_is_coeff[i * T + j] && !d->n_conv) {
         if (!d->hand || !d->hand_limbs) return fail(c, HM_ERR_ARG, "hm_ntt_inner_product: transformed digits need the hand-off buffer");
         if (d->hand_limbs[i * T + j] > 0xFFFFu) return fail(c, HM_ERR_ARG, "hm_ntt_inner_product: limb index exceeds 65535");
         cin.push_back(d->x_limbs[i * T + j]); chand.push_back(d->hand_limbs[i * T + j]); cmod.push_back(d->mod_ids[i]);
@@ -1448,6 +1528,77 @@ extern "C" hm_status hm_bconv_batch(hm_ctx *c, const hm_bconv_desc *descs, uint3
       if (grp.size() == HM_BCONV_MAX_PROB) { hm_status st = launch(); if (st) return st; }
     }
     if (!grp.empty()) { hm_status st = launch(); if (st) return st; }
+    HM_HIP(c, hipGetLastError());
+  }
+  return HM_OK;
+}
+
+
+// conversion + first transform pass in one kernel (see k_bconv_col).  Same descriptors as hm_bconv_batch; `out` receives the COL pass's
+// hand-off of NTT(conversion), the form k_ntt_row_ip reads.  N = 2^16, n_in <= HM_BCOL_MAX_IN.
+#define HM_BCOL_MAX_IN 15   // 16 inputs: hipcc leaves the input arrays in scratch (1 KB per lane)
+typedef void (*hm_bcol_kernel)(HmBcolArgs);
+static const hm_bcol_kernel k_bconv_col_by_n_in[HM_BCOL_MAX_IN + 1] = {
+    nullptr,
+#define HM_K(n) k_bconv_col<n>,
+    HM_K(1) HM_K(2) HM_K(3) HM_K(4) HM_K(5) HM_K(6) HM_K(7) HM_K(8) HM_K(9) HM_K(10) HM_K(11) HM_K(12) HM_K(13) HM_K(14) HM_K(15)
+#undef HM_K
+};
+static hm_status bconv_col_launch(hm_ctx *c, const hm_bconv_desc *descs, uint32_t n_desc) {
+  if (!c || !descs || n_desc == 0) return HM_ERR_ARG;
+  if (c->P.logN != 16) return fail(c, HM_ERR_UNSUPPORTED, "fused conversion: N = 2^16 only");
+  HM_HIP(c, hipSetDevice(c->device));
+  std::map<uint32_t, std::vector<HmBcolProb>> byIn;
+  for (uint32_t pi = 0; pi < n_desc; ++pi) {
+    const hm_bconv_desc &d = descs[pi];
+    if (!d.in || !d.out || !d.in_ids || !d.out_ids) return fail(c, HM_ERR_ARG, "fused conversion: null argument");
+    if (d.n_in == 0 || d.n_in > HM_BCOL_MAX_IN) return fail(c, HM_ERR_UNSUPPORTED, "fused conversion: n_in %u not in [1,%d]", d.n_in, HM_BCOL_MAX_IN);
+    if (d.n_out == 0 || d.n_out > HM_BCONV_MAX_OUT) return fail(c, HM_ERR_ARG, "fused conversion: n_out %u not in [1,%d]", d.n_out, HM_BCONV_MAX_OUT);
+    if (d.log_len && d.log_len != c->P.logN) return fail(c, HM_ERR_UNSUPPORTED, "fused conversion: whole limb-polys only");
+    hm_status cst;
+    if ((cst = check_limbs(c, "fused conversion", d.in_limbs, d.n_in)) || (cst = check_limbs(c, "fused conversion", d.out_limbs, d.n_out)) ||
+        (cst = check_mods(c, "fused conversion", d.in_ids, d.n_in)) || (cst = check_mods(c, "fused conversion", d.out_ids, d.n_out)))
+      return cst;
+    for (uint32_t i = 0; i < d.n_in; ++i)
+      for (uint32_t t = 0; t < d.n_out; ++t)
+        if (d.in_ids[i] == d.out_ids[t]) return fail(c, HM_ERR_ARG, "fused conversion: modulus %u is in both bases", d.in_ids[i]);
+    std::vector<uint32_t> key;
+    key.push_back(d.n_in);
+    key.insert(key.end(), d.in_ids, d.in_ids + d.n_in);
+    key.insert(key.end(), d.out_ids, d.out_ids + d.n_out);
+    auto it = c->bconv_tables.find(key);
+    if (it == c->bconv_tables.end()) {
+      std::vector<uint64_t> qh(d.n_in), tb((size_t)d.n_in * d.n_out);
+      c->P.bconv_consts(d.in_ids, d.n_in, d.out_ids, d.n_out, qh.data(), tb.data());
+      const uint32_t row = HM_BCONV_ROW(d.n_in);
+      std::vector<uint64_t> tt((size_t)row * d.n_out, 0);
+      for (uint32_t i = 0; i < d.n_in; ++i)
+        for (uint32_t t = 0; t < d.n_out; ++t) tt[(size_t)t * row + i] = hm_bconv_entry(tb[(size_t)i * d.n_out + t], c->P.modc[d.out_ids[t]]);
+      for (uint32_t t = 0; t < d.n_out; ++t) { tt.push_back(c->P.modc[d.out_ids[t]].q); tt.push_back(c->P.modc[d.out_ids[t]].nqinv); }
+      uint64_t *dev = nullptr;
+      HM_HIP(c, hipMalloc(&dev, 8ull * tt.size()));
+      HM_HIP(c, hipMemcpy(dev, tt.data(), 8ull * tt.size(), hipMemcpyHostToDevice));
+      it = c->bconv_tables.emplace(key, dev).first;
+    }
+    HmBcolProb p;
+    memset(&p, 0, sizeof p);
+    p.in = d.in; p.table = it->second; p.qn = it->second + (size_t)HM_BCONV_ROW(d.n_in) * d.n_out; p.n_in = d.n_in; p.n_out = d.n_out;
+    for (uint32_t i = 0; i < d.n_in; ++i) p.in_limb[i] = limb_at(d.in_limbs, i);
+    for (uint32_t t = 0; t < d.n_out; ++t) { p.out_limb[t] = limb_at(d.out_limbs, t); p.out_mod[t] = d.out_ids[t]; }
+    byIn[d.n_in].push_back(p);
+  }
+  for (auto &kv : byIn) {
+    auto &grp = kv.second;
+    uint32_t max_out = 0;
+    uint64_t *out = descs[0].out;   // one hand-off buffer for the call (checked by the caller below)
+    for (auto &p : grp) max_out = std::max(max_out, p.n_out);
+    const void *dtab = nullptr;
+    hm_status st = device_table(c, grp.data(), sizeof(HmBcolProb) * grp.size(), &dtab);
+    if (st) return st;
+    HmBcolArgs a = {static_cast<const HmBcolProb *>(dtab), out, c->d_tw_fwd, c->P.logN, (uint32_t)grp.size(), max_out};
+    const uint32_t pairs = ((uint32_t)grp.size() * (c->P.N >> HM_TL_COL) + 7) / 8 * 8;
+    const dim3 grid(pairs * max_out), block((1 << HM_TL_COL) / HM_EPT);
+    hipLaunchKernelGGL(k_bconv_col_by_n_in[kv.first], grid, block, 0, c->stream, a);
     HM_HIP(c, hipGetLastError());
   }
   return HM_OK;

@@ -131,7 +131,9 @@ struct HmBconvArgs {
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef const HmBconvProb __attribute__((address_space(4))) *HmConstProb;
 #define HM_CONST_PROB(p) ((HmConstProb)(uintptr_t)(p))
+#define HM_CONST_PROB_T(T, p) ((const T __attribute__((address_space(4))) *)(uintptr_t)(p))
 #else
+#define HM_CONST_PROB_T(T, p) ((const T *)(p))
 typedef const HmBconvProb *HmConstProb;
 #define HM_CONST_PROB(p) (p)
 #endif

@@ -200,7 +200,7 @@ HM_HD int hm_lds_idx(int x, int c) {
   if (STRIDED) {
     constexpr int LOGC = TL - LOGR;
     int w = (x << LOGC) | c;
-    if (LOGC <= 4) w ^= ((x >> 2) & ((1 << (5 - LOGC)) - 1)) << LOGC;  // a row is 2^(LOGC+3) bytes; 256 bytes span all banks
+    if (LOGC <= 4) w ^= ((x >> 2) & ((1 << (LOGC <= 4 ? 5 - LOGC : 0)) - 1)) << LOGC;  // a row is 2^(LOGC+3) bytes; 256 bytes span all banks
     return w;
   }
   int w = (c << LOGR) | x;

@@ -30,7 +30,7 @@ class hm_ntt_fused_desc(C.Structure):
 class hm_ntt_ip_desc(C.Structure):
     _fields_ = [("x", C.c_void_p), ("x_limbs", C.c_void_p), ("x_is_coeff", C.c_void_p), ("hand", C.c_void_p), ("hand_limbs", C.c_void_p),
                 ("y", C.c_void_p), ("y_limbs", C.c_void_p), ("out", C.c_void_p), ("out_limbs", C.c_void_p), ("mod_ids", C.c_void_p),
-                ("n", C.c_uint32), ("n_terms", C.c_uint32), ("n_out", C.c_uint32)]
+                ("n", C.c_uint32), ("n_terms", C.c_uint32), ("n_out", C.c_uint32), ("conv", C.c_void_p), ("n_conv", C.c_uint32)]
 
 
 class hm_bconv_desc(C.Structure):
@@ -223,12 +223,23 @@ class Context:
         self._ck(self.L.hm_inner_product(self.h, x.ptr, keep[0][1], y.ptr, keep[1][1], out.ptr, keep[2][1], keep[3][1], len(mod_ids),
                                          n_terms, n_out))
 
-    def ntt_inner_product(self, x, x_limbs, x_is_coeff, hand, hand_limbs, y, y_limbs, out, out_limbs, mod_ids, n_terms, n_out):
-        """out[i][k] = sum_j (NTT(x[i][j]) if x_is_coeff[i][j] else x[i][j]) * y[i][k][j]: the HPIP unit as a fused NTT-epilogue x key MAC"""
+    def ntt_inner_product(self, x, x_limbs, x_is_coeff, hand, hand_limbs, y, y_limbs, out, out_limbs, mod_ids, n_terms, n_out, conv=None):
+        """out[i][k] = sum_j (NTT(x[i][j]) if x_is_coeff[i][j] else x[i][j]) * y[i][k][j]: the HPIP unit as a fused NTT-epilogue x key MAC.
+        conv = [(src, in_limbs, in_ids, hand_out_limbs, out_ids), ...]: the transformed digits are these base conversions, computed inside
+        the transforms' first pass (their outputs are hand-off limbs of `hand`)"""
         keep = [_u32(v) for v in (x_limbs, hand_limbs, y_limbs, out_limbs, mod_ids)]
         flags = np.ascontiguousarray(np.asarray(x_is_coeff, dtype=np.uint8))
+        descs, keep2 = None, []
+        if conv:
+            descs = (hm_bconv_desc * len(conv))()
+            for dd, (src, in_limbs, in_ids, out_limbs_, out_ids) in zip(descs, conv):
+                arrs = [_u32(in_limbs), _u32(in_ids), _u32(out_limbs_), _u32(out_ids)]
+                keep2.append(arrs)
+                dd.in_, dd.in_limbs, dd.in_ids, dd.n_in = src.ptr, arrs[0][1], arrs[1][1], len(in_ids)
+                dd.out, dd.out_limbs, dd.out_ids, dd.n_out, dd.log_len = hand.ptr, arrs[2][1], arrs[3][1], len(out_ids), 0
         d = hm_ntt_ip_desc(x.ptr, keep[0][1], flags.ctypes.data_as(C.c_void_p), None if hand is None else hand.ptr, keep[1][1], y.ptr, keep[2][1],
-                           out.ptr, keep[3][1], keep[4][1], len(mod_ids), n_terms, n_out)
+                           out.ptr, keep[3][1], keep[4][1], len(mod_ids), n_terms, n_out,
+                           C.cast(descs, C.c_void_p) if conv else None, len(conv) if conv else 0)
         self._ck(self.L.hm_ntt_inner_product(self.h, C.byref(d)))
 
     def automorph(self, src, dst, n, galois, in_limbs=None, out_limbs=None):

@@ -47,6 +47,10 @@ public:
   // transform would have written: NTTOut_beta(j)) then only serves as the scratch of its first pass
   std::vector<AddrType> ipSrc;
   std::vector<uint8_t> ipCoeff;
+  // (8) the base conversion that produces such a digit moves into the transform's first pass as well: ipConvIn[j] = the conversion's
+  // input limbs, ipConvMods[j] their moduli (empty: digit j is not converted inside the kernel)
+  std::vector<std::vector<AddrType>> ipConvIn;
+  std::vector<std::vector<uint32_t>> ipConvMods;
   std::vector<Instruction *> depsInsList;
 
   Instruction(std::string name, ins_ops op, uint32_t level) : ops(op), Name(std::move(name)), level_id(level) {}

@@ -77,6 +77,10 @@ Arch::Arch(Config *cfg) : config(cfg) {
   // the SIMULATED machine (backend = sim).  On the GPU the fused kernel is a scheduling decision of the backend: `fuse_hpip`.
   fuseHpip = cfg->getValueOr("fuse_hpip", 1) != 0;
   if (const char *e = getenv("HOMULATOR_FUSE_HPIP")) fuseHpip = std::string(e) != "0";
+  // ... and the ModUp base conversion inside the first pass of that transform (BConvOut_(j) never reaches HBM): N = 2^16, up to 15
+  // input limbs per digit, one GPU (a sharded conversion works on coefficient slices)
+  fuseBconv = cfg->getValueOr("fuse_bconv", 1) != 0;
+  if (const char *e = getenv("HOMULATOR_FUSE_BCONV")) fuseBconv = std::string(e) != "0";
   // sharded runs: the exchanges of digit j+1 run on the context's exchange stream while digit j converts and transforms (SURVEY.md 7:
   // 2 beta + 2 all-to-alls per key switch instead of 4, same order on every rank).  The per-digit transforms must then stay separate
   // launches, so the fused NTT x key kernel (which needs all digits) is not used.
@@ -460,6 +464,8 @@ void Arch::fusePasses(std::vector<Stage> &st) {
         if (ip->ops != IP || ip->ipX.empty() || dead.count(ip)) continue;
         ip->ipSrc = ip->ipX;
         ip->ipCoeff.assign(ip->ipX.size(), 0);
+        std::vector<Instruction *> conv(ip->ipX.size(), nullptr);
+        bool allConv = fuseBconv && world_ == 1 && logN == 16;
         for (size_t j = 0; j < ip->ipX.size(); ++j) {
           auto p = producer.find(ip->ipX[j]);
           if (p == producer.end()) continue;
@@ -471,6 +477,24 @@ void Arch::fusePasses(std::vector<Stage> &st) {
           ip->ipCoeff[j] = 1;
           ip->refInstructions += t->refInstructions;
           dead.insert(t);
+          // (8) is the transform's input a conversion output that nobody else reads?
+          auto pb = producer.find(t->operandList[0]);
+          auto &rb = readers[t->operandList[0]];
+          if (pb != producer.end() && pb->second->ops == BCONV_STEP2 && !dead.count(pb->second) && rb.size() == 1 && rb[0] == t &&
+              pb->second->operandList.size() - 1 <= 15 && pb->second->mod_id == ip->mod_id)
+            conv[j] = pb->second;
+          else allConv = false;
+        }
+        if (allConv && std::find(ip->ipCoeff.begin(), ip->ipCoeff.end(), 1) != ip->ipCoeff.end()) {
+          ip->ipConvIn.assign(ip->ipX.size(), {});
+          ip->ipConvMods.assign(ip->ipX.size(), {});
+          for (size_t j = 0; j < ip->ipX.size(); ++j) {
+            if (!conv[j]) continue;
+            ip->ipConvIn[j].assign(conv[j]->operandList.begin(), conv[j]->operandList.end() - 1);
+            ip->ipConvMods[j] = conv[j]->inMods;
+            ip->refInstructions += conv[j]->refInstructions * (unsigned long long)config->getValueOr("bconv_num_high", 1) * config->getValueOr("bconv_num_width", 1);
+            dead.insert(conv[j]);
+          }
         }
       }
   }
@@ -525,6 +549,8 @@ void Arch::buildLaunches() {
     std::vector<AddrType> v;
     if (i->ops == IP && !i->ipX.empty()) {
       v = i->ipSrc.empty() ? i->ipX : i->ipSrc;
+      for (size_t j = 0; j < i->ipConvIn.size(); ++j)
+        if (!i->ipConvIn[j].empty()) { v[j] = i->ipConvIn[j][0]; v.insert(v.end(), i->ipConvIn[j].begin() + 1, i->ipConvIn[j].end()); }
       for (auto &y : i->ipY) v.insert(v.end(), y.begin(), y.end());
       return v;
     }
@@ -664,12 +690,24 @@ void Arch::buildLaunches() {
               L->a.push_back(limbOf(i->ipSrc[j])); L->c.push_back(limbOf(i->ipX[j])); L->ipCoeff.push_back(i->ipCoeff[j]);
               lp += i->ipCoeff[j] ? 3 : 1;       // transformed digit: source read, hand-off written and read; own limb: read
             }
+            for (size_t j = 0; j < i->ipConvIn.size(); ++j) {   // (8): the digit's conversion runs inside its first pass
+              if (i->ipConvIn[j].empty()) continue;
+              std::vector<uint32_t> in;
+              for (AddrType x : i->ipConvIn[j]) in.push_back(limbOf(x));
+              Launch::Prob *pr = nullptr;
+              for (auto &q : L->probs) if (q.in == in && q.inMods == i->ipConvMods[j]) pr = &q;
+              if (!pr) { L->probs.push_back(Launch::Prob{in, i->ipConvMods[j], {}, {}}); pr = &L->probs.back(); }
+              pr->out.push_back(limbOf(i->ipX[j]));      // the hand-off limb of (limb, digit)
+              pr->outMods.push_back(i->mod_id);
+              lp -= 1;                                      // the converted limb is neither written nor read: source = the conversion's inputs
+            }
             for (auto &y : i->ipY) for (AddrType yy : y) L->b.push_back(limbOf(yy));
             L->out.push_back(limbOf(i->OutputOperand));
             for (AddrType o : i->extraOutputs) L->out.push_back(limbOf(o));
             L->mods.push_back(i->mod_id);
             lp += (unsigned long long)L->ipTerms * L->ipOuts + L->ipOuts;
           }
+        for (auto &q : L->probs) lp += q.in.size();
         L->bytes = lp * LP;
       } else if (f->ops == IP && !f->ipX.empty()) {
         L->kind = Launch::L_IP; L->statKey = "EWE";
@@ -864,6 +902,14 @@ void Arch::replicateForBatch() {
       };
       inter(l->a, l->ipTerms, true); inter(l->b, (size_t)l->ipTerms * l->ipOuts, true); inter(l->out, l->ipOuts, true); inter(l->mods, 1, false);
       if (l->kind == Launch::L_NTT_IP) {
+        const size_t p0 = l->probs.size();
+        for (uint32_t c = 1; c < batch_; ++c)
+          for (size_t i = 0; i < p0; ++i) {
+            Launch::Prob q = l->probs[i];
+            for (uint32_t &x : q.in) x += c * per;
+            for (uint32_t &x : q.out) x += c * per;
+            l->probs.push_back(q);
+          }
         inter(l->c, l->ipTerms, true);
         std::vector<uint32_t> f(l->ipCoeff.begin(), l->ipCoeff.end());
         inter(f, l->ipTerms, false);
@@ -1014,8 +1060,10 @@ void Arch::enqueue(Launch &l) {
     st = hm_inner_product(ctx, pool, l.a.data(), pool, l.b.data(), pool, l.out.data(), l.mods.data(), (uint32_t)l.mods.size(), l.ipTerms, l.ipOuts);
     break;
   case Launch::L_NTT_IP: {
+    for (auto &q : l.probs)
+      descs.push_back(hm_bconv_desc{pool, q.in.data(), q.inMods.data(), (uint32_t)q.in.size(), pool, q.out.data(), q.outMods.data(), (uint32_t)q.out.size(), 0});
     hm_ntt_ip_desc d = {pool, l.a.data(), l.ipCoeff.data(), pool, l.c.data(), pool, l.b.data(), pool, l.out.data(), l.mods.data(),
-                        (uint32_t)l.mods.size(), l.ipTerms, l.ipOuts};
+                        (uint32_t)l.mods.size(), l.ipTerms, l.ipOuts, descs.empty() ? nullptr : descs.data(), (uint32_t)descs.size()};
     st = hm_ntt_inner_product(ctx, &d);
     break;
   }

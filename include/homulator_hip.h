@@ -149,6 +149,7 @@ hm_status hm_inner_product(hm_ctx *ctx, const uint64_t *x, const uint32_t *x_lim
  * out_limbs [i * n_out + k].  x_is_coeff[i][j] != 0: x[i][j] is in coefficient form (a converted limb) and is transformed;
  * hand + hand_limbs[i][j] * N is N words of scratch for its first pass (contents undefined afterwards); 0: x[i][j] is already
  * in evaluation form (a digit's own limbs).  `out` must not alias x, hand or y.  Bit-identical to hm_ntt + hm_inner_product. */
+struct hm_bconv_desc;
 typedef struct hm_ntt_ip_desc {
   const uint64_t *x;    const uint32_t *x_limbs;   const uint8_t *x_is_coeff;
   uint64_t *hand;       const uint32_t *hand_limbs;
@@ -156,6 +157,15 @@ typedef struct hm_ntt_ip_desc {
   uint64_t *out;        const uint32_t *out_limbs;
   const uint32_t *mod_ids;
   uint32_t n, n_terms, n_out;
+  /* optional (NULL / 0: none): the transformed digits are base conversions that have not been computed yet —
+   * ModUp_BCONV_(j) + ModUp_NTT_(j) + the inner product (src/Operation.cpp:137-414) in one call.  conv[k] describes conversion k
+   * exactly as for hm_bconv_batch, except that conv[k].out + conv[k].out_limbs[t] * N must be the hand-off limb
+   * (hand + hand_limbs[i][j] * N) of the (limb, digit) its output t feeds: the conversion runs INSIDE the first pass of that
+   * transform (the workgroup of an output limb's column tile converts its own coefficients from the input tiles), so the
+   * converted limb-polys (BConvOut_(j)) are never written to HBM or read back; x / x_limbs of those digits are ignored.
+   * N = 2^16 and n_in <= 15 (HM_ERR_UNSUPPORTED otherwise: convert with hm_bconv_batch first).  Bit-identical to
+   * hm_bconv_batch + hm_ntt_inner_product. */
+  const struct hm_bconv_desc *conv; uint32_t n_conv;
 } hm_ntt_ip_desc;
 hm_status hm_ntt_inner_product(hm_ctx *ctx, const hm_ntt_ip_desc *desc);
 
@@ -169,11 +179,12 @@ hm_status hm_bconv(hm_ctx *ctx, const uint64_t *in, const uint32_t *in_limbs, co
                    uint32_t n_out);
 /* several independent conversions in ONE launch (the beta digits of a ModUp, the two keys of a ModDown:
  * src/Operation.cpp:31-35 loops over the digits, :489-519 over the keys) */
-typedef struct hm_bconv_desc {
+typedef struct hm_bconv_desc hm_bconv_desc;
+struct hm_bconv_desc {
   const uint64_t *in; const uint32_t *in_limbs; const uint32_t *in_ids; uint32_t n_in;
   uint64_t *out; const uint32_t *out_limbs; const uint32_t *out_ids; uint32_t n_out;
   uint32_t log_len; /* coefficients per limb in `in`/`out` = 2^log_len; 0 = N.  N/world for coefficient slices */
-} hm_bconv_desc;
+};
 hm_status hm_bconv_batch(hm_ctx *ctx, const hm_bconv_desc *descs, uint32_t n_desc);
 /* host-side constants of a conversion: qhat_inv[n_in], table[n_in][n_out] (either may be NULL) */
 hm_status hm_bconv_consts(hm_ctx *ctx, const uint32_t *in_ids, uint32_t n_in, const uint32_t *out_ids,

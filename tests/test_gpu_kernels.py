@@ -330,3 +330,52 @@ def test_ntt_inner_product_fused(env, terms, outs):
         assert np.array_equal(got[k * n:(k + 1) * n], exp), (k, terms)
     for b_ in (xb, yb, out, hand):
         b_.free()
+
+
+@pytest.mark.parametrize("n_in", [1, 2, 5, 9, 15])
+def test_ntt_inner_product_with_conversion_inside(n_in):
+    """ModUp_BCONV + ModUp_NTT + inner product in one call (hm_ntt_ip_desc.conv): the conversion runs inside the first pass of the
+    transform that consumes it (k_bconv_col), the converted limb-polys never exist.  Against the oracle's conversion, transform and
+    MAC chain; two digits of n_in limbs each, two "ops" sharing the key, output limbs = everything outside the digit."""
+    from homulator_amd import hip
+    L, K = 2 * n_in, 3
+    ctx, o = hip.Context(16, L, K), Oracle(16, L, K)
+    try:
+        ell, beta, nops = 2 * n_in, 2, 2
+        ext = o.ext_ids(ell); E = len(ext)
+        digits = [list(range(0, n_in)), list(range(n_in, 2 * n_in))]
+        own = o.fill_uniform(list(range(ell)) * nops, 5).reshape(nops, ell, -1)          # evaluation-form limbs (a digit's own)
+        scaled = o.fill_uniform(list(range(ell)) * nops, 6).reshape(nops, ell, -1)       # coefficient-form, already x q_hat^-1
+        scaled[0, 0, :] = o.moduli[0] - 1
+        evk = np.stack([o.fill_uniform(ext, 100 + 10 * k + j) for k in range(2) for j in range(beta)])   # limb (k*beta + j)*E + t
+        src, ownb, evkb = ctx.from_host(scaled.reshape(-1, 1 << 16)), ctx.from_host(own.reshape(-1, 1 << 16)), ctx.from_host(evk.reshape(-1, 1 << 16))
+        hand, out = ctx.alloc(nops * beta * E), ctx.alloc(nops * 2 * E)
+        conv, xl, flags, hl, yl, ol, mods = [], [], [], [], [], [], []
+        for b in range(nops):
+            for j, dj in enumerate(digits):
+                outs = [t for t in range(E) if t not in dj]
+                conv.append((src, [b * ell + i for i in dj], dj, [(b * beta + j) * E + t for t in outs], [ext[t] for t in outs]))
+            for t in range(E):
+                for j, dj in enumerate(digits):
+                    isown = t in dj
+                    xl.append(b * ell + t if isown else 0); hl.append((b * beta + j) * E + t); flags.append(0 if isown else 1)
+                for k in range(2):
+                    yl += [(k * beta + j) * E + t for j in range(beta)]
+                    ol.append((b * 2 + k) * E + t)
+                mods.append(ext[t])
+        ctx.ntt_inner_product(ownb, xl, flags, hand, hl, evkb, yl, out, ol, mods, beta, 2, conv=conv)
+        got = out.download().reshape(nops, 2, E, -1)
+        for b in range(nops):
+            X = []
+            for j, dj in enumerate(digits):
+                outs = [t for t in range(E) if t not in dj]
+                z = o.ntt([ext[t] for t in outs], o.bconv_matmul(dj, [ext[t] for t in outs], scaled[b, dj]))
+                full = np.zeros((E, 1 << 16), dtype=np.uint64)
+                full[outs] = z
+                full[dj] = own[b, dj]
+                X.append(full)
+            for k in range(2):
+                exp = o.ewe(1, ext, X[0], evk[k * beta + 0], X[1], evk[k * beta + 1])
+                assert np.array_equal(got[b, k], exp), (n_in, b, k)
+    finally:
+        ctx.close()

@@ -54,16 +54,18 @@ CASES = [("config_4_N15.cfg", 15, 16, 10, 4), ("config_4_N15.cfg", 15, 8, 8, 8),
 
 
 @pytest.mark.parametrize("cfg,logN,L,ell,alpha", CASES)
-@pytest.mark.parametrize("fuse", [False, True, "no_hpip"])
+@pytest.mark.parametrize("fuse", [False, True, "no_hpip", "no_bconv"])
 def test_hmult_bit_exact(cfg, logN, L, ell, alpha, fuse):
-    """fuse = True is the bench path (with the fused NTT-epilogue x key MAC); "no_hpip" = fused plan with separate ModUp
-    transforms and inner product (config key fuse_hpip = 0)"""
+    """fuse = True is the bench path (ModUp conversion + transforms + key MAC in one C-ABI call: k_bconv_col, k_ntt_row_ip);
+    "no_bconv" = the same with the conversion as its own launch (fuse_bconv = 0); "no_hpip" = fused plan with separate ModUp
+    transforms and inner product (fuse_hpip = 0)"""
     from homulator_amd import host
     o = oracle(logN, L, alpha)
     ct1, ct2, evk = inputs(o, ell)
     ids = list(range(ell))
-    hpip = fuse is True
-    op = host.Op(cfg, "hmult", L, ell, alpha, fuse=bool(fuse), overrides={"fuse_hpip": 0} if fuse == "no_hpip" else None)
+    hpip = fuse is True or fuse == "no_bconv"   # "no_bconv": fused transform x key kernel fed by a separate conversion launch
+    op = host.Op(cfg, "hmult", L, ell, alpha, fuse=bool(fuse),
+                 overrides={"fuse_hpip": 0} if fuse == "no_hpip" else {"fuse_bconv": 0} if fuse == "no_bconv" else None)
     fuse = bool(fuse)
     op.execute(1)
     assert np.array_equal(op.read("ct1.c0"), ct1[0]) and np.array_equal(op.read("ct2.c1"), ct2[1])
