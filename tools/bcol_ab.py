@@ -1,5 +1,6 @@
-"""EXPERIMENT: base conversion fused into the transform's first pass (k_bconv_col) against k_bconv + k_ntt_col, ModUp of
-config_4.cfg hmult 45 35 15 at batch B.  Checks the hand-off bit for bit, then runs both forms a few times (for rocprofv3).
+"""ModUp of config_4.cfg hmult 45 35 15 at batch B through the C ABI: conversion inside the transform's first pass (k_bconv_col +
+k_ntt_row_ip: hm_ntt_ip_desc.conv) against a separate conversion (k_bconv, then k_ntt_col + k_ntt_row_ip).  Checks hand-off and outputs
+bit for bit, then times both forms (or runs them a few times for rocprofv3).
 usage: python3 tools/bcol_ab.py [batch] [rounds]"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,12 +10,11 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 R = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 Lq, ell, K = 45, 35, 15
 ctx = hip.Context(16, Lq, K)
-ctx.L.hm_x_bconv_col.argtypes = [C.c_void_p, C.POINTER(hip.hm_bconv_desc), C.c_uint32]
 ext = ctx.ext_ids(ell); E = len(ext); beta = 3
 src = ctx.alloc(ell * B)                    # scaled digits (ModUpDecompOut), per op
 bc = ctx.alloc(beta * E * B)                # BConvOut
 hand_a, hand_b = ctx.alloc(beta * E * B), ctx.alloc(beta * E * B)
-evk = ctx.alloc(2 * beta * E); outb = ctx.alloc(2 * E * B)
+evk = ctx.alloc(2 * beta * E); outb = ctx.alloc(2 * E * B); outb2 = ctx.alloc(2 * E * B)
 ctx.fill_uniform(src, [i % ell for i in range(ell * B)], 7)
 ctx.fill_uniform(evk, (ext * (2 * beta)), 9)
 probs = []
@@ -32,7 +32,7 @@ def descs(dst):
         d.out, d.out_limbs, d.out_ids, d.n_out, d.log_len = dst.ptr, a[2][1], a[3][1], len(outs), 0
     return keep, arr
 ka, da = descs(bc)
-kb, db = descs(hand_b)
+conv_b = [(src, [b * ell + i for i in ins], ins, [(b * beta + j) * E + t for t in outs], [ext[t] for t in outs]) for (b, j, ins, outs) in probs]
 # path A: conversion, then the fused transform x key product whose first kernel is the COL pass into hand_a
 xl, flags, hl, yl, ol, mods = [], [], [], [], [], []
 for b in range(B):
@@ -48,12 +48,12 @@ def path_a():
     ctx._ck(ctx.L.hm_bconv_batch(ctx.h, da, len(probs)))
     ctx.ntt_inner_product(bc, xl, flags, hand_a, hl, evk, yl, outb, ol, mods, beta, 2)
 def path_b():
-    ctx._ck(ctx.L.hm_x_bconv_col(ctx.h, db, len(probs)))
+    ctx.ntt_inner_product(bc, xl, flags, hand_b, hl, evk, yl, outb2, ol, mods, beta, 2, conv=conv_b)
 path_a(); path_b(); ctx.sync()
 if B <= 2:
     A, Bh = hand_a.download(), hand_b.download()
     sel = [(b * beta + j) * E + t for (b, j, ins, outs) in probs for t in outs]
-    print("hand-off identical:", np.array_equal(A[sel], Bh[sel]), len(sel), "limb-polys")
+    print("hand-off identical:", np.array_equal(A[sel], Bh[sel]), len(sel), "limb-polys; outputs identical:", np.array_equal(outb.download(), outb2.download()))
 for _ in range(R):
     path_a()
 for _ in range(R):
@@ -63,4 +63,4 @@ def t(fn, n=10):
     ctx.sync(); ctx.timer_start()
     for _ in range(n): fn()
     return ctx.timer_stop() / n * 1e-3
-print(f"batch {B}: conversion + transform x key (k_bconv, k_ntt_col, k_ntt_row_ip) {t(path_a)/B:.1f} us/op; fused conversion + first pass alone (k_bconv_col) {t(path_b)/B:.1f} us/op; k_bconv alone {t(lambda: ctx._ck(ctx.L.hm_bconv_batch(ctx.h, da, len(probs))))/B:.1f} us/op")
+print(f"batch {B}: separate conversion (k_bconv, k_ntt_col, k_ntt_row_ip) {t(path_a)/B:.1f} us/op; conversion inside the first pass (k_bconv_col, k_ntt_row_ip) {t(path_b)/B:.1f} us/op; k_bconv alone {t(lambda: ctx._ck(ctx.L.hm_bconv_batch(ctx.h, da, len(probs))))/B:.1f} us/op")
