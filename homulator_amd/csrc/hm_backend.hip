@@ -1342,6 +1342,11 @@ extern "C" hm_status hm_ntt_inner_product(hm_ctx *c, const hm_ntt_ip_desc *d) {
       (st = check_limbs(c, "hm_ntt_inner_product", d->out_limbs, n * K)) || (st = check_mods(c, "hm_ntt_inner_product", d->mod_ids, n)))
     return st;
   // 1. first pass of every transformed (limb, digit): x -> hand; or conversion + first pass in one kernel: conv -> hand
+  for (uint32_t i = 0; i < n * T; ++i)
+    if (d->x_is_coeff[i]) {
+      if (!d->hand || !d->hand_limbs) return fail(c, HM_ERR_ARG, "hm_ntt_inner_product: transformed digits need the hand-off buffer and its limb list");
+      if (d->hand_limbs[i] > 0xFFFFu) return fail(c, HM_ERR_ARG, "hm_ntt_inner_product: limb index exceeds 65535");
+    }
   if (d->n_conv) {
     if (!d->conv || !d->hand) return fail(c, HM_ERR_ARG, "hm_ntt_inner_product: conversions need their descriptors and the hand-off buffer");
     for (uint32_t k = 0; k < d->n_conv; ++k)
@@ -1352,8 +1357,6 @@ extern "C" hm_status hm_ntt_inner_product(hm_ctx *c, const hm_ntt_ip_desc *d) {
   for (uint32_t i = 0; i < n; ++i)
     for (uint32_t j = 0; j < T; ++j)
       if (d->x_is_coeff[i * T + j] && !d->n_conv) {
-        if (!d->hand || !d->hand_limbs) return fail(c, HM_ERR_ARG, "hm_ntt_inner_product: transformed digits need the hand-off buffer");
-        if (d->hand_limbs[i * T + j] > 0xFFFFu) return fail(c, HM_ERR_ARG, "hm_ntt_inner_product: limb index exceeds 65535");
         cin.push_back(d->x_limbs[i * T + j]); chand.push_back(d->hand_limbs[i * T + j]); cmod.push_back(d->mod_ids[i]);
       }
   if (!cin.empty()) {
