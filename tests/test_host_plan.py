@@ -1,0 +1,52 @@
+"""Launch plans of the host layer on the count backend (no GPU): which fusion passes apply where.  The instruction total of every plan
+must stay upstream's getTotalIns() whatever is fused (tests/test_host_structural.py pins the totals against the compiled reference)."""
+import re
+
+import pytest
+
+from homulator_amd import host
+
+
+def plan(cfg, op, L, ell, alpha, **ov):
+    o = host.Op(cfg, op, L, ell, alpha, backend=host.BACKEND_COUNT, overrides=ov or None)
+    try:
+        return o.plan(), o.total_instructions(), o.launch_count()
+    finally:
+        o.close()
+
+
+def kinds(p):
+    return [ln.split()[0] for ln in p]
+
+
+def test_headline_plan_is_seven_launches():
+    p, total, n = plan("config_4.cfg", "hmult", 45, 35, 15)
+    assert n == 7 and kinds(p) == ["TENSOR", "INTT", "NTT_IP", "INTT", "BCONV", "EWE", "NTT_SUBSCALE"]
+    assert total == 7381760                                   # upstream's total for this command line
+    # the ModUp conversion, the ModUp transforms and the inner product are ONE launch; its instruction share = all three stages'
+    ref = {ln.split()[0]: int(re.search(r"ref=(\d+)", ln).group(1)) for ln in p}
+    p8, total8, n8 = plan("config_4.cfg", "hmult", 45, 35, 15, fuse_bconv=0)
+    assert n8 == 8 and kinds(p8)[2:4] == ["BCONV", "NTT_IP"] and total8 == total
+    r8 = [int(re.search(r"ref=(\d+)", ln).group(1)) for ln in p8]
+    assert ref["NTT_IP"] == r8[2] + r8[3]
+    p9, total9, n9 = plan("config_4.cfg", "hmult", 45, 35, 15, fuse_hpip=0)
+    assert n9 == 9 and kinds(p9)[2:5] == ["BCONV", "NTT", "IP"] and total9 == total
+    ph, totalh, nh = plan("config_4.cfg", "hrotate", 45, 35, 15)
+    assert nh == 6 and kinds(ph) == ["AUTO", "INTT", "NTT_IP", "INTT", "BCONV", "NTT_SUBSCALE"] and totalh == 7328000
+
+
+@pytest.mark.parametrize("cfg,L,ell,alpha,conv_inside", [
+    ("config_4_N15.cfg", 16, 10, 4, False),    # N = 2^15: the fused conversion exists for N = 2^16 only
+    ("config_4.cfg", 28, 28, 28, False),       # parameter set A: 28 input limbs per digit (> 15)
+    ("config_4.cfg", 24, 24, 6, True),         # set C: beta = 4
+    ("config_4.cfg", 26, 20, 9, True),         # set D: uneven last digit (9, 9, 2)
+    ("config_4.cfg", 8, 8, 8, True),           # beta = 1: the digit's own limbs need no transform
+])
+def test_where_the_conversion_moves_into_the_transform(cfg, L, ell, alpha, conv_inside):
+    p, total, n = plan(cfg, "hmult", L, ell, alpha)
+    k = kinds(p)
+    assert "NTT_IP" in k                                      # the transform x key fusion applies at every shape
+    modup_bconv = [ln for ln in p if ln.startswith("BCONV") and "ModUp_BCONV" in ln]
+    assert (len(modup_bconv) == 0) == conv_inside, p
+    p0, total0, _ = plan(cfg, "hmult", L, ell, alpha, fuse_hpip=0, fuse_bconv=0)
+    assert total0 == total
