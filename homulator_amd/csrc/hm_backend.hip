@@ -594,6 +594,7 @@ struct hm_ctx {
   HmNttSync *ntt_ws = nullptr;
   unsigned *err_host = nullptr, *err_dev = nullptr;
   bool small_ept8 = true;      // launches of at most small_limbs entries use the 8-coefficient geometry (N = 2^16)
+  uint32_t small_mode = 3;     // which passes of a small launch use it: bit 0 COL, bit 1 ROW
   uint32_t small_limbs = 64;   // measured (tools/ntt_small_ab.py): 2-3 us per launch faster up to ~64 entries, equal at 115, slower from 128
   bool fused_ntt = false;  // measured slower and no lighter on HBM: opt-in
   // multi-GPU
@@ -860,6 +861,7 @@ extern "C" hm_status hm_wait_for(hm_ctx *c, hm_ctx *producer) {
 extern "C" hm_status hm_set_option(hm_ctx *c, const char *name, uint64_t value) {
   if (!c || !name) return HM_ERR_ARG;
   if (!strcmp(name, "ntt_fused")) { c->fused_ntt = value != 0; return HM_OK; }
+  if (!strcmp(name, "ntt_small_mode")) { c->small_mode = (uint32_t)value & 3u; return HM_OK; }
   if (!strcmp(name, "ntt_small_limbs")) { c->small_ept8 = value != 0; c->small_limbs = (uint32_t)value; return HM_OK; }
   return fail(c, HM_ERR_ARG, "hm_set_option: unknown option %s", name);
 }
@@ -959,15 +961,18 @@ static void launch_ntt(hm_ctx *c, const HmNttArgs &a, bool fusedEpilogue, bool m
   // small launches (one round of workgroups on the chip): the 8-coefficient geometry halves the serial work per wave
   if constexpr (LOG1 == 8) {
     if (c->small_ept8 && !firstPassOnly && !c->fused_ntt && a.n_limbs <= c->small_limbs) {
+      // small_mode: bit 0 = COL pass in the 8-coefficient geometry, bit 1 = ROW pass (the hand-off between the passes is the same)
       const dim3 grid8(a.n_limbs * (c->P.N >> HM_TL_ROW)), block8((1 << HM_TL_ROW) / 8);
+      const dim3 grid16(a.n_limbs * (c->P.N >> HM_TL_ROW)), block16((1 << HM_TL_ROW) / HM_EPT);
+      const bool c8 = c->small_mode & 1, r8 = c->small_mode & 2;
       if (!inverse) {
-        if (mixPrologue) hipLaunchKernelGGL((k_ntt_col8<false, 4>), grid8, block8, 0, c->stream, a);
-        else hipLaunchKernelGGL((k_ntt_col8<false, 0>), grid8, block8, 0, c->stream, a);
-        if (fusedEpilogue) hipLaunchKernelGGL((k_ntt_row8<false, 3>), grid8, block8, 0, c->stream, a);
-        else hipLaunchKernelGGL((k_ntt_row8<false, 1>), grid8, block8, 0, c->stream, a);
+        if (mixPrologue) { if (c8) hipLaunchKernelGGL((k_ntt_col8<false, 4>), grid8, block8, 0, c->stream, a); else hipLaunchKernelGGL((k_ntt_col<LOG1, false, 4>), grid16, block16, 0, c->stream, a); }
+        else { if (c8) hipLaunchKernelGGL((k_ntt_col8<false, 0>), grid8, block8, 0, c->stream, a); else hipLaunchKernelGGL((k_ntt_col<LOG1, false, 0>), grid16, block16, 0, c->stream, a); }
+        if (fusedEpilogue) { if (r8) hipLaunchKernelGGL((k_ntt_row8<false, 3>), grid8, block8, 0, c->stream, a); else hipLaunchKernelGGL((k_ntt_row<false, 3>), grid16, block16, 0, c->stream, a); }
+        else { if (r8) hipLaunchKernelGGL((k_ntt_row8<false, 1>), grid8, block8, 0, c->stream, a); else hipLaunchKernelGGL((k_ntt_row<false, 1>), grid16, block16, 0, c->stream, a); }
       } else {
-        hipLaunchKernelGGL((k_ntt_row8<true, 0>), grid8, block8, 0, c->stream, a);
-        hipLaunchKernelGGL((k_ntt_col8<true, 2>), grid8, block8, 0, c->stream, a);
+        if (r8) hipLaunchKernelGGL((k_ntt_row8<true, 0>), grid8, block8, 0, c->stream, a); else hipLaunchKernelGGL((k_ntt_row<true, 0>), grid16, block16, 0, c->stream, a);
+        if (c8) hipLaunchKernelGGL((k_ntt_col8<true, 2>), grid8, block8, 0, c->stream, a); else hipLaunchKernelGGL((k_ntt_col<LOG1, true, 2>), grid16, block16, 0, c->stream, a);
       }
       return;
     }

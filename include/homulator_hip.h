@@ -255,6 +255,7 @@ void hm_graph_destroy(hm_graph *graph);
  *                allocate on a store).  Env HOMULATOR_NTT_FUSED sets the default.
  *   "ntt_small_limbs"  transform launches of at most this many limb-poly entries (default 64, N = 2^16) use the small-launch
  *                geometry (512-thread workgroups, 8 coefficients per thread); 0 switches it off.  Env HOMULATOR_NTT_SMALL_LIMBS.
+ *   "ntt_small_mode"   which passes of such a launch use it: bit 0 = COL, bit 1 = ROW (default 3; the hand-off is the same).
  * Counters:
  *   "ntt_cross_xcd"  limb-polys whose workgroups were NOT all placed on one XCD and took the agent-scope hand-off
  *                    (slow, still correct); expected 0 under the dispatcher's observed round-robin placement.
