@@ -173,6 +173,10 @@ def main():
                          "default of 10 (pick_batch)")
     ap.add_argument("--op", default=OP, choices=["hmult", "hrotate"],
                     help="hmult = BASELINE.json's metric (default); hrotate = BASELINE configs[3], for information")
+    ap.add_argument("--graph", type=int, default=1,
+                    help="1 GPU: the throughput instances replay their launch plan as ONE captured HIP graph per enqueue (config key `graph`): "
+                         "the host then takes ~20 us per launch set instead of ~0.3 ms of argument preparation, which matters for a 20-step "
+                         "timed region (one launch set per instance); the one-op-at-a-time instance always enqueues directly")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -215,7 +219,7 @@ def main():
     opn = args.op
     alg_bytes = HMULT_ALG_BYTES if opn == "hmult" else HROTATE_ALG_BYTES
     ops = [host.Op(CFG, opn, L, ELL, ALPHA, device=local_rank, rank=rank, world=world,
-                   overrides={"seed": host.SEED + 7 * i, **({"batch": batch} if batch > 1 else {})})
+                   overrides={"seed": host.SEED + 7 * i, **({"batch": batch} if batch > 1 else {}), **({"graph": 1} if world == 1 and args.graph else {})})
            for i in range(streams)]
     op = ops[0]
     # steps that do not fill a batch run through a one-op instance, so that EXACTLY --steps hmults are timed
@@ -333,6 +337,7 @@ def main():
             "config": {"workload": f"{CFG} {opn} L={L} l={ELL} alpha={ALPHA} (N=2^16, beta=3, " + ("full hybrid key switch + rescale)" if opn == "hmult" else "automorphism + full hybrid key switch)"),
                        "parallelism": "single GPU" if world == 1 else f"limbs sharded over {world} GPUs (limb e -> e % {world}); RCCL all-to-all around every digit's ModUp conversion and around the ModDown conversion (2 beta + 2 per key switch, digit j+1's exchange on the exchange stream beside digit j's conversion and transform) + replicate of the rescale residue; {batch} hmults per launch share the exchanges",
                        "launches_per_op": op.launch_count(), "streams": streams, "batch": batch, "transport": transport,
+                       "hip_graph": bool(world == 1 and args.graph),
                        "evk_note": "the ops of a batch share ONE evaluation key: the 157 MB key stream that the algorithmic figure charges per op is read from HBM once per batch, the other readers hit cache",
                        "streams_note": "`streams` instances in flight (own HBM pool / HIP stream each), each carrying `batch` independent hmults per launch (own inputs, one evaluation key); a step is one hmult"},
             "single_stream_ops_per_s": single,

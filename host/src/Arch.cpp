@@ -66,7 +66,9 @@ Arch::Arch(Config *cfg) : config(cfg) {
   }
   if (rank_ >= world_) throw std::runtime_error("rank must be below world");
   if (world_ & (world_ - 1)) throw std::runtime_error("world must be a power of two");
-  useGraph = cfg->getValueOr("graph", 0) != 0;  // measured: no gain on one GPU (the op is GPU-bound: 2 440 vs 2 422 ops/s)
+  // HIP-graph replay of the whole plan: no gain in steady state (the op is GPU-bound), but the host prepares a launch set in ~20 us instead of
+  // ~0.3 ms: +3-5 % on a 20-step timed region of batched instances (bench.py turns it on for them), -4 % one op at a time (replay overhead)
+  useGraph = cfg->getValueOr("graph", 0) != 0;
   if (const char *e = getenv("HOMULATOR_GRAPH")) useGraph = std::string(e) != "0";
   batch_ = std::max<uint32_t>(1, cfg->getValueOr("batch", 1));
   if (const char *e = getenv("HOMULATOR_BATCH")) batch_ = std::max(1, atoi(e));
