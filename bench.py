@@ -157,6 +157,12 @@ def pick_batch(steps, streams, default=DEFAULT_BATCH):
     return max(1, min(default, steps // max(1, streams)))
 
 
+def loaded_hip_library():
+    """the backend build this process really mapped (an A/B build named by HOMULATOR_HIP_LIB must show up here, not beside the in-tree one)"""
+    libs = sorted({ln.split()[-1] for ln in open("/proc/self/maps") if "libhomulator_hip" in ln or "/libhm_" in ln})
+    return [os.path.relpath(p, ROOT) if p.startswith(ROOT) else p for p in libs]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -340,6 +346,7 @@ def main():
                        "hip_graph": bool(world == 1 and args.graph),
                        "evk_note": "the ops of a batch share ONE evaluation key: the 157 MB key stream that the algorithmic figure charges per op is read from HBM once per batch, the other readers hit cache",
                        "streams_note": "`streams` instances in flight (own HBM pool / HIP stream each), each carrying `batch` independent hmults per launch (own inputs, one evaluation key); a step is one hmult"},
+            "hip_library": loaded_hip_library(),
             "single_stream_ops_per_s": single,
             "sustained_ops_per_s": sustained,
             "launches_in_timed_region_per_instance": args.steps // (batch * streams),

@@ -285,6 +285,14 @@ typedef const HmNipLimb __attribute__((address_space(4))) *HmConstNipLimb;
 #ifndef HM_NIP_MAC_CH
 #define HM_NIP_MAC_CH 1   // access units of key words in flight per multiply-accumulate step
 #endif
+// cache policy (hm_gld2's AUX bits: 2 = nt) of the once-read operand loads and of the output stores: streamed data marked non-temporal
+// leaves the L2 to the key words, which the ops of a batch share
+#ifndef HM_NIP_LD_AUX
+#define HM_NIP_LD_AUX 0
+#endif
+#ifndef HM_NIP_ST_AUX
+#define HM_NIP_ST_AUX 0
+#endif
 template <int OUTS>
 __global__ void __launch_bounds__((1 << HM_TL_ROW) / HM_EPT) __attribute__((amdgpu_waves_per_eu(HM_NIP_WAVES))) k_ntt_row_ip(HmNipArgs a) {
   constexpr int TL = HM_TL_ROW, LOGR = HM_ROW_LOG, R2 = HmRounds<LOGR>::n - 1;
@@ -331,12 +339,12 @@ __global__ void __launch_bounds__((1 << HM_TL_ROW) / HM_EPT) __attribute__((amdg
       const HmTw sc = {0, 0};
       const HmEpi ep = hm_epi_none();
       if (j) __syncthreads();   // the previous digit's last round has read the tile
-      hm_ntt_pass_phases<TL, LOGR, false, false, 5>(st, tid, lds, src, nullptr, tile, twl, twt, s0, prefix0, m.q, sc, ep, [] { __syncthreads(); });
+      hm_ntt_pass_phases<TL, LOGR, false, false, 5, HM_NIP_LD_AUX>(st, tid, lds, src, nullptr, tile, twl, twt, s0, prefix0, m.q, sc, ep, [] { __syncthreads(); });
 #if HM_NIP_WIDE
       hm_ph_below_2q(st, m.q);
 #endif
     } else {
-      hm_ph_load_global<TL, LOGR, false, R2>(st, tid, a.x + (size_t)xl * N, tile);
+      hm_ph_load_global<TL, LOGR, false, R2, HM_NIP_LD_AUX>(st, tid, a.x + (size_t)xl * N, tile);
     }
 #if HM_NIP_PREFETCH
     hm_ph_mac_regs<OUTS, Acc>(st, acc, e, m);
@@ -347,7 +355,7 @@ __global__ void __launch_bounds__((1 << HM_TL_ROW) / HM_EPT) __attribute__((amdg
   uint64_t *out[OUTS];
 #pragma unroll
   for (int k = 0; k < OUTS; ++k) out[k] = a.out + (size_t)rec->out[k] * N;
-  hm_ph_mac_store<TL, LOGR, R2, OUTS, Acc>(acc, threadIdx.x, out, tile, m);
+  hm_ph_mac_store<TL, LOGR, R2, OUTS, Acc, HM_NIP_ST_AUX>(acc, threadIdx.x, out, tile, m);
 }
 
 // ---- base conversion fused into the first pass of the transform that consumes it (round 3) --------------------------------
@@ -401,8 +409,13 @@ __global__ void __launch_bounds__((1 << HM_TL_COL) / HM_EPT) __attribute__((amdg
     for (int i = 0; i < N_IN; ++i) {
       uint64_t v0, v1;
       hm_gld2<G0>(p.in + (size_t)p.in_limb[i] * N, tile, tid, u, v0, v1);
+#if defined(HM_ABL_BCOL_PACKED)   // timing-only ablation: inputs taken as if already stored split (no shift / mask per input and output)
+      yl[0][i] = (uint32_t)v0; yh[0][i] = (uint32_t)(v0 >> 32);
+      yl[1][i] = (uint32_t)v1; yh[1][i] = (uint32_t)(v1 >> 32);
+#else
       yl[0][i] = (uint32_t)v0 & 0x3FFFFFFFu; yh[0][i] = (uint32_t)(v0 >> 30);
       yl[1][i] = (uint32_t)v1 & 0x3FFFFFFFu; yh[1][i] = (uint32_t)(v1 >> 30);
+#endif
     }
     st.v[i0] = hm_bconv_dot<N_IN>(yl[0], yh[0], row, m.q, m.nqinv);
     st.v[i1] = hm_bconv_dot<N_IN>(yl[1], yh[1], row, m.q, m.nqinv);

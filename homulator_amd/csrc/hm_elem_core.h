@@ -187,8 +187,10 @@ HM_HD uint64_t hm_bconv_dot(const uint32_t (&yl)[N_IN], const uint32_t (&yh)[N_I
         const uint64_t w = row[i >> 3].w[i & 7];
         const uint32_t wl = (uint32_t)w, wh = (uint32_t)(w >> 32);
         s00 += (uint64_t)yl[i] * wl;
+#if !defined(HM_ABL_BCONV_HALF)   // (timing-only ablation: half of the multiply-adds of a conversion)
         s01 += (uint64_t)yl[i] * wh;
         s10 += (uint64_t)yh[i] * wl;
+#endif
         s11 += (uint64_t)yh[i] * wh;
       }
     }

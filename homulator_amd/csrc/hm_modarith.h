@@ -160,8 +160,10 @@ HM_HD void hm_bfly_fwd(uint64_t &X, uint64_t &Y, const HmTw &t, const HmBflyMod 
 template <int KIND>
 HM_HD void hm_bfly_fwd_k(uint64_t &X, uint64_t &Y, const HmTw &t, const HmBflyMod &m) {
   uint64_t x = X;
+#if !defined(HM_ABL_NOCSUB)   // (timing-only ablation: butterflies without their conditional subtractions)
   if (KIND >= 1) x = hm_csub_neg(x, m.nq8);
   if (KIND == 2) x = hm_csub_neg(x, m.nq4);
+#endif
   const uint64_t xn = hm_shoup_lazy4_acc(x, Y, t, m);
   Y = ((x << 1) + m.q4) - xn;
   X = xn;
@@ -169,7 +171,11 @@ HM_HD void hm_bfly_fwd_k(uint64_t &X, uint64_t &Y, const HmTw &t, const HmBflyMo
 // inverse (Gentleman-Sande): X, Y in [0, 4q) -> X', Y' in [0, 4q)
 HM_HD void hm_bfly_inv(uint64_t &X, uint64_t &Y, const HmTw &t, const HmBflyMod &m) {
   const uint64_t d = (X + m.q4) - Y;
+#if defined(HM_ABL_NOCSUB)
+  X = X + Y;
+#else
   X = hm_csub_neg(X + Y, m.nq4);
+#endif
   Y = hm_shoup_lazy4_acc(0, d, t, m);
 }
 // [0, 8q) -> [0, q)

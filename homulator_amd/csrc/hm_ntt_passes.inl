@@ -445,7 +445,15 @@ HM_HD void hm_ntt_pass_phases(HmNttState &st, int tid, uint64_t *lds, const uint
 // registers for both keys); hm_u128 — the raw 128-bit products are summed (12 instructions per product: x < 2q and y < q keep 4
 // terms below 2^123 once x is brought below 2q) and reduced once per output by hm_barrett, at the price of 128 accumulator
 // registers (two waves per SIMD).
+#if defined(HM_ABL_NIP_FAKE_SHOUP)   // timing-only ablation (tools/ablate.sh): the instruction count of a Shoup product, wrong values
+HM_HD void hm_mac_add(uint64_t &acc, uint64_t x, uint64_t y, const HmMod &m) {
+  const HmTw t = {y, y * 3 + 1};
+  HmBflyMod b; b.z = hm_opaque_zero(); b.nq = b.z - m.q;
+  acc = hm_shoup_lazy4_acc(acc, x, t, b);
+}
+#else
 HM_HD void hm_mac_add(uint64_t &acc, uint64_t x, uint64_t y, const HmMod &m) { acc += hm_barrett_lazy((hm_u128)x * y, m); }
+#endif
 HM_HD void hm_mac_add(hm_u128 &acc, uint64_t x, uint64_t y, const HmMod &) { acc += (hm_u128)x * y; }
 HM_HD uint64_t hm_mac_final(uint64_t acc, const HmMod &m) { return hm_reduce16(acc, m.q); }
 HM_HD uint64_t hm_mac_final(hm_u128 acc, const HmMod &m) { return hm_barrett(acc, m); }   // 4 terms x (x < 2q) x (y < q) < 2^123
@@ -501,7 +509,7 @@ HM_HD void hm_ph_mac_regs(const HmNttState &st, ACC (&acc)[OUTS][HM_EPT], const 
 #pragma unroll
     for (int i = 0; i < HM_EPT; ++i) hm_mac_add(acc[k][i], st.v[i], e[k][i], m);
 }
-template <int TL, int LOGR, int R, int OUTS, class ACC>
+template <int TL, int LOGR, int R, int OUTS, class ACC, int AUX = 0>
 HM_HD void hm_ph_mac_store(const ACC (&acc)[OUTS][HM_EPT], int tid, uint64_t *const (&out)[OUTS], uint32_t tile, const HmMod &m) {
   using G = HmRound<TL, LOGR, false, R>;
 #pragma unroll
@@ -510,7 +518,7 @@ HM_HD void hm_ph_mac_store(const ACC (&acc)[OUTS][HM_EPT], int tid, uint64_t *co
     for (int a = 0; a < HM_UNITS; ++a) {
       int i0, i1, x, c;
       G::unit(tid, a, i0, i1, x, c);
-      hm_gst2<G>(out[k], tile, tid, a, hm_mac_final(acc[k][i0], m), hm_mac_final(acc[k][i1], m));
+      hm_gst2<G, AUX>(out[k], tile, tid, a, hm_mac_final(acc[k][i0], m), hm_mac_final(acc[k][i1], m));
     }
 }
 

@@ -20,6 +20,11 @@ def load():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} is missing: run __graft_entry__.build() (make -C host)")
+        if os.environ.get("HOMULATOR_HIP_LIB"):
+            # an A/B build of the backend: load it first — the host library's NEEDED entry (soname libhomulator_hip.so) then binds
+            # to it instead of the in-tree build on its runpath
+            from . import hip
+            hip.load()
         L = C.CDLL(LIB_PATH)
         vp, u32, u64p = C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64)
         L.hh_op_create.argtypes = [C.POINTER(vp), C.c_char_p, C.c_char_p, u32, u32, u32, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int]
