@@ -347,9 +347,9 @@ __global__ void __launch_bounds__((1 << HM_TL_ROW) / HM_EPT) __attribute__((amdg
       hm_ph_load_global<TL, LOGR, false, R2, HM_NIP_LD_AUX>(st, tid, a.x + (size_t)xl * N, tile);
     }
 #if HM_NIP_PREFETCH
-    hm_ph_mac_regs<OUTS, Acc>(st, acc, e, m);
+    hm_ph_mac_regs<OUTS, Acc>(st, acc, e, m, j);
 #else
-    hm_ph_mac<TL, LOGR, R2, OUTS, HM_NIP_MAC_CH, Acc>(st, acc, tid, y, tile, m);
+    hm_ph_mac<TL, LOGR, R2, OUTS, HM_NIP_MAC_CH, Acc>(st, acc, tid, y, tile, m, j);
 #endif
   }
   uint64_t *out[OUTS];

@@ -438,23 +438,53 @@ HM_HD void hm_ntt_pass_phases(HmNttState &st, int tid, uint64_t *lds, const uint
 // evk MAC: HPIP src/Components.cpp:571-668, InsGen::GenHPIP src/InsGen.cpp:356-406, KeySwitch::InnerProduceOperation
 // src/Operation.cpp:294-414).  After the ROW pass of digit j (MODE 5) a thread holds 16 coefficients of ext_j in the layout
 // of the pass's last round; hm_ph_mac adds ext_j * evk_{j,k} for both keys to the thread's accumulators, which live in
-// registers across the digits: the extended digit never exists in HBM.  Accumulators are lazy: every product is reduced
-// to [0, 3q) (hm_barrett_lazy; x may be any value below 8q), up to 4 terms stay below 12q < 2^64; hm_ph_mac_store reduces once.
+// registers across the digits: the extended digit never exists in HBM.  Accumulators are lazy (below 16q, x may be any value below
+// 8q); hm_ph_mac_store reduces once.
 // ---------------------------------------------------------------------------------------------------
-// Accumulator forms: uint64_t — every product reduced to [0, 3q) before it is added (about 40 instructions per product, 64
-// registers for both keys); hm_u128 — the raw 128-bit products are summed (12 instructions per product: x < 2q and y < q keep 4
-// terms below 2^123 once x is brought below 2q) and reduced once per output by hm_barrett, at the price of 128 accumulator
-// registers (two waves per SIMD).
+// Accumulator forms: uint64_t — every product reduced lazily before it is added (64 registers for both keys); hm_u128 — the raw 128-bit
+// products are summed (12 instructions per product: x < 2q and y < q keep 4 terms below 2^123 once x is brought below 2q) and reduced
+// once per output by hm_barrett, at the price of 128 accumulator registers (two waves per SIMD).
+//
+// The lazy product (HM_NIP_BARRETT = 1, default): Barrett's quotient from two APPROXIMATE high products and no 128-bit shift.  With
+// X = 2x (x < 8q < 2^63) and Y = y 2^(64-k) (y < q < 2^k) the high word of X Y IS floor(x y / 2^(k-1)); hm_shoup_quot gives it and then
+// floor(zh mu / 2^64) from three v_mad_u64_u32 each, at most 2 below the true value.  The estimate never exceeds floor(x y / q) and is
+// at most 2 (Barrett) + 2 (zh) + 2 (second product) = 6 below it, so x y - qe q lies in [0, 7q): about 19 instructions per product
+// against 31 for the exact form (hm_barrett_lazy: full 128-bit product, variable shift, exact high product; [0, 3q)).  Two products fit
+// a word (14q < 16q <= 2^64); from the third term on the accumulator is first brought below 8q (one conditional subtraction per
+// accumulator and digit), so any number of terms stays below 15q; hm_mac_final reduces from below 16q.
+#ifndef HM_NIP_BARRETT
+#define HM_NIP_BARRETT 1
+#endif
+struct HmMacMod {
+  uint64_t mu, nq, nq8, z;
+  uint32_t ysh;
+};
+HM_HD HmMacMod hm_mac_mod(const HmMod &m) {
+  HmMacMod r;
+  r.z = hm_opaque_zero();
+  r.mu = m.mu;
+  r.nq = r.z - m.q;
+  r.nq8 = r.z - 8 * m.q;
+  r.ysh = 63 - m.sh;
+  return r;
+}
 #if defined(HM_ABL_NIP_FAKE_SHOUP)   // timing-only ablation (tools/ablate.sh): the instruction count of a Shoup product, wrong values
-HM_HD void hm_mac_add(uint64_t &acc, uint64_t x, uint64_t y, const HmMod &m) {
+HM_HD void hm_mac_add(uint64_t &acc, uint64_t x, uint64_t y, const HmMod &m, const HmMacMod &mm, bool) {
   const HmTw t = {y, y * 3 + 1};
-  HmBflyMod b; b.z = hm_opaque_zero(); b.nq = b.z - m.q;
+  HmBflyMod b; b.z = mm.z; b.nq = mm.nq;
   acc = hm_shoup_lazy4_acc(acc, x, t, b);
 }
+#elif HM_NIP_BARRETT == 1
+HM_HD void hm_mac_add(uint64_t &acc, uint64_t x, uint64_t y, const HmMod &, const HmMacMod &mm, bool fold) {
+  if (fold) acc = hm_csub_neg(acc, mm.nq8);                        // [0, 15q) -> [0, 8q)
+  const uint64_t zh = hm_shoup_quot(x << 1, y << mm.ysh, mm.z);    // floor(x y / 2^(k-1)) - {0, 1, 2}
+  const uint64_t qe = hm_shoup_quot(zh, mm.mu, mm.z);              // floor(x y / q) - {0 .. 6}
+  acc = acc + x * y + qe * mm.nq;                                  // + (x y mod q) + {0 .. 6} q, exact in the low word
+}
 #else
-HM_HD void hm_mac_add(uint64_t &acc, uint64_t x, uint64_t y, const HmMod &m) { acc += hm_barrett_lazy((hm_u128)x * y, m); }
+HM_HD void hm_mac_add(uint64_t &acc, uint64_t x, uint64_t y, const HmMod &m, const HmMacMod &, bool) { acc += hm_barrett_lazy((hm_u128)x * y, m); }   // [0, 3q): 4 terms below 12q
 #endif
-HM_HD void hm_mac_add(hm_u128 &acc, uint64_t x, uint64_t y, const HmMod &) { acc += (hm_u128)x * y; }
+HM_HD void hm_mac_add(hm_u128 &acc, uint64_t x, uint64_t y, const HmMod &, const HmMacMod &, bool) { acc += (hm_u128)x * y; }
 HM_HD uint64_t hm_mac_final(uint64_t acc, const HmMod &m) { return hm_reduce16(acc, m.q); }
 HM_HD uint64_t hm_mac_final(hm_u128 acc, const HmMod &m) { return hm_barrett(acc, m); }   // 4 terms x (x < 2q) x (y < q) < 2^123
 // [0, 8q) -> [0, 2q): the wide accumulators take transform outputs below 2q, so that the sum stays inside hm_barrett's range
@@ -464,8 +494,10 @@ HM_HD void hm_ph_below_2q(HmNttState &st, uint64_t q) {
   for (int i = 0; i < HM_EPT; ++i) st.v[i] = hm_csub_neg(hm_csub_neg(st.v[i], m.nq4), m.z - 2 * q);
 }
 template <int TL, int LOGR, int R, int OUTS, int CH = 2, class ACC = uint64_t>
-HM_HD void hm_ph_mac(const HmNttState &st, ACC (&acc)[OUTS][HM_EPT], int tid, const uint64_t *const (&y)[OUTS], uint32_t tile, const HmMod &m) {
+HM_HD void hm_ph_mac(const HmNttState &st, ACC (&acc)[OUTS][HM_EPT], int tid, const uint64_t *const (&y)[OUTS], uint32_t tile, const HmMod &m, uint32_t term) {
   using G = HmRound<TL, LOGR, false, R>;
+  const HmMacMod mm = hm_mac_mod(m);
+  const bool fold = term >= 2;   // wave-uniform
 #pragma unroll
   for (int a2 = 0; a2 < HM_UNITS; a2 += CH) {
     uint64_t e[OUTS][2 * CH];
@@ -479,8 +511,8 @@ HM_HD void hm_ph_mac(const HmNttState &st, ACC (&acc)[OUTS][HM_EPT], int tid, co
       G::unit(tid, a2 + c, i0, i1, x, cc);
 #pragma unroll
       for (int k = 0; k < OUTS; ++k) {
-        hm_mac_add(acc[k][i0], st.v[i0], e[k][2 * c], m);
-        hm_mac_add(acc[k][i1], st.v[i1], e[k][2 * c + 1], m);
+        hm_mac_add(acc[k][i0], st.v[i0], e[k][2 * c], m, mm, fold);
+        hm_mac_add(acc[k][i1], st.v[i1], e[k][2 * c + 1], m, mm, fold);
       }
     }
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -503,11 +535,13 @@ HM_HD void hm_ph_key_load(uint64_t (&e)[OUTS][HM_EPT], int tid, const uint64_t *
     }
 }
 template <int OUTS, class ACC>
-HM_HD void hm_ph_mac_regs(const HmNttState &st, ACC (&acc)[OUTS][HM_EPT], const uint64_t (&e)[OUTS][HM_EPT], const HmMod &m) {
+HM_HD void hm_ph_mac_regs(const HmNttState &st, ACC (&acc)[OUTS][HM_EPT], const uint64_t (&e)[OUTS][HM_EPT], const HmMod &m, uint32_t term) {
+  const HmMacMod mm = hm_mac_mod(m);
+  const bool fold = term >= 2;
 #pragma unroll
   for (int k = 0; k < OUTS; ++k)
 #pragma unroll
-    for (int i = 0; i < HM_EPT; ++i) hm_mac_add(acc[k][i], st.v[i], e[k][i], m);
+    for (int i = 0; i < HM_EPT; ++i) hm_mac_add(acc[k][i], st.v[i], e[k][i], m, mm, fold);
 }
 template <int TL, int LOGR, int R, int OUTS, class ACC, int AUX = 0>
 HM_HD void hm_ph_mac_store(const ACC (&acc)[OUTS][HM_EPT], int tid, uint64_t *const (&out)[OUTS], uint32_t tile, const HmMod &m) {

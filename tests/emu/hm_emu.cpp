@@ -100,6 +100,13 @@ void *emu_create(uint32_t logN, uint32_t L, uint32_t K) {
   }
   return e;
 }
+// the same with a caller-chosen chain (q: L moduli, p: K special moduli; primes = 1 mod 2N below 2^60): only the modulus constants are
+// built, for the element-wise checks that need no twiddle tables
+void *emu_create_mods(uint32_t logN, uint32_t L, uint32_t K, const uint64_t *q, const uint64_t *p) {
+  Emu *e = new Emu;
+  e->P.init(logN, L, K, q, p, nullptr);
+  return e;
+}
 void emu_destroy(void *h) { delete (Emu *)h; }
 uint64_t emu_modulus(void *h, uint32_t m) { return ((Emu *)h)->P.mod[m]; }
 uint64_t emu_psi(void *h, uint32_t m) { return ((Emu *)h)->P.psi[m]; }
@@ -220,4 +227,15 @@ void emu_fill(void *h, uint32_t mod, uint64_t stream, uint64_t *out) {
   Emu &e = *(Emu *)h;
   for (uint32_t x = 0; x < e.P.N; ++x) out[x] = hm_synth(stream, x, e.P.mod[mod]);
 }
+
+// the fused kernel's key multiply-accumulate (hm_mac_add, lazy form) element by element: acc[i] (+)= x[i] * y[i], `fold` as for the third
+// and later terms; returns the raw lazy accumulators (the test checks range and congruence), and the final reduction separately
+int emu_mac(void *h, uint32_t mod, uint64_t *acc, const uint64_t *x, const uint64_t *y, uint32_t n, int fold) {
+  Emu &e = *(Emu *)h;
+  const HmMod &m = e.P.modc[mod];
+  const hm16::HmMacMod mm = hm16::hm_mac_mod(m);
+  for (uint32_t i = 0; i < n; ++i) hm16::hm_mac_add(acc[i], x[i], y[i], m, mm, fold != 0);
+  return 0;
+}
+uint64_t emu_mac_final(void *h, uint32_t mod, uint64_t acc) { return hm16::hm_mac_final(acc, ((Emu *)h)->P.modc[mod]); }
 }

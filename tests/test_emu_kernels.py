@@ -233,3 +233,50 @@ def test_emu_ntt_eight_coefficients_per_thread(emu):
         assert np.array_equal(out, o.ewe(6, [m], mn[None], None, o.ntt([m], x[None]), k=[k])[0])
     finally:
         emu.emu_destroy(h)
+
+
+def test_emu_key_mac_lazy_ranges(emu):
+    """the fused transform x key kernel's multiply-accumulate (hm_mac_add): Barrett's quotient from two approximate high products.
+    For x anywhere below 8q (the transform's lazy output), y below q: every product adds x*y mod q plus at most 6q, two terms stay
+    below 14q, with the fold from the third term on any number of terms stays below 15q, and the final reduction is x.y mod q —
+    with the extreme operands (0, 1, q-1, 8q-1, values next to powers of two) and random ones, for the default chain (60-bit moduli)
+    and for 59-, 45- and 31-bit moduli (the operand shift 64 - k and the quotient constant depend on the width k)"""
+    emu.emu_mac.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]
+    emu.emu_mac_final.restype = C.c_uint64
+    emu.emu_mac_final.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64]
+    from sympy import isprime
+    emu.emu_create_mods.restype = C.c_void_p
+    emu.emu_create_mods.argtypes = [C.c_uint32] * 3 + [C.c_void_p] * 2
+    small = []
+    for bits in (59, 45, 31, 59, 45, 31):
+        c = (1 << bits) - (1 << 14) + 1 - (len(small) << 20)
+        while not isprime(c) or c in small:
+            c -= 1 << 14
+        small.append(c)
+    chain = np.array(small, dtype=np.uint64)
+    rng = np.random.default_rng(5)
+    for h, mod in [(emu.emu_create(13, 4, 2), m) for m in range(6)] + [(emu.emu_create_mods(13, 4, 2, p(chain[:4]), p(chain[4:])), m) for m in range(6)]:
+        q = emu.emu_modulus(h, mod)
+        xs = [0, 1, q - 1, q, 2 * q, 4 * q - 1, 8 * q - 1, 8 * q - 2, (1 << 32) - 1, 1 << 32, (1 << 62) + 1, (1 << 32) + 1]
+        ys = [0, 1, q - 1, q - 2, (1 << 32) - 1, 1 << 32, (1 << 59) + 12345, q >> 1]
+        ex = [(x, y) for x in xs if x < 8 * q for y in ys if y < q]
+        n = 4096
+        X = np.concatenate([np.array([e[0] for e in ex], dtype=np.uint64), (rng.integers(0, 1 << 63, n, dtype=np.uint64) % np.uint64(8 * q))])
+        Y = np.concatenate([np.array([e[1] for e in ex], dtype=np.uint64), (rng.integers(0, 1 << 63, n, dtype=np.uint64) % np.uint64(q))])
+        n = len(X)
+        acc = np.zeros(n, dtype=np.uint64)
+        want = [0] * n
+        for term in range(6):   # more terms than the kernel takes: the fold keeps the sum in range for any number
+            Xt, Yt = np.roll(X, term * 7), np.roll(Y, term * 3)
+            before = acc.copy()
+            emu.emu_mac(h, mod, p(acc), p(Xt), p(Yt), n, 1 if term >= 2 else 0)
+            for i in range(n):
+                want[i] = (want[i] + int(Xt[i]) * int(Yt[i])) % q
+                a = int(acc[i])
+                assert a % q == want[i], (mod, term, i)
+                assert a < (14 * q if term < 2 else 15 * q), (mod, term, i, a // q)
+                if term < 2:
+                    assert a - int(before[i]) < 7 * q
+        for i in range(0, n, 97):
+            assert emu.emu_mac_final(h, mod, int(acc[i])) == want[i]
+        emu.emu_destroy(h)
