@@ -608,6 +608,8 @@ struct hm_ctx {
   unsigned *err_host = nullptr, *err_dev = nullptr;
   bool small_ept8 = true;      // launches of at most small_limbs entries use the 8-coefficient geometry (N = 2^16)
   uint32_t small_mode = 3;     // which passes of a small launch use it: bit 0 COL, bit 1 ROW
+  bool side_launches = false;   // independent small launches of one call side by side (hm_set_option "side_launches"): measured SLOWER, see bconv_col_launch
+  uint32_t side_max_wgs = 4096;   // ... when together they are at most this many workgroups (4 rounds of the chip)
   uint32_t small_limbs = 64;   // measured (tools/ntt_small_ab.py): 2-3 us per launch faster up to ~64 entries, equal at 115, slower from 128
   bool fused_ntt = false;  // measured slower and no lighter on HBM: opt-in
   // multi-GPU
@@ -619,6 +621,8 @@ struct hm_ctx {
   size_t stage_words = 0;
   // exchange / compute overlap inside one op: the exchanges run on a stream of their own (hm_exchange_stream), ordered against the
   // compute stream by marks (events)
+  hipStream_t sstream = nullptr;   // side stream of small independent launches (the two conversion sizes of a ModUp): fork / join by events
+  hipEvent_t sfork = nullptr, sjoin = nullptr;
   hipStream_t xstream = nullptr;
   bool xasync = false;
   hipEvent_t xdep = nullptr;
@@ -739,6 +743,7 @@ extern "C" hm_status hm_create(hm_ctx **out, const hm_params *p) {
   HM_HIP(nullptr, hipHostGetDevicePointer(reinterpret_cast<void **>(&cc->err_dev), cc->err_host, 0));
   if (const char *e = getenv("HOMULATOR_NTT_FUSED")) cc->fused_ntt = std::string(e) != "0";
   if (const char *e = getenv("HOMULATOR_NTT_SMALL_LIMBS")) { cc->small_limbs = (uint32_t)atoi(e); cc->small_ept8 = cc->small_limbs != 0; }
+  if (const char *e = getenv("HOMULATOR_SIDE_LAUNCHES")) cc->side_launches = std::string(e) != "0";
   *out = c.release();
   return HM_OK;
 }
@@ -759,6 +764,9 @@ extern "C" void hm_destroy(hm_ctx *c) {
   (void)hipFree(c->d_mods);
   (void)hipFree(c->ntt_ws);
   (void)hipHostFree(c->err_host);
+  if (c->sstream) { (void)hipStreamSynchronize(c->sstream); (void)hipStreamDestroy(c->sstream); }
+  if (c->sfork) (void)hipEventDestroy(c->sfork);
+  if (c->sjoin) (void)hipEventDestroy(c->sjoin);
   if (c->xstream) { (void)hipStreamSynchronize(c->xstream); (void)hipStreamDestroy(c->xstream); }
   if (c->xdep) (void)hipEventDestroy(c->xdep);
   for (hipEvent_t e : c->xmarks) (void)hipEventDestroy(e);
@@ -875,6 +883,7 @@ extern "C" hm_status hm_set_option(hm_ctx *c, const char *name, uint64_t value) 
   if (!c || !name) return HM_ERR_ARG;
   if (!strcmp(name, "ntt_fused")) { c->fused_ntt = value != 0; return HM_OK; }
   if (!strcmp(name, "ntt_small_mode")) { c->small_mode = (uint32_t)value & 3u; return HM_OK; }
+  if (!strcmp(name, "side_launches")) { c->side_launches = value != 0; if (value > 1) c->side_max_wgs = (uint32_t)value; return HM_OK; }
   if (!strcmp(name, "ntt_small_limbs")) { c->small_ept8 = value != 0; c->small_limbs = (uint32_t)value; return HM_OK; }
   return fail(c, HM_ERR_ARG, "hm_set_option: unknown option %s", name);
 }
@@ -1608,6 +1617,9 @@ static hm_status bconv_col_launch(hm_ctx *c, const hm_bconv_desc *descs, uint32_
     for (uint32_t t = 0; t < d.n_out; ++t) { p.out_limb[t] = limb_at(d.out_limbs, t); p.out_mod[t] = d.out_ids[t]; }
     byIn[d.n_in].push_back(p);
   }
+  struct Lnch { uint32_t n_in; dim3 grid; HmBcolArgs a; };
+  std::vector<Lnch> ls;
+  size_t totalWgs = 0;
   for (auto &kv : byIn) {
     auto &grp = kv.second;
     uint32_t max_out = 0;
@@ -1618,9 +1630,36 @@ static hm_status bconv_col_launch(hm_ctx *c, const hm_bconv_desc *descs, uint32_
     if (st) return st;
     HmBcolArgs a = {static_cast<const HmBcolProb *>(dtab), out, c->d_tw_fwd, c->P.logN, (uint32_t)grp.size(), max_out};
     const uint32_t pairs = ((uint32_t)grp.size() * (c->P.N >> HM_TL_COL) + 7) / 8 * 8;
-    const dim3 grid(pairs * max_out), block((1 << HM_TL_COL) / HM_EPT);
-    hipLaunchKernelGGL(k_bconv_col_by_n_in[kv.first], grid, block, 0, c->stream, a);
+    ls.push_back(Lnch{kv.first, dim3(pairs * max_out), a});
+    totalWgs += (size_t)pairs * max_out;
+  }
+  // Digits of different size are launches of different kernels (N_IN is a template parameter) that depend on nothing of each other.
+  // When both are small — one op at a time: 1 120 + 720 workgroups on the chip's 1 024 slots — they run side by side: the later ones go to
+  // a side stream between a fork and a join event (inside a captured plan these become graph edges), so the partly filled last round of
+  // one kernel is filled by the other.  Opt-in: measured on MI355X the two cross-stream dependencies cost more than the overlap gains
+  // (ModUp of one hmult: 147 -> 168 us, 3 050 -> 2 890 hmult/s one at a time).
+  bool fork = c->side_launches && ls.size() > 1 && totalWgs <= (size_t)c->side_max_wgs;
+  if (fork && !c->sstream) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(c->stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) fork = false;   // created on an earlier, eager run
+    else {
+      HM_HIP(c, hipStreamCreateWithFlags(&c->sstream, hipStreamNonBlocking));
+      HM_HIP(c, hipEventCreateWithFlags(&c->sfork, hipEventDisableTiming));
+      HM_HIP(c, hipEventCreateWithFlags(&c->sjoin, hipEventDisableTiming));
+    }
+  }
+  const dim3 block((1 << HM_TL_COL) / HM_EPT);
+  if (fork) {
+    HM_HIP(c, hipEventRecord(c->sfork, c->stream));
+    HM_HIP(c, hipStreamWaitEvent(c->sstream, c->sfork, 0));
+  }
+  for (size_t i = 0; i < ls.size(); ++i) {
+    hipLaunchKernelGGL(k_bconv_col_by_n_in[ls[i].n_in], ls[i].grid, block, 0, fork && i > 0 ? c->sstream : c->stream, ls[i].a);
     HM_HIP(c, hipGetLastError());
+  }
+  if (fork) {
+    HM_HIP(c, hipEventRecord(c->sjoin, c->sstream));
+    HM_HIP(c, hipStreamWaitEvent(c->stream, c->sjoin, 0));
   }
   return HM_OK;
 }

@@ -256,6 +256,11 @@ void hm_graph_destroy(hm_graph *graph);
  *   "ntt_small_limbs"  transform launches of at most this many limb-poly entries (default 64, N = 2^16) use the small-launch
  *                geometry (512-thread workgroups, 8 coefficients per thread); 0 switches it off.  Env HOMULATOR_NTT_SMALL_LIMBS.
  *   "ntt_small_mode"   which passes of such a launch use it: bit 0 = COL, bit 1 = ROW (default 3; the hand-off is the same).
+ *   "side_launches"    0 (default); 1: independent small kernels of one call (the conversion sizes of a ModUp inside
+ *                hm_ntt_inner_product) run side by side, the later ones on a side stream between a fork and a join event;
+ *                (measured slower on MI355X: the two cross-stream dependencies cost ~20 us); a value > 1 also sets the size limit in
+ *                workgroups (4096).
+ *                Env HOMULATOR_SIDE_LAUNCHES sets the default.
  * Counters:
  *   "ntt_cross_xcd"  limb-polys whose workgroups were NOT all placed on one XCD and took the agent-scope hand-off
  *                    (slow, still correct); expected 0 under the dispatcher's observed round-robin placement.
