@@ -38,6 +38,20 @@ __device__ __forceinline__ bool hm_block_map(uint32_t tiles_per_limb, uint32_t n
   return entry < n_entries;
 }
 
+// Synchronisation between the rounds of a pass.  COL pass: the exchange crosses the waves of the workgroup, every one is a barrier.
+// ROW pass: a 256-point row lives on 16 (hm16) or 32 (hm8) lanes of ONE wave in every round (HmRound::group: c = tid / lanes per row),
+// so a wave only ever reads tile words it wrote itself; LDS operations of a wave execute in order, so after the first barrier (behind
+// which the staged shared twiddles are visible) the later exchanges need no barrier at all, only that the compiler keeps the order
+// (HM_ROW_WAVE_SYNC = 1: bit-exact, 96 GPU tests; measured without difference — 4 800 hmult/s either way — so the barriers stay).
+#ifndef HM_ROW_WAVE_SYNC
+#define HM_ROW_WAVE_SYNC 0
+#endif
+template <bool STRIDED>
+__device__ __forceinline__ void hm_pass_sync(int nth) {
+  if (STRIDED || !HM_ROW_WAVE_SYNC || nth == 0) __syncthreads();
+  else { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+}
+
 // One pass of a transform over tile `tile` of limb-poly `entry`, in the workgroup's LDS buffer.
 // the two geometries of the passes (hm_ntt_core.h)
 struct Geo16 {
@@ -90,7 +104,9 @@ __device__ __forceinline__ void hm_ntt_pass_run(const HmNttArgs &a, uint64_t *ld
     ep.bk.w = en.mixk.w; ep.bk.ws = en.mixk.ws;
   }
   typename GEO::State st;
-  GEO::template phases<TL, LOGR, STRIDED, INV, MODE, LDAUX, STAUX, EPICH>(st, tid, lds, src, dst, tile, twl, twt, s0, prefix0, q, sc, ep, [] { __syncthreads(); });
+  int nsync = 0;
+  GEO::template phases<TL, LOGR, STRIDED, INV, MODE, LDAUX, STAUX, EPICH>(st, tid, lds, src, dst, tile, twl, twt, s0, prefix0, q, sc, ep,
+                                                                           [&] { hm_pass_sync<STRIDED>(nsync++); });
 }
 
 template <int LOGR, bool STRIDED, bool INV, int MODE, class GEO = Geo16>
@@ -339,7 +355,8 @@ __global__ void __launch_bounds__((1 << HM_TL_ROW) / HM_EPT) __attribute__((amdg
       const HmTw sc = {0, 0};
       const HmEpi ep = hm_epi_none();
       if (j) __syncthreads();   // the previous digit's last round has read the tile
-      hm_ntt_pass_phases<TL, LOGR, false, false, 5, HM_NIP_LD_AUX>(st, tid, lds, src, nullptr, tile, twl, twt, s0, prefix0, m.q, sc, ep, [] { __syncthreads(); });
+      int nsync = 0;
+      hm_ntt_pass_phases<TL, LOGR, false, false, 5, HM_NIP_LD_AUX>(st, tid, lds, src, nullptr, tile, twl, twt, s0, prefix0, m.q, sc, ep, [&] { hm_pass_sync<false>(nsync++); });
 #if HM_NIP_WIDE
       hm_ph_below_2q(st, m.q);
 #endif
