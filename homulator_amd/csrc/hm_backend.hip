@@ -350,7 +350,11 @@ __global__ void __launch_bounds__((1 << HM_TL_ROW) / HM_EPT) __attribute__((amdg
     uint64_t e[OUTS][HM_EPT];
     hm_ph_key_load<TL, LOGR, R2, OUTS>(e, tid, y, tile);
 #endif
+#if defined(HM_ABL_NIP_NOTRANSFORM)   // timing-only ablation: every digit taken as if already in evaluation form (loads + key MAC only)
+    if (false) {
+#else
     if (mask & (1u << j)) {   // wave-uniform
+#endif
       const uint64_t *src = a.hand + (size_t)xl * N;
       const HmTw sc = {0, 0};
       const HmEpi ep = hm_epi_none();
@@ -366,7 +370,14 @@ __global__ void __launch_bounds__((1 << HM_TL_ROW) / HM_EPT) __attribute__((amdg
 #if HM_NIP_PREFETCH
     hm_ph_mac_regs<OUTS, Acc>(st, acc, e, m, j);
 #else
+#if defined(HM_ABL_NIP_NOMAC)          // timing-only ablation: transforms only (no key loads, no products)
+#pragma unroll
+    for (int k = 0; k < OUTS; ++k)
+#pragma unroll
+      for (int i = 0; i < HM_EPT; ++i) acc[k][i] += st.v[i] + k;
+#else
     hm_ph_mac<TL, LOGR, R2, OUTS, HM_NIP_MAC_CH, Acc>(st, acc, tid, y, tile, m, j);
+#endif
 #endif
   }
   uint64_t *out[OUTS];

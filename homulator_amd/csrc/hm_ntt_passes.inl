@@ -504,7 +504,11 @@ HM_HD void hm_ph_mac(const HmNttState &st, ACC (&acc)[OUTS][HM_EPT], int tid, co
 #pragma unroll
     for (int k = 0; k < OUTS; ++k)
 #pragma unroll
+#if defined(HM_ABL_NIP_NOKEYLOAD)   // timing-only ablation: the products without the key loads
+      for (int c = 0; c < CH; ++c) { e[k][2 * c] = (uint64_t)(uintptr_t)y[k] + a2; e[k][2 * c + 1] = e[k][2 * c] + tid; }
+#else
       for (int c = 0; c < CH; ++c) hm_gld2<G>(y[k], tile, tid, a2 + c, e[k][2 * c], e[k][2 * c + 1]);
+#endif
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
       int i0, i1, x, cc;
