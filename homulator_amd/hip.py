@@ -144,10 +144,15 @@ class DeviceBuf:
 class Context:
     """One GPU, one parameter set.  Thin, 1:1 with the C ABI."""
 
-    def __init__(self, logN, L, K, device=0):
+    def __init__(self, logN, L, K, device=0, q=None, p=None):
+        """q / p: the L chain moduli and the K special moduli (primes = 1 mod 2N below 2^60); default: the library's own chain"""
         self.L = load()
         self.h = C.c_void_p()
-        prm = hm_params(logN, L, K, device, None, None, None)
+        qa = None if q is None else np.ascontiguousarray(np.asarray(q, dtype=np.uint64))
+        pa = None if p is None else np.ascontiguousarray(np.asarray(p, dtype=np.uint64))
+        if (qa is not None and len(qa) != L) or (pa is not None and len(pa) != K):
+            raise ValueError("q needs L entries and p needs K")
+        prm = hm_params(logN, L, K, device, None if qa is None else qa.ctypes.data_as(C.c_void_p), None if pa is None else pa.ctypes.data_as(C.c_void_p), None)
         st = self.L.hm_create(C.byref(self.h), C.byref(prm))
         if st != 0:
             raise HmError(f"hm_create failed ({st}): {self.L.hm_last_error(None).decode()}")

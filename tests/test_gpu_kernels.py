@@ -379,3 +379,48 @@ def test_ntt_inner_product_with_conversion_inside(n_in):
                 assert np.array_equal(got[b, k], exp), (n_in, b, k)
     finally:
         ctx.close()
+
+
+def test_inner_product_with_narrow_moduli():
+    """the key multiply-accumulate of hm_ntt_inner_product over a caller-chosen chain of 59-, 45- and 31-bit moduli (the lazy product's
+    operand shift and quotient constant depend on the modulus width): evaluation-form operands only (no transform, so no oracle is
+    needed), 4 terms, both keys, extreme operands; expected values from Python integers"""
+    from sympy import isprime
+    from homulator_amd import hip
+    logN, N = 13, 1 << 13
+    chain = []
+    for bits in (59, 45, 31, 59, 45, 31):
+        c = (1 << bits) - (1 << 14) + 1 - (len(chain) << 20)
+        while not isprime(c) or c in chain:
+            c -= 1 << 14
+        chain.append(c)
+    ctx = hip.Context(logN, 4, 2, q=chain[:4], p=chain[4:])
+    try:
+        assert ctx.moduli == chain
+        ids = [0, 1, 2, 3, 4, 5, 2, 2]
+        n, terms, outs = len(ids), 4, 2
+        rng = np.random.default_rng(11)
+        def rnd(m):
+            v = rng.integers(0, 1 << 62, N, dtype=np.uint64) % np.uint64(chain[m])
+            v[:4] = [chain[m] - 1, 0, 1, chain[m] - 2]
+            return v
+        X = np.stack([np.stack([rnd(m) for m in ids]) for _ in range(terms)])                      # [term][limb]
+        Y = np.stack([np.stack([np.stack([rnd(m) for m in ids]) for _ in range(terms)]) for _ in range(outs)])   # [key][term][limb]
+        X[:, 0, :] = chain[ids[0]] - 1
+        Y[:, :, 0, :64] = chain[ids[0]] - 1
+        xb, yb = ctx.from_host(X.reshape(-1, N)), ctx.from_host(Y.reshape(-1, N))
+        out = ctx.alloc(n * outs)
+        xl = [j * n + i for i in range(n) for j in range(terms)]
+        yl = [(k * terms + j) * n + i for i in range(n) for k in range(outs) for j in range(terms)]
+        ol = [k * n + i for i in range(n) for k in range(outs)]
+        ctx.ntt_inner_product(xb, xl, [0] * (n * terms), None, xl, yb, yl, out, ol, ids, terms, outs)
+        got = out.download()
+        for k in range(outs):
+            for i, m in enumerate(ids):
+                q = chain[m]
+                acc = np.zeros(N, dtype=object)
+                for j in range(terms):
+                    acc = (acc + X[j, i].astype(object) * Y[k, j, i].astype(object)) % q
+                assert np.array_equal(got[k * n + i].astype(object), acc), (k, i, m)
+    finally:
+        ctx.close()
