@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 #include <rccl/rccl.h>
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -1444,6 +1445,19 @@ extern "C" hm_status hm_ntt_inner_product(hm_ctx *c, const hm_ntt_ip_desc *d) {
       g.resize(G, -1);
       groups.push_back(g);
     }
+  }
+  // longest first: a limb whose digits all go through the transform (the special limbs of a ModUp: beta transforms) costs more than one
+  // with a digit of its own; workgroups are dispatched in entry order, so the heavy ones start first and the partly filled last round of a
+  // small launch holds light ones
+  {
+    auto weight = [&](const std::vector<int> &g) {
+      uint32_t w = 0;
+      for (int gi : g)
+        if (gi >= 0)
+          for (uint32_t j = 0; j < T; ++j) w += d->x_is_coeff[(uint32_t)gi * T + j] ? 3 : 1;
+      return w;
+    };
+    std::stable_sort(groups.begin(), groups.end(), [&](const std::vector<int> &a, const std::vector<int> &b) { return weight(a) > weight(b); });
   }
   const uint32_t maxGroups = HM_NIP_MAX_LIMBS / G / 8 * 8;
   const uint32_t nLaunch = ((uint32_t)groups.size() + maxGroups - 1) / maxGroups;
