@@ -209,3 +209,25 @@ def test_concurrent_instances_stay_bit_exact():
             exp = o.hmult(10, o.synth_ct(10, s), o.synth_ct(10, s + 2000), o.synth_evk(10, SEED + 7 * i + 10000))
             assert np.array_equal(op.read("out.c0", copy=c), exp[0]) and np.array_equal(op.read("out.c1", copy=c), exp[1]), (i, c)
         op.close()
+
+
+def test_bench_timed_region_configuration_is_bit_exact():
+    """exactly what bench.py times: BASELINE configs[1] (config_4.cfg hmult 45/35/15, N = 2^16), two instances in flight with their own
+    pool and stream, 10 hmults per launch, the plan replayed as a HIP graph, enqueued alternately; afterwards every one of the 20 ops
+    equals the oracle on its own inputs"""
+    from homulator_amd import host
+    L, ell, alpha = 45, 35, 15
+    o = oracle(16, L, alpha)
+    o.set_threads(16)
+    ops = [host.Op("config_4.cfg", "hmult", L, ell, alpha, overrides={"seed": SEED + 7 * i, "batch": 10, "graph": 1}) for i in range(2)]
+    for it in range(12):   # per instance: direct, capture, then four replays
+        ops[it % 2].enqueue(1)
+    for op in ops:
+        op.sync()
+    for i, op in enumerate(ops):
+        evk = o.synth_evk(ell, SEED + 7 * i + 10000)
+        for c in range(op.batch):
+            s = SEED + 7 * i + c * BATCH_SEED_STRIDE
+            exp = o.hmult(ell, o.synth_ct(ell, s), o.synth_ct(ell, s + 2000), evk, rescale=True)
+            assert np.array_equal(op.read("out.c0", copy=c), exp[0]) and np.array_equal(op.read("out.c1", copy=c), exp[1]), (i, c)
+        op.close()
