@@ -300,7 +300,7 @@ typedef const HmNipLimb __attribute__((address_space(4))) *HmConstNipLimb;
 #define HM_NIP_PREFETCH 0  // 1: all key words of a digit requested before its transform (needs HM_NIP_WAVES = 2: 64 more registers)
 #endif
 #ifndef HM_NIP_MAC_CH
-#define HM_NIP_MAC_CH 1   // access units of key words in flight per multiply-accumulate step
+#define HM_NIP_MAC_CH 2   // access units of key words in flight per multiply-accumulate step (2: +0.6 % over 1; 4 needs two waves per SIMD and gains nothing)
 #endif
 // cache policy (hm_gld2's AUX bits: 2 = nt) of the once-read operand loads and of the output stores: streamed data marked non-temporal
 // leaves the L2 to the key words, which the ops of a batch share

@@ -58,6 +58,8 @@
 #define HM_TW_LDS_ROW 1
 #endif
 #define HM_TW_IN_LDS(STRIDED) ((STRIDED) ? HM_TW_LDS_COL : HM_TW_LDS_ROW)
+// access units of the fused epilogue's operands (minuend, addend: 16 bytes per lane each) requested together before they are used.  2 units =
+// 4 loads in flight per lane beside the pass's own; 4 units spill in the 128-register ROW kernel (profiles/r03_knobs.txt)
 #ifndef HM_EPI_CHUNK
 #define HM_EPI_CHUNK 2
 #endif

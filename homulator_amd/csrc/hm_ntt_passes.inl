@@ -248,17 +248,23 @@ HM_HD void hm_ph_store_global(const HmNttState &st, int tid, uint64_t *g, uint32
   using G = HmRound<TL, LOGR, STRIDED, R>;
   // MODE 3: the epilogue operands are requested two units at a time, right before they are used (with a scheduling
   // fence in between): prefetching all of them before the last round costs 32 registers
-  // CH = units per chunk: 2 in the two-kernel transform, 1 inside the one-launch transform (whose second pass has less room)
+  // CH = units per chunk (HM_EPI_CHUNK in the two-kernel transform, 1 inside the one-launch transform, whose second pass has less room)
 #pragma unroll
   for (int a2 = 0; a2 < HM_UNITS; a2 += CH) {
-    uint64_t ea[4] = {0, 0, 0, 0}, ed[4] = {0, 0, 0, 0};
+    uint64_t ea[2 * CH], ed[2 * CH];
+#pragma unroll
+    for (int k = 0; k < 2 * CH; ++k) ea[k] = ed[k] = 0;
     if (MODE == 3) {
 #pragma unroll
       for (int k = 0; k < CH; ++k) {
         int i0, i1, x, c;
         G::unit(tid, a2 + k, i0, i1, x, c);
+#if !defined(HM_ABL_EPI_NOA)   // (timing-only ablations: the fused epilogue without its minuend / addend loads)
         hm_gld2<G>(ep.a, tile, tid, a2 + k, ea[2 * k], ea[2 * k + 1]);
+#endif
+#if !defined(HM_ABL_EPI_NOD)
         if (ep.d) hm_gld2<G>(ep.d, tile, tid, a2 + k, ed[2 * k], ed[2 * k + 1]);
+#endif
       }
     }
 #pragma unroll
