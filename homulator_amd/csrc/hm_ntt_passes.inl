@@ -256,7 +256,7 @@ HM_HD void hm_ph_store_global(const HmNttState &st, int tid, uint64_t *g, uint32
     for (int k = 0; k < 2 * CH; ++k) ea[k] = ed[k] = 0;
     if (MODE == 3) {
 #pragma unroll
-      for (int k = 0; k < CH; ++k) {
+      for (int k = 0; k < CH && a2 + k < HM_UNITS; ++k) {
         int i0, i1, x, c;
         G::unit(tid, a2 + k, i0, i1, x, c);
 #if !defined(HM_ABL_EPI_NOA)   // (timing-only ablations: the fused epilogue without its minuend / addend loads)
@@ -268,7 +268,7 @@ HM_HD void hm_ph_store_global(const HmNttState &st, int tid, uint64_t *g, uint32
       }
     }
 #pragma unroll
-    for (int k = 0; k < CH; ++k) {
+    for (int k = 0; k < CH && a2 + k < HM_UNITS; ++k) {
       int i0, i1, x, c;
       G::unit(tid, a2 + k, i0, i1, x, c);
 #if defined(HM_ABL_NOMEM)
