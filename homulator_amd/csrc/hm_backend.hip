@@ -630,6 +630,7 @@ struct hm_ctx {
   std::map<std::vector<uint32_t>, uint64_t *> bconv_tables;  // key: n_in, in_ids..., out_ids...
   std::map<std::string, void *> ntt_tables;                  // launch tables (device_table), key: their bytes
   int live_graphs = 0;                                        // captured graphs that reference the tables: no eviction while > 0
+  std::vector<struct hm_graph *> graphs;                      // ... the graphs themselves: hm_destroy detaches them (a late hm_graph_destroy must not touch a freed context)
   bool capturing = false;
   std::string err;
   // one-launch transforms (k_ntt_fused): rendezvous words in HBM, a host-visible error word, and the switch
@@ -641,6 +642,7 @@ struct hm_ctx {
   uint32_t side_max_wgs = 4096;   // ... when together they are at most this many workgroups (4 rounds of the chip)
   uint32_t small_limbs = 64;   // measured (tools/ntt_small_ab.py): 2-3 us per launch faster up to ~64 entries, equal at 115, slower from 128
   bool fused_ntt = false;  // measured slower and no lighter on HBM: opt-in
+  uint32_t fused_extra_lds = 0;   // dynamic LDS added to every k_ntt_fused workgroup: occupancy throttle of the L2 hand-off experiment
   // multi-GPU
   int rank = 0, world = 1;
   ncclComm_t comm = nullptr;
@@ -771,16 +773,19 @@ extern "C" hm_status hm_create(hm_ctx **out, const hm_params *p) {
   memset(cc->err_host, 0, 64);
   HM_HIP(nullptr, hipHostGetDevicePointer(reinterpret_cast<void **>(&cc->err_dev), cc->err_host, 0));
   if (const char *e = getenv("HOMULATOR_NTT_FUSED")) cc->fused_ntt = std::string(e) != "0";
+  if (const char *e = getenv("HOMULATOR_NTT_FUSED_LDS")) cc->fused_extra_lds = (uint32_t)std::min(120 * 1024, std::max(0, atoi(e)));
   if (const char *e = getenv("HOMULATOR_NTT_SMALL_LIMBS")) { cc->small_limbs = (uint32_t)atoi(e); cc->small_ept8 = cc->small_limbs != 0; }
   if (const char *e = getenv("HOMULATOR_SIDE_LAUNCHES")) cc->side_launches = std::string(e) != "0";
   *out = c.release();
   return HM_OK;
 }
 
+static void detach_graphs(hm_ctx *c);
 extern "C" void hm_destroy(hm_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
+  detach_graphs(c);
   for (auto &kv : c->bconv_tables) (void)hipFree(kv.second);
   if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
   (void)hipFree(c->stage_send);
@@ -911,6 +916,7 @@ extern "C" hm_status hm_wait_for(hm_ctx *c, hm_ctx *producer) {
 extern "C" hm_status hm_set_option(hm_ctx *c, const char *name, uint64_t value) {
   if (!c || !name) return HM_ERR_ARG;
   if (!strcmp(name, "ntt_fused")) { c->fused_ntt = value != 0; return HM_OK; }
+  if (!strcmp(name, "ntt_fused_lds")) { if (value > 120 * 1024) return fail(c, HM_ERR_ARG, "hm_set_option: ntt_fused_lds above 120 KiB"); c->fused_extra_lds = (uint32_t)value; return HM_OK; }
   if (!strcmp(name, "ntt_small_mode")) { c->small_mode = (uint32_t)value & 3u; return HM_OK; }
   if (!strcmp(name, "side_launches")) { c->side_launches = value != 0; if (value > 1) c->side_max_wgs = (uint32_t)value; return HM_OK; }
   if (!strcmp(name, "ntt_small_limbs")) { c->small_ept8 = value != 0; c->small_limbs = (uint32_t)value; return HM_OK; }
@@ -933,6 +939,10 @@ struct hm_graph {
   hipGraphExec_t exec = nullptr;
   hm_ctx *owner = nullptr;   // its kernel nodes keep device addresses of the owner's launch tables: destroy graphs before their context
 };
+static void detach_graphs(hm_ctx *c) {
+  for (hm_graph *g : c->graphs) g->owner = nullptr;
+  c->graphs.clear();
+}
 extern "C" hm_status hm_capture_begin(hm_ctx *c) {
   if (!c) return HM_ERR_ARG;
   if (c->ext_fn) return fail(c, HM_ERR_UNSUPPORTED, "hm_capture_begin: an external exchange transport cannot be captured");
@@ -954,18 +964,24 @@ extern "C" hm_status hm_capture_end(hm_ctx *c, hm_graph **out) {
     return fail(c, HM_ERR_HIP, "hm_capture_end: %s", hipGetErrorString(e));
   }
   g->owner = c;
+  c->graphs.push_back(g);
   c->live_graphs++;   // the launch-table cache is pinned while this graph lives (released in hm_graph_destroy)
   *out = g;
   return HM_OK;
 }
 extern "C" hm_status hm_graph_launch(hm_ctx *c, hm_graph *g) {
   if (!c || !g) return HM_ERR_ARG;
+  if (g->owner != c) return fail(c, HM_ERR_ARG, "hm_graph_launch: the graph was captured from another (or a destroyed) context");
   HM_HIP(c, hipGraphLaunch(g->exec, c->stream));
   return HM_OK;
 }
 extern "C" void hm_graph_destroy(hm_graph *g) {
   if (!g) return;
-  if (g->owner && g->owner->live_graphs > 0) g->owner->live_graphs--;
+  if (g->owner) {
+    if (g->owner->live_graphs > 0) g->owner->live_graphs--;
+    auto &v = g->owner->graphs;
+    v.erase(std::remove(v.begin(), v.end(), g), v.end());
+  }
   (void)hipGraphExecDestroy(g->exec);
   (void)hipGraphDestroy(g->graph);
   delete g;
@@ -1034,10 +1050,17 @@ static void launch_ntt(hm_ctx *c, const HmNttArgs &a, bool fusedEpilogue, bool m
   }
   if (c->fused_ntt) {   // both passes in one launch, hand-off through the XCD's L2
     const HmNttFusedArgs f = {c->ntt_ws, c->err_dev};
-    if (inverse) hipLaunchKernelGGL((k_ntt_fused<LOG1, true, 0, 2>), gridR, blockR, 0, c->stream, a, f);
-    else if (mixPrologue) hipLaunchKernelGGL((k_ntt_fused<LOG1, false, 4, 3>), gridR, blockR, 0, c->stream, a, f);
-    else if (fusedEpilogue) hipLaunchKernelGGL((k_ntt_fused<LOG1, false, 0, 3>), gridR, blockR, 0, c->stream, a, f);
-    else hipLaunchKernelGGL((k_ntt_fused<LOG1, false, 0, 1>), gridR, blockR, 0, c->stream, a, f);
+    // "ntt_fused_lds": extra dynamic LDS per workgroup = an occupancy throttle (100 KiB: one workgroup per CU = 32 per XCD = two
+    // limb-polys in flight per XCD, 3 MiB live per 4 MiB L2): the capacity-controlled form of the hand-off experiment
+    const uint32_t xl = c->fused_extra_lds;
+    auto go = [&](auto kern) {
+      if (xl > 24 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)xl);
+      hipLaunchKernelGGL(kern, gridR, blockR, xl, c->stream, a, f);
+    };
+    if (inverse) go(k_ntt_fused<LOG1, true, 0, 2>);
+    else if (mixPrologue) go(k_ntt_fused<LOG1, false, 4, 3>);
+    else if (fusedEpilogue) go(k_ntt_fused<LOG1, false, 0, 3>);
+    else go(k_ntt_fused<LOG1, false, 0, 1>);
     return;
   }
   if (!inverse) {
@@ -1409,11 +1432,23 @@ extern "C" hm_status hm_ntt_inner_product(hm_ctx *c, const hm_ntt_ip_desc *d) {
       if (d->conv[k].out != d->hand) return fail(c, HM_ERR_ARG, "hm_ntt_inner_product: conv[%u].out must be the hand-off buffer", k);
     if ((st = bconv_col_launch(c, d->conv, d->n_conv))) return st;
   }
+  // a launch may mix digits whose conversion runs inside their first pass with digits that arrive converted (Arch decides per
+  // inner-product record: a digit of more than HM_BCOL_MAX_IN limbs keeps its own conversion): every transformed (limb, digit) whose
+  // hand-off limb no conversion writes gets its first pass here
+  std::vector<char> covered;
+  for (uint32_t k = 0; k < d->n_conv; ++k)
+    for (uint32_t t = 0; t < d->conv[k].n_out; ++t) {
+      const uint32_t hl = limb_at(d->conv[k].out_limbs, t);
+      if (hl >= covered.size()) covered.resize((size_t)hl + 1, 0);
+      covered[hl] = 1;
+    }
   std::vector<uint32_t> cin, chand, cmod;
   for (uint32_t i = 0; i < n; ++i)
     for (uint32_t j = 0; j < T; ++j)
-      if (d->x_is_coeff[i * T + j] && !d->n_conv) {
-        cin.push_back(d->x_limbs[i * T + j]); chand.push_back(d->hand_limbs[i * T + j]); cmod.push_back(d->mod_ids[i]);
+      if (d->x_is_coeff[i * T + j]) {
+        const uint32_t hl = d->hand_limbs[i * T + j];
+        if (hl < covered.size() && covered[hl]) continue;
+        cin.push_back(d->x_limbs[i * T + j]); chand.push_back(hl); cmod.push_back(d->mod_ids[i]);
       }
   if (!cin.empty()) {
     NttFused f;

@@ -163,6 +163,9 @@ typedef struct hm_ntt_ip_desc {
    * (hand + hand_limbs[i][j] * N) of the (limb, digit) its output t feeds: the conversion runs INSIDE the first pass of that
    * transform (the workgroup of an output limb's column tile converts its own coefficients from the input tiles), so the
    * converted limb-polys (BConvOut_(j)) are never written to HBM or read back; x / x_limbs of those digits are ignored.
+   * The conversions need not cover every transformed digit: a transformed (limb, digit) whose hand-off limb is not an output of
+   * any conv[k] is read from x / x_limbs as usual (one call may mix both kinds, e.g. a ModUp whose first digit is wider than the
+   * fused conversion admits).
    * N = 2^16 and n_in <= 15 (HM_ERR_UNSUPPORTED otherwise: convert with hm_bconv_batch first).  Bit-identical to
    * hm_bconv_batch + hm_ntt_inner_product. */
   const struct hm_bconv_desc *conv; uint32_t n_conv;
@@ -247,6 +250,8 @@ typedef struct hm_graph hm_graph;
 hm_status hm_capture_begin(hm_ctx *ctx);
 hm_status hm_capture_end(hm_ctx *ctx, hm_graph **graph);
 hm_status hm_graph_launch(hm_ctx *ctx, hm_graph *graph);
+/* Destroy a context's graphs BEFORE hm_destroy(ctx): a graph's kernel nodes hold device addresses of the context's launch
+ * tables.  (hm_destroy detaches graphs that are still alive, so a late hm_graph_destroy is safe; replaying one is not.) */
 void hm_graph_destroy(hm_graph *graph);
 
 /* Execution options of a context (A/B measurements, tests; every option has a working default):

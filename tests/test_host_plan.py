@@ -50,3 +50,21 @@ def test_where_the_conversion_moves_into_the_transform(cfg, L, ell, alpha, conv_
     assert (len(modup_bconv) == 0) == conv_inside, p
     p0, total0, _ = plan(cfg, "hmult", L, ell, alpha, fuse_hpip=0, fuse_bconv=0)
     assert total0 == total
+
+
+def test_mixed_launch_keeps_the_wide_digits_conversion():
+    """config_4.cfg hmult 45 20 16: digits of 16 and 4 limbs.  The 4-limb digit's conversion moves into the first pass of its transforms
+    (16 limbs: the ones whose only transformed digit it is); the 16-limb digit is wider than the fused conversion admits and keeps its own
+    BCONV launch.  ONE NTT_IP launch then mixes both kinds: the backend runs the first pass of every transformed (limb, digit) that no
+    conversion of the call covers (round 3 skipped it as soon as any conversion was fused: ADVICE round 3, tests/test_gpu_ops.py has
+    the parity case)."""
+    p, total, n = plan("config_4.cfg", "hmult", 45, 20, 16)
+    modup_bconv = [ln for ln in p if ln.startswith("BCONV") and "ModUp_BCONV" in ln]
+    nip = [ln for ln in p if ln.startswith("NTT_IP")]
+    assert len(modup_bconv) == 1 and len(nip) == 1, p
+    # 20 outputs of the wide digit + the 16 special limbs of the narrow one (both of their digits are transformed, one of them not
+    # fusable, so the record keeps both conversions); the other 16 outputs of the narrow digit are converted inside their first pass
+    assert int(re.search(r"n=(\d+)", modup_bconv[0]).group(1)) == 20 + 16
+    assert int(re.search(r"n=(\d+)", nip[0]).group(1)) == 36
+    p0, total0, _ = plan("config_4.cfg", "hmult", 45, 20, 16, fuse_hpip=0, fuse_bconv=0)
+    assert total0 == total

@@ -41,11 +41,13 @@ def _path(L, env):
 
 def test_name_is_unique_to_the_run():
     L = _lib()
-    base = {"HOMULATOR_RCCL_ID_FILE": None, "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29500", "TORCHELASTIC_RUN_ID": None}
+    base = {"HOMULATOR_RCCL_ID_FILE": None, "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29500", "TORCHELASTIC_RUN_ID": None, "TORCHELASTIC_RESTART_COUNT": None}
     a = _path(L, base)
     assert str(os.getppid()) in a and "29500" in a          # the launcher's pid: shared by the ranks of ONE launch
     assert _path(L, {**base, "TORCHELASTIC_RUN_ID": "run-1"}) != _path(L, {**base, "TORCHELASTIC_RUN_ID": "run-2"}) != a
     assert _path(L, {**base, "MASTER_PORT": "29501"}) != a
+    # a restarted attempt of the same launcher (same agent pid, same run id) must not find the dead attempt's file
+    assert _path(L, {**base, "TORCHELASTIC_RUN_ID": "run-1", "TORCHELASTIC_RESTART_COUNT": "1"}) != _path(L, {**base, "TORCHELASTIC_RUN_ID": "run-1", "TORCHELASTIC_RESTART_COUNT": "0"})
     assert _path(L, {**base, "HOMULATOR_RCCL_ID_FILE": "/tmp/x.id"}) == "/tmp/x.id"
 
 
@@ -67,6 +69,21 @@ def test_stale_file_and_slow_rank(tmp_path):
     got2 = C.create_string_buffer(128)
     assert L.hh_rccl_id_fetch(p, got2, 200) == 0 and got2.raw == fresh
     assert L.hh_rccl_id_remove(p) == 0 and not os.path.exists(p)
+
+
+def test_publish_does_not_follow_a_planted_symlink(tmp_path):
+    L = _lib()
+    p = str(tmp_path / "id")
+    victim = tmp_path / "victim"
+    victim.write_bytes(b"precious")
+    os.symlink(victim, p + ".tmp")                           # someone else pre-created the temporary name as a link
+    assert L.hh_rccl_id_publish(p.encode(), bytes(range(128))) == 0
+    assert victim.read_bytes() == b"precious" and not os.path.islink(p)
+    assert (os.stat(p).st_mode & 0o777) == 0o600
+    os.unlink(p)
+    os.symlink(victim, p)                                    # ... or the final name: a waiting rank does not read through it
+    got = C.create_string_buffer(128)
+    assert L.hh_rccl_id_fetch(p.encode(), got, 100) != 0
 
 
 def test_library_ops_ignore_the_launcher_environment(monkeypatch):
