@@ -268,6 +268,159 @@ __global__ void __launch_bounds__((1 << HM_TL_ROW) / HM_EPT) __attribute__((amdg
   hm_limb_leave(f.ws, entry, members, !same);
 }
 
+// ---- both passes of a transform in ONE persistent launch, fed from per-XCD work queues (round 4) ----------------------------------
+// What round 4's counters say about the hand-off between the passes (profiles/r04_l2_handoff.txt): the XCD's L2 is WRITE-BACK for plain
+// stores — with at most ~3 MiB live per L2 the first pass's stores never reach the fabric when the second pass's final stores land on the
+// same lines (WRITE_SIZE halves) — and the second pass's loads of the hand-off HIT (TCC_MISS falls by exactly the hand-off's line count);
+// a line that was allocated by a store is still filled from the fabric once when it is first read (TCC_EA0_RDREQ keeps the hand-off's
+// lines), unless it was resident before the store: a transform IN PLACE (in == out) moves each limb-poly across the fabric twice, not four
+// times.  Round 3's one-launch kernel could not show it: a workgroup per tile with a rendezvous in the middle keeps 8 limb-polys in flight
+// per XCD (12 MiB through a 4 MiB L2) and idles every slot at the rendezvous.
+//
+// Here the grid is PERSISTENT (a few workgroups per CU, the launch decides how many) and every workgroup pulls work items from the queue of
+// the XCD it really runs on (HW_REG_XCC_ID):
+//   * an item = one pass over one 4096-coefficient tile of one limb-poly; a queue's items come in blocks of (group of Gc same-modulus
+//     limb-polys) x (tiles), in the order  A(0) .. A(LA-1), B(0), A(LA), B(1), A(LA+1), ...  (A = first pass, B = second pass, LA = look-ahead
+//     in groups): the second pass of a group is handed out when its first pass finished LA blocks ago, so nobody waits in steady state, and
+//     at most LA + (workgroups in flight / tiles) groups are between their passes: the hand-off stays in the L2;
+//   * a queue's slot s gets its group from a global counter when its first item is pulled: limb-polys are dealt to the XCDs on demand (the
+//     50 limb-polys of a sweep do not divide by 8), and ALL items of a limb-poly run on ONE XCD by construction — whatever the dispatcher does
+//     with the grid, the hand-off never crosses XCDs (no agent-scope path, no placement assumption); an XCD without workgroups takes nothing;
+//   * a waiting workgroup only ever waits for items that running workgroups have already pulled: no residency assumption either.
+// Hand-off protocol (same as k_ntt_fused's same-XCD path): plain stores, every storing wave s_waitcnt vmcnt(0), workgroup barrier, one lane
+// adds to the limb-poly's counter; the consumer polls that counter (agent-scope relaxed load), barrier, then reads the hand-off with loads
+// that bypass its CU's vector L1 (sc1 / nt), which another CU's stores never refresh.
+#define HM_Q_MAX_SLOTS (HM_NTT_MAX_ENTRIES + 32)
+#define HM_Q_NONE 0xFFFFFFFFu
+struct HmNttQueue {                  // device; all zero between launches (the last workgroup out resets what the launch touched)
+  unsigned next_group, exited, pad0[14];
+  struct Xcd {
+    unsigned next_item, pad[15];
+    unsigned slot_group[HM_Q_MAX_SLOTS];   // 0 = unclaimed, 1 = being claimed, else group + 2 (HM_Q_NONE: no group left)
+  } xcd[8];
+  unsigned first_done[HM_NTT_MAX_ENTRIES];  // per limb-poly: tiles whose first pass has been stored
+};
+struct HmNttQueueArgs {
+  HmNttQueue *q;
+  unsigned *err;          // host-visible: 3 = a queue wait timed out
+  uint32_t n_groups;      // groups of `gc` consecutive entries of HmNttArgs::limb (dense: entry = group * gc + member)
+  uint32_t gc;            // limb-polys per group (same modulus: their tiles are handed out side by side and share the row twiddles in L2)
+  uint32_t lookahead;     // LA >= 1
+};
+#ifndef HM_Q_IN_AUX
+#define HM_Q_IN_AUX 0     // cache policy of the first pass's input loads (2 = nt: streamed once)
+#endif
+#ifndef HM_Q_OUT_AUX
+#define HM_Q_OUT_AUX 0    // ... of the second pass's output stores
+#endif
+#ifndef HM_Q_MID_AUX
+#define HM_Q_MID_AUX 16   // the hand-off loads: sc1 (L1 bypass, served by the XCD's L2)
+#endif
+__device__ __forceinline__ unsigned hm_q_load(unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// group of slot s on this XCD's queue (claimed from the global counter by whoever needs it first; claims are made in slot order, so the
+// groups of a queue increase with s and "no group left" is final)
+__device__ __forceinline__ unsigned hm_q_slot_group(HmNttQueue *Q, HmNttQueue::Xcd *x, unsigned s, unsigned n_groups, unsigned *err) {
+  if (s >= HM_Q_MAX_SLOTS) return HM_Q_NONE;
+  unsigned v = hm_q_load(&x->slot_group[s]);
+  unsigned spins = 0;
+  while (v < 2) {
+    if (v == 0) {
+      if (s > 0) {   // in slot order
+        while (hm_q_load(&x->slot_group[s - 1]) < 2) { __builtin_amdgcn_s_sleep(2); if (++spins > HM_SPIN_LIMIT) { __hip_atomic_store(err, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return HM_Q_NONE; } }
+      }
+      unsigned expect = 0;
+      if (__hip_atomic_compare_exchange_strong(&x->slot_group[s], &expect, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+        const unsigned g = __hip_atomic_fetch_add(&Q->next_group, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v = g < n_groups ? g + 2 : HM_Q_NONE;
+        __hip_atomic_store(&x->slot_group[s], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return v;
+      }
+    }
+    __builtin_amdgcn_s_sleep(2);
+    if (++spins > HM_SPIN_LIMIT) { __hip_atomic_store(err, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return HM_Q_NONE; }
+    v = hm_q_load(&x->slot_group[s]);
+  }
+  return v;
+}
+// MODE_A: first pass (0, or 4 = mix prologue); MODE_B: last pass (1 forward, 3 fused epilogue, 2 inverse)
+template <int LOG1, bool INV, int MODE_A, int MODE_B, class GEO>
+__device__ __forceinline__ void hm_ntt_queue_body(const HmNttArgs &a, const HmNttQueueArgs &f) {
+  static_assert(HM_TL_COL == HM_TL_ROW, "one tile size for both passes");
+  constexpr int TL = HM_TL_ROW;
+  constexpr int W1 = GEO::template ldsWords<TL, LOG1, true>(), W2 = GEO::template ldsWords<TL, HM_ROW_LOG, false>();
+  __shared__ __attribute__((aligned(16))) uint64_t lds[(W1 > W2 ? W1 : W2) + 2];
+  volatile uint32_t *ctl = reinterpret_cast<volatile uint32_t *>(lds + (W1 > W2 ? W1 : W2));   // [0] entry (HM_Q_NONE: leave, NONE - 1: skip), [1] tile, [2] pass
+  const uint32_t tiles = 1u << (a.logN - TL);
+  const uint32_t per_block = tiles * f.gc;
+  HmNttQueue *Q = f.q;
+  HmNttQueue::Xcd *x = &Q->xcd[hm_xcc_id()];
+#pragma unroll 1
+  for (;;) {
+    if (threadIdx.x == 0) {
+      const unsigned i = __hip_atomic_fetch_add(&x->next_item, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned j = i / per_block, w = i % per_block;
+      unsigned second, s;
+      if (j < f.lookahead) { second = 0; s = j; }
+      else { const unsigned m = j - f.lookahead; second = (m & 1u) ^ 1u; s = second ? m / 2 : f.lookahead + m / 2; }
+      const unsigned v = hm_q_slot_group(Q, x, s, f.n_groups, f.err);
+      unsigned entry = HM_Q_NONE;
+      if (v != HM_Q_NONE) {
+        entry = (v - 2) * f.gc + w % f.gc;
+        if (entry >= a.n_limbs || a.limb[entry].mod == HM_NTT_NONE) entry = HM_Q_NONE - 1;   // padding of the last group
+        else if (second) {
+          unsigned spins = 0;
+          while (hm_q_load(&Q->first_done[entry]) < tiles) {
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > HM_SPIN_LIMIT) { __hip_atomic_store(f.err, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+          }
+        }
+      } else if (!second) entry = HM_Q_NONE - 1;   // a first-pass block beyond the last group: later blocks may still hold second passes
+      ctl[0] = entry; ctl[1] = w / f.gc; ctl[2] = second;
+    }
+    __syncthreads();
+    const uint32_t entry = ctl[0], tile = ctl[1], second = ctl[2];
+    __syncthreads();   // ctl is rewritten by the next pull; the passes below start with their own LDS traffic
+    if (entry == HM_Q_NONE) break;
+    if (entry == HM_Q_NONE - 1) continue;
+    // a thread id the compiler cannot connect across the items (see k_ntt_fused)
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    __builtin_assume(tid >= 0 && tid < (1 << TL) / GEO::EPT);
+    if (!second) {
+      if (!INV) hm_ntt_pass_run<LOG1, true, false, MODE_A, HM_Q_IN_AUX, 0, HM_EPI_CHUNK, GEO>(a, lds, entry, tile, tid);
+      else hm_ntt_pass_run<HM_ROW_LOG, false, true, MODE_A, HM_Q_IN_AUX, 0, HM_EPI_CHUNK, GEO>(a, lds, entry, tile, tid);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave: its stores have reached the L2
+      __syncthreads();
+      if (threadIdx.x == 0) __hip_atomic_fetch_add(&Q->first_done[entry], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      if (!INV) hm_ntt_pass_run<HM_ROW_LOG, false, false, MODE_B, HM_Q_MID_AUX, HM_Q_OUT_AUX, 1, GEO>(a, lds, entry, tile, tid);
+      else hm_ntt_pass_run<LOG1, true, true, MODE_B, HM_Q_MID_AUX, HM_Q_OUT_AUX, HM_EPI_CHUNK, GEO>(a, lds, entry, tile, tid);
+    }   // (the barriers at the top of the loop keep the next item's LDS writes behind this item's last reads)
+  }
+  // the last workgroup out resets the words this launch touched (everybody else has made its last access)
+  __shared__ unsigned last;
+  if (threadIdx.x == 0) last = __hip_atomic_fetch_add(&Q->exited, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+  __syncthreads();
+  if (last) {
+    for (uint32_t k = 0; k < 8; ++k) {
+      const unsigned used = min((unsigned)HM_Q_MAX_SLOTS, hm_q_load(&Q->xcd[k].next_item) / per_block + 2u);
+      for (uint32_t s = threadIdx.x; s < used; s += blockDim.x) Q->xcd[k].slot_group[s] = 0;
+    }
+    for (uint32_t e = threadIdx.x; e < a.n_limbs; e += blockDim.x) Q->first_done[e] = 0;
+    __syncthreads();
+    if (threadIdx.x < 8) Q->xcd[threadIdx.x].next_item = 0;
+    if (threadIdx.x == 0) { Q->next_group = 0; Q->exited = 0; }
+  }
+}
+template <int LOG1, bool INV, int MODE_A, int MODE_B>
+__global__ void __launch_bounds__((1 << HM_TL_ROW) / HM_EPT) __attribute__((amdgpu_waves_per_eu(HM_NTT_MIN_WAVES))) k_ntt_queue(HmNttArgs a, HmNttQueueArgs f) {
+  hm_ntt_queue_body<LOG1, INV, MODE_A, MODE_B, Geo16>(a, f);
+}
+template <bool INV, int MODE_A, int MODE_B>
+__global__ void __launch_bounds__((1 << HM_TL_ROW) / 8) k_ntt_queue8(HmNttArgs a, HmNttQueueArgs f) {
+  hm_ntt_queue_body<8, INV, MODE_A, MODE_B, Geo8>(a, f);
+}
+
 // ---- K1 x K5: last transform pass x evaluation key, both keys, all digits of one extended limb in one workgroup ---------
 #define HM_NIP_MAX_TERMS 4
 #define HM_NIP_MAX_OUT 2
@@ -643,6 +796,10 @@ struct hm_ctx {
   uint32_t small_limbs = 64;   // measured (tools/ntt_small_ab.py): 2-3 us per launch faster up to ~64 entries, equal at 115, slower from 128
   bool fused_ntt = false;  // measured slower and no lighter on HBM: opt-in
   uint32_t fused_extra_lds = 0;   // dynamic LDS added to every k_ntt_fused workgroup: occupancy throttle of the L2 hand-off experiment
+  // persistent two-pass transform fed from per-XCD queues (k_ntt_queue): 0 off, 1 = 8-coefficient geometry (N = 2^16), 2 = 16-coefficient
+  uint32_t queue_ntt = 0, queue_wgs = 0 /* workgroups of the grid; 0 = 2 (geometry 8) or 4 (16) per CU */, queue_la = 2, queue_gc = 0 /* 0 = auto */;
+  HmNttQueue *ntt_q = nullptr;
+  int n_cu = 256;
   // multi-GPU
   int rank = 0, world = 1;
   ncclComm_t comm = nullptr;
@@ -769,6 +926,16 @@ extern "C" hm_status hm_create(hm_ctx **out, const hm_params *p) {
   HM_HIP(nullptr, hipMemcpy(cc->d_mods, cc->P.modc.data(), sizeof(HmMod) * M, hipMemcpyHostToDevice));
   HM_HIP(nullptr, hipMalloc(&cc->ntt_ws, sizeof(HmNttSync)));
   HM_HIP(nullptr, hipMemset(cc->ntt_ws, 0, sizeof(HmNttSync)));
+  HM_HIP(nullptr, hipMalloc(&cc->ntt_q, sizeof(HmNttQueue)));
+  HM_HIP(nullptr, hipMemset(cc->ntt_q, 0, sizeof(HmNttQueue)));
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, cc->device) == hipSuccess && prop.multiProcessorCount > 0) cc->n_cu = prop.multiProcessorCount;
+  }
+  if (const char *e = getenv("HOMULATOR_NTT_QUEUE")) cc->queue_ntt = (uint32_t)std::min(2, std::max(0, atoi(e)));
+  if (const char *e = getenv("HOMULATOR_NTT_QUEUE_WGS")) cc->queue_wgs = (uint32_t)std::min(8192, std::max(0, atoi(e)));
+  if (const char *e = getenv("HOMULATOR_NTT_QUEUE_LA")) cc->queue_la = (uint32_t)std::min(16, std::max(1, atoi(e)));
+  if (const char *e = getenv("HOMULATOR_NTT_QUEUE_GROUP")) cc->queue_gc = (uint32_t)std::min(8, std::max(0, atoi(e)));
   HM_HIP(nullptr, hipHostMalloc(reinterpret_cast<void **>(&cc->err_host), 64, hipHostMallocMapped));
   memset(cc->err_host, 0, 64);
   HM_HIP(nullptr, hipHostGetDevicePointer(reinterpret_cast<void **>(&cc->err_dev), cc->err_host, 0));
@@ -797,6 +964,7 @@ extern "C" void hm_destroy(hm_ctx *c) {
   (void)hipFree(c->d_twist_inv);
   (void)hipFree(c->d_mods);
   (void)hipFree(c->ntt_ws);
+  (void)hipFree(c->ntt_q);
   (void)hipHostFree(c->err_host);
   if (c->sstream) { (void)hipStreamSynchronize(c->sstream); (void)hipStreamDestroy(c->sstream); }
   if (c->sfork) (void)hipEventDestroy(c->sfork);
@@ -859,6 +1027,8 @@ static hm_status check_device_error(hm_ctx *c) {
     *c->err_host = 0;
     c->fused_ntt = false;
     (void)hipMemsetAsync(c->ntt_ws, 0, sizeof(HmNttSync), c->stream);
+    (void)hipMemsetAsync(c->ntt_q, 0, sizeof(HmNttQueue), c->stream);
+    c->queue_ntt = 0;
     (void)hipStreamSynchronize(c->stream);
     return fail(c, HM_ERR_HIP, "one-launch transform: rendezvous %u timed out (workgroups of a limb-poly not co-resident); results of the last launches are invalid, the context now uses two-kernel transforms", code);
   }
@@ -917,6 +1087,10 @@ extern "C" hm_status hm_set_option(hm_ctx *c, const char *name, uint64_t value) 
   if (!c || !name) return HM_ERR_ARG;
   if (!strcmp(name, "ntt_fused")) { c->fused_ntt = value != 0; return HM_OK; }
   if (!strcmp(name, "ntt_fused_lds")) { if (value > 120 * 1024) return fail(c, HM_ERR_ARG, "hm_set_option: ntt_fused_lds above 120 KiB"); c->fused_extra_lds = (uint32_t)value; return HM_OK; }
+  if (!strcmp(name, "ntt_queue")) { if (value > 2) return fail(c, HM_ERR_ARG, "hm_set_option: ntt_queue is 0, 1 or 2"); c->queue_ntt = (uint32_t)value; return HM_OK; }
+  if (!strcmp(name, "ntt_queue_wgs")) { if (value > 8192) return fail(c, HM_ERR_ARG, "hm_set_option: ntt_queue_wgs above 8192"); c->queue_wgs = (uint32_t)value; return HM_OK; }
+  if (!strcmp(name, "ntt_queue_lookahead")) { if (value < 1 || value > 16) return fail(c, HM_ERR_ARG, "hm_set_option: ntt_queue_lookahead in [1,16]"); c->queue_la = (uint32_t)value; return HM_OK; }
+  if (!strcmp(name, "ntt_queue_group")) { if (value > 8) return fail(c, HM_ERR_ARG, "hm_set_option: ntt_queue_group in [0,8]"); c->queue_gc = (uint32_t)value; return HM_OK; }
   if (!strcmp(name, "ntt_small_mode")) { c->small_mode = (uint32_t)value & 3u; return HM_OK; }
   if (!strcmp(name, "side_launches")) { c->side_launches = value != 0; if (value > 1) c->side_max_wgs = (uint32_t)value; return HM_OK; }
   if (!strcmp(name, "ntt_small_limbs")) { c->small_ept8 = value != 0; c->small_limbs = (uint32_t)value; return HM_OK; }
@@ -1137,6 +1311,92 @@ static hm_status ntt_common(hm_ctx *c, const char *what, const uint64_t *in, con
     if (f.addend_k && f.addend_k[g] == 0) return fail(c, HM_ERR_ARG, "%s: addend_k[%u] is zero (pass addend = NULL instead)", what, g);
   }
   HM_HIP(c, hipSetDevice(c->device));
+  // persistent two-pass transform from per-XCD queues (k_ntt_queue); the 8-coefficient geometry exists for N = 2^16
+  if (c->queue_ntt && !f.firstPassOnly && true) {
+    const bool geo8 = c->queue_ntt == 1 && c->P.logN == 16;
+    // dense entry list, same-modulus limb-polys adjacent (their tiles are handed out side by side: one fetch of the row twiddles per group)
+    std::vector<uint32_t> order(n);
+    for (uint32_t i = 0; i < n; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return mod_ids[x] < mod_ids[y]; });
+    uint32_t gc = c->queue_gc;
+    if (!gc) {   // auto: pairs when (nearly) every modulus of a large launch comes at least twice
+      std::map<uint32_t, uint32_t> cnt;
+      for (uint32_t i = 0; i < n; ++i) cnt[mod_ids[i]]++;
+      size_t paired = 0;
+      for (auto &kv : cnt) paired += kv.second / 2 * 2;
+      gc = (n >= 64 && paired * 8 >= (size_t)n * 7) ? 2 : 1;
+    }
+    const uint32_t maxE = HM_NTT_MAX_ENTRIES / gc * gc;
+    for (uint32_t base = 0; base < n; base += maxE) {
+      const uint32_t cnt = std::min(maxE, n - base);
+      std::vector<HmNttEntry> tab(cnt);
+      memset(tab.data(), 0, sizeof(HmNttEntry) * cnt);
+      HmNttArgs a;
+      for (uint32_t e = 0; e < cnt; ++e) {
+        const uint32_t g = order[base + e], m = mod_ids[g];
+        const uint64_t q = c->P.mod[m];
+        HmNttEntry &t = tab[e];
+        a.limb[e] = HmLimb{(uint16_t)limb_at(in_limbs, g), (uint16_t)limb_at(out_limbs, g), (uint16_t)m, 0};
+        if (inverse) {
+          uint64_t v = c->P.modc[m].ninv;
+          if (k) v = hm::mulmod(v, k[g], q);
+          t.sc = HmTw{v, hm::shoup(v, q)};
+        } else if (fused) {
+          t.sc = HmTw{k[g], hm::shoup(k[g], q)};
+          a.limb[e].aux = (uint16_t)limb_at(f.minuend_limbs, g);
+          t.alimb = f.addend_limbs && f.addend_limbs[g] == HM_NO_LIMB ? (uint16_t)HM_NTT_NONE : (uint16_t)limb_at(f.addend_limbs, g);
+          if (f.addend_k) t.ak = HmTw{f.addend_k[g], hm::shoup(f.addend_k[g], q)};
+          if (f.mix) {
+            t.mixlimb = (uint16_t)limb_at(f.mix_limbs, g);
+            t.mixk = HmTw{f.mix_k[g], hm::shoup(f.mix_k[g], q)};
+          }
+        }
+      }
+      const HmNttEntry *dtab = nullptr;
+      if (inverse || fused) {
+        if ((st = ntt_table(c, tab, &dtab))) return st;
+      }
+      a.in = in; a.out = out;
+      a.tw = inverse ? c->d_tw_inv : c->d_tw_fwd;
+      a.twist = inverse ? c->d_twist_inv : c->d_twist_fwd;
+      a.mods = c->d_mods;
+      a.entry = dtab;
+      a.minuend = f.minuend; a.addend = f.addend; a.mix = f.mix;
+      a.logN = c->P.logN; a.n_limbs = cnt; a.logG = 0;
+      HmNttQueueArgs qa;
+      qa.q = c->ntt_q; qa.err = c->err_dev; qa.gc = gc; qa.n_groups = (cnt + gc - 1) / gc; qa.lookahead = c->queue_la;
+      const uint32_t items = 2 * qa.n_groups * gc * (c->P.N >> HM_TL_ROW);
+      uint32_t wgs = c->queue_wgs ? c->queue_wgs : (uint32_t)c->n_cu * (geo8 ? 2u : 4u);
+      wgs = std::max(8u, std::min(wgs, items));
+      const bool mixPro = fused && f.mix;
+      const dim3 grid(wgs), block((1 << HM_TL_ROW) / (geo8 ? 8 : HM_EPT));
+#define HM_QGO(L1) \
+      do { \
+        if (geo8) { \
+          if (inverse) hipLaunchKernelGGL((k_ntt_queue8<true, 0, 2>), grid, block, 0, c->stream, a, qa); \
+          else if (mixPro) hipLaunchKernelGGL((k_ntt_queue8<false, 4, 3>), grid, block, 0, c->stream, a, qa); \
+          else if (fused) hipLaunchKernelGGL((k_ntt_queue8<false, 0, 3>), grid, block, 0, c->stream, a, qa); \
+          else hipLaunchKernelGGL((k_ntt_queue8<false, 0, 1>), grid, block, 0, c->stream, a, qa); \
+        } else { \
+          if (inverse) hipLaunchKernelGGL((k_ntt_queue<L1, true, 0, 2>), grid, block, 0, c->stream, a, qa); \
+          else if (mixPro) hipLaunchKernelGGL((k_ntt_queue<L1, false, 4, 3>), grid, block, 0, c->stream, a, qa); \
+          else if (fused) hipLaunchKernelGGL((k_ntt_queue<L1, false, 0, 3>), grid, block, 0, c->stream, a, qa); \
+          else hipLaunchKernelGGL((k_ntt_queue<L1, false, 0, 1>), grid, block, 0, c->stream, a, qa); \
+        } \
+      } while (0)
+      switch (c->P.logN - HM_ROW_LOG) {
+      case 5: HM_QGO(5); break;
+      case 6: HM_QGO(6); break;
+      case 7: HM_QGO(7); break;
+      case 8: HM_QGO(8); break;
+      case 9: HM_QGO(9); break;
+      default: return fail(c, HM_ERR_UNSUPPORTED, "%s: logN %u", what, c->P.logN);
+      }
+#undef HM_QGO
+      HM_HIP(c, hipGetLastError());
+    }
+    return HM_OK;
+  }
   // group limb-polys that share a modulus (see hm_block_map): G = the largest of 8, 4, 2 for which at least 7 of 8 limb-polys
   // of the call fall into full same-modulus groups (a batch of 10 ops x 2 keys has 20 limb-polys per modulus, a 50-limb sweep
   // of the extended basis one: G = 2 then costs nothing); leftovers of a modulus share groups with other leftovers
