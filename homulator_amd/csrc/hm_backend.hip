@@ -75,7 +75,7 @@ __device__ __forceinline__ void hm_ntt_pass_run(const HmNttArgs &a, uint64_t *ld
   const HmLimb lb = a.limb[entry];
   const uint32_t mod = lb.mod;
   const size_t N = (size_t)1 << a.logN;
-  const uint64_t q = a.mods[mod].q;
+  const uint64_t q = HM_CONST_MODS(a.mods)[mod].q;   // through the scalar cache (read-only for the lifetime of the context)
   const HmTw *twl = a.tw + (size_t)mod * N;
   const uint32_t s0 = STRIDED ? 0u : (a.logN - HM_ROW_LOG);
   const uint32_t prefix0 = STRIDED ? 0u : (tile << (TL - LOGR));
@@ -292,6 +292,7 @@ __global__ void __launch_bounds__((1 << HM_TL_ROW) / HM_EPT) __attribute__((amdg
 // that bypass its CU's vector L1 (sc1 / nt), which another CU's stores never refresh.
 #define HM_Q_MAX_SLOTS (HM_NTT_MAX_ENTRIES + 32)
 #define HM_Q_NONE 0xFFFFFFFFu
+#define HM_Q_SPIN_LIMIT (1u << 17)   // ~0.2 s of polling: a queue wait that long is a bug, reported through the context
 struct HmNttQueue {                  // device; all zero between launches (the last workgroup out resets what the launch touched)
   unsigned next_group, exited, pad0[14];
   struct Xcd {
@@ -306,6 +307,7 @@ struct HmNttQueueArgs {
   uint32_t n_groups;      // groups of `gc` consecutive entries of HmNttArgs::limb (dense: entry = group * gc + member)
   uint32_t gc;            // limb-polys per group (same modulus: their tiles are handed out side by side and share the row twiddles in L2)
   uint32_t lookahead;     // LA >= 1
+  unsigned *trace;        // bring-up aid (HOMULATOR_NTT_QUEUE_TRACE=1): host-mapped, 256 words per workgroup: [0] count, then (item, slot value, entry, pass) per pull
 };
 #ifndef HM_Q_IN_AUX
 #define HM_Q_IN_AUX 0     // cache policy of the first pass's input loads (2 = nt: streamed once)
@@ -326,7 +328,7 @@ __device__ __forceinline__ unsigned hm_q_slot_group(HmNttQueue *Q, HmNttQueue::X
   while (v < 2) {
     if (v == 0) {
       if (s > 0) {   // in slot order
-        while (hm_q_load(&x->slot_group[s - 1]) < 2) { __builtin_amdgcn_s_sleep(2); if (++spins > HM_SPIN_LIMIT) { __hip_atomic_store(err, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return HM_Q_NONE; } }
+        while (hm_q_load(&x->slot_group[s - 1]) < 2) { __builtin_amdgcn_s_sleep(2); if (++spins > HM_Q_SPIN_LIMIT) { __hip_atomic_store(err, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return HM_Q_NONE; } }
       }
       unsigned expect = 0;
       if (__hip_atomic_compare_exchange_strong(&x->slot_group[s], &expect, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
@@ -337,7 +339,7 @@ __device__ __forceinline__ unsigned hm_q_slot_group(HmNttQueue *Q, HmNttQueue::X
       }
     }
     __builtin_amdgcn_s_sleep(2);
-    if (++spins > HM_SPIN_LIMIT) { __hip_atomic_store(err, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return HM_Q_NONE; }
+    if (++spins > HM_Q_SPIN_LIMIT) { __hip_atomic_store(err, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return HM_Q_NONE; }
     v = hm_q_load(&x->slot_group[s]);
   }
   return v;
@@ -348,8 +350,8 @@ __device__ __forceinline__ void hm_ntt_queue_body(const HmNttArgs &a, const HmNt
   static_assert(HM_TL_COL == HM_TL_ROW, "one tile size for both passes");
   constexpr int TL = HM_TL_ROW;
   constexpr int W1 = GEO::template ldsWords<TL, LOG1, true>(), W2 = GEO::template ldsWords<TL, HM_ROW_LOG, false>();
-  __shared__ __attribute__((aligned(16))) uint64_t lds[(W1 > W2 ? W1 : W2) + 2];
-  volatile uint32_t *ctl = reinterpret_cast<volatile uint32_t *>(lds + (W1 > W2 ? W1 : W2));   // [0] entry (HM_Q_NONE: leave, NONE - 1: skip), [1] tile, [2] pass
+  __shared__ __attribute__((aligned(16))) uint64_t lds[W1 > W2 ? W1 : W2];
+  __shared__ uint32_t ctl[4];   // [0] entry (HM_Q_NONE: leave, NONE - 1: skip), [1] tile, [2] pass
   const uint32_t tiles = 1u << (a.logN - TL);
   const uint32_t per_block = tiles * f.gc;
   HmNttQueue *Q = f.q;
@@ -371,14 +373,28 @@ __device__ __forceinline__ void hm_ntt_queue_body(const HmNttArgs &a, const HmNt
           unsigned spins = 0;
           while (hm_q_load(&Q->first_done[entry]) < tiles) {
             __builtin_amdgcn_s_sleep(4);
-            if (++spins > HM_SPIN_LIMIT) { __hip_atomic_store(f.err, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+            if (++spins > HM_Q_SPIN_LIMIT) { __hip_atomic_store(f.err, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
           }
         }
       } else if (!second) entry = HM_Q_NONE - 1;   // a first-pass block beyond the last group: later blocks may still hold second passes
       ctl[0] = entry; ctl[1] = w / f.gc; ctl[2] = second;
+      if (f.trace && blockIdx.x < 64) {
+        unsigned *t = f.trace + blockIdx.x * 256;
+        const unsigned k = t[0];
+        if (k < 63) {
+          __hip_atomic_store(&t[1 + 4 * k], i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store(&t[2 + 4 * k], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store(&t[3 + 4 * k], entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store(&t[4 + 4 * k], second | (hm_xcc_id() << 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store(&t[0], k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+      }
     }
     __syncthreads();
-    const uint32_t entry = ctl[0], tile = ctl[1], second = ctl[2];
+    // wave-uniform by construction: scalar registers (as VGPR values they made every descriptor and branch below look divergent)
+    const uint32_t entry = __builtin_amdgcn_readfirstlane(ctl[0]), tile = __builtin_amdgcn_readfirstlane(ctl[1]), second = __builtin_amdgcn_readfirstlane(ctl[2]);
+#define HM_Q_MARK(code) do { if (f.trace && blockIdx.x < 64 && threadIdx.x == 0) __hip_atomic_store(&f.trace[blockIdx.x * 256 + 255], (unsigned)(code), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } while (0)
+    HM_Q_MARK(1);
     __syncthreads();   // ctl is rewritten by the next pull; the passes below start with their own LDS traffic
     if (entry == HM_Q_NONE) break;
     if (entry == HM_Q_NONE - 1) continue;
@@ -389,9 +405,12 @@ __device__ __forceinline__ void hm_ntt_queue_body(const HmNttArgs &a, const HmNt
     if (!second) {
       if (!INV) hm_ntt_pass_run<LOG1, true, false, MODE_A, HM_Q_IN_AUX, 0, HM_EPI_CHUNK, GEO>(a, lds, entry, tile, tid);
       else hm_ntt_pass_run<HM_ROW_LOG, false, true, MODE_A, HM_Q_IN_AUX, 0, HM_EPI_CHUNK, GEO>(a, lds, entry, tile, tid);
+      HM_Q_MARK(2);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave: its stores have reached the L2
       __syncthreads();
+      HM_Q_MARK(3);
       if (threadIdx.x == 0) __hip_atomic_fetch_add(&Q->first_done[entry], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      HM_Q_MARK(4);
     } else {
       if (!INV) hm_ntt_pass_run<HM_ROW_LOG, false, false, MODE_B, HM_Q_MID_AUX, HM_Q_OUT_AUX, 1, GEO>(a, lds, entry, tile, tid);
       else hm_ntt_pass_run<LOG1, true, true, MODE_B, HM_Q_MID_AUX, HM_Q_OUT_AUX, HM_EPI_CHUNK, GEO>(a, lds, entry, tile, tid);
@@ -799,6 +818,7 @@ struct hm_ctx {
   // persistent two-pass transform fed from per-XCD queues (k_ntt_queue): 0 off, 1 = 8-coefficient geometry (N = 2^16), 2 = 16-coefficient
   uint32_t queue_ntt = 0, queue_wgs = 0 /* workgroups of the grid; 0 = 2 (geometry 8) or 4 (16) per CU */, queue_la = 2, queue_gc = 0 /* 0 = auto */;
   HmNttQueue *ntt_q = nullptr;
+  unsigned *q_trace_host = nullptr, *q_trace_dev = nullptr;   // HOMULATOR_NTT_QUEUE_TRACE
   int n_cu = 256;
   // multi-GPU
   int rank = 0, world = 1;
@@ -931,6 +951,11 @@ extern "C" hm_status hm_create(hm_ctx **out, const hm_params *p) {
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, cc->device) == hipSuccess && prop.multiProcessorCount > 0) cc->n_cu = prop.multiProcessorCount;
+  }
+  if (getenv("HOMULATOR_NTT_QUEUE_TRACE")) {
+    HM_HIP(nullptr, hipHostMalloc(reinterpret_cast<void **>(&cc->q_trace_host), 64 * 256 * 4, hipHostMallocMapped));
+    memset(cc->q_trace_host, 0, 64 * 256 * 4);
+    HM_HIP(nullptr, hipHostGetDevicePointer(reinterpret_cast<void **>(&cc->q_trace_dev), cc->q_trace_host, 0));
   }
   if (const char *e = getenv("HOMULATOR_NTT_QUEUE")) cc->queue_ntt = (uint32_t)std::min(2, std::max(0, atoi(e)));
   if (const char *e = getenv("HOMULATOR_NTT_QUEUE_WGS")) cc->queue_wgs = (uint32_t)std::min(8192, std::max(0, atoi(e)));
@@ -1098,6 +1123,21 @@ extern "C" hm_status hm_set_option(hm_ctx *c, const char *name, uint64_t value) 
 }
 extern "C" hm_status hm_get_counter(hm_ctx *c, const char *name, uint64_t *value) {
   if (!c || !name || !value) return HM_ERR_ARG;
+  if (!strcmp(name, "ntt_queue_trace")) {   // bring-up aid: prints the pull trace (host-mapped memory: readable while a kernel hangs); does NOT synchronise
+    *value = 0;
+    if (!c->q_trace_host) return HM_OK;
+    for (int b = 0; b < 64; ++b) {
+      const volatile unsigned *t = c->q_trace_host + b * 256;
+      const unsigned k = t[0];
+      if (!k) continue;
+      fprintf(stderr, "wg %2d (mark %u):", b, t[255]);
+      for (unsigned i = 0; i < k && i < 63; ++i) fprintf(stderr, " [i=%u v=%d e=%d p=%u x=%u]", t[1 + 4 * i], (int)t[2 + 4 * i], (int)t[3 + 4 * i], t[4 + 4 * i] & 1, t[4 + 4 * i] >> 8);
+      fprintf(stderr, "\n");
+      *value += k;
+    }
+    fprintf(stderr, "err word: %u\n", c->err_host ? *c->err_host : 0);
+    return HM_OK;
+  }
   if (!strcmp(name, "ntt_cross_xcd")) {
     HM_HIP(c, hipStreamSynchronize(c->stream));
     unsigned v = 0;
@@ -1364,6 +1404,8 @@ static hm_status ntt_common(hm_ctx *c, const char *what, const uint64_t *in, con
       a.minuend = f.minuend; a.addend = f.addend; a.mix = f.mix;
       a.logN = c->P.logN; a.n_limbs = cnt; a.logG = 0;
       HmNttQueueArgs qa;
+      qa.trace = c->q_trace_dev;
+      if (c->q_trace_host) memset(c->q_trace_host, 0, 64 * 256 * 4);
       qa.q = c->ntt_q; qa.err = c->err_dev; qa.gc = gc; qa.n_groups = (cnt + gc - 1) / gc; qa.lookahead = c->queue_la;
       const uint32_t items = 2 * qa.n_groups * gc * (c->P.N >> HM_TL_ROW);
       uint32_t wgs = c->queue_wgs ? c->queue_wgs : (uint32_t)c->n_cu * (geo8 ? 2u : 4u);

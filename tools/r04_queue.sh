@@ -2,7 +2,7 @@
 # round 4: parity, timing and fabric counters of the persistent queue transform
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/${1:-r04q}; mkdir -p $OUT
 export TMPDIR=/tmp
-timeout -k 10 600 python3 -m pytest tests/test_gpu_ntt_queue.py -x -q -m gpu > $OUT/tests.log 2>&1 || { tail -30 $OUT/tests.log; echo "PARITY FAILED"; exit 1; }
+timeout -k 10 600 python3 -u -m pytest tests/test_gpu_ntt_queue.py -x -v -m gpu > $OUT/tests.log 2>&1 || { tail -30 $OUT/tests.log; echo "PARITY FAILED"; exit 1; }
 tail -2 $OUT/tests.log
 timeout -k 10 400 python3 tools/ntt_queue_ab.py > $OUT/ab.txt 2>&1; cat $OUT/ab.txt
 cd /tmp
