@@ -61,6 +61,8 @@ struct Geo16 {
   template <int TL, int LOGR, bool STRIDED> static constexpr int ldsWords() { return hm16::HmLds<TL, LOGR, STRIDED>::WORDS; }
   template <int TL, int LOGR, bool STRIDED, bool INV, int MODE, int LDAUX, int STAUX, int EPICH, class... A>
   static __device__ __forceinline__ void phases(A &&...a) { hm16::hm_ntt_pass_phases<TL, LOGR, STRIDED, INV, MODE, LDAUX, STAUX, EPICH>(a...); }
+  template <int TL, int LOGR, bool STRIDED, bool INV, int MODE, class... A>
+  static __device__ __forceinline__ void phases_dma(A &&...a) { hm16::hm_ntt_pass_phases<TL, LOGR, STRIDED, INV, MODE, 0, 0, HM_EPI_CHUNK, 1>(a...); }
 };
 struct Geo8 {
   static constexpr int EPT = 8;
@@ -68,6 +70,8 @@ struct Geo8 {
   template <int TL, int LOGR, bool STRIDED> static constexpr int ldsWords() { return hm8::HmLds<TL, LOGR, STRIDED>::WORDS; }
   template <int TL, int LOGR, bool STRIDED, bool INV, int MODE, int LDAUX, int STAUX, int EPICH, class... A>
   static __device__ __forceinline__ void phases(A &&...a) { hm8::hm_ntt_pass_phases<TL, LOGR, STRIDED, INV, MODE, LDAUX, STAUX, EPICH>(a...); }
+  template <int TL, int LOGR, bool STRIDED, bool INV, int MODE, class... A>
+  static __device__ __forceinline__ void phases_dma(A &&...a) { hm8::hm_ntt_pass_phases<TL, LOGR, STRIDED, INV, MODE, 0, 0, HM_EPI_CHUNK, 1>(a...); }
 };
 template <int LOGR, bool STRIDED, bool INV, int MODE, int LDAUX = 0, int STAUX = 0, int EPICH = HM_EPI_CHUNK, class GEO = Geo16>
 __device__ __forceinline__ void hm_ntt_pass_run(const HmNttArgs &a, uint64_t *lds, uint32_t entry, uint32_t tile, int tid) {
@@ -439,6 +443,159 @@ template <bool INV, int MODE_A, int MODE_B>
 __global__ void __launch_bounds__((1 << HM_TL_ROW) / 8) k_ntt_queue8(HmNttArgs a, HmNttQueueArgs f) {
   hm_ntt_queue_body<8, INV, MODE_A, MODE_B, Geo8>(a, f);
 }
+
+#ifndef HM_DMA_IN_AUX
+#define HM_DMA_IN_AUX 0   // cache policy of the DMA'd tile loads (2 = nt)
+#endif
+// ---- persistent, double-buffered passes: the next tile arrives by LDS-DMA while the current one is transformed (round 4) -------------
+// A workgroup walks a run of tiles (virtual block ids blockIdx.x, + gridDim.x, ...: the same XCD-aware map as the one-tile kernels).  Its
+// LDS holds TWO tile images with the shared twiddles of each tile's modulus behind them.  While it runs the rounds of tile t in image
+// t & 1, `buffer_load_dwordx4 ... lds` instructions (no VGPR destination: the data never passes through registers) fill image (t + 1) & 1
+// with tile t + 1 and its twiddles: every wave-instruction writes 1 KiB of LDS linearly, and the XOR swizzle of the image is applied
+// through the per-lane SOURCE addresses.  At the top of an iteration a counted `s_waitcnt vmcnt(stores of the previous tile)` retires this
+// wave's DMA pieces of tile t while the previous tile's stores are still draining, and one raw s_barrier publishes all waves' pieces and
+// frees the other image; the barriers between the rounds are raw too (`__syncthreads()` would wait for vmcnt(0) and drain the DMA).
+// The first round reads its elements from the image (phase SRC = 1) instead of from global memory.
+template <int TL, int LOGR, bool STRIDED, bool INV, int MODE, class GEO, class ISSUE>
+__device__ __forceinline__ void hm_dma_tile(uint64_t *__restrict__ cur, uint64_t *__restrict__ nxt, int tid, uint64_t *dst, uint32_t tile, const HmTw *twl,
+                                            const HmTw *twt, uint32_t s0, uint32_t prefix0, uint64_t q, HmTw sc, HmEpi ep, ISSUE issue_next) {
+  typename GEO::State st;
+  GEO::template phases_dma<TL, LOGR, STRIDED, INV, MODE>(st, tid, cur, nullptr, dst, tile, twl, twt, s0, prefix0, q, sc, ep,
+                                                        [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }, cur + (1 << TL),
+                                                        [&] { issue_next(nxt); });   // behind this tile's own global requests: the next tile's DMA
+}
+template <int LOGR, bool STRIDED, bool INV, int MODE, class GEO, int TL = HM_TL(STRIDED)>
+__device__ __forceinline__ void hm_ntt_pass_dma_body(const HmNttArgs &a) {
+#if defined(__HIP_DEVICE_COMPILE__)   // (buffer descriptors and the LDS-DMA builtins exist in the device pass only)
+  constexpr int TILE = 1 << TL, THREADS = TILE / GEO::EPT, WAVES = THREADS / 64;
+  constexpr int NTWW = (STRIDED ? (1 << LOGR) : 128) * 2;          // staged twiddle words behind a tile image
+  constexpr int CH_TILE = TILE * 8 / 1024, CH_TW = (NTWW * 8 + 1023) / 1024;  // 1 KiB pieces (a short twiddle list is copied with what follows it in the table)
+  constexpr int IMG = TILE + CH_TW * 128;                           // words per buffer
+  constexpr int NDMA = (CH_TILE + CH_TW + WAVES - 1) / WAVES;
+  constexpr int LOGC = TL - LOGR;
+  static_assert(!STRIDED || LOGC >= 3, "tile image swizzle");
+  static_assert(HM_TW_IN_LDS(STRIDED), "the passes read their shared twiddles from the staged copy");
+  __shared__ __attribute__((aligned(16))) uint64_t lds[2 * IMG];
+  typedef __attribute__((address_space(3))) void *LdsPtr;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t tiles = 1u << (a.logN - TL);
+  const uint32_t total = a.n_limbs * tiles;
+  const size_t N = (size_t)1 << a.logN;
+  constexpr bool FIRST = (STRIDED != INV);
+  // per-lane source offsets (bytes inside the limb-poly, without the tile's part) of this wave's pieces: loop-invariant
+  uint32_t voff[NDMA];
+#pragma unroll
+  for (int k = 0; k < NDMA; ++k) {
+    const int c = k * WAVES + wave;                 // piece number; pieces >= CH_TILE carry the twiddles
+    int x, cc;
+    hm_lds_unidx<TL, LOGR, STRIDED>((c * 128 + lane * 2) & (TILE - 1), x, cc);
+    voff[k] = c < CH_TILE ? (STRIDED ? (((uint32_t)x << HM_ROW_LOG) + (uint32_t)cc) << 3 : (((uint32_t)cc << LOGR) + (uint32_t)x) << 3)
+                          : (uint32_t)((c - CH_TILE) * 1024 + lane * 16);
+  }
+  const uint32_t logPer = a.logN - TL + a.logG;   // tiles per limb-poly x group size: powers of two, shifts instead of a (vector-unit) division
+  // one 8-byte scalar load per record (a lone 16-bit field at a 2-byte offset has no scalar load: it became a vector load whose
+  // vmcnt(0) drained the DMA)
+  auto record = [&](uint32_t entry) -> uint64_t {
+    uint64_t raw;
+    __builtin_memcpy(&raw, &a.limb[entry], 8);
+    return raw;
+  };
+  auto decode = [&](uint32_t vb, uint32_t &entry, uint32_t &tile, uint64_t &rec) -> bool {   // hm_block_map for a virtual block id
+    vb = __builtin_amdgcn_readfirstlane(vb);
+    const uint32_t xcd = vb & 7u, slot = vb >> 3;
+    const uint32_t grp = slot >> logPer, within = slot & ((1u << logPer) - 1u);
+    tile = within >> a.logG;
+    entry = (grp << (3 + a.logG)) + (within & ((1u << a.logG) - 1u)) * 8u + xcd;
+    if (vb >= total || entry >= a.n_limbs) return false;
+    rec = record(entry);
+    return ((rec >> 32) & 0xFFFFu) != HM_NTT_NONE;
+  };
+  auto next_valid = [&](uint32_t vb, uint32_t &entry, uint32_t &tile, uint64_t &rec) -> uint32_t {
+    while (vb < total && !decode(vb, entry, tile, rec)) vb += gridDim.x;
+    return vb;
+  };
+  auto unpack = [](uint64_t rec) { return HmLimb{(uint16_t)rec, (uint16_t)(rec >> 16), (uint16_t)(rec >> 32), (uint16_t)(rec >> 48)}; };
+  auto issue = [&](uint64_t rec, uint32_t tile, uint64_t *img) {
+    const HmLimb lb = unpack(rec);
+    const uint64_t *src = FIRST ? a.in + (size_t)lb.in * N : a.out + (size_t)lb.out * N;
+    const uint32_t soff = STRIDED ? tile << (LOGC + 3) : tile << (TL + 3);
+    const __amdgpu_buffer_rsrc_t rs = hm_rsrc(src), rt = hm_rsrc(reinterpret_cast<const uint64_t *>(a.tw + (size_t)lb.mod * N));
+#pragma unroll
+    for (int k = 0; k < NDMA; ++k) {
+      const int c = k * WAVES + wave;
+      if (c < CH_TILE) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (LdsPtr)(img + c * 128), 16, voff[k], soff, 0, HM_DMA_IN_AUX);
+      else if (c < CH_TILE + CH_TW) __builtin_amdgcn_raw_ptr_buffer_load_lds(rt, (LdsPtr)(img + c * 128), 16, voff[k], 0, 0, 0);
+    }
+  };
+  uint32_t entry, tile, nentry = 0, ntile = 0;
+  uint64_t rec = 0, nrec = 0;
+  uint32_t vb = next_valid(blockIdx.x, entry, tile, rec);
+  if (vb >= total) return;
+  issue(rec, tile, lds);
+#pragma unroll 1
+  for (uint32_t it = 0; vb < total; ++it) {
+    uint64_t *cur = lds + (it & 1) * IMG, *nxt = lds + ((it + 1) & 1) * IMG;
+    const uint32_t nvb = next_valid(vb + gridDim.x, nentry, ntile, nrec);
+    // this wave's DMA pieces of tile `it` have landed (everything older than the previous tile's stores has retired: vmcnt counts in order);
+    // the barrier publishes every wave's pieces and says that all waves are done reading the other image
+    if (it == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // nothing was issued behind the first tile's pieces
+    else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(GEO::EPT / 2) : "memory");
+    {
+      const HmLimb lb = unpack(rec);
+      const uint32_t mod = lb.mod;
+      const uint64_t q = HM_CONST_MODS(a.mods)[mod].q;
+      const HmTw *twl = a.tw + (size_t)mod * N;
+      const uint32_t s0 = STRIDED ? 0u : (a.logN - HM_ROW_LOG);
+      const uint32_t prefix0 = STRIDED ? 0u : (tile << (TL - LOGR));
+      const HmTw *twt = STRIDED ? nullptr : a.twist + ((size_t)mod * (N >> HM_ROW_LOG) + prefix0) * 3;
+      uint64_t *dst = a.out + (size_t)lb.out * N;
+      HmTw sc = {0, 0};
+      HmEpi ep = hm_epi_none();
+      typedef const HmNttEntry __attribute__((address_space(4))) *ConstEntry;
+      const ConstEntry entries = (ConstEntry)(uintptr_t)a.entry;
+      if constexpr (MODE == 2) { sc.w = entries[entry].sc.w; sc.ws = entries[entry].sc.ws; }
+      if constexpr (MODE == 3) {
+        const auto &en = entries[entry];
+        sc.w = en.sc.w; sc.ws = en.sc.ws;
+        ep.a = a.minuend + (size_t)lb.aux * N;
+        ep.d = a.addend && en.alimb != HM_NTT_NONE ? a.addend + (size_t)en.alimb * N : nullptr;
+        ep.dk.w = en.ak.w; ep.dk.ws = en.ak.ws;
+      }
+      if constexpr (MODE == 4) {
+        const auto &en = entries[entry];
+        ep.b = a.mix + (size_t)en.mixlimb * N;
+        ep.bk.w = en.mixk.w; ep.bk.ws = en.mixk.ws;
+      }
+      int t2 = tid;
+      asm volatile("" : "+v"(t2));   // lane offsets are recomputed per tile instead of living (spilled) across the loop
+      __builtin_assume(t2 >= 0 && t2 < THREADS);
+      // `cur` and `nxt` as __restrict__ parameters of an inlined function: the inliner then tags the accesses of the two images with
+      // alias scopes, and the waitcnt pass no longer puts s_waitcnt vmcnt(0) in front of the first LDS read of `cur` on account of the
+      // DMA that is writing `nxt`
+      hm_dma_tile<TL, LOGR, STRIDED, INV, MODE, GEO>(cur, nxt, t2, dst, tile, twl, twt, s0, prefix0, q, sc, ep, [&](uint64_t *img) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (nvb < total) issue(nrec, ntile, img);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    }
+    vb = nvb; entry = nentry; tile = ntile; rec = nrec;
+  }
+#endif
+}
+template <int LOGR, bool INV, int MODE>
+__global__ void __launch_bounds__((1 << HM_TL_COL) / HM_EPT) k_ntt_col_dma(HmNttArgs a) { hm_ntt_pass_dma_body<LOGR, true, INV, MODE, Geo16>(a); }
+template <bool INV, int MODE>
+__global__ void __launch_bounds__((1 << HM_TL_ROW) / HM_EPT) k_ntt_row_dma(HmNttArgs a) { hm_ntt_pass_dma_body<HM_ROW_LOG, false, INV, MODE, Geo16>(a); }
+template <bool INV, int MODE>
+__global__ void __launch_bounds__((1 << HM_TL_COL) / 8) k_ntt_col8_dma(HmNttArgs a) { hm_ntt_pass_dma_body<8, true, INV, MODE, Geo8>(a); }
+template <bool INV, int MODE>
+__global__ void __launch_bounds__((1 << HM_TL_ROW) / 8) k_ntt_row8_dma(HmNttArgs a) { hm_ntt_pass_dma_body<HM_ROW_LOG, false, INV, MODE, Geo8>(a); }
+// ... on 2048-coefficient tiles: 256-thread workgroups with 2 x 18 (20) KiB of LDS, four per CU as in the one-tile kernels
+template <bool INV, int MODE>
+__global__ void __launch_bounds__(256) k_ntt_col8_dma11(HmNttArgs a) { hm_ntt_pass_dma_body<8, true, INV, MODE, Geo8, 11>(a); }
+template <bool INV, int MODE>
+__global__ void __launch_bounds__(256) k_ntt_row8_dma11(HmNttArgs a) { hm_ntt_pass_dma_body<HM_ROW_LOG, false, INV, MODE, Geo8, 11>(a); }
 
 // ---- K1 x K5: last transform pass x evaluation key, both keys, all digits of one extended limb in one workgroup ---------
 #define HM_NIP_MAX_TERMS 4
@@ -817,6 +974,7 @@ struct hm_ctx {
   uint32_t fused_extra_lds = 0;   // dynamic LDS added to every k_ntt_fused workgroup: occupancy throttle of the L2 hand-off experiment
   // persistent two-pass transform fed from per-XCD queues (k_ntt_queue): 0 off, 1 = 8-coefficient geometry (N = 2^16), 2 = 16-coefficient
   uint32_t queue_ntt = 0, queue_wgs = 0 /* workgroups of the grid; 0 = 2 (geometry 8) or 4 (16) per CU */, queue_la = 2, queue_gc = 0 /* 0 = auto */;
+  uint32_t dma_ntt = 0, dma_wgs = 0;   // persistent double-buffered passes (k_ntt_*_dma): 0 off, 1 = 8-coefficient geometry (N = 2^16), 2 = 16-coefficient; workgroups per launch (0 = 2 per CU)
   HmNttQueue *ntt_q = nullptr;
   unsigned *q_trace_host = nullptr, *q_trace_dev = nullptr;   // HOMULATOR_NTT_QUEUE_TRACE
   int n_cu = 256;
@@ -957,6 +1115,8 @@ extern "C" hm_status hm_create(hm_ctx **out, const hm_params *p) {
     memset(cc->q_trace_host, 0, 64 * 256 * 4);
     HM_HIP(nullptr, hipHostGetDevicePointer(reinterpret_cast<void **>(&cc->q_trace_dev), cc->q_trace_host, 0));
   }
+  if (const char *e = getenv("HOMULATOR_NTT_DMA")) cc->dma_ntt = (uint32_t)std::min(3, std::max(0, atoi(e)));
+  if (const char *e = getenv("HOMULATOR_NTT_DMA_WGS")) cc->dma_wgs = (uint32_t)std::min(8192, std::max(0, atoi(e)));
   if (const char *e = getenv("HOMULATOR_NTT_QUEUE")) cc->queue_ntt = (uint32_t)std::min(2, std::max(0, atoi(e)));
   if (const char *e = getenv("HOMULATOR_NTT_QUEUE_WGS")) cc->queue_wgs = (uint32_t)std::min(8192, std::max(0, atoi(e)));
   if (const char *e = getenv("HOMULATOR_NTT_QUEUE_LA")) cc->queue_la = (uint32_t)std::min(16, std::max(1, atoi(e)));
@@ -1112,6 +1272,8 @@ extern "C" hm_status hm_set_option(hm_ctx *c, const char *name, uint64_t value) 
   if (!c || !name) return HM_ERR_ARG;
   if (!strcmp(name, "ntt_fused")) { c->fused_ntt = value != 0; return HM_OK; }
   if (!strcmp(name, "ntt_fused_lds")) { if (value > 120 * 1024) return fail(c, HM_ERR_ARG, "hm_set_option: ntt_fused_lds above 120 KiB"); c->fused_extra_lds = (uint32_t)value; return HM_OK; }
+  if (!strcmp(name, "ntt_dma")) { if (value > 3) return fail(c, HM_ERR_ARG, "hm_set_option: ntt_dma is 0 .. 3"); c->dma_ntt = (uint32_t)value; return HM_OK; }
+  if (!strcmp(name, "ntt_dma_wgs")) { if (value > 8192) return fail(c, HM_ERR_ARG, "hm_set_option: ntt_dma_wgs above 8192"); c->dma_wgs = (uint32_t)value; return HM_OK; }
   if (!strcmp(name, "ntt_queue")) { if (value > 2) return fail(c, HM_ERR_ARG, "hm_set_option: ntt_queue is 0, 1 or 2"); c->queue_ntt = (uint32_t)value; return HM_OK; }
   if (!strcmp(name, "ntt_queue_wgs")) { if (value > 8192) return fail(c, HM_ERR_ARG, "hm_set_option: ntt_queue_wgs above 8192"); c->queue_wgs = (uint32_t)value; return HM_OK; }
   if (!strcmp(name, "ntt_queue_lookahead")) { if (value < 1 || value > 16) return fail(c, HM_ERR_ARG, "hm_set_option: ntt_queue_lookahead in [1,16]"); c->queue_la = (uint32_t)value; return HM_OK; }
@@ -1241,7 +1403,7 @@ static void launch_ntt(hm_ctx *c, const HmNttArgs &a, bool fusedEpilogue, bool m
   const dim3 gridR(a.n_limbs * (c->P.N >> HM_TL_ROW)), blockR((1 << HM_TL_ROW) / HM_EPT);
   // small launches (one round of workgroups on the chip): the 8-coefficient geometry halves the serial work per wave
   if constexpr (LOG1 == 8) {
-    if (c->small_ept8 && !firstPassOnly && !c->fused_ntt && a.n_limbs <= c->small_limbs) {
+    if (c->small_ept8 && !firstPassOnly && !c->fused_ntt && !c->dma_ntt && a.n_limbs <= c->small_limbs) {
       // small_mode: bit 0 = COL pass in the 8-coefficient geometry, bit 1 = ROW pass (the hand-off between the passes is the same)
       const dim3 grid8(a.n_limbs * (c->P.N >> HM_TL_ROW)), block8((1 << HM_TL_ROW) / 8);
       const dim3 grid16(a.n_limbs * (c->P.N >> HM_TL_ROW)), block16((1 << HM_TL_ROW) / HM_EPT);
@@ -1257,6 +1419,26 @@ static void launch_ntt(hm_ctx *c, const HmNttArgs &a, bool fusedEpilogue, bool m
       }
       return;
     }
+  }
+  if (c->dma_ntt && !c->fused_ntt && (c->dma_ntt == 2 || LOG1 == 8)) {   // persistent double-buffered passes
+    const bool g8 = c->dma_ntt == 1, g11 = c->dma_ntt == 3;   // 3: 8-coefficient geometry on 2048-coefficient tiles (four workgroups per CU)
+    const uint32_t allTiles = g11 ? 2 * gridC.x : gridC.x;
+    uint32_t wgs = c->dma_wgs ? c->dma_wgs : (g11 ? 4u : 2u) * (uint32_t)c->n_cu;
+    wgs = std::max(8u, std::min(wgs, allTiles) / 8u * 8u);
+    const dim3 grid(wgs), block(g11 ? 256 : (1 << HM_TL_ROW) / (g8 ? 8 : HM_EPT));
+#define HM_DGO(K11, K8, K16) do { if constexpr (LOG1 == 8) { if (g11) hipLaunchKernelGGL(K11, grid, block, 0, c->stream, a); else if (g8) hipLaunchKernelGGL(K8, grid, block, 0, c->stream, a); else hipLaunchKernelGGL(K16, grid, block, 0, c->stream, a); } else hipLaunchKernelGGL(K16, grid, block, 0, c->stream, a); } while (0)
+    if (!inverse) {
+      if (mixPrologue) HM_DGO((k_ntt_col8_dma11<false, 4>), (k_ntt_col8_dma<false, 4>), (k_ntt_col_dma<LOG1, false, 4>));
+      else HM_DGO((k_ntt_col8_dma11<false, 0>), (k_ntt_col8_dma<false, 0>), (k_ntt_col_dma<LOG1, false, 0>));
+      if (firstPassOnly) return;
+      if (fusedEpilogue) HM_DGO((k_ntt_row8_dma11<false, 3>), (k_ntt_row8_dma<false, 3>), (k_ntt_row_dma<false, 3>));
+      else HM_DGO((k_ntt_row8_dma11<false, 1>), (k_ntt_row8_dma<false, 1>), (k_ntt_row_dma<false, 1>));
+    } else {
+      HM_DGO((k_ntt_row8_dma11<true, 0>), (k_ntt_row8_dma<true, 0>), (k_ntt_row_dma<true, 0>));
+      HM_DGO((k_ntt_col8_dma11<true, 2>), (k_ntt_col8_dma<true, 2>), (k_ntt_col_dma<LOG1, true, 2>));
+    }
+#undef HM_DGO
+    return;
   }
   if (firstPassOnly) {  // forward COL pass alone: hm_ntt_inner_product runs the ROW pass inside its own kernel
     hipLaunchKernelGGL((k_ntt_col<LOG1, false, 0>), gridC, blockC, 0, c->stream, a);

@@ -293,6 +293,21 @@ HM_HD void hm_ph_load_lds(HmNttState &st, int tid, const uint64_t *lds) {
     hm_ld2(lds + hm_lds_idx<TL, LOGR, STRIDED>(x, c), st.v[i0], st.v[i1]);
   }
 }
+// MODE 4 with the tile in LDS: x = tile + k * mix, the mix operand straight from global memory
+template <int TL, int LOGR, bool STRIDED, int R, int AUX = 0>
+HM_HD void hm_ph_load_lds_mix(HmNttState &st, int tid, const uint64_t *lds, uint32_t tile, uint64_t q, HmEpi ep) {
+  using G = HmRound<TL, LOGR, STRIDED, R>;
+#pragma unroll
+  for (int a = 0; a < HM_UNITS; ++a) {
+    int i0, i1, x, c;
+    G::unit(tid, a, i0, i1, x, c);
+    uint64_t p0, p1, b0, b1;
+    hm_gld2<G, AUX>(ep.b, tile, tid, a, b0, b1);
+    hm_ld2(lds + hm_lds_idx<TL, LOGR, STRIDED>(x, c), p0, p1);
+    st.v[i0] = hm_addmod(p0, hm_shoup(b0, ep.bk.w, ep.bk.ws, q), q);
+    st.v[i1] = hm_addmod(p1, hm_shoup(b1, ep.bk.w, ep.bk.ws, q), q);
+  }
+}
 template <int TL, int LOGR, bool STRIDED, int R>
 HM_HD void hm_ph_store_lds(const HmNttState &st, int tid, uint64_t *lds) {
   using G = HmRound<TL, LOGR, STRIDED, R>;
@@ -356,15 +371,19 @@ HM_HD void hm_ph_twist(HmNttState &st, uint64_t q) {
 //   Pn:      tw[exec n-1] (if LDS), LDS -> v, [forward twist], compute exec n-1, v -> global (MODE 5: stays in registers)
 // twl = table of the modulus; twist_tile = twist constants of the tile's first row (ROW pass)
 // LDAUX / STAUX: cache-policy bits of the pass's data loads / stores (hm_gld2)
-template <int TL, int LOGR, bool STRIDED, bool INV, int MODE, int PHASE, int LDAUX = 0, int STAUX = 0, int EPICH = HM_EPI_CHUNK>
+// SRC = 1 (the persistent double-buffered passes, hm_ntt_dma.inl / k_ntt_*_dma): the tile already sits in `lds` in the image of
+// hm_lds_idx (an LDS-DMA put it there while the previous tile was being transformed), the first round reads it from there; the shared
+// twiddles were staged by the caller at `lds_tw` (a pass over several tiles stages them once per modulus).
+template <int TL, int LOGR, bool STRIDED, bool INV, int MODE, int PHASE, int LDAUX = 0, int STAUX = 0, int EPICH = HM_EPI_CHUNK, int SRC = 0>
 HM_HD void hm_ntt_phase(HmNttState &st, int tid, uint64_t *lds, const uint64_t *src, uint64_t *dst, uint32_t tile,
-                        const HmTw *twl, const HmTw *twist_tile, uint32_t s0, uint32_t prefix0, uint64_t q, HmTw sc, HmEpi ep) {
+                        const HmTw *twl, const HmTw *twist_tile, uint32_t s0, uint32_t prefix0, uint64_t q, HmTw sc, HmEpi ep,
+                        const uint64_t *lds_tw = nullptr) {
   using PS = HmPass<LOGR, STRIDED, INV>;
   constexpr int n = PS::n;
   static_assert(PHASE >= 0 && PHASE <= n, "a pass of n rounds has phases 0 .. n");
   constexpr int TWR = PS::twistRound;
   constexpr int iTW = TWR < 0 ? -1 : (INV ? n - 1 - TWR : TWR);   // execution index of the twisted round
-  const HmTw *ltw = reinterpret_cast<const HmTw *>(lds + (1 << TL));
+  const HmTw *ltw = reinterpret_cast<const HmTw *>(SRC ? lds_tw : lds + (1 << TL));
   // register pressure: the inverse ROW pass has 120 registers of loads in flight in its first phase (data, the first
   // round's shared twiddles, the twist constants and the NEXT round's private twiddles); inside the one-launch transform
   // that no longer fits 128.  The next round's twiddles are then requested after the first round's butterflies instead
@@ -372,9 +391,14 @@ HM_HD void hm_ntt_phase(HmNttState &st, int tid, uint64_t *lds, const uint64_t *
   constexpr bool LATE_TW1 = ((INV && HM_LATE_TW1) || MODE == 5) && !STRIDED;   // MODE 5: 64 accumulator registers are live beside the pass
   if constexpr (PHASE == 0) {
     constexpr int r0 = PS::exec(0), r1 = PS::exec(1);
-    if (PS::anyLds()) hm_ph_stage_tw<TL, LOGR, STRIDED>(tid, lds, twl);
-    hm_ph_load_tw<TL, LOGR, STRIDED, r0, PS::shared(r0)>(st, tid, twl, s0, prefix0);
-    if (MODE == 4) hm_ph_load_global_mix<TL, LOGR, STRIDED, r0, LDAUX>(st, tid, src, tile, q, ep);
+    if (PS::anyLds() && !SRC) hm_ph_stage_tw<TL, LOGR, STRIDED>(tid, lds, twl);
+    // SRC = 1: every shared round reads the staged copy, the first one included (it was staged for an earlier tile)
+    if (SRC && HM_TW_IN_LDS(STRIDED) && PS::shared(r0)) { /* from the staged copy: hm_ntt_phase_lds0 */ }
+    else hm_ph_load_tw<TL, LOGR, STRIDED, r0, PS::shared(r0)>(st, tid, twl, s0, prefix0);
+    if (SRC) {   // the tile is read from its LDS image by hm_ntt_phase_lds0 (after the caller has issued the next tile's DMA);
+      // here only what comes from global memory is requested: the MODE 4 operand lands in st.v for the time being
+      if (MODE == 4) hm_ph_load_global<TL, LOGR, STRIDED, r0, LDAUX>(st, tid, ep.b, tile);
+    } else if (MODE == 4) hm_ph_load_global_mix<TL, LOGR, STRIDED, r0, LDAUX>(st, tid, src, tile, q, ep);
     else hm_ph_load_global<TL, LOGR, STRIDED, r0, LDAUX>(st, tid, src, tile);
     // the twist constants are requested one phase ahead of the twisted round (phase iTW + 1)
     if (iTW >= 0 && iTW <= 1) hm_ph_load_twist<TL, LOGR, STRIDED, (TWR >= 0 ? TWR : 0)>(st, tid, twist_tile);
@@ -420,23 +444,67 @@ HM_HD void hm_ntt_phase(HmNttState &st, int tid, uint64_t *lds, const uint64_t *
     hm_ph_store_global<TL, LOGR, STRIDED, rl, MODE, STAUX, EPICH>(st, tid, dst, tile, q, sc, ep);
   }
 }
+// SRC = 1: the LDS half of phase 0 — the first round's elements from the tile image (MODE 4: plus k * the operand requested in phase 0),
+// its shared twiddles from the staged copy
+template <int TL, int LOGR, bool STRIDED, bool INV, int MODE>
+HM_HD void hm_ntt_phase_lds0(HmNttState &st, int tid, const uint64_t *lds, const uint64_t *lds_tw, uint32_t s0, uint32_t prefix0, uint64_t q, HmEpi ep) {
+  using PS = HmPass<LOGR, STRIDED, INV>;
+  constexpr int r0 = PS::exec(0);
+  using G = HmRound<TL, LOGR, STRIDED, r0>;
+  if (HM_TW_IN_LDS(STRIDED) && PS::shared(r0)) hm_ph_load_tw<TL, LOGR, STRIDED, r0, true>(st, tid, reinterpret_cast<const HmTw *>(lds_tw), s0, prefix0);
+#pragma unroll
+  for (int a = 0; a < HM_UNITS; ++a) {
+    int i0, i1, x, c;
+    G::unit(tid, a, i0, i1, x, c);
+    uint64_t p0, p1;
+    hm_ld2(lds + hm_lds_idx<TL, LOGR, STRIDED>(x, c), p0, p1);
+    if (MODE == 4) {
+      st.v[i0] = hm_addmod(p0, hm_shoup(st.v[i0], ep.bk.w, ep.bk.ws, q), q);
+      st.v[i1] = hm_addmod(p1, hm_shoup(st.v[i1], ep.bk.w, ep.bk.ws, q), q);
+    } else { st.v[i0] = p0; st.v[i1] = p1; }
+  }
+}
+struct HmNoMid { HM_HD void operator()() const {} };
 // all phases of a pass with `sync()` between them (the GPU passes __syncthreads, the emulator runs the phases itself)
-template <int TL, int LOGR, bool STRIDED, bool INV, int MODE, int LDAUX = 0, int STAUX = 0, int EPICH = HM_EPI_CHUNK, class SYNC>
+// SRC = 1: mid() runs between the global requests of phase 0 and the LDS reads of the tile image (the caller issues the next tile's DMA
+// there: requests behind the DMA would wait for it, vmcnt retires in order)
+template <int TL, int LOGR, bool STRIDED, bool INV, int MODE, int LDAUX = 0, int STAUX = 0, int EPICH = HM_EPI_CHUNK, int SRC = 0, class SYNC, class MID = HmNoMid>
 HM_HD void hm_ntt_pass_phases(HmNttState &st, int tid, uint64_t *lds, const uint64_t *src, uint64_t *dst, uint32_t tile,
-                              const HmTw *twl, const HmTw *twist_tile, uint32_t s0, uint32_t prefix0, uint64_t q, HmTw sc, HmEpi ep, SYNC sync) {
+                              const HmTw *twl, const HmTw *twist_tile, uint32_t s0, uint32_t prefix0, uint64_t q, HmTw sc, HmEpi ep, SYNC sync,
+                              const uint64_t *lds_tw = nullptr, MID mid = MID()) {
   constexpr int n = HmRounds<LOGR>::n;
-  hm_ntt_phase<TL, LOGR, STRIDED, INV, MODE, 0, LDAUX, STAUX, EPICH>(st, tid, lds, src, dst, tile, twl, twist_tile, s0, prefix0, q, sc, ep);
-  hm_ntt_phase<TL, LOGR, STRIDED, INV, MODE, 1, LDAUX, STAUX, EPICH>(st, tid, lds, src, dst, tile, twl, twist_tile, s0, prefix0, q, sc, ep);
+  hm_ntt_phase<TL, LOGR, STRIDED, INV, MODE, 0, LDAUX, STAUX, EPICH, SRC>(st, tid, lds, src, dst, tile, twl, twist_tile, s0, prefix0, q, sc, ep, lds_tw);
+  if constexpr (SRC != 0) {
+    mid();
+    hm_ntt_phase_lds0<TL, LOGR, STRIDED, INV, MODE>(st, tid, lds, lds_tw, s0, prefix0, q, ep);
+  }
+  hm_ntt_phase<TL, LOGR, STRIDED, INV, MODE, 1, LDAUX, STAUX, EPICH, SRC>(st, tid, lds, src, dst, tile, twl, twist_tile, s0, prefix0, q, sc, ep, lds_tw);
   sync();
-  hm_ntt_phase<TL, LOGR, STRIDED, INV, MODE, 2, LDAUX, STAUX, EPICH>(st, tid, lds, src, dst, tile, twl, twist_tile, s0, prefix0, q, sc, ep);
+  hm_ntt_phase<TL, LOGR, STRIDED, INV, MODE, 2, LDAUX, STAUX, EPICH, SRC>(st, tid, lds, src, dst, tile, twl, twist_tile, s0, prefix0, q, sc, ep, lds_tw);
   if constexpr (n >= 3) {
     sync();
-    hm_ntt_phase<TL, LOGR, STRIDED, INV, MODE, 3, LDAUX, STAUX, EPICH>(st, tid, lds, src, dst, tile, twl, twist_tile, s0, prefix0, q, sc, ep);
+    hm_ntt_phase<TL, LOGR, STRIDED, INV, MODE, 3, LDAUX, STAUX, EPICH, SRC>(st, tid, lds, src, dst, tile, twl, twist_tile, s0, prefix0, q, sc, ep, lds_tw);
   }
   if constexpr (n >= 4) {
     sync();
-    hm_ntt_phase<TL, LOGR, STRIDED, INV, MODE, 4, LDAUX, STAUX, EPICH>(st, tid, lds, src, dst, tile, twl, twist_tile, s0, prefix0, q, sc, ep);
+    hm_ntt_phase<TL, LOGR, STRIDED, INV, MODE, 4, LDAUX, STAUX, EPICH, SRC>(st, tid, lds, src, dst, tile, twl, twist_tile, s0, prefix0, q, sc, ep, lds_tw);
   }
+}
+// inverse of hm_lds_idx for the 16-byte unit at even word w of the tile image: coordinates (x, c) of its first word
+template <int TL, int LOGR, bool STRIDED>
+HM_HD void hm_lds_unidx(int w, int &x, int &c) {
+  if (STRIDED) {
+    constexpr int LOGC = TL - LOGR;
+    int xf = w >> LOGC;
+    c = w & ((1 << LOGC) - 1);
+    if (LOGC <= 4) xf ^= (xf >> 2) & ((1 << (LOGC <= 4 ? 5 - LOGC : 0)) - 1);   // the swizzle moves bits [0, 5 - LOGC) of x by bits [2, ..): an involution
+    x = xf;
+    return;
+  }
+  c = w >> LOGR;
+  int xw = w & ((1 << LOGR) - 1);
+  if (LOGR == 8) xw ^= (((xw >> 5) & 7) << 2) ^ (((xw >> 5) & 1) << 1);
+  x = xw;
 }
 
 // ---------------------------------------------------------------------------------------------------
