@@ -716,84 +716,7 @@ __global__ void __launch_bounds__((1 << HM_TL_ROW) / HM_EPT) __attribute__((amdg
   hm_ph_mac_store<TL, LOGR, R2, OUTS, Acc, HM_NIP_ST_AUX>(acc, threadIdx.x, out, tile, m);
 }
 
-// ---- base conversion fused into the first pass of the transform that consumes it (round 3) --------------------------------
-// The COL workgroup of (conversion p, output limb o, column tile t) computes its 4096 coefficients of output o from the N_IN input
-// tiles (the workgroups of the same (p, t) for the other outputs sit in neighbouring dispatch slots of one XCD and find the inputs in
-// L2), then runs the COL pass on them: the converted limb-poly never exists in HBM, only the first pass's hand-off does.
-struct HmBcolProb {
-  const uint64_t *in;
-  const uint64_t *table, *qn;
-  uint32_t n_in, n_out;
-  uint32_t in_limb[HM_BCONV_MAX_IN];
-  uint32_t out_limb[HM_BCONV_MAX_OUT];   // where the hand-off of output o goes (limb of `out`)
-  uint32_t out_mod[HM_BCONV_MAX_OUT];    // its modulus id (shared twiddles)
-};
-struct HmBcolArgs {
-  const HmBcolProb *prob;   // device
-  uint64_t *out;
-  const HmTw *tw;
-  uint32_t logN, n_prob, max_out;
-};
-template <int N_IN>
-__global__ void __launch_bounds__((1 << HM_TL_COL) / HM_EPT) __attribute__((amdgpu_waves_per_eu(HM_NTT_MIN_WAVES))) k_bconv_col(HmBcolArgs a) {
-  constexpr int TL = HM_TL_COL, LOG1 = 8;
-  using PS = HmPass<LOG1, true, false>;
-  using G0 = HmRound<TL, LOG1, true, PS::exec(0)>;
-  __shared__ __attribute__((aligned(16))) uint64_t lds[HmLds<TL, LOG1, true>::WORDS];
-  // blocks b, b + 8 share an XCD; inside an XCD: (conversion, tile) pairs, each with its max_out outputs in consecutive slots
-  const uint32_t b = blockIdx.x, xcd = b & 7u, slot = b >> 3;
-  const uint32_t pair = (slot / a.max_out) * 8u + xcd, o = slot % a.max_out;
-  const uint32_t tiles = 1u << (a.logN - TL);
-  const uint32_t pi = pair / tiles, tile = pair % tiles;
-  if (pi >= a.n_prob) return;
-  const auto &p = HM_CONST_PROB_T(HmBcolProb, a.prob)[pi];
-  if (o >= p.n_out) return;
-  const int tid = threadIdx.x;
-  const size_t N = (size_t)1 << a.logN;
-  constexpr int NG = (N_IN + 7) / 8;
-  HmRow8 row[NG];
-#pragma unroll
-  for (int g = 0; g < NG; ++g) row[g] = HM_CONST_ROWS(p.table)[o * NG + g];
-  const HmQn m = HM_CONST_QN(p.qn)[o];
-  const HmTw *twl = a.tw + (size_t)p.out_mod[o] * N;
-  hm_ph_stage_tw<TL, LOG1, true>(tid, lds, twl);   // every round reads its shared twiddles from LDS (after the barrier below)
-  HmNttState st;
-#pragma unroll
-  for (int u = 0; u < HM_UNITS; ++u) {
-    int i0, i1, x, c;
-    G0::unit(tid, u, i0, i1, x, c);
-    uint32_t yl[2][N_IN], yh[2][N_IN];
-#pragma unroll
-    for (int i = 0; i < N_IN; ++i) {
-      uint64_t v0, v1;
-      hm_gld2<G0>(p.in + (size_t)p.in_limb[i] * N, tile, tid, u, v0, v1);
-#if defined(HM_ABL_BCOL_PACKED)   // timing-only ablation: inputs taken as if already stored split (no shift / mask per input and output)
-      yl[0][i] = (uint32_t)v0; yh[0][i] = (uint32_t)(v0 >> 32);
-      yl[1][i] = (uint32_t)v1; yh[1][i] = (uint32_t)(v1 >> 32);
-#else
-      yl[0][i] = (uint32_t)v0 & 0x3FFFFFFFu; yh[0][i] = (uint32_t)(v0 >> 30);
-      yl[1][i] = (uint32_t)v1 & 0x3FFFFFFFu; yh[1][i] = (uint32_t)(v1 >> 30);
-#endif
-    }
-    st.v[i0] = hm_bconv_dot<N_IN>(yl[0], yh[0], row, m.q, m.nqinv);
-    st.v[i1] = hm_bconv_dot<N_IN>(yl[1], yh[1], row, m.q, m.nqinv);
-    __builtin_amdgcn_sched_barrier(0);   // one unit's loads in flight at a time (15 x 16 bytes per lane)
-  }
-  __syncthreads();
-  const HmTw *ltw = reinterpret_cast<const HmTw *>(lds + (1 << TL));
-  constexpr int r0 = PS::exec(0);
-  hm_ph_load_tw<TL, LOG1, true, r0, true>(st, tid, ltw, 0, 0);
-  hm_ph_compute<TL, LOG1, true, r0, false>(st, m.q);
-  hm_ph_store_lds<TL, LOG1, true, r0>(st, tid, lds);
-  __syncthreads();
-  uint64_t *dst = a.out + (size_t)p.out_limb[o] * N;
-  const HmTw sc = {0, 0};
-  const HmEpi ep = hm_epi_none();
-  hm_ntt_phase<TL, LOG1, true, false, 0, 2>(st, tid, lds, nullptr, dst, tile, twl, nullptr, 0, 0, m.q, sc, ep);
-  __syncthreads();
-  hm_ntt_phase<TL, LOG1, true, false, 0, 3>(st, tid, lds, nullptr, dst, tile, twl, nullptr, 0, 0, m.q, sc, ep);
-}
-
+#include "hm_bcol.h"
 __global__ void __launch_bounds__(256) k_tensor(HmTensorArgs a) {
   const uint32_t N = 1u << a.logN;
   const uint32_t per_limb = N / 512;
@@ -974,6 +897,7 @@ struct hm_ctx {
   uint32_t fused_extra_lds = 0;   // dynamic LDS added to every k_ntt_fused workgroup: occupancy throttle of the L2 hand-off experiment
   // persistent two-pass transform fed from per-XCD queues (k_ntt_queue): 0 off, 1 = 8-coefficient geometry (N = 2^16), 2 = 16-coefficient
   uint32_t queue_ntt = 0, queue_wgs = 0 /* workgroups of the grid; 0 = 2 (geometry 8) or 4 (16) per CU */, queue_la = 2, queue_gc = 0 /* 0 = auto */;
+  uint32_t bcol_outs = 0;   // output limbs per workgroup of the fused conversion + first pass (1 | 2; 0 = by launch size)
   uint32_t dma_ntt = 0, dma_wgs = 0;   // persistent double-buffered passes (k_ntt_*_dma): 0 off, 1 = 8-coefficient geometry (N = 2^16), 2 = 16-coefficient; workgroups per launch (0 = 2 per CU)
   HmNttQueue *ntt_q = nullptr;
   unsigned *q_trace_host = nullptr, *q_trace_dev = nullptr;   // HOMULATOR_NTT_QUEUE_TRACE
@@ -1115,6 +1039,7 @@ extern "C" hm_status hm_create(hm_ctx **out, const hm_params *p) {
     memset(cc->q_trace_host, 0, 64 * 256 * 4);
     HM_HIP(nullptr, hipHostGetDevicePointer(reinterpret_cast<void **>(&cc->q_trace_dev), cc->q_trace_host, 0));
   }
+  if (const char *e = getenv("HOMULATOR_BCOL_OUTS")) cc->bcol_outs = (uint32_t)std::min(2, std::max(0, atoi(e)));
   if (const char *e = getenv("HOMULATOR_NTT_DMA")) cc->dma_ntt = (uint32_t)std::min(3, std::max(0, atoi(e)));
   if (const char *e = getenv("HOMULATOR_NTT_DMA_WGS")) cc->dma_wgs = (uint32_t)std::min(8192, std::max(0, atoi(e)));
   if (const char *e = getenv("HOMULATOR_NTT_QUEUE")) cc->queue_ntt = (uint32_t)std::min(2, std::max(0, atoi(e)));
@@ -1272,6 +1197,7 @@ extern "C" hm_status hm_set_option(hm_ctx *c, const char *name, uint64_t value) 
   if (!c || !name) return HM_ERR_ARG;
   if (!strcmp(name, "ntt_fused")) { c->fused_ntt = value != 0; return HM_OK; }
   if (!strcmp(name, "ntt_fused_lds")) { if (value > 120 * 1024) return fail(c, HM_ERR_ARG, "hm_set_option: ntt_fused_lds above 120 KiB"); c->fused_extra_lds = (uint32_t)value; return HM_OK; }
+  if (!strcmp(name, "bconv_col_outs")) { if (value > 2) return fail(c, HM_ERR_ARG, "hm_set_option: bconv_col_outs is 0 (by launch size), 1 or 2"); c->bcol_outs = (uint32_t)value; return HM_OK; }
   if (!strcmp(name, "ntt_dma")) { if (value > 3) return fail(c, HM_ERR_ARG, "hm_set_option: ntt_dma is 0 .. 3"); c->dma_ntt = (uint32_t)value; return HM_OK; }
   if (!strcmp(name, "ntt_dma_wgs")) { if (value > 8192) return fail(c, HM_ERR_ARG, "hm_set_option: ntt_dma_wgs above 8192"); c->dma_wgs = (uint32_t)value; return HM_OK; }
   if (!strcmp(name, "ntt_queue")) { if (value > 2) return fail(c, HM_ERR_ARG, "hm_set_option: ntt_queue is 0, 1 or 2"); c->queue_ntt = (uint32_t)value; return HM_OK; }
@@ -1397,10 +1323,23 @@ static hm_status check_mods(hm_ctx *c, const char *what, const uint32_t *m, uint
 }
 
 template <int LOG1>
-static void launch_ntt(hm_ctx *c, const HmNttArgs &a, bool fusedEpilogue, bool mixPrologue, bool inverse, bool firstPassOnly) {
+static void launch_ntt(hm_ctx *c, const HmNttArgs &a, bool fusedEpilogue, bool mixPrologue, bool inverse, bool firstPassOnly, bool secondPassOnly = false) {
   // n_limbs = entries, a multiple of 16 (pairs x 8 XCDs); one workgroup per tile of each pass
   const dim3 gridC(a.n_limbs * (c->P.N >> HM_TL_COL)), blockC((1 << HM_TL_COL) / HM_EPT);
   const dim3 gridR(a.n_limbs * (c->P.N >> HM_TL_ROW)), blockR((1 << HM_TL_ROW) / HM_EPT);
+  if (secondPassOnly) {   // the hand-off was written by a fused conversion + first pass (bconv_col_launch)
+    if constexpr (LOG1 == 8) {
+      if (c->small_ept8 && (c->small_mode & 2) && a.n_limbs <= c->small_limbs) {
+        const dim3 grid8(a.n_limbs * (c->P.N >> HM_TL_ROW)), block8((1 << HM_TL_ROW) / 8);
+        if (fusedEpilogue) hipLaunchKernelGGL((k_ntt_row8<false, 3>), grid8, block8, 0, c->stream, a);
+        else hipLaunchKernelGGL((k_ntt_row8<false, 1>), grid8, block8, 0, c->stream, a);
+        return;
+      }
+    }
+    if (fusedEpilogue) hipLaunchKernelGGL((k_ntt_row<false, 3>), gridR, blockR, 0, c->stream, a);
+    else hipLaunchKernelGGL((k_ntt_row<false, 1>), gridR, blockR, 0, c->stream, a);
+    return;
+  }
   // small launches (one round of workgroups on the chip): the 8-coefficient geometry halves the serial work per wave
   if constexpr (LOG1 == 8) {
     if (c->small_ept8 && !firstPassOnly && !c->fused_ntt && !c->dma_ntt && a.n_limbs <= c->small_limbs) {
@@ -1511,6 +1450,7 @@ struct NttFused {
   const uint32_t *mix_limbs = nullptr;
   const uint64_t *mix_k = nullptr;
   bool firstPassOnly = false;   // forward transform: run the COL pass only (the hand-off stays in `out`)
+  bool secondPassOnly = false;  // forward transform: the hand-off is already in `out` (a fused conversion wrote it): run the ROW pass only
 };
 
 // common body of hm_ntt / hm_ntt_sub_scale / hm_ntt_mix_sub_scale.  `k`: inverse -> optional extra scale; fused forward ->
@@ -1534,7 +1474,7 @@ static hm_status ntt_common(hm_ctx *c, const char *what, const uint64_t *in, con
   }
   HM_HIP(c, hipSetDevice(c->device));
   // persistent two-pass transform from per-XCD queues (k_ntt_queue); the 8-coefficient geometry exists for N = 2^16
-  if (c->queue_ntt && !f.firstPassOnly && true) {
+  if (c->queue_ntt && !f.firstPassOnly && !f.secondPassOnly) {
     const bool geo8 = c->queue_ntt == 1 && c->P.logN == 16;
     // dense entry list, same-modulus limb-polys adjacent (their tiles are handed out side by side: one fetch of the row twiddles per group)
     std::vector<uint32_t> order(n);
@@ -1703,11 +1643,11 @@ static hm_status ntt_common(hm_ctx *c, const char *what, const uint64_t *in, con
     a.logN = c->P.logN; a.n_limbs = cnt; a.logG = logG;
     const bool mixPro = fused && f.mix;
     switch (c->P.logN - HM_ROW_LOG) {
-    case 5: launch_ntt<5>(c, a, fused, mixPro, inverse, f.firstPassOnly); break;
-    case 6: launch_ntt<6>(c, a, fused, mixPro, inverse, f.firstPassOnly); break;
-    case 7: launch_ntt<7>(c, a, fused, mixPro, inverse, f.firstPassOnly); break;
-    case 8: launch_ntt<8>(c, a, fused, mixPro, inverse, f.firstPassOnly); break;
-    case 9: launch_ntt<9>(c, a, fused, mixPro, inverse, f.firstPassOnly); break;
+    case 5: launch_ntt<5>(c, a, fused, mixPro, inverse, f.firstPassOnly, f.secondPassOnly); break;
+    case 6: launch_ntt<6>(c, a, fused, mixPro, inverse, f.firstPassOnly, f.secondPassOnly); break;
+    case 7: launch_ntt<7>(c, a, fused, mixPro, inverse, f.firstPassOnly, f.secondPassOnly); break;
+    case 8: launch_ntt<8>(c, a, fused, mixPro, inverse, f.firstPassOnly, f.secondPassOnly); break;
+    case 9: launch_ntt<9>(c, a, fused, mixPro, inverse, f.firstPassOnly, f.secondPassOnly); break;
     default: return fail(c, HM_ERR_UNSUPPORTED, "%s: logN %u", what, c->P.logN);
     }
     HM_HIP(c, hipGetLastError());
@@ -1735,15 +1675,74 @@ extern "C" hm_status hm_ntt_sub_scale(hm_ctx *c, const uint64_t *in, const uint3
   return ntt_common(c, "hm_ntt_sub_scale", in, in_limbs, out, out_limbs, mod_ids, n, 0, k, f);
 }
 
+static hm_status bconv_col_launch(hm_ctx *c, const hm_bconv_desc *descs, uint32_t n_desc, const struct BcolMix *mix);
+struct BcolMix {   // the MODE 4 prologue of a fused conversion (x = conv + k * mix): per conversion, per output, the operand's limb and the constant
+  const uint64_t *mix;
+  const uint32_t *const *mix_limbs;
+  const uint64_t *const *mix_k;
+};
 extern "C" hm_status hm_ntt_mix_sub_scale(hm_ctx *c, const hm_ntt_fused_desc *d) {
   if (!c) return HM_ERR_ARG;
-  if (!d || !d->in || !d->out || !d->minuend || !d->k) return fail(c, HM_ERR_ARG, "hm_ntt_mix_sub_scale: null argument");
+  if (!d || (!d->in && !d->n_conv) || !d->out || !d->minuend || !d->k) return fail(c, HM_ERR_ARG, "hm_ntt_mix_sub_scale: null argument");
   if ((d->mix != nullptr) != (d->mix_k != nullptr)) return fail(c, HM_ERR_ARG, "hm_ntt_mix_sub_scale: mix and mix_k go together");
   if (d->addend_k && !d->addend) return fail(c, HM_ERR_ARG, "hm_ntt_mix_sub_scale: addend_k without addend");
   NttFused f;
   f.minuend = d->minuend; f.minuend_limbs = d->minuend_limbs; f.addend = d->addend; f.addend_limbs = d->addend_limbs;
   f.addend_k = d->addend_k; f.mix = d->mix; f.mix_limbs = d->mix_limbs; f.mix_k = d->mix_k;
-  return ntt_common(c, "hm_ntt_mix_sub_scale", d->in, d->in_limbs, d->out, d->out_limbs, d->mod_ids, d->n, 0, d->k, f);
+  if (!d->n_conv) return ntt_common(c, "hm_ntt_mix_sub_scale", d->in, d->in_limbs, d->out, d->out_limbs, d->mod_ids, d->n, 0, d->k, f);
+  // ---- some or all inputs are conversions that run inside their transform's first pass (round 4: the ModDown side)
+  if (!d->conv) return fail(c, HM_ERR_ARG, "hm_ntt_mix_sub_scale: n_conv without descriptors");
+  const uint32_t n = d->n;
+  std::map<uint32_t, uint32_t> byOut;   // output limb -> limb-poly of the call
+  for (uint32_t i = 0; i < n; ++i)
+    if (!byOut.emplace(limb_at(d->out_limbs, i), i).second) return fail(c, HM_ERR_ARG, "hm_ntt_mix_sub_scale: output limb %u appears twice", limb_at(d->out_limbs, i));
+  std::vector<char> covered(n, 0);
+  std::vector<std::vector<uint32_t>> mixLimbs(d->n_conv);
+  std::vector<std::vector<uint64_t>> mixK(d->n_conv);
+  std::vector<const uint32_t *> mlp(d->n_conv);
+  std::vector<const uint64_t *> mkp(d->n_conv);
+  for (uint32_t j = 0; j < d->n_conv; ++j) {
+    const hm_bconv_desc &cv = d->conv[j];
+    if (cv.out != d->out) return fail(c, HM_ERR_ARG, "hm_ntt_mix_sub_scale: conv[%u].out must be the output buffer", j);
+    if (!cv.out_ids || cv.n_out == 0 || cv.n_out > HM_BCONV_MAX_OUT) return fail(c, HM_ERR_ARG, "hm_ntt_mix_sub_scale: conv[%u]: bad output basis", j);
+    for (uint32_t t = 0; t < cv.n_out; ++t) {
+      auto it = byOut.find(limb_at(cv.out_limbs, t));
+      if (it == byOut.end()) return fail(c, HM_ERR_ARG, "hm_ntt_mix_sub_scale: conv[%u] output %u feeds no limb-poly of the call", j, t);
+      const uint32_t i = it->second;
+      if (covered[i]) return fail(c, HM_ERR_ARG, "hm_ntt_mix_sub_scale: limb-poly %u is fed by two conversions", i);
+      if (cv.out_ids[t] != d->mod_ids[i]) return fail(c, HM_ERR_ARG, "hm_ntt_mix_sub_scale: conv[%u] output %u has another modulus than the limb-poly it feeds", j, t);
+      covered[i] = 1;
+      mixLimbs[j].push_back(d->mix ? limb_at(d->mix_limbs, i) : 0);
+      mixK[j].push_back(d->mix ? d->mix_k[i] : 0);
+    }
+    mlp[j] = mixLimbs[j].data(); mkp[j] = mixK[j].data();
+  }
+  const BcolMix bm = {d->mix, mlp.data(), mkp.data()};
+  hm_status st;
+  if ((st = bconv_col_launch(c, d->conv, d->n_conv, d->mix ? &bm : nullptr))) return st;
+  // the covered limb-polys: last pass only (in place on the hand-off the conversions wrote); the others: the whole transform
+  auto sub = [&](char want, bool second) -> hm_status {
+    std::vector<uint32_t> il, ml, mnl, al, ol, mods;
+    std::vector<uint64_t> mk, ak, kk;
+    for (uint32_t i = 0; i < n; ++i) {
+      if (covered[i] != want) continue;
+      il.push_back(limb_at(d->in_limbs, i)); ol.push_back(limb_at(d->out_limbs, i)); mnl.push_back(limb_at(d->minuend_limbs, i));
+      mods.push_back(d->mod_ids[i]); kk.push_back(d->k[i]);
+      if (d->mix) { ml.push_back(limb_at(d->mix_limbs, i)); mk.push_back(d->mix_k[i]); }
+      if (d->addend) al.push_back(limb_at(d->addend_limbs, i));
+      if (d->addend_k) ak.push_back(d->addend_k[i]);
+    }
+    if (mods.empty()) return HM_OK;
+    if (!second && !d->in) return fail(c, HM_ERR_ARG, "hm_ntt_mix_sub_scale: `in` is null but not every limb-poly is fed by a conversion");
+    NttFused g = f;
+    g.minuend_limbs = mnl.data(); g.addend_limbs = d->addend ? al.data() : nullptr; g.addend_k = d->addend_k ? ak.data() : nullptr;
+    g.mix_limbs = d->mix ? ml.data() : nullptr; g.mix_k = d->mix ? mk.data() : nullptr;
+    g.secondPassOnly = second;
+    if (second) { g.mix = nullptr; g.mix_limbs = nullptr; g.mix_k = nullptr; }   // the prologue ran inside the conversion kernel
+    return ntt_common(c, "hm_ntt_mix_sub_scale", second ? d->out : d->in, second ? ol.data() : il.data(), d->out, ol.data(), mods.data(), (uint32_t)mods.size(), 0, kk.data(), g);
+  };
+  if ((st = sub(1, true))) return st;
+  return sub(0, false);
 }
 
 extern "C" hm_status hm_tensor(hm_ctx *c, const uint64_t *pa, const uint32_t *la, const uint64_t *pb, const uint32_t *lb,
@@ -1889,7 +1888,6 @@ extern "C" hm_status hm_inner_product(hm_ctx *c, const uint64_t *x, const uint32
 }
 
 
-static hm_status bconv_col_launch(hm_ctx *c, const hm_bconv_desc *descs, uint32_t n_desc);
 // K1 x K5: out[i][k] = sum_j X_j[i] * y[i][k][j] with X_j[i] = NTT(x[i][j]) for the digits that go through
 // the transform (x_is_coeff) and x[i][j] itself for a digit's own limbs.  Two launches: the COL pass of every transformed
 // (limb, digit) into `hand`, then k_ntt_row_ip: ROW pass, product with both keys, accumulation over the digits in registers.
@@ -1914,7 +1912,7 @@ extern "C" hm_status hm_ntt_inner_product(hm_ctx *c, const hm_ntt_ip_desc *d) {
     if (!d->conv || !d->hand) return fail(c, HM_ERR_ARG, "hm_ntt_inner_product: conversions need their descriptors and the hand-off buffer");
     for (uint32_t k = 0; k < d->n_conv; ++k)
       if (d->conv[k].out != d->hand) return fail(c, HM_ERR_ARG, "hm_ntt_inner_product: conv[%u].out must be the hand-off buffer", k);
-    if ((st = bconv_col_launch(c, d->conv, d->n_conv))) return st;
+    if ((st = bconv_col_launch(c, d->conv, d->n_conv, nullptr))) return st;
   }
   // a launch may mix digits whose conversion runs inside their first pass with digits that arrive converted (Arch decides per
   // inner-product record: a digit of more than HM_BCOL_MAX_IN limbs keeps its own conversion): every transformed (limb, digit) whose
@@ -2077,11 +2075,29 @@ extern "C" hm_status hm_bconv_batch(hm_ctx *c, const hm_bconv_desc *descs, uint3
       it = c->bconv_tables.emplace(key, dev).first;
     }
     HmBconvProb &p = probs[pi];
+    memset(&p, 0, sizeof p);
     p.in = d.in; p.out = d.out; p.table = it->second; p.n_in = d.n_in; p.n_out = d.n_out;
     p.qn = it->second + (size_t)HM_BCONV_ROW(d.n_in) * d.n_out;
     for (uint32_t i = 0; i < d.n_in; ++i) p.in_limb[i] = limb_at(d.in_limbs, i);
     for (uint32_t t = 0; t < d.n_out; ++t) {
       p.out_limb[t] = limb_at(d.out_limbs, t);
+    }
+    if (d.sub_from) {   // epilogue out = (sub_from - conv) * k [+ add]
+      if (!d.sub_k) return fail(c, HM_ERR_ARG, "hm_bconv: the epilogue needs its constants (sub_k)");
+      if (d.log_len && d.log_len != c->P.logN) return fail(c, HM_ERR_UNSUPPORTED, "hm_bconv: the epilogue works on whole limb-polys");
+      hm_status est;
+      if ((est = check_limbs(c, "hm_bconv", d.sub_from_limbs, d.n_out)) || (est = check_limbs(c, "hm_bconv", d.add_limbs, d.n_out))) return est;
+      std::vector<HmTw> ek(d.n_out);
+      for (uint32_t t = 0; t < d.n_out; ++t) {
+        const uint64_t q = c->P.mod[d.out_ids[t]];
+        if (d.sub_k[t] >= q) return fail(c, HM_ERR_ARG, "hm_bconv: sub_k[%u] is not reduced", t);
+        ek[t] = HmTw{d.sub_k[t], hm::shoup(d.sub_k[t], q)};
+        p.ep_a_limb[t] = limb_at(d.sub_from_limbs, t);
+        p.ep_b_limb[t] = d.add ? limb_at(d.add_limbs, t) : 0;
+      }
+      const void *dk = nullptr;
+      if ((est = device_table(c, ek.data(), sizeof(HmTw) * ek.size(), &dk))) return est;
+      p.ep_a = d.sub_from; p.ep_b = d.add; p.ep_k = static_cast<const HmTw *>(dk);
     }
   }
   // one launch per distinct input-basis size (the digits of a ModUp differ only in the last, shorter digit), up to
@@ -2127,18 +2143,18 @@ extern "C" hm_status hm_bconv_batch(hm_ctx *c, const hm_bconv_desc *descs, uint3
 
 // conversion + first transform pass in one kernel (see k_bconv_col).  Same descriptors as hm_bconv_batch; `out` receives the COL pass's
 // hand-off of NTT(conversion), the form k_ntt_row_ip reads.  N = 2^16, n_in <= HM_BCOL_MAX_IN.
-#define HM_BCOL_MAX_IN 15   // 16 inputs: hipcc leaves the input arrays in scratch (1 KB per lane)
-typedef void (*hm_bcol_kernel)(HmBcolArgs);
-static const hm_bcol_kernel k_bconv_col_by_n_in[HM_BCOL_MAX_IN + 1] = {
-    nullptr,
-#define HM_K(n) k_bconv_col<n>,
-    HM_K(1) HM_K(2) HM_K(3) HM_K(4) HM_K(5) HM_K(6) HM_K(7) HM_K(8) HM_K(9) HM_K(10) HM_K(11) HM_K(12) HM_K(13) HM_K(14) HM_K(15)
-#undef HM_K
-};
-static hm_status bconv_col_launch(hm_ctx *c, const hm_bconv_desc *descs, uint32_t n_desc) {
+static hm_status bconv_col_launch(hm_ctx *c, const hm_bconv_desc *descs, uint32_t n_desc, const BcolMix *mix) {
   if (!c || !descs || n_desc == 0) return HM_ERR_ARG;
-  if (c->P.logN != 16) return fail(c, HM_ERR_UNSUPPORTED, "fused conversion: N = 2^16 only");
+  if (c->P.logN != 16 && c->P.logN != 15) return fail(c, HM_ERR_UNSUPPORTED, "fused conversion: N = 2^15 or 2^16 only");
   HM_HIP(c, hipSetDevice(c->device));
+  // output limbs per workgroup: two share the loaded and split inputs (+2 % hmult/s at batch 10), but halve the workgroups of a launch that
+  // fills the chip only once or twice (one op at a time: -2 %): by launch size unless the option says otherwise
+  uint32_t NOUT = c->bcol_outs;
+  if (!NOUT) {
+    size_t wgs = 0;
+    for (uint32_t pi = 0; pi < n_desc; ++pi) wgs += (size_t)descs[pi].n_out * (c->P.N >> HM_TL_COL);
+    NOUT = wgs > 4096 ? 2 : 1;
+  }
   std::map<uint32_t, std::vector<HmBcolProb>> byIn;
   for (uint32_t pi = 0; pi < n_desc; ++pi) {
     const hm_bconv_desc &d = descs[pi];
@@ -2146,6 +2162,7 @@ static hm_status bconv_col_launch(hm_ctx *c, const hm_bconv_desc *descs, uint32_
     if (d.n_in == 0 || d.n_in > HM_BCOL_MAX_IN) return fail(c, HM_ERR_UNSUPPORTED, "fused conversion: n_in %u not in [1,%d]", d.n_in, HM_BCOL_MAX_IN);
     if (d.n_out == 0 || d.n_out > HM_BCONV_MAX_OUT) return fail(c, HM_ERR_ARG, "fused conversion: n_out %u not in [1,%d]", d.n_out, HM_BCONV_MAX_OUT);
     if (d.log_len && d.log_len != c->P.logN) return fail(c, HM_ERR_UNSUPPORTED, "fused conversion: whole limb-polys only");
+    if (d.out != descs[0].out) return fail(c, HM_ERR_ARG, "fused conversion: one hand-off buffer per call");
     hm_status cst;
     if ((cst = check_limbs(c, "fused conversion", d.in_limbs, d.n_in)) || (cst = check_limbs(c, "fused conversion", d.out_limbs, d.n_out)) ||
         (cst = check_mods(c, "fused conversion", d.in_ids, d.n_in)) || (cst = check_mods(c, "fused conversion", d.out_ids, d.n_out)))
@@ -2176,6 +2193,20 @@ static hm_status bconv_col_launch(hm_ctx *c, const hm_bconv_desc *descs, uint32_
     p.in = d.in; p.table = it->second; p.qn = it->second + (size_t)HM_BCONV_ROW(d.n_in) * d.n_out; p.n_in = d.n_in; p.n_out = d.n_out;
     for (uint32_t i = 0; i < d.n_in; ++i) p.in_limb[i] = limb_at(d.in_limbs, i);
     for (uint32_t t = 0; t < d.n_out; ++t) { p.out_limb[t] = limb_at(d.out_limbs, t); p.out_mod[t] = d.out_ids[t]; }
+    if (mix) {   // x = conv + k * mix before the first butterfly: constants in Shoup form, a device table cached by content
+      std::vector<HmTw> mk(d.n_out);
+      for (uint32_t t = 0; t < d.n_out; ++t) {
+        const uint64_t q = c->P.mod[d.out_ids[t]], k = mix->mix_k[pi][t];
+        if (k >= q) return fail(c, HM_ERR_ARG, "fused conversion: mix constant [%u][%u] is not reduced", pi, t);
+        if (mix->mix_limbs[pi][t] > 0xFFFFu) return fail(c, HM_ERR_ARG, "fused conversion: limb index exceeds 65535");
+        mk[t] = HmTw{k, hm::shoup(k, q)};
+        p.mix_limb[t] = mix->mix_limbs[pi][t];
+      }
+      const void *dk = nullptr;
+      hm_status st = device_table(c, mk.data(), sizeof(HmTw) * mk.size(), &dk);
+      if (st) return st;
+      p.mixk = static_cast<const HmTw *>(dk);
+    }
     byIn[d.n_in].push_back(p);
   }
   struct Lnch { uint32_t n_in; dim3 grid; HmBcolArgs a; };
@@ -2184,15 +2215,16 @@ static hm_status bconv_col_launch(hm_ctx *c, const hm_bconv_desc *descs, uint32_
   for (auto &kv : byIn) {
     auto &grp = kv.second;
     uint32_t max_out = 0;
-    uint64_t *out = descs[0].out;   // one hand-off buffer for the call (checked by the caller below)
+    uint64_t *out = descs[0].out;   // one hand-off buffer for the call (checked above)
     for (auto &p : grp) max_out = std::max(max_out, p.n_out);
+    const uint32_t groups = (max_out + NOUT - 1) / NOUT;   // output groups per (conversion, tile)
     const void *dtab = nullptr;
     hm_status st = device_table(c, grp.data(), sizeof(HmBcolProb) * grp.size(), &dtab);
     if (st) return st;
-    HmBcolArgs a = {static_cast<const HmBcolProb *>(dtab), out, c->d_tw_fwd, c->P.logN, (uint32_t)grp.size(), max_out};
+    HmBcolArgs a = {static_cast<const HmBcolProb *>(dtab), out, c->d_tw_fwd, c->P.logN, (uint32_t)grp.size(), groups, mix ? mix->mix : nullptr};
     const uint32_t pairs = ((uint32_t)grp.size() * (c->P.N >> HM_TL_COL) + 7) / 8 * 8;
-    ls.push_back(Lnch{kv.first, dim3(pairs * max_out), a});
-    totalWgs += (size_t)pairs * max_out;
+    ls.push_back(Lnch{kv.first, dim3(pairs * groups), a});
+    totalWgs += (size_t)pairs * groups;
   }
   // Digits of different size are launches of different kernels (N_IN is a template parameter) that depend on nothing of each other.
   // When both are small — one op at a time: 1 120 + 720 workgroups on the chip's 1 024 slots — they run side by side: the later ones go to
@@ -2215,7 +2247,9 @@ static hm_status bconv_col_launch(hm_ctx *c, const hm_bconv_desc *descs, uint32_
     HM_HIP(c, hipStreamWaitEvent(c->sstream, c->sfork, 0));
   }
   for (size_t i = 0; i < ls.size(); ++i) {
-    hipLaunchKernelGGL(k_bconv_col_by_n_in[ls[i].n_in], ls[i].grid, block, 0, fork && i > 0 ? c->sstream : c->stream, ls[i].a);
+    const hm_bcol_kernel kern = hm_bcol_kernel_for(ls[i].n_in, c->P.logN, NOUT, mix != nullptr);
+    if (!kern) return fail(c, HM_ERR_UNSUPPORTED, "fused conversion: no kernel for n_in %u at N = 2^%u", ls[i].n_in, c->P.logN);
+    hipLaunchKernelGGL(kern, ls[i].grid, block, 0, fork && i > 0 ? c->sstream : c->stream, ls[i].a);
     HM_HIP(c, hipGetLastError());
   }
   if (fork) {

@@ -122,6 +122,10 @@ struct HmBconvProb {
   // was a second serialised global-memory round trip per output (the kernel was latency-bound on these two loads)
   uint32_t in_limb[HM_BCONV_MAX_IN];
   uint32_t out_limb[HM_BCONV_MAX_OUT];
+  // optional epilogue (ep_a != nullptr): out_t = (ep_a[ep_a_limb[t]] - conv_t) * ep_k[t] [+ ep_b[ep_b_limb[t]]]
+  const uint64_t *ep_a, *ep_b;
+  const HmTw *ep_k;                      // device, [n_out]
+  uint32_t ep_a_limb[HM_BCONV_MAX_OUT], ep_b_limb[HM_BCONV_MAX_OUT];
 };
 struct HmBconvArgs {
   const HmBconvProb *prob;  // device, [n_prob]: read with scalar loads (wave-uniform index)
@@ -253,6 +257,26 @@ HM_HD void hm_bconv_thread(const PROB &p, uint32_t logN, uint32_t x, uint32_t t0
     uint64_t r[2] = {0, 0};
 #pragma unroll
     for (int c = 0; c < CPT; ++c) r[c] = hm_bconv_dot<N_IN>(yl[c], yh[c], row, m.q, m.nqinv);
+    if (p.ep_a) {   // (wave-uniform) out = (a - conv) * k [+ b]
+#if defined(__HIP_DEVICE_COMPILE__)
+      typedef const HmTw __attribute__((address_space(4))) *ConstTw;
+      const HmTw k = {((ConstTw)(uintptr_t)p.ep_k)[t].w, ((ConstTw)(uintptr_t)p.ep_k)[t].ws};
+#else
+      const HmTw k = p.ep_k[t];
+#endif
+      uint64_t av[2] = {0, 0}, bv[2] = {0, 0};
+      if (CPT == 2) hm_bld2(p.ep_a + (size_t)p.ep_a_limb[t] * N, x << 3, av[0], av[1]);
+      else av[0] = p.ep_a[(size_t)p.ep_a_limb[t] * N + x];
+      if (p.ep_b) {
+        if (CPT == 2) hm_bld2(p.ep_b + (size_t)p.ep_b_limb[t] * N, x << 3, bv[0], bv[1]);
+        else bv[0] = p.ep_b[(size_t)p.ep_b_limb[t] * N + x];
+      }
+#pragma unroll
+      for (int c = 0; c < CPT; ++c) {
+        r[c] = hm_shoup(av[c] + m.q - r[c], k.w, k.ws, m.q);
+        if (p.ep_b) r[c] = hm_addmod(r[c], bv[c], m.q);
+      }
+    }
     if (CPT == 2) hm_bst2(p.out + (size_t)p.out_limb[t] * N, x << 3, r[0], r[1]);
     else p.out[(size_t)p.out_limb[t] * N + x] = r[0];
   }

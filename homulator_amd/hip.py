@@ -24,7 +24,7 @@ class hm_ntt_fused_desc(C.Structure):
     _fields_ = [("in_", C.c_void_p), ("in_limbs", C.c_void_p), ("mix", C.c_void_p), ("mix_limbs", C.c_void_p), ("mix_k", C.c_void_p),
                 ("minuend", C.c_void_p), ("minuend_limbs", C.c_void_p), ("addend", C.c_void_p), ("addend_limbs", C.c_void_p),
                 ("addend_k", C.c_void_p), ("out", C.c_void_p), ("out_limbs", C.c_void_p), ("mod_ids", C.c_void_p), ("n", C.c_uint32),
-                ("k", C.c_void_p)]
+                ("k", C.c_void_p), ("conv", C.c_void_p), ("n_conv", C.c_uint32)]
 
 
 class hm_ntt_ip_desc(C.Structure):
@@ -36,7 +36,8 @@ class hm_ntt_ip_desc(C.Structure):
 class hm_bconv_desc(C.Structure):
     _fields_ = [("in_", C.c_void_p), ("in_limbs", C.c_void_p), ("in_ids", C.c_void_p), ("n_in", C.c_uint32),
                 ("out", C.c_void_p), ("out_limbs", C.c_void_p), ("out_ids", C.c_void_p), ("n_out", C.c_uint32),
-                ("log_len", C.c_uint32)]
+                ("log_len", C.c_uint32), ("sub_from", C.c_void_p), ("sub_from_limbs", C.c_void_p), ("add", C.c_void_p), ("add_limbs", C.c_void_p),
+                ("sub_k", C.c_void_p)]
 
 
 class hm_params(C.Structure):
@@ -208,13 +209,23 @@ class Context:
                                          keep[2][1], out.ptr, keep[3][1], keep[4][1], len(mod_ids), pk))
 
     def ntt_mix_sub_scale(self, src, minuend, out, mod_ids, k, mix=None, mix_k=None, addend=None, addend_k=None, in_limbs=None,
-                          mix_limbs=None, minuend_limbs=None, addend_limbs=None, out_limbs=None):
-        """out = (minuend - NTT(src + mix_k * mix)) * k + addend * addend_k (merged ModDown + rescale of one limb)"""
+                          mix_limbs=None, minuend_limbs=None, addend_limbs=None, out_limbs=None, conv=None):
+        """out = (minuend - NTT(src + mix_k * mix)) * k + addend * addend_k (merged ModDown + rescale of one limb).
+        conv = [(src, in_limbs, in_ids, out_limbs_of_the_fed_limb_polys, out_ids), ...]: `src` of those limb-polys is this base conversion,
+        computed inside the transform's first pass (src may then be None)"""
         keep = [_u32(x) for x in (in_limbs, mix_limbs, minuend_limbs, addend_limbs, out_limbs, mod_ids)]
         ks = [_u64(x) for x in (mix_k, addend_k, k)]
         ptr = lambda v: None if v is None else v.ptr
-        d = hm_ntt_fused_desc(src.ptr, keep[0][1], ptr(mix), keep[1][1], ks[0][1], minuend.ptr, keep[2][1], ptr(addend), keep[3][1], ks[1][1],
-                              out.ptr, keep[4][1], keep[5][1], len(mod_ids), ks[2][1])
+        descs, keep2 = None, []
+        if conv:
+            descs = (hm_bconv_desc * len(conv))()
+            for dd, (csrc, c_in_limbs, in_ids, c_out_limbs, out_ids) in zip(descs, conv):
+                arrs = [_u32(c_in_limbs), _u32(in_ids), _u32(c_out_limbs), _u32(out_ids)]
+                keep2.append(arrs)
+                dd.in_, dd.in_limbs, dd.in_ids, dd.n_in = csrc.ptr, arrs[0][1], arrs[1][1], len(in_ids)
+                dd.out, dd.out_limbs, dd.out_ids, dd.n_out, dd.log_len = out.ptr, arrs[2][1], arrs[3][1], len(out_ids), 0
+        d = hm_ntt_fused_desc(ptr(src) if src is not None else out.ptr, keep[0][1], ptr(mix), keep[1][1], ks[0][1], minuend.ptr, keep[2][1], ptr(addend), keep[3][1], ks[1][1],
+                              out.ptr, keep[4][1], keep[5][1], len(mod_ids), ks[2][1], C.cast(descs, C.c_void_p) if conv else None, len(conv) if conv else 0)
         self._ck(self.L.hm_ntt_mix_sub_scale(self.h, C.byref(d)))
 
     def tensor(self, a, b, c, d, o0, o1, o2, mod_ids, limbs=None):

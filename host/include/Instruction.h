@@ -31,12 +31,19 @@ public:
   bool passthrough = false;  // an NTT-kind instruction whose input is already in evaluation form (copy)
   std::vector<uint32_t> inMods;  // BCONV: modulus ids of the inputs
   unsigned long long refInstructions = 0;  // upstream instructions this record stands for
+  unsigned long long refExtra = 0;         // ... of records folded into a BCONV record (not scaled by its MAC-port count)
   // set by the backend's fusion passes (Arch::fusePasses), never by the generators:
   bool fusedSubScale = false;          // forward NTT whose epilogue is out = (minuend - NTT(in)) * constant [+ addend]
   AddrType fMinuend = 0, fAddend = 0;  // fAddend == 0: no addend
   // merged ModDown + rescale: the transform's input is in + fMixConst * fMix, the addend is scaled by fAddendConst
   AddrType fMix = 0;                   // 0: no prologue
   uint64_t fMixConst = 0, fAddendConst = 0;  // fAddendConst == 0: addend as is
+  // (9) the transform's input operandList[0] is this base conversion, computed inside the transform's first pass (never written)
+  std::vector<AddrType> fConvIn;
+  std::vector<uint32_t> fConvMods;     // ... its input moduli
+  // (10) a BCONV_STEP2 record with the element-wise epilogue out = (fSubFrom - conv) * constant [+ fAdd] (the rescale residue of 4c)
+  bool fusedEpi = false;
+  AddrType fSubFrom = 0, fAdd = 0;
   bool fusedTensor = false;            // MAC2 record that also produces d0 -> extraOutputs[0] and d2 -> extraOutputs[1]
   std::vector<AddrType> extraOutputs;
   // fused inner product (ops == IP): out_k = sum_j ipX[j] * ipY[k][j]; out_0 = OutputOperand, out_1 = extraOutputs[0]

@@ -24,7 +24,7 @@ struct Arch::Launch {
   int opcode = 0;
   uint32_t galois = 0;
   std::vector<uint32_t> a, b, c, d, out, out1, out2, mods, inMods;
-  struct Prob { std::vector<uint32_t> in, inMods, out, outMods; };
+  struct Prob { std::vector<uint32_t> in, inMods, out, outMods, epA, epB; std::vector<uint64_t> epK; bool epi = false, epAdd = false; };
   std::vector<Prob> probs;  // BCONV: independent conversions batched into one launch
   // multi-GPU: exchange steps (limb list + owner of each limb) and the coefficient-slice buffers of a sharded BCONV
   std::vector<uint32_t> exLimbs, exOwners;
@@ -83,6 +83,13 @@ Arch::Arch(Config *cfg) : config(cfg) {
   // input limbs per digit, one GPU (a sharded conversion works on coefficient slices)
   fuseBconv = cfg->getValueOr("fuse_bconv", 1) != 0;
   if (const char *e = getenv("HOMULATOR_FUSE_BCONV")) fuseBconv = std::string(e) != "0";
+  // ... and the ModDown conversion inside the first pass of the merged ModDown + rescale transform (round 4, pass 9): built, bit-exact, and
+  // measured SLOWER on MI355X in both modes (profiles/r04_fuse_ab.txt: batch 10 conversion 18.5 + transform 51.7 us per op against 3.6 + 70.8
+  // fused; one at a time 24.9 + 70.5 against 9.5 + 89.2): the separate conversion kernel converts to all 35 outputs of a key from inputs it
+  // loads and splits ONCE, the fused form loads the 15 input tiles again for every pair of outputs, and the 73 MB of ModdownBConvOut traffic it
+  // saves is worth less than that.  Opt-in (config key fuse_moddown = 1).
+  fuseModDown = cfg->getValueOr("fuse_moddown", 0) != 0;
+  if (const char *e = getenv("HOMULATOR_FUSE_MODDOWN")) fuseModDown = std::string(e) != "0";
   // sharded runs: the exchanges of digit j+1 run on the context's exchange stream while digit j converts and transforms (SURVEY.md 7:
   // 2 beta + 2 all-to-alls per key switch instead of 4, same order on every rank).  The per-digit transforms must then stay separate
   // launches, so the fused NTT x key kernel (which needs all digits) is not used.
@@ -467,7 +474,7 @@ void Arch::fusePasses(std::vector<Stage> &st) {
         ip->ipSrc = ip->ipX;
         ip->ipCoeff.assign(ip->ipX.size(), 0);
         std::vector<Instruction *> conv(ip->ipX.size(), nullptr);
-        bool allConv = fuseBconv && world_ == 1 && logN == 16;
+        bool allConv = fuseBconv && world_ == 1 && (logN == 16 || logN == 15);
         for (size_t j = 0; j < ip->ipX.size(); ++j) {
           auto p = producer.find(ip->ipX[j]);
           if (p == producer.end()) continue;
@@ -498,6 +505,77 @@ void Arch::fusePasses(std::vector<Stage> &st) {
             dead.insert(conv[j]);
           }
         }
+      }
+  }
+  // (9, round 4) the ModDown side of (8): a fused forward transform (ModDowNTT + ModDownSub [+ rescale]) whose input is a P -> Q conversion
+  //     output that nobody else reads takes the conversion into its first pass (src/Operation.cpp:489-590): ModdownBConvOut_Key(k) is
+  //     never written or read back.  The last limb of a key keeps its conversion: the rescale residue is formed from it element-wise (4c).
+  if (fuseBconv && fuseModDown && world_ == 1 && (logN == 16 || logN == 15)) {
+    std::map<AddrType, std::vector<Instruction *>> readers;
+    for (auto &s : st)
+      for (Instruction *i : s.ins) {
+        if (dead.count(i)) continue;
+        if (i->ops == IP && !i->ipX.empty()) {
+          for (AddrType x : (i->ipSrc.empty() ? i->ipX : i->ipSrc)) readers[x].push_back(i);
+          for (auto &cin : i->ipConvIn) for (AddrType x : cin) readers[x].push_back(i);
+          for (auto &y : i->ipY) for (AddrType yy : y) readers[yy].push_back(i);
+        } else {
+          for (AddrType a : operands(i)) readers[a].push_back(i);
+          if (i->fusedSubScale) { readers[i->fMinuend].push_back(i); if (i->fAddend) readers[i->fAddend].push_back(i); if (i->fMix) readers[i->fMix].push_back(i); }
+        }
+      }
+    for (auto &s : st)
+      for (Instruction *t : s.ins) {
+        if (t->ops != NTT || !t->fusedSubScale || t->passthrough || dead.count(t)) continue;
+        auto pb = producer.find(t->operandList[0]);
+        if (pb == producer.end() || pb->second->ops != BCONV_STEP2 || dead.count(pb->second) || pb->second->mod_id != t->mod_id) continue;
+        auto &rb = readers[t->operandList[0]];
+        if (rb.size() != 1 || rb[0] != t || pb->second->operandList.size() - 1 > 15) continue;
+        t->fConvIn.assign(pb->second->operandList.begin(), pb->second->operandList.end() - 1);
+        t->fConvMods = pb->second->inMods;
+        t->refInstructions += pb->second->refInstructions * (unsigned long long)config->getValueOr("bconv_num_high", 1) * config->getValueOr("bconv_num_width", 1);
+        dead.insert(pb->second);
+      }
+  }
+  // (10, round 4) r = (wa - conv_last) * kT [+ wb] (4c) directly behind the conversion that produces conv_last: the one-limb element-wise
+  //      launch becomes the conversion kernel's epilogue (hm_bconv_desc::sub_from)
+  if (fuseBconv && world_ == 1) {
+    std::map<AddrType, int> nread;
+    for (auto &s : st)
+      for (Instruction *i : s.ins) {
+        if (dead.count(i)) continue;
+        if (i->ops == IP && !i->ipX.empty()) {
+          for (AddrType x : (i->ipSrc.empty() ? i->ipX : i->ipSrc)) nread[x]++;
+          for (auto &cin : i->ipConvIn) for (AddrType x : cin) nread[x]++;
+          for (auto &y : i->ipY) for (AddrType yy : y) nread[yy]++;
+        } else {
+          for (AddrType a : operands(i)) nread[a]++;
+          if (i->fusedSubScale) { nread[i->fMinuend]++; if (i->fAddend) nread[i->fAddend]++; if (i->fMix) nread[i->fMix]++; }
+          for (AddrType x : i->fConvIn) nread[x]++;
+        }
+      }
+    for (auto &s : st)
+      for (size_t ei = 0; ei < s.ins.size(); ++ei) {
+        Instruction *e = s.ins[ei];
+        if (e->ops != MULT || dead.count(e) || (e->opcode != EWE_SUB_SCALE && e->opcode != EWE_SUB_SCALE_ADD)) continue;
+        auto pb = producer.find(e->operandList[2]);
+        if (pb == producer.end() || pb->second->ops != BCONV_STEP2 || dead.count(pb->second) || pb->second->fusedEpi || pb->second->mod_id != e->mod_id ||
+            nread[e->operandList[2]] != 1)
+          continue;
+        Instruction *cv = pb->second;
+        cv->fusedEpi = true;
+        cv->fSubFrom = e->operandList[0];
+        cv->fAdd = e->opcode == EWE_SUB_SCALE_ADD ? e->operandList[3] : 0;
+        cv->hasConstant = true;
+        cv->constant = e->constant;
+        cv->OutputOperand = e->OutputOperand;
+        cv->refExtra += e->refInstructions;   // (a conversion's own count is scaled by the MAC ports at launch time, the epilogue's is not)
+        producer[cv->OutputOperand] = cv;
+        // the conversion now reads what e read (the inverse transforms of 4c, queued in e's stage): it takes e's place in the stage list,
+        // which stays a topological order
+        for (auto &s2 : st) s2.ins.erase(std::remove(s2.ins.begin(), s2.ins.end(), cv), s2.ins.end());
+        std::replace(s.ins.begin(), s.ins.end(), e, cv);
+        dead.insert(e);
       }
   }
   // drop dead instructions and empty stages; upstream instructions of eliminated pass-through records are
@@ -535,7 +613,7 @@ void Arch::buildLaunches() {
     size_t first = parts.size();
     for (Instruction *i : s.ins) {
       const bool nip = i->ops == IP && std::find(i->ipCoeff.begin(), i->ipCoeff.end(), 1) != i->ipCoeff.end();
-      int key = nip ? 400 + (int)i->ipX.size() * 10 + (int)i->ipY.size() : i->ops == IP && !i->ipX.empty() ? 300 + (int)i->ipX.size() * 10 + (int)i->ipY.size() : i->fusedTensor ? 200 : i->fusedSubScale ? (i->fMix ? 203 : 201) : i->ops == MULT ? 100 + i->opcode : (i->ops == NTT && i->passthrough) ? 100 + EWE_COPY : i->ops == AUTO ? 1000 + (int)i->galois : (int)i->ops;
+      int key = nip ? 400 + (int)i->ipX.size() * 10 + (int)i->ipY.size() : i->ops == IP && !i->ipX.empty() ? 300 + (int)i->ipX.size() * 10 + (int)i->ipY.size() : i->fusedTensor ? 200 : i->fusedSubScale ? (i->fMix ? 203 : 201) + (i->fConvIn.empty() ? 0 : 4) : i->ops == MULT ? 100 + i->opcode : (i->ops == NTT && i->passthrough) ? 100 + EWE_COPY : i->ops == AUTO ? 1000 + (int)i->galois : (int)i->ops;
       size_t p = first;
       for (; p < parts.size(); ++p)
         if (parts[p].key == key) break;
@@ -560,6 +638,8 @@ void Arch::buildLaunches() {
     else if (i->ops == MULT) { for (int b = 0; b < 4; ++b) if (useMask[i->opcode] & (1 << b)) v.push_back(i->operandList[b]); }
     else v.push_back(i->operandList[0]);
     if (i->fusedSubScale) { v.push_back(i->fMinuend); if (i->fAddend) v.push_back(i->fAddend); if (i->fMix) v.push_back(i->fMix); }
+    if (!i->fConvIn.empty()) { v[0] = i->fConvIn[0]; v.insert(v.end(), i->fConvIn.begin() + 1, i->fConvIn.end()); }
+    if (i->fusedEpi) { v.push_back(i->fSubFrom); if (i->fAdd) v.push_back(i->fAdd); }
     return v;
   };
   auto writes = [&](Instruction *i) {
@@ -681,7 +761,7 @@ void Arch::buildLaunches() {
       for (const Part *g : group) L->name += (L->name.empty() ? "" : "+") + g->name;
       size_t count = 0;
       for (const Part *g : group)
-        for (Instruction *i : g->ins) { L->refInstructions += i->refInstructions * (i->ops == BCONV_STEP2 ? bconvPorts : 1ull); ++count; }
+        for (Instruction *i : g->ins) { L->refInstructions += i->refInstructions * (i->ops == BCONV_STEP2 ? bconvPorts : 1ull) + i->refExtra; ++count; }
       if (f->ops == IP && std::find(f->ipCoeff.begin(), f->ipCoeff.end(), 1) != f->ipCoeff.end()) {
         L->kind = Launch::L_NTT_IP; L->statKey = "NTT";
         L->ipTerms = (uint32_t)f->ipX.size(); L->ipOuts = (uint32_t)f->ipY.size();
@@ -750,6 +830,18 @@ void Arch::buildLaunches() {
           }
         L->hasK = true;
         L->bytes = (anyAddend ? 4 : 3) * LP * count;
+        for (const Part *g : group)
+          for (Instruction *i : g->ins) {   // (9): the conversion of this limb-poly runs inside its first pass
+            if (i->fConvIn.empty()) continue;
+            std::vector<uint32_t> in;
+            for (AddrType x : i->fConvIn) in.push_back(limbOf(x));
+            Launch::Prob *pr = nullptr;
+            for (auto &q : L->probs) if (q.in == in && q.inMods == i->fConvMods) pr = &q;
+            if (!pr) { L->probs.push_back(Launch::Prob{in, i->fConvMods, {}, {}}); pr = &L->probs.back(); L->bytes += LP * in.size(); }
+            pr->out.push_back(limbOf(i->OutputOperand));   // the hand-off lands in the output limb
+            pr->outMods.push_back(i->mod_id);
+            L->bytes -= LP;                                  // the converted limb-poly is neither written nor read
+          }
       } else if (f->ops == NTT && f->passthrough) {  // unfused mode: materialise the copy
         L->kind = Launch::L_EWE; L->opcode = EWE_COPY; L->statKey = "EWE";
         for (const Part *g : group)
@@ -791,10 +883,15 @@ void Arch::buildLaunches() {
             std::vector<uint32_t> in;
             for (size_t x = 0; x + 1 < i->operandList.size(); ++x) in.push_back(limbOf(i->operandList[x]));
             Launch::Prob *pr = nullptr;
-            for (auto &q : L->probs) if (q.in == in && q.inMods == i->inMods) pr = &q;
-            if (!pr) { L->probs.push_back(Launch::Prob{in, i->inMods, {}, {}}); pr = &L->probs.back(); }
+            for (auto &q : L->probs) if (q.in == in && q.inMods == i->inMods && q.epi == i->fusedEpi && q.epAdd == (i->fAdd != 0)) pr = &q;
+            if (!pr) { L->probs.push_back(Launch::Prob{in, i->inMods, {}, {}}); pr = &L->probs.back(); pr->epi = i->fusedEpi; pr->epAdd = i->fAdd != 0; }
             pr->out.push_back(limbOf(i->OutputOperand));
             pr->outMods.push_back(i->mod_id);
+            if (i->fusedEpi) {   // (10): out = (fSubFrom - conv) * k [+ fAdd]
+              pr->epA.push_back(limbOf(i->fSubFrom)); pr->epK.push_back(i->constant);
+              if (i->fAdd) pr->epB.push_back(limbOf(i->fAdd));
+              L->bytes += LP * (i->fAdd ? 2 : 1);
+            }
           }
         }
         if (world_ > 1 && batch_ > 1) {  // sharded batch: the ops of the batch share the exchanges around the conversion
@@ -910,6 +1007,8 @@ void Arch::replicateForBatch() {
             Launch::Prob q = l->probs[i];
             for (uint32_t &x : q.in) x += c * per;
             for (uint32_t &x : q.out) x += c * per;
+            for (uint32_t &x : q.epA) x += c * per;
+            for (uint32_t &x : q.epB) x += c * per;
             l->probs.push_back(q);
           }
         inter(l->c, l->ipTerms, true);
@@ -931,6 +1030,8 @@ void Arch::replicateForBatch() {
           Launch::Prob q = l->probs[i];
           for (uint32_t &x : q.in) x += c * per;
           for (uint32_t &x : q.out) x += c * per;
+          for (uint32_t &x : q.epA) x += c * per;
+          for (uint32_t &x : q.epB) x += c * per;
           l->probs.push_back(q);
         }
     }
@@ -1048,10 +1149,12 @@ void Arch::enqueue(Launch &l) {
     st = hm_ntt(ctx, pool, l.a.data(), pool, l.out.data(), l.mods.data(), cnt, 1, l.hasK ? l.k.data() : nullptr);
     break;
   case Launch::L_NTT_SUBSCALE:
-    if (!l.mixK.empty()) {
-      hm_ntt_fused_desc d = {pool, l.a.data(), pool, l.d.data(), l.mixK.data(), pool, l.b.data(), l.c.empty() ? nullptr : pool,
-                             l.c.empty() ? nullptr : l.c.data(), l.addK.empty() ? nullptr : l.addK.data(), pool, l.out.data(), l.mods.data(), cnt,
-                             l.k.data()};
+    if (!l.mixK.empty() || !l.probs.empty()) {
+      for (auto &q : l.probs)
+        descs.push_back(hm_bconv_desc{pool, q.in.data(), q.inMods.data(), (uint32_t)q.in.size(), pool, q.out.data(), q.outMods.data(), (uint32_t)q.out.size(), 0});
+      hm_ntt_fused_desc d = {pool, l.a.data(), l.mixK.empty() ? nullptr : pool, l.mixK.empty() ? nullptr : l.d.data(), l.mixK.empty() ? nullptr : l.mixK.data(), pool, l.b.data(),
+                             l.c.empty() ? nullptr : pool, l.c.empty() ? nullptr : l.c.data(), l.addK.empty() ? nullptr : l.addK.data(), pool, l.out.data(), l.mods.data(), cnt,
+                             l.k.data(), descs.empty() ? nullptr : descs.data(), (uint32_t)descs.size()};
       st = hm_ntt_mix_sub_scale(ctx, &d);
     } else {
       st = hm_ntt_sub_scale(ctx, pool, l.a.data(), pool, l.b.data(), l.c.empty() ? nullptr : pool, l.c.empty() ? nullptr : l.c.data(), pool,
@@ -1092,7 +1195,9 @@ void Arch::enqueue(Launch &l) {
   case Launch::L_BCONV:
     for (auto &q : l.probs)
       descs.push_back(hm_bconv_desc{l.slicesIn ? l.slicesIn : pool, q.in.data(), q.inMods.data(), (uint32_t)q.in.size(),
-                                    l.slicesOut ? l.slicesOut : pool, q.out.data(), q.outMods.data(), (uint32_t)q.out.size(), l.logLen});
+                                    l.slicesOut ? l.slicesOut : pool, q.out.data(), q.outMods.data(), (uint32_t)q.out.size(), l.logLen,
+                                    q.epi ? pool : nullptr, q.epi ? q.epA.data() : nullptr, q.epAdd ? pool : nullptr, q.epAdd ? q.epB.data() : nullptr,
+                                    q.epi ? q.epK.data() : nullptr});
     st = hm_bconv_batch(ctx, descs.data(), (uint32_t)descs.size());
     break;
   }

@@ -88,6 +88,7 @@ hm_status hm_ntt_sub_scale(hm_ctx *ctx, const uint64_t *in, const uint32_t *in_l
  * host arrays of n residues mod the limb's modulus.  `out` must not alias `in`, `mix`, `minuend` or `addend`.
  * addend_limbs[i] == HM_NO_LIMB drops the addend for limb-poly i only (both this call and hm_ntt_sub_scale). */
 #define HM_NO_LIMB 0xFFFFFFFFu
+struct hm_bconv_desc;
 typedef struct hm_ntt_fused_desc {
   const uint64_t *in;      const uint32_t *in_limbs;
   const uint64_t *mix;     const uint32_t *mix_limbs;     const uint64_t *mix_k;
@@ -96,6 +97,14 @@ typedef struct hm_ntt_fused_desc {
   uint64_t *out;           const uint32_t *out_limbs;
   const uint32_t *mod_ids; uint32_t n;
   const uint64_t *k;
+  /* optional (NULL / 0: none; round 4): `in` of some or all limb-polys is a base conversion that has not been computed yet —
+   * ModDown_BCONV_Key(k) + ModDowNTT + ModDownSub [+ the rescale] (src/Operation.cpp:489-590) in one call.  conv[j] describes
+   * conversion j exactly as for hm_bconv_batch, except that conv[j].out must be `out` and conv[j].out_limbs[t] the OUTPUT limb
+   * (out_limbs[i]) of the limb-poly i its output t feeds: the conversion runs inside the first pass of that transform (with the
+   * mix prologue of limb-poly i), so ModdownBConvOut_Key(k) is never written to HBM or read back; `in` / in_limbs of the covered
+   * limb-polys are ignored, the others are transformed as usual.  N = 2^15 or 2^16 and n_in <= 15 (HM_ERR_UNSUPPORTED otherwise).
+   * Bit-identical to hm_bconv_batch + the call without conv. */
+  const struct hm_bconv_desc *conv; uint32_t n_conv;
 } hm_ntt_fused_desc;
 hm_status hm_ntt_mix_sub_scale(hm_ctx *ctx, const hm_ntt_fused_desc *desc);
 
@@ -166,7 +175,7 @@ typedef struct hm_ntt_ip_desc {
    * The conversions need not cover every transformed digit: a transformed (limb, digit) whose hand-off limb is not an output of
    * any conv[k] is read from x / x_limbs as usual (one call may mix both kinds, e.g. a ModUp whose first digit is wider than the
    * fused conversion admits).
-   * N = 2^16 and n_in <= 15 (HM_ERR_UNSUPPORTED otherwise: convert with hm_bconv_batch first).  Bit-identical to
+   * N = 2^15 or 2^16 and n_in <= 15 (HM_ERR_UNSUPPORTED otherwise: convert with hm_bconv_batch first).  Bit-identical to
    * hm_bconv_batch + hm_ntt_inner_product. */
   const struct hm_bconv_desc *conv; uint32_t n_conv;
 } hm_ntt_ip_desc;
@@ -187,6 +196,11 @@ struct hm_bconv_desc {
   const uint64_t *in; const uint32_t *in_limbs; const uint32_t *in_ids; uint32_t n_in;
   uint64_t *out; const uint32_t *out_limbs; const uint32_t *out_ids; uint32_t n_out;
   uint32_t log_len; /* coefficients per limb in `in`/`out` = 2^log_len; 0 = N.  N/world for coefficient slices */
+  /* optional epilogue (round 4; sub_from == NULL: none): out_t = (sub_from_t - conv_t) * sub_k[t] [+ add_t] instead of conv_t — the
+   * rescale residue r = (INTT(ip_last) - conv_last) * P^-1 + INTT(d_last) of the merged ModDown + rescale (src/Operation.cpp:521-590,
+   * 806-822) formed by the conversion kernel itself: one launch less than conversion + HM_OP_SUB_SCALE_ADD.  sub_k: host array of n_out
+   * residues; add may be NULL.  hm_bconv_batch only (not the conversions of hm_ntt_ip_desc / hm_ntt_fused_desc). */
+  const uint64_t *sub_from; const uint32_t *sub_from_limbs; const uint64_t *add; const uint32_t *add_limbs; const uint64_t *sub_k;
 };
 hm_status hm_bconv_batch(hm_ctx *ctx, const hm_bconv_desc *descs, uint32_t n_desc);
 /* host-side constants of a conversion: qhat_inv[n_in], table[n_in][n_out] (either may be NULL) */

@@ -381,6 +381,59 @@ def test_ntt_inner_product_with_conversion_inside(n_in):
         ctx.close()
 
 
+@pytest.mark.parametrize("logN", [16, 15])
+@pytest.mark.parametrize("n_in,outs_per_wg", [(1, 0), (2, 2), (5, 1), (9, 2), (15, 2), (15, 1)])
+def test_mix_sub_scale_with_conversion_inside(logN, n_in, outs_per_wg):
+    """ModDown_BCONV + ModDowNTT + ModDownSub + rescale in one call (hm_ntt_fused_desc.conv, round 4): the P -> Q conversion runs inside the
+    first pass of the merged transform (k_bconv_col with the mix prologue), ModdownBConvOut never exists.  Two "keys" of n_in special limbs
+    each converted to an ODD number of Q limbs (the last output group of a workgroup pair is half empty), with and without the mix operand,
+    plus limb-polys that are NOT fed by a conversion in the same call; one or two outputs per workgroup; N = 2^16 and 2^15.  Against the
+    oracle's conversion, transform and element-wise chain."""
+    from homulator_amd import hip
+    ell, K, N = 7, n_in, 1 << logN
+    ctx, o = hip.Context(logN, ell, K), Oracle(logN, ell, K)
+    try:
+        ctx.set_option("bconv_col_outs", outs_per_wg)
+        qs, ps = list(range(ell)), list(range(ell, ell + K))
+        nkeys = 2
+        y = o.fill_uniform(ps * nkeys, 21).reshape(nkeys, K, N)              # coefficient form, already x p_hat^-1
+        y[0, 0, :] = o.moduli[ps[0]] - 1
+        extra_ids = [1, 4]                                                    # two limb-polys with an ordinary input (not converted)
+        extra = o.fill_uniform(extra_ids, 22)
+        nq = nkeys * ell + len(extra_ids)
+        ids = qs * nkeys + extra_ids
+        mn, ad, mx = (o.fill_uniform(ids, s) for s in (23, 24, 25))
+        k = [o.moduli[m] - 2 - r for r, m in enumerate(ids)]
+        mk = [(kk * 3 + 1) % o.moduli[m] for kk, m in zip(k, ids)]
+        ak = [(kk * 5 + 1) % o.moduli[m] for kk, m in zip(k, ids)]
+        ysrc, xsrc = ctx.from_host(y.reshape(-1, N)), ctx.from_host(extra)
+        dmn, dad, dmx, out = ctx.from_host(mn), ctx.from_host(ad), ctx.from_host(mx), ctx.alloc(nq)
+        conv = [(ysrc, [kk_ * K + i for i in range(K)], ps, [kk_ * ell + t for t in range(ell)], qs) for kk_ in range(nkeys)]
+        in_limbs = [0] * (nkeys * ell) + [0, 1]
+        # expected: the input of every limb-poly, then the fused chain
+        xin = np.concatenate([o.bconv_matmul(ps, qs, y[kk_]) for kk_ in range(nkeys)] + [extra])
+        for with_mix in (True, False):
+            x = o.ewe(3, ids, xin, None, o.ewe(5, ids, mx, k=mk)) if with_mix else xin
+            exp = o.ewe(3, ids, o.ewe(6, ids, mn, None, o.ntt(ids, x), k=k), None, o.ewe(5, ids, ad, k=ak))
+            ctx.fill_uniform(out, ids, 99)
+            ctx.ntt_mix_sub_scale(xsrc, dmn, out, ids, k, addend=dad, addend_k=ak, mix=dmx if with_mix else None, mix_k=mk if with_mix else None,
+                                  in_limbs=in_limbs, conv=conv)
+            assert np.array_equal(out.download(), exp), (logN, n_in, with_mix)
+        # every limb-poly converted, no `in` at all
+        sel = list(range(nkeys * ell))
+        sub = lambda a: a[sel]
+        ids2 = [ids[i] for i in sel]
+        out2 = ctx.alloc(len(sel))
+        d2 = [ctx.from_host(sub(a)) for a in (mn, ad, mx)]
+        x = o.ewe(3, ids2, sub(xin), None, o.ewe(5, ids2, sub(mx), k=[mk[i] for i in sel]))
+        exp = o.ewe(3, ids2, o.ewe(6, ids2, sub(mn), None, o.ntt(ids2, x), k=[k[i] for i in sel]), None, o.ewe(5, ids2, sub(ad), k=[ak[i] for i in sel]))
+        ctx.ntt_mix_sub_scale(None, d2[0], out2, ids2, [k[i] for i in sel], addend=d2[1], addend_k=[ak[i] for i in sel], mix=d2[2], mix_k=[mk[i] for i in sel],
+                              conv=[(ysrc, c_[1], c_[2], c_[3], c_[4]) for c_ in conv])
+        assert np.array_equal(out2.download(), exp)
+    finally:
+        ctx.close()
+
+
 def test_inner_product_with_narrow_moduli():
     """the key multiply-accumulate of hm_ntt_inner_product over a caller-chosen chain of 59-, 45- and 31-bit moduli (the lazy product's
     operand shift and quotient constant depend on the modulus width): evaluation-form operands only (no transform, so no oracle is

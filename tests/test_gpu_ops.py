@@ -26,9 +26,11 @@ def inputs(o, ell):
     return o.synth_ct(ell, SEED), o.synth_ct(ell, SEED + 2000), o.synth_evk(ell, SEED + 10000)
 
 
-def check_keyswitch_buffers(op, dd, ell, K, beta, fused, hpip=True):
+def check_keyswitch_buffers(op, dd, ell, K, beta, fused, hpip=True, bconv=True):   # bconv: True | "residue" | "moddown"
     """hpip (fused only): the ModUp transforms' last pass runs inside the inner-product kernel: NTTOut_beta(j) is
-    then only first-pass scratch and InnerProduceOut_Key{k} is compared with the oracle's `ip` dump instead"""
+    then only first-pass scratch and InnerProduceOut_Key{k} is compared with the oracle's `ip` dump instead.  bconv (fused only,
+    round 4): the ModDown conversion runs inside the first pass of the transform that consumes it: ModdownBConvOut_Key{k} no longer
+    exists (the results are compared through the outputs)"""
     E = ell + K
     if not fused:
         assert np.array_equal(op.read("ModUpINTTOut"), dd["modup_intt"])
@@ -44,7 +46,11 @@ def check_keyswitch_buffers(op, dd, ell, K, beta, fused, hpip=True):
         assert np.array_equal(got[sel], dd["ext"][j][sel]), f"NTTOut_beta({j})"
     for k in range(2):
         assert np.array_equal(op.read(f"InnerProduceOut_Key{k}"), dd["ip"][k]), f"InnerProduceOut_Key{k}"
-        assert np.array_equal(op.read(f"ModdownBConvOut_Key{k}"), dd["moddown_bconv"][k])
+        if bconv == "moddown":      # pass 9: the conversion runs inside its consumer, the buffer is never written
+            continue
+        got_c = op.read(f"ModdownBConvOut_Key{k}")
+        rows = slice(0, ell - 1) if (fused and bconv == "residue") else slice(0, ell)   # pass 10 (hmult): the last limb's conversion goes
+        assert np.array_equal(got_c[rows], dd["moddown_bconv"][k][rows])                # straight into the rescale residue
         if not fused:   # fused: the ModDown NTT output only exists inside the fused transform's epilogue
             assert np.array_equal(op.read(f"NTTOut_ModDown_Key({k})"), dd["moddown_ntt"][k])
 
@@ -54,7 +60,7 @@ CASES = [("config_4_N15.cfg", 15, 16, 10, 4), ("config_4_N15.cfg", 15, 8, 8, 8),
 
 
 @pytest.mark.parametrize("cfg,logN,L,ell,alpha", CASES)
-@pytest.mark.parametrize("fuse", [False, True, "no_hpip", "no_bconv"])
+@pytest.mark.parametrize("fuse", [False, True, "no_hpip", "no_bconv", "moddown"])
 def test_hmult_bit_exact(cfg, logN, L, ell, alpha, fuse):
     """fuse = True is the bench path (ModUp conversion + transforms + key MAC in one C-ABI call: k_bconv_col, k_ntt_row_ip);
     "no_bconv" = the same with the conversion as its own launch (fuse_bconv = 0); "no_hpip" = fused plan with separate ModUp
@@ -63,9 +69,10 @@ def test_hmult_bit_exact(cfg, logN, L, ell, alpha, fuse):
     o = oracle(logN, L, alpha)
     ct1, ct2, evk = inputs(o, ell)
     ids = list(range(ell))
-    hpip = fuse is True or fuse == "no_bconv"   # "no_bconv": fused transform x key kernel fed by a separate conversion launch
+    hpip = fuse in (True, "no_bconv", "moddown")   # "no_bconv": fused transform x key kernel fed by a separate conversion launch; "moddown": pass 9 on
+    mode = fuse
     op = host.Op(cfg, "hmult", L, ell, alpha, fuse=bool(fuse),
-                 overrides={"fuse_hpip": 0} if fuse == "no_hpip" else {"fuse_bconv": 0} if fuse == "no_bconv" else None)
+                 overrides={"fuse_hpip": 0} if fuse == "no_hpip" else {"fuse_bconv": 0} if fuse == "no_bconv" else {"fuse_moddown": 1} if fuse == "moddown" else None)
     fuse = bool(fuse)
     op.execute(1)
     assert np.array_equal(op.read("ct1.c0"), ct1[0]) and np.array_equal(op.read("ct2.c1"), ct2[1])
@@ -76,7 +83,7 @@ def test_hmult_bit_exact(cfg, logN, L, ell, alpha, fuse):
     assert np.array_equal(op.read("TensorD1Out"), d1)
     assert np.array_equal(op.read("TensorD2Out"), d2)
     k0, k1, dd = o.keyswitch(ell, d2, evk, dump=True)
-    check_keyswitch_buffers(op, dd, ell, alpha, o.beta(ell), fuse, hpip)
+    check_keyswitch_buffers(op, dd, ell, alpha, o.beta(ell), fuse, hpip, bconv="moddown" if mode == "moddown" else "residue" if mode in (True, "no_hpip") else True)
     if not fuse:
         assert np.array_equal(op.read("KeySwitchFinalOutput_Key(0)"), k0)
         assert np.array_equal(op.read("KeySwitchFinalOutput_Key(1)"), k1)

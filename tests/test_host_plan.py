@@ -19,24 +19,36 @@ def kinds(p):
     return [ln.split()[0] for ln in p]
 
 
-def test_headline_plan_is_seven_launches():
+def test_headline_plan_is_six_launches():
     p, total, n = plan("config_4.cfg", "hmult", 45, 35, 15)
-    assert n == 7 and kinds(p) == ["TENSOR", "INTT", "NTT_IP", "INTT", "BCONV", "EWE", "NTT_SUBSCALE"]
+    assert n == 6 and kinds(p) == ["TENSOR", "INTT", "NTT_IP", "INTT", "BCONV", "NTT_SUBSCALE"]
     assert total == 7381760                                   # upstream's total for this command line
+    sizes = [int(re.search(r" n=(\d+)", ln).group(1)) for ln in p]
+    assert sizes[4] == 70 and sizes[5] == 68                  # round 4: the rescale residue is formed in the ModDown conversion's epilogue (no EWE launch)
     # the ModUp conversion, the ModUp transforms and the inner product are ONE launch; its instruction share = all three stages'
     ref = {ln.split()[0]: int(re.search(r"ref=(\d+)", ln).group(1)) for ln in p}
     p8, total8, n8 = plan("config_4.cfg", "hmult", 45, 35, 15, fuse_bconv=0)
-    assert n8 == 8 and kinds(p8)[2:4] == ["BCONV", "NTT_IP"] and total8 == total
+    assert n8 == 8 and kinds(p8) == ["TENSOR", "INTT", "BCONV", "NTT_IP", "INTT", "BCONV", "EWE", "NTT_SUBSCALE"] and total8 == total
     r8 = [int(re.search(r"ref=(\d+)", ln).group(1)) for ln in p8]
     assert ref["NTT_IP"] == r8[2] + r8[3]
+    assert ref["BCONV"] == r8[5] + r8[6]                      # conversion + residue: the same instructions in one launch
+    # opt-in (pass 9): the ModDown conversion of 68 limb-polys inside the merged transform's first pass; the conversion launch that is left
+    # converts the two last limbs (the residue comes from them)
+    pm, totalm, nm = plan("config_4.cfg", "hmult", 45, 35, 15, fuse_moddown=1)
+    sm = [int(re.search(r" n=(\d+)", ln).group(1)) for ln in pm]
+    rm = {ln.split()[0]: int(re.search(r"ref=(\d+)", ln).group(1)) for ln in pm}
+    assert nm == 6 and kinds(pm) == kinds(p) and sm[4] == 2 and sm[5] == 68 and totalm == total
+    assert rm["BCONV"] + rm["NTT_SUBSCALE"] == r8[5] + r8[6] + r8[7]
     p9, total9, n9 = plan("config_4.cfg", "hmult", 45, 35, 15, fuse_hpip=0)
-    assert n9 == 9 and kinds(p9)[2:5] == ["BCONV", "NTT", "IP"] and total9 == total
+    assert kinds(p9)[2:5] == ["BCONV", "NTT", "IP"] and total9 == total
     ph, totalh, nh = plan("config_4.cfg", "hrotate", 45, 35, 15)
     assert nh == 6 and kinds(ph) == ["AUTO", "INTT", "NTT_IP", "INTT", "BCONV", "NTT_SUBSCALE"] and totalh == 7328000
+    phm, _, nhm = plan("config_4.cfg", "hrotate", 45, 35, 15, fuse_moddown=1)
+    assert nhm == 5 and kinds(phm) == ["AUTO", "INTT", "NTT_IP", "INTT", "NTT_SUBSCALE"]   # no conversion launch at all
 
 
 @pytest.mark.parametrize("cfg,L,ell,alpha,conv_inside", [
-    ("config_4_N15.cfg", 16, 10, 4, False),    # N = 2^15: the fused conversion exists for N = 2^16 only
+    ("config_4_N15.cfg", 16, 10, 4, True),     # N = 2^15 (round 4: the fused conversion exists for N = 2^15 and 2^16)
     ("config_4.cfg", 28, 28, 28, False),       # parameter set A: 28 input limbs per digit (> 15)
     ("config_4.cfg", 24, 24, 6, True),         # set C: beta = 4
     ("config_4.cfg", 26, 20, 9, True),         # set D: uneven last digit (9, 9, 2)
