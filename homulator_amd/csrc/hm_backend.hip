@@ -828,6 +828,25 @@ __global__ void __launch_bounds__(256) k_chunk_copy(HmChunkArgs a) {
   *reinterpret_cast<ulonglong2 *>(a.dst + (size_t)a.dst_off[chunk] * a.len + x) = v;
 }
 
+// column-block copy (round 4: the exchange in the transposed domain): block c copies the `cw` words [col, col + cw) of every row of a
+// limb-poly-shaped array (rows of `stride` words) to another one: limb layout (stride 256) <-> compact staging (stride cw)
+struct HmColArgs {
+  const uint64_t *src;
+  uint64_t *dst;
+  uint32_t rows, cw, src_stride, dst_stride, n_chunks;
+  uint32_t src_off[HM_MAX_CHUNKS / 2], dst_off[HM_MAX_CHUNKS / 2];   // offset of the block's first element in 16-byte units (limb 65535 of N = 2^16 is past 2^32 words)
+};
+__global__ void __launch_bounds__(256) k_col_copy(HmColArgs a) {
+  const uint32_t per = (a.rows * a.cw / 2 + 255) / 256;   // blocks per chunk, two words per thread
+  const uint32_t chunk = blockIdx.x / per, part = blockIdx.x % per;
+  if (chunk >= a.n_chunks) return;
+  const uint32_t e = (part * 256 + threadIdx.x) * 2;      // element of the block
+  if (e >= a.rows * a.cw) return;
+  const uint32_t r = e / a.cw, x = e % a.cw;
+  const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(a.src + 2 * (size_t)a.src_off[chunk] + (size_t)r * a.src_stride + x);
+  *reinterpret_cast<ulonglong2 *>(a.dst + 2 * (size_t)a.dst_off[chunk] + (size_t)r * a.dst_stride + x) = v;
+}
+
 struct HmAutoArgs {
   const uint64_t *in;
   uint64_t *out;
@@ -1675,7 +1694,7 @@ extern "C" hm_status hm_ntt_sub_scale(hm_ctx *c, const uint64_t *in, const uint3
   return ntt_common(c, "hm_ntt_sub_scale", in, in_limbs, out, out_limbs, mod_ids, n, 0, k, f);
 }
 
-static hm_status bconv_col_launch(hm_ctx *c, const hm_bconv_desc *descs, uint32_t n_desc, const struct BcolMix *mix);
+static hm_status bconv_col_launch(hm_ctx *c, const hm_bconv_desc *descs, uint32_t n_desc, const struct BcolMix *mix, uint32_t tile0 = 0, uint32_t n_tiles = 0);
 struct BcolMix {   // the MODE 4 prologue of a fused conversion (x = conv + k * mix): per conversion, per output, the operand's limb and the constant
   const uint64_t *mix;
   const uint32_t *const *mix_limbs;
@@ -1929,6 +1948,7 @@ extern "C" hm_status hm_ntt_inner_product(hm_ctx *c, const hm_ntt_ip_desc *d) {
     for (uint32_t j = 0; j < T; ++j)
       if (d->x_is_coeff[i * T + j]) {
         const uint32_t hl = d->hand_limbs[i * T + j];
+        if (d->x_is_coeff[i * T + j] == 2) continue;   // the caller has run the first pass already (hm_bconv_col + the exchange back)
         if (hl < covered.size() && covered[hl]) continue;
         cin.push_back(d->x_limbs[i * T + j]); chand.push_back(hl); cmod.push_back(d->mod_ids[i]);
       }
@@ -2013,6 +2033,16 @@ extern "C" hm_status hm_ntt_inner_product(hm_ctx *c, const hm_ntt_ip_desc *d) {
     HM_HIP(c, hipGetLastError());
   }
   return HM_OK;
+}
+
+// conversion + first transform pass as a call of its own, on a range of column tiles: what a rank runs on its column slice between the two
+// transposed-domain exchanges (hm_limbs_to_colslices -> hm_bconv_col -> hm_colslices_to_limbs -> hm_ntt_inner_product with x_is_coeff = 2)
+extern "C" hm_status hm_bconv_col(hm_ctx *c, const hm_bconv_desc *descs, uint32_t n_desc, uint32_t tile0, uint32_t n_tiles) {
+  if (!c) return HM_ERR_ARG;
+  if (!descs || n_desc == 0) return fail(c, HM_ERR_ARG, "hm_bconv_col: no problems");
+  for (uint32_t k = 0; k < n_desc; ++k)
+    if (descs[k].sub_from) return fail(c, HM_ERR_UNSUPPORTED, "hm_bconv_col: no epilogue on a fused conversion");
+  return bconv_col_launch(c, descs, n_desc, nullptr, tile0, n_tiles);
 }
 
 extern "C" hm_status hm_bconv_consts(hm_ctx *c, const uint32_t *in_ids, uint32_t n_in, const uint32_t *out_ids,
@@ -2143,8 +2173,12 @@ extern "C" hm_status hm_bconv_batch(hm_ctx *c, const hm_bconv_desc *descs, uint3
 
 // conversion + first transform pass in one kernel (see k_bconv_col).  Same descriptors as hm_bconv_batch; `out` receives the COL pass's
 // hand-off of NTT(conversion), the form k_ntt_row_ip reads.  N = 2^16, n_in <= HM_BCOL_MAX_IN.
-static hm_status bconv_col_launch(hm_ctx *c, const hm_bconv_desc *descs, uint32_t n_desc, const BcolMix *mix) {
+// tile0 / n_tiles: the column tiles (16 columns each) to work on — all of them (n_tiles = 0) or a rank's column slice (hm_bconv_col)
+static hm_status bconv_col_launch(hm_ctx *c, const hm_bconv_desc *descs, uint32_t n_desc, const BcolMix *mix, uint32_t tile0, uint32_t n_tiles) {
   if (!c || !descs || n_desc == 0) return HM_ERR_ARG;
+  const uint32_t allTiles = c->P.N >> HM_TL_COL;
+  if (!n_tiles) { tile0 = 0; n_tiles = allTiles; }
+  if ((n_tiles & (n_tiles - 1)) || tile0 % n_tiles || tile0 + n_tiles > allTiles) return fail(c, HM_ERR_ARG, "fused conversion: tile range [%u, %u) of %u", tile0, tile0 + n_tiles, allTiles);
   if (c->P.logN != 16 && c->P.logN != 15) return fail(c, HM_ERR_UNSUPPORTED, "fused conversion: N = 2^15 or 2^16 only");
   HM_HIP(c, hipSetDevice(c->device));
   // output limbs per workgroup: two share the loaded and split inputs (+2 % hmult/s at batch 10), but halve the workgroups of a launch that
@@ -2152,7 +2186,7 @@ static hm_status bconv_col_launch(hm_ctx *c, const hm_bconv_desc *descs, uint32_
   uint32_t NOUT = c->bcol_outs;
   if (!NOUT) {
     size_t wgs = 0;
-    for (uint32_t pi = 0; pi < n_desc; ++pi) wgs += (size_t)descs[pi].n_out * (c->P.N >> HM_TL_COL);
+    for (uint32_t pi = 0; pi < n_desc; ++pi) wgs += (size_t)descs[pi].n_out * n_tiles;
     NOUT = wgs > 4096 ? 2 : 1;
   }
   std::map<uint32_t, std::vector<HmBcolProb>> byIn;
@@ -2221,8 +2255,10 @@ static hm_status bconv_col_launch(hm_ctx *c, const hm_bconv_desc *descs, uint32_
     const void *dtab = nullptr;
     hm_status st = device_table(c, grp.data(), sizeof(HmBcolProb) * grp.size(), &dtab);
     if (st) return st;
-    HmBcolArgs a = {static_cast<const HmBcolProb *>(dtab), out, c->d_tw_fwd, c->P.logN, (uint32_t)grp.size(), groups, mix ? mix->mix : nullptr};
-    const uint32_t pairs = ((uint32_t)grp.size() * (c->P.N >> HM_TL_COL) + 7) / 8 * 8;
+    uint32_t logTiles = 0;
+    while ((1u << logTiles) < n_tiles) ++logTiles;
+    HmBcolArgs a = {static_cast<const HmBcolProb *>(dtab), out, c->d_tw_fwd, c->P.logN, (uint32_t)grp.size(), groups, mix ? mix->mix : nullptr, tile0, logTiles};
+    const uint32_t pairs = ((uint32_t)grp.size() * n_tiles + 7) / 8 * 8;
     ls.push_back(Lnch{kv.first, dim3(pairs * groups), a});
     totalWgs += (size_t)pairs * groups;
   }
@@ -2445,6 +2481,128 @@ extern "C" hm_status hm_slices_to_limbs(hm_ctx *c, const uint64_t *slices, uint6
   }
   if ((st = chunk_copy(c, S, slices, buf, len, so_self, do_self))) return st;
   return chunk_copy(c, S, c->stage_recv, buf, len, so, dof);
+}
+
+// ---- the same exchanges in the TRANSPOSED domain (round 4).  Index i = x1 * 256 + x2: rank p's slice of a limb-poly is the column block
+// x2 in [p * cw, (p + 1) * cw), cw = 256 / world, of every row x1.  A length-(N/256) transform over x1 (the COL pass) is local to a column, so
+// the slice holder runs base conversion AND first transform pass (hm_bconv_col) on its columns and the exchange back carries the first
+// pass's hand-off; the limb owner only runs the second pass.  `slices` keeps the limb-poly layout (n rows of N words, only this rank's
+// columns are valid): the kernels address it like any limb-poly.  Same bytes on the wire as the contiguous slices.
+static hm_status col_copy(hm_ctx *c, hipStream_t S, const uint64_t *src, uint64_t *dst, uint32_t rows, uint32_t cw, uint32_t ss, uint32_t ds,
+                          const std::vector<uint32_t> &so, const std::vector<uint32_t> &dof) {
+  for (size_t base = 0; base < so.size(); base += HM_MAX_CHUNKS / 2) {
+    const uint32_t cnt = (uint32_t)std::min<size_t>(HM_MAX_CHUNKS / 2, so.size() - base);
+    HmColArgs a;
+    a.src = src; a.dst = dst; a.rows = rows; a.cw = cw; a.src_stride = ss; a.dst_stride = ds; a.n_chunks = cnt;
+    for (uint32_t i = 0; i < cnt; ++i) { a.src_off[i] = so[base + i]; a.dst_off[i] = dof[base + i]; }
+    const uint32_t per = (rows * cw / 2 + 255) / 256;
+    hipLaunchKernelGGL(k_col_copy, dim3(cnt * per), dim3(256), 0, S, a);
+    HM_HIP(c, hipGetLastError());
+  }
+  return HM_OK;
+}
+static hm_status col_geometry(hm_ctx *c, const char *what, uint32_t &rowsN, uint32_t &cw) {
+  const uint32_t W = (uint32_t)c->world;
+  if (W > (c->P.N >> HM_TL_COL) || (256u % W)) return fail(c, HM_ERR_UNSUPPORTED, "%s: column slices need world <= N / 4096 (a rank holds one first-pass tile at least)", what);
+  rowsN = c->P.N >> HM_ROW_LOG;
+  cw = 256u / W;
+  return HM_OK;
+}
+extern "C" hm_status hm_limbs_to_colslices(hm_ctx *c, const uint64_t *buf, const uint32_t *limbs, const uint32_t *owners, uint32_t n, uint64_t *slices) {
+  if (!c) return HM_ERR_ARG;
+  if (!buf || !limbs || !owners || !slices) return fail(c, HM_ERR_ARG, "hm_limbs_to_colslices: null argument");
+  const uint32_t W = (uint32_t)c->world, me = (uint32_t)c->rank, len = c->P.N / W, N = c->P.N;
+  uint32_t R = 0, cw = 0;
+  hm_status st = col_geometry(c, "hm_limbs_to_colslices", R, cw);
+  if (st) return st;
+  std::vector<uint32_t> rows(n);
+  if (hm_slice_rows(owners, n, W, rows.data())) return fail(c, HM_ERR_ARG, "hm_limbs_to_colslices: owner out of range");
+  auto U = [N](uint32_t limb, uint32_t col) { return (uint32_t)(((size_t)limb * N + col) / 2); };   // 16-byte units
+  HM_HIP(c, hipSetDevice(c->device));
+  std::vector<uint32_t> cnt(W, 0);
+  for (uint32_t i = 0; i < n; ++i) cnt[owners[i]]++;
+  const uint32_t mine = cnt[me];
+  // staging: send = [peer][my limbs][R][cw] (self skipped), recv = [source][its limbs][R][cw]
+  if ((st = ensure_stage(c, (size_t)std::max<uint32_t>(std::max(mine, n), 1) * W * len))) return st;
+  std::vector<size_t> send_off(W, 0), send_bytes(W, 0), recv_off(W, 0), recv_bytes(W, 0);
+  size_t acc = 0;
+  for (uint32_t p = 0; p < W; ++p) { send_off[p] = acc; send_bytes[p] = p == me ? 0 : (size_t)mine * len * 8; acc += send_bytes[p]; }
+  uint32_t first = 0;
+  for (uint32_t p = 0; p < W; ++p) { recv_off[p] = (size_t)first * len * 8; recv_bytes[p] = (size_t)cnt[p] * len * 8; first += cnt[p]; }
+  std::vector<uint32_t> so, dof, so_self, do_self;
+  for (uint32_t p = 0; p < W; ++p) {
+    uint32_t j = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+      if (owners[i] != me) continue;
+      if (p == me) { so_self.push_back(U(limbs[i], p * cw)); do_self.push_back(U(rows[i], me * cw)); }
+      else { so.push_back(U(limbs[i], p * cw)); dof.push_back((uint32_t)((send_off[p] / 8 + (size_t)j * len) / 2)); }
+      ++j;
+    }
+  }
+  hipStream_t S;
+  if ((st = exchange_stream_begin(c, &S))) return st;
+  if ((st = col_copy(c, S, buf, slices, R, cw, 256, 256, so_self, do_self))) return st;                 // my own limbs' block: straight into place
+  if ((st = col_copy(c, S, buf, c->stage_send, R, cw, 256, cw, so, dof))) return st;                   // pack
+  if ((st = all_to_all(c, S, c->stage_send, send_off, send_bytes, c->stage_recv, recv_off, recv_bytes))) return st;
+  so.clear(); dof.clear();
+  for (uint32_t p = 0; p < W; ++p) {                                                                    // unpack: source p's limbs, my columns
+    if (p == me) continue;
+    uint32_t j = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+      if (owners[i] != p) continue;
+      so.push_back((uint32_t)((recv_off[p] / 8 + (size_t)j * len) / 2)); dof.push_back(U(rows[i], me * cw));
+      ++j;
+    }
+  }
+  return col_copy(c, S, c->stage_recv, slices, R, cw, cw, 256, so, dof);
+}
+extern "C" hm_status hm_colslices_to_limbs(hm_ctx *c, const uint64_t *slices, uint64_t *buf, const uint32_t *limbs, const uint32_t *owners, uint32_t n) {
+  if (!c) return HM_ERR_ARG;
+  if (!buf || !limbs || !owners || !slices) return fail(c, HM_ERR_ARG, "hm_colslices_to_limbs: null argument");
+  const uint32_t W = (uint32_t)c->world, me = (uint32_t)c->rank, len = c->P.N / W, N = c->P.N;
+  uint32_t R = 0, cw = 0;
+  hm_status st = col_geometry(c, "hm_colslices_to_limbs", R, cw);
+  if (st) return st;
+  std::vector<uint32_t> rows(n);
+  if (hm_slice_rows(owners, n, W, rows.data())) return fail(c, HM_ERR_ARG, "hm_colslices_to_limbs: owner out of range");
+  auto U = [N](uint32_t limb, uint32_t col) { return (uint32_t)(((size_t)limb * N + col) / 2); };   // 16-byte units
+  HM_HIP(c, hipSetDevice(c->device));
+  std::vector<uint32_t> cnt(W, 0);
+  for (uint32_t i = 0; i < n; ++i) cnt[owners[i]]++;
+  const uint32_t mine = cnt[me];
+  if ((st = ensure_stage(c, (size_t)std::max<uint32_t>(std::max(mine, n), 1) * W * len))) return st;
+  // send: to owner p my column block of each of ITS limbs (compact, in list order); receive: from every rank its block of each of MY limbs
+  std::vector<size_t> send_off(W, 0), send_bytes(W, 0), recv_off(W, 0), recv_bytes(W, 0);
+  uint32_t first = 0;
+  for (uint32_t p = 0; p < W; ++p) { send_off[p] = (size_t)first * len * 8; send_bytes[p] = (size_t)cnt[p] * len * 8; first += cnt[p]; }
+  size_t acc = 0;
+  for (uint32_t p = 0; p < W; ++p) { recv_off[p] = acc; recv_bytes[p] = p == me ? 0 : (size_t)mine * len * 8; acc += recv_bytes[p]; }
+  std::vector<uint32_t> so, dof, so_self, do_self;
+  for (uint32_t p = 0; p < W; ++p) {
+    uint32_t j = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+      if (owners[i] != p) continue;
+      if (p == me) { so_self.push_back(U(rows[i], me * cw)); do_self.push_back(U(limbs[i], me * cw)); }
+      else { so.push_back(U(rows[i], me * cw)); dof.push_back((uint32_t)((send_off[p] / 8 + (size_t)j * len) / 2)); }
+      ++j;
+    }
+  }
+  hipStream_t S;
+  if ((st = exchange_stream_begin(c, &S))) return st;
+  if ((st = col_copy(c, S, slices, buf, R, cw, 256, 256, so_self, do_self))) return st;
+  if ((st = col_copy(c, S, slices, c->stage_send, R, cw, 256, cw, so, dof))) return st;
+  if ((st = all_to_all(c, S, c->stage_send, send_off, send_bytes, c->stage_recv, recv_off, recv_bytes))) return st;
+  so.clear(); dof.clear();
+  for (uint32_t p = 0; p < W; ++p) {
+    if (p == me) continue;
+    uint32_t j = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+      if (owners[i] != me) continue;
+      so.push_back((uint32_t)((recv_off[p] / 8 + (size_t)j * len) / 2)); dof.push_back(U(limbs[i], p * cw));
+      ++j;
+    }
+  }
+  return col_copy(c, S, c->stage_recv, buf, R, cw, cw, 256, so, dof);
 }
 
 extern "C" hm_status hm_replicate_limbs(hm_ctx *c, uint64_t *buf, const uint32_t *limbs, const uint32_t *owners, uint32_t n) {

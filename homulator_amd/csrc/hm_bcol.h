@@ -29,6 +29,7 @@ struct HmBcolArgs {
   const HmTw *tw;
   uint32_t logN, n_prob, max_out;   // max_out: output GROUPS (of NOUT limbs) per (conversion, tile)
   const uint64_t *mix;
+  uint32_t tile0, logTiles;         // the column tiles this launch works on: [tile0, tile0 + 2^logTiles) (all of them, or a rank's column slice)
 };
 // One workgroup = (conversion, NOUT consecutive output limbs, column tile).  NOUT = 2 (round 4): the N_IN input access units of a thread
 // are loaded and split ONCE and multiplied into both outputs (half the L2 requests, the shift / mask work of the split amortised), then
@@ -88,8 +89,8 @@ __device__ __forceinline__ void hm_bconv_col_body(const HmBcolArgs &a) {
   // (the division runs on the vector unit: its results are made scalar again by hand, or every buffer access below becomes a waterfall loop)
   const uint32_t sdiv = __builtin_amdgcn_readfirstlane(slot / a.max_out);
   const uint32_t pair = sdiv * 8u + xcd, og = slot - sdiv * a.max_out;
-  const uint32_t logT = a.logN - TL;
-  const uint32_t pi = pair >> logT, tile = pair & ((1u << logT) - 1u);
+  const uint32_t logT = a.logTiles;
+  const uint32_t pi = pair >> logT, tile = a.tile0 + (pair & ((1u << logT) - 1u));
   if (pi >= a.n_prob) return;
   const auto &p = HM_CONST_PROB_T(HmBcolProb, a.prob)[pi];
   const uint32_t o0 = og * NOUT;

@@ -17,6 +17,7 @@ SYMBOLS = [
     "hm_bconv", "hm_bconv_batch", "hm_bconv_consts", "hm_fill_uniform", "hm_timer_start", "hm_timer_stop", "hm_comm_unique_id", "hm_comm_init_rccl", "hm_comm_init_external",
     "hm_capture_begin", "hm_capture_end", "hm_graph_launch", "hm_graph_destroy", "hm_comm_info", "hm_slice_rows", "hm_limbs_to_slices", "hm_slices_to_limbs", "hm_replicate_limbs",
     "hm_set_option", "hm_get_counter", "hm_ntt_inner_product", "hm_exchange_stream", "hm_exchange_mark", "hm_exchange_wait",
+    "hm_bconv_col", "hm_limbs_to_colslices", "hm_colslices_to_limbs",
 ]
 
 

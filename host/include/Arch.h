@@ -109,6 +109,7 @@ private:
   Config *config;
   Backend backendKind;
   bool fuse;
+  bool shardFused = false;      // sharded: conversion + first pass on column slices, transform x key kernel on the owner (config key shard_fused)
   bool pipelineDigits = false;  // sharded: per-digit exchanges on the exchange stream (config key pipeline_digits, default 1 when world > 1)
   bool fuseHpip = true;
   bool fuseBconv = true;  // config key fuse_bconv: the ModUp conversion runs inside the first pass of the fused transform x key kernel   // config key fuse_hpip: the ModUp transforms' last pass runs inside the inner-product kernel

@@ -13,7 +13,8 @@
 
 // one C-ABI call, with its argument arrays prebuilt so that run() is a tight loop of calls
 struct Arch::Launch {
-  enum Kind { L_NTT, L_INTT, L_EWE, L_BCONV, L_AUTO, L_NTT_SUBSCALE, L_TENSOR, L_EXCH_IN, L_EXCH_OUT, L_REPLICATE, L_IP, L_NTT_IP } kind;
+  enum Kind { L_NTT, L_INTT, L_EWE, L_BCONV, L_AUTO, L_NTT_SUBSCALE, L_TENSOR, L_EXCH_IN, L_EXCH_OUT, L_REPLICATE, L_IP, L_NTT_IP,
+              L_BCONV_COL, L_EXCH_IN_COL, L_EXCH_OUT_COL } kind;   // round 4: conversion + first pass on a rank's column slice, between the transposed-domain exchanges
   Launch *xin = nullptr, *xout = nullptr;   // sharded BCONV: the exchange launches around it (they share its slice buffers)
   int recordSlot = -1;            // exchange launches of a pipelined sharded plan: the mark set behind them (hm_exchange_mark)
   std::vector<int> waitSlots;     // marks the compute stream waits for before this launch (hm_exchange_wait)
@@ -95,7 +96,12 @@ Arch::Arch(Config *cfg) : config(cfg) {
   // launches, so the fused NTT x key kernel (which needs all digits) is not used.
   pipelineDigits = world_ > 1 && cfg->getValueOr("pipeline_digits", 1) != 0;
   if (const char *e = getenv("HOMULATOR_PIPELINE_DIGITS")) pipelineDigits = world_ > 1 && std::string(e) != "0";
-  if (pipelineDigits) fuseHpip = false;
+  // round 4: the fused kernels serve the sharded plan too — the ModUp conversion AND the first pass of its transforms run on the slice
+  // holder's COLUMN slice (exchange in the transposed domain), the limb owner runs the transform x key kernel's second pass (config key
+  // shard_fused, default 1; needs world <= N / 4096 and N = 2^15 | 2^16).  Otherwise the per-digit transforms stay launches of their own.
+  shardFused = world_ > 1 && cfg->getValueOr("shard_fused", 1) != 0 && fuseHpip && fuseBconv && (logN == 16 || logN == 15) && world_ <= (n >> 12);
+  if (const char *e = getenv("HOMULATOR_SHARD_FUSED")) shardFused = shardFused && std::string(e) != "0";
+  if (pipelineDigits && !shardFused) fuseHpip = false;
   stat = new Statistic();
 }
 
@@ -474,7 +480,7 @@ void Arch::fusePasses(std::vector<Stage> &st) {
         ip->ipSrc = ip->ipX;
         ip->ipCoeff.assign(ip->ipX.size(), 0);
         std::vector<Instruction *> conv(ip->ipX.size(), nullptr);
-        bool allConv = fuseBconv && world_ == 1 && (logN == 16 || logN == 15);
+        bool allConv = fuseBconv && (world_ == 1 || shardFused) && (logN == 16 || logN == 15);
         for (size_t j = 0; j < ip->ipX.size(); ++j) {
           auto p = producer.find(ip->ipX[j]);
           if (p == producer.end()) continue;
@@ -695,6 +701,107 @@ void Arch::buildLaunches() {
         if (parts[pj].depth == d && parts[pj].key == key) group.push_back(&parts[pj]);
       Instruction *f = group[0]->ins[0];
       std::vector<Part> mineParts;
+      bool nipSharded = false;
+      if (world_ > 1 && f->ops == IP)
+        for (const Part *g : group)
+          for (Instruction *i : g->ins)
+            for (auto &cin : i->ipConvIn) nipSharded |= !cin.empty();
+      if (nipSharded) {
+        // ---- sharded ModUp with the fused kernels (round 4).  Per digit j: limbs -> COLUMN slices of the digit's limbs (all-to-all), conversion +
+        // first pass on this rank's columns for EVERY output limb (hm_bconv_col), column slices -> limbs of the first-pass hand-off
+        // (all-to-all back); then ONE transform x key launch over this rank's extended limbs (second pass + MAC with both keys).
+        // Every rank issues every exchange (the lists come from the global graph), also a rank that owns no extended limb.
+        struct Dig { std::vector<uint32_t> in, inMods, hand, handMods; };
+        std::vector<Dig> digs;
+        for (const Part *g : group)
+          for (Instruction *i : g->ins)
+            for (size_t j = 0; j < i->ipConvIn.size(); ++j) {
+              if (i->ipConvIn[j].empty()) continue;
+              std::vector<uint32_t> in;
+              for (AddrType x : i->ipConvIn[j]) in.push_back(limbOf(x));
+              Dig *dg = nullptr;
+              for (auto &q : digs) if (q.in == in && q.inMods == i->ipConvMods[j]) dg = &q;
+              if (!dg) { digs.push_back(Dig{in, i->ipConvMods[j], {}, {}}); dg = &digs.back(); }
+              dg->hand.push_back(limbOf(i->ipX[j]));
+              dg->handMods.push_back(i->mod_id);
+            }
+        const uint32_t per = (uint32_t)limbIndex.size();
+        std::vector<Launch *> front, back;
+        std::vector<int> outSlots;
+        const uint32_t nTiles = (n >> 12) / world_;
+        for (size_t dj = 0; dj < digs.size(); ++dj) {
+          Dig &dg = digs[dj];
+          Launch *XI = new Launch, *BC = new Launch, *XO = new Launch;
+          XI->kind = Launch::L_EXCH_IN_COL; BC->kind = Launch::L_BCONV_COL; XO->kind = Launch::L_EXCH_OUT_COL;
+          XI->statKey = XO->statKey = "XCHG"; BC->statKey = "BCONV";
+          BC->name = "ModUp_BCONV_COL_(" + std::to_string(dj) + ")";
+          XI->name = BC->name + ":limbs->columns"; XO->name = BC->name + ":columns->limbs";
+          for (uint32_t c = 0; c < batch_; ++c) {   // the ops of a batch share the exchanges
+            for (size_t x = 0; x < dg.in.size(); ++x) { XI->exLimbs.push_back(dg.in[x] + c * per); XI->exOwners.push_back(owner(dg.inMods[x])); }
+            for (size_t x = 0; x < dg.hand.size(); ++x) { XO->exLimbs.push_back(dg.hand[x] + c * per); XO->exOwners.push_back(owner(dg.handMods[x])); }
+          }
+          std::vector<uint32_t> inRows(XI->exLimbs.size()), outRows(XO->exLimbs.size());
+          hm_slice_rows(XI->exOwners.data(), (uint32_t)inRows.size(), world_, inRows.data());
+          hm_slice_rows(XO->exOwners.data(), (uint32_t)outRows.size(), world_, outRows.data());
+          for (uint32_t c = 0; c < batch_; ++c) {
+            Launch::Prob q{{}, dg.inMods, {}, dg.handMods};
+            for (size_t x = 0; x < dg.in.size(); ++x) q.in.push_back(inRows[c * dg.in.size() + x]);
+            for (size_t x = 0; x < dg.hand.size(); ++x) q.out.push_back(outRows[c * dg.hand.size() + x]);
+            BC->probs.push_back(q);
+          }
+          BC->galois = rank_ * nTiles;    // first column tile of this rank's slice
+          BC->logLen = nTiles;            // ... and how many
+          BC->refInstructions = 0;        // (accounted on the transform x key launch, as in the one-GPU plan)
+          XI->bytes = LP * XI->exLimbs.size() / world_;
+          XO->bytes = LP * XO->exLimbs.size() / world_;
+          BC->bytes = (XI->bytes + XO->bytes);
+          if (pipelineDigits) {
+            XI->recordSlot = nextSlot++;
+            BC->waitSlots = {XI->recordSlot};
+            XO->recordSlot = nextSlot++;
+          }
+          outSlots.push_back(XO->recordSlot);
+          BC->xin = XI; BC->xout = XO;
+          (pipelineDigits ? front : back).push_back(XI);
+          back.push_back(BC);
+          back.push_back(XO);
+          algBytes += BC->bytes;
+        }
+        // this rank's extended limbs
+        Launch *L = new Launch;
+        L->kind = Launch::L_NTT_IP; L->statKey = "NTT";
+        L->ipTerms = (uint32_t)f->ipX.size(); L->ipOuts = (uint32_t)f->ipY.size();
+        unsigned long long lp = 0;
+        for (const Part *g : group) {
+          bool any = false;
+          for (Instruction *i : g->ins) {
+            L->refInstructions += owner(i->mod_id) == rank_ ? i->refInstructions : 0;
+            if (owner(i->mod_id) != rank_) continue;
+            any = true;
+            for (size_t j = 0; j < i->ipX.size(); ++j) {
+              const bool conv = j < i->ipConvIn.size() && !i->ipConvIn[j].empty();
+              L->a.push_back(limbOf(i->ipSrc[j])); L->c.push_back(limbOf(i->ipX[j]));
+              L->ipCoeff.push_back(conv ? 2 : i->ipCoeff[j]);
+              lp += i->ipCoeff[j] ? 1 : 1;
+            }
+            for (auto &y : i->ipY) for (AddrType yy : y) L->b.push_back(limbOf(yy));
+            L->out.push_back(limbOf(i->OutputOperand));
+            for (AddrType o : i->extraOutputs) L->out.push_back(limbOf(o));
+            L->mods.push_back(i->mod_id);
+            lp += (unsigned long long)L->ipTerms * L->ipOuts + L->ipOuts;
+          }
+          if (any) L->name += (L->name.empty() ? "" : "+") + g->name;
+        }
+        L->bytes = lp * LP;
+        if (pipelineDigits) for (int sl : outSlots) L->waitSlots.push_back(sl);
+        launches.insert(launches.end(), front.begin(), front.end());
+        launches.insert(launches.end(), back.begin(), back.end());
+        if (!L->mods.empty()) { algBytes += L->bytes; launches.push_back(L); }
+        else {   // a rank without extended limbs still waits for nothing: its exchanges are complete on their own stream
+          delete L;
+        }
+        continue;
+      }
       if (world_ > 1 && f->ops != BCONV_STEP2) {
         // (a) operands written on another rank (the rescale's r = INTT(x_last)): replicate them first — every
         //     rank derives the same list from the global graph, so the collective is entered by all
@@ -978,6 +1085,7 @@ void Arch::replicateForBatch() {
   };
   for (Launch *l : launches) {
     if (world_ > 1 && (l->kind == Launch::L_BCONV || l->kind == Launch::L_EXCH_IN || l->kind == Launch::L_EXCH_OUT)) continue;  // built batched
+    if (l->kind == Launch::L_BCONV_COL || l->kind == Launch::L_EXCH_IN_COL || l->kind == Launch::L_EXCH_OUT_COL) continue;           // built batched
     if (l->kind == Launch::L_REPLICATE) {
       const size_t n0 = l->exLimbs.size();
       for (uint32_t c = 1; c < batch_; ++c)
@@ -1061,6 +1169,16 @@ void Arch::prepare() {
     if (!commReady) throw std::runtime_error("world > 1 but no transport was set (commInitRccl / commInitExternal)");
     if (pipelineDigits && hm_exchange_stream(ctx, 1) != HM_OK) throw std::runtime_error(std::string("hm_exchange_stream: ") + hm_last_error(ctx));
     for (Launch *bc : launches) {
+      if (bc->kind != Launch::L_BCONV_COL || !bc->xin) continue;
+      Launch *xi = bc->xin, *xo = bc->xout;
+      void *si = nullptr, *so = nullptr;   // limb-poly layout: a row per limb-poly, this rank's columns valid
+      if (hm_malloc(ctx, (size_t)xi->exLimbs.size() * n * 8, &si) != HM_OK || hm_malloc(ctx, (size_t)xo->exLimbs.size() * n * 8, &so) != HM_OK)
+        throw std::runtime_error(std::string("hm_malloc (column slices): ") + hm_last_error(ctx));
+      sliceBuffers.push_back(si); sliceBuffers.push_back(so);
+      xi->slicesIn = bc->slicesIn = static_cast<uint64_t *>(si);
+      bc->slicesOut = xo->slicesOut = static_cast<uint64_t *>(so);
+    }
+    for (Launch *bc : launches) {
       if (bc->kind != Launch::L_BCONV || !bc->xin) continue;
       Launch *xi = bc->xin, *xo = bc->xout;
       void *si = nullptr, *so = nullptr;
@@ -1093,7 +1211,8 @@ void Arch::prepare() {
   hm_sync(ctx);
 }
 
-static const char *const kLaunchKindNames[] = {"NTT", "INTT", "EWE", "BCONV", "AUTO", "NTT_SUBSCALE", "TENSOR", "EXCH_IN", "EXCH_OUT", "REPLICATE", "IP", "NTT_IP"};
+static const char *const kLaunchKindNames[] = {"NTT", "INTT", "EWE", "BCONV", "AUTO", "NTT_SUBSCALE", "TENSOR", "EXCH_IN", "EXCH_OUT", "REPLICATE", "IP", "NTT_IP",
+                                               "BCONV_COL", "EXCH_IN_COL", "EXCH_OUT_COL"};
 
 // Per-launch device time (SURVEY.md §8d "per-stage hipEvent times", exchange time at N > 1): every launch of the plan
 // bracketed by its own event pair, in plan order so that the data dependencies (and, sharded, the collectives) line up.
@@ -1121,7 +1240,7 @@ std::string Arch::planText() const {
   std::string out;
   for (const Launch *l : launches) {
     size_t cnt = l->out.size();
-    if (l->kind == Launch::L_BCONV) { cnt = 0; for (auto &q : l->probs) cnt += q.out.size(); }
+    if (l->kind == Launch::L_BCONV || l->kind == Launch::L_BCONV_COL) { cnt = 0; for (auto &q : l->probs) cnt += q.out.size(); }
     if (l->kind == Launch::L_IP || l->kind == Launch::L_NTT_IP) cnt = l->mods.size();
     out += std::string(names[l->kind]) + " " + l->name + " n=" + std::to_string(cnt) + " ref=" + std::to_string(l->refInstructions);
     if (l->recordSlot >= 0) out += " mark=" + std::to_string(l->recordSlot);
@@ -1181,6 +1300,17 @@ void Arch::enqueue(Launch &l) {
     break;
   case Launch::L_EXCH_OUT:
     st = hm_slices_to_limbs(ctx, l.slicesOut, pool, l.exLimbs.data(), l.exOwners.data(), (uint32_t)l.exLimbs.size());
+    break;
+  case Launch::L_EXCH_IN_COL:
+    st = hm_limbs_to_colslices(ctx, pool, l.exLimbs.data(), l.exOwners.data(), (uint32_t)l.exLimbs.size(), l.slicesIn);
+    break;
+  case Launch::L_EXCH_OUT_COL:
+    st = hm_colslices_to_limbs(ctx, l.slicesOut, pool, l.exLimbs.data(), l.exOwners.data(), (uint32_t)l.exLimbs.size());
+    break;
+  case Launch::L_BCONV_COL:
+    for (auto &q : l.probs)
+      descs.push_back(hm_bconv_desc{l.slicesIn, q.in.data(), q.inMods.data(), (uint32_t)q.in.size(), l.slicesOut, q.out.data(), q.outMods.data(), (uint32_t)q.out.size(), 0});
+    st = hm_bconv_col(ctx, descs.data(), (uint32_t)descs.size(), l.galois, l.logLen);
     break;
   case Launch::L_REPLICATE:
     st = hm_replicate_limbs(ctx, pool, l.exLimbs.data(), l.exOwners.data(), (uint32_t)l.exLimbs.size());

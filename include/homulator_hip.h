@@ -157,7 +157,8 @@ hm_status hm_inner_product(hm_ctx *ctx, const uint64_t *x, const uint32_t *x_lim
  * Row-major lists: x_limbs / x_is_coeff / hand_limbs [i * n_terms + j], y_limbs [(i * n_out + k) * n_terms + j],
  * out_limbs [i * n_out + k].  x_is_coeff[i][j] != 0: x[i][j] is in coefficient form (a converted limb) and is transformed;
  * hand + hand_limbs[i][j] * N is N words of scratch for its first pass (contents undefined afterwards); 0: x[i][j] is already
- * in evaluation form (a digit's own limbs).  `out` must not alias x, hand or y.  Bit-identical to hm_ntt + hm_inner_product. */
+ * in evaluation form (a digit's own limbs); 2 (round 4): transformed as for 1, but the first pass has already been run into the hand-off
+ * limb by the caller (hm_bconv_col, possibly on another rank: see hm_colslices_to_limbs): only the second pass runs here.  `out` must not alias x, hand or y.  Bit-identical to hm_ntt + hm_inner_product. */
 struct hm_bconv_desc;
 typedef struct hm_ntt_ip_desc {
   const uint64_t *x;    const uint32_t *x_limbs;   const uint8_t *x_is_coeff;
@@ -203,6 +204,14 @@ struct hm_bconv_desc {
   const uint64_t *sub_from; const uint32_t *sub_from_limbs; const uint64_t *add; const uint32_t *add_limbs; const uint64_t *sub_k;
 };
 hm_status hm_bconv_batch(hm_ctx *ctx, const hm_bconv_desc *descs, uint32_t n_desc);
+/* K4 + first pass of K1 in one kernel, as a call of its own (round 4): every output of every conversion is converted AND taken through the
+ * COL pass of its forward transform; descs[k].out + out_limbs[t] * N receives the first pass's hand-off (what hm_ntt_inner_product reads
+ * for a digit with x_is_coeff = 2), the converted limb-polys never exist.  tile0 / n_tiles: the column tiles (16 columns x2 of index
+ * i = x1 * 256 + x2 each) to work on; n_tiles = 0: all N / 4096 of them; a power of two that divides tile0.  A rank of a sharded run passes
+ * its column slice (tile0 = rank * 16 / world, n_tiles = 16 / world at N = 2^16).  N = 2^15 or 2^16, n_in <= 15.  Same reference
+ * interface as hm_bconv_batch + hm_ntt: issueIns(cluster, h, w, group, ...) include/Arch.h:277 for InsGen::GenBCONV (src/InsGen.cpp:263-313)
+ * and issueIns(cluster, name, group) include/Arch.h:276 for the first half of InsGen::GenNTT (src/InsGen.cpp:17-44). */
+hm_status hm_bconv_col(hm_ctx *ctx, const hm_bconv_desc *descs, uint32_t n_desc, uint32_t tile0, uint32_t n_tiles);
 /* host-side constants of a conversion: qhat_inv[n_in], table[n_in][n_out] (either may be NULL) */
 hm_status hm_bconv_consts(hm_ctx *ctx, const uint32_t *in_ids, uint32_t n_in, const uint32_t *out_ids,
                           uint32_t n_out, uint64_t *qhat_inv, uint64_t *table);
@@ -234,6 +243,17 @@ hm_status hm_limbs_to_slices(hm_ctx *ctx, const uint64_t *buf, const uint32_t *l
  * whole limb at buf + limbs[i] * N. */
 hm_status hm_slices_to_limbs(hm_ctx *ctx, const uint64_t *slices, uint64_t *buf, const uint32_t *limbs,
                              const uint32_t *owners, uint32_t n);
+/* The same two exchanges in the TRANSPOSED domain (round 4; same bytes on the wire): with i = x1 * 256 + x2, rank p's slice of a limb-poly
+ * is the column block x2 in [p * 256 / world, (p + 1) * 256 / world) of every row x1.  The first pass of a forward transform (length N / 256
+ * over x1) is local to a column, so the slice holder runs base conversion AND first pass on its columns (hm_bconv_col) and the exchange
+ * back carries the first pass's hand-off: the fused kernels of the one-GPU plan serve the sharded one, first-pass work is spread over all
+ * ranks and the limb owner only runs hm_ntt_inner_product's second pass (x_is_coeff = 2).  `slices`: n rows of N words in the limb-poly
+ * layout (row rows[i] of hm_slice_rows; only this rank's columns are valid).  world <= 16.  Reference: the placement of every unit by
+ * limb % cluster, HPIP included (include/Driver.h:155-246), and its one communication, the inter-cluster fetch (src/mem.cpp:78-100). */
+hm_status hm_limbs_to_colslices(hm_ctx *ctx, const uint64_t *buf, const uint32_t *limbs, const uint32_t *owners,
+                                uint32_t n, uint64_t *slices);
+hm_status hm_colslices_to_limbs(hm_ctx *ctx, const uint64_t *slices, uint64_t *buf, const uint32_t *limbs,
+                                const uint32_t *owners, uint32_t n);
 
 /* Exchange / compute overlap inside ONE op ("overlap digit j+1's exchange with digit j's NTT"; upstream's digit loop
  * src/Operation.cpp:31-35, its only communication src/mem.cpp:78-100).  hm_exchange_stream(ctx, 1): from now on the three exchange

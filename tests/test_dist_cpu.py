@@ -40,60 +40,88 @@ def test_gloo_transport_world2():
 
 @pytest.mark.parametrize("opname", ["hmult", "hrotate"])
 @pytest.mark.parametrize("pipeline", [1, 0])
+@pytest.mark.parametrize("fused", [1, 0])
 @pytest.mark.parametrize("world,batch", [(2, 1), (4, 1), (8, 1), (2, 4), (8, 16)])
-def test_sharded_plans_are_collectively_consistent(opname, world, batch, pipeline):
-    """pipeline = 1 (default when sharded): per-digit exchanges, 2 beta + 2 all-to-alls per key switch, every launch behind an
-    exchange waits for that exchange's mark only; pipeline = 0: one all-to-all pair per base-conversion stage"""
+def test_sharded_plans_are_collectively_consistent(opname, world, batch, pipeline, fused):
+    """fused = 1 (round 4, default): the ModUp runs on the fused kernels — per digit limbs -> COLUMN slices, conversion + first pass on the
+    rank's columns (BCONV_COL), column slices -> limbs of the hand-off, then ONE transform x key launch (NTT_IP) per rank: beta + 1 ModUp
+    launches per rank instead of 2 beta + 1; fused = 0 (shard_fused = 0): the round-3 plan (conversion on contiguous slices, per-digit
+    transforms, inner product).  pipeline = 1 (default when sharded): per-digit exchanges, 2 beta + 2 all-to-alls per key switch, every
+    launch behind an exchange waits for that exchange's mark only; pipeline = 0 (fused = 0 only changes the grouping): one pair per stage"""
     from homulator_amd import host
     L, ell, alpha = 45, 35, 15
     beta = -(-ell // alpha)
-    ov = {"pipeline_digits": pipeline, "fuse_hpip": 0 if pipeline else 1, **({"batch": batch} if batch > 1 else {})}
+    ov = {"pipeline_digits": pipeline, **({"batch": batch} if batch > 1 else {})}
+    if not fused:
+        ov.update({"shard_fused": 0, "fuse_hpip": 0 if pipeline else 1})
     single = host.Op("config_4.cfg", opname, L, ell, alpha, backend=host.BACKEND_COUNT, overrides=ov)
     total_ref = sum(int(re.search(r"ref=(\d+)", ln).group(1)) for ln in single.plan())
     plans = []
     for r in range(world):
         o = host.Op("config_4.cfg", opname, L, ell, alpha, backend=host.BACKEND_COUNT, rank=r, world=world, overrides=ov)
         plans.append(o.plan())
-    coll = [[ln for ln in pl if ln.split()[0] in ("EXCH_IN", "EXCH_OUT", "REPLICATE")] for pl in plans]
+    XK = ("EXCH_IN", "EXCH_OUT", "REPLICATE", "EXCH_IN_COL", "EXCH_OUT_COL")
+    coll = [[ln for ln in pl if ln.split()[0] in XK] for pl in plans]
     # every rank enters the same collectives, in the same order, with the same limb:owner lists
     assert all(c == coll[0] for c in coll)
-    n_bconv = sum(1 for ln in plans[0] if ln.startswith("BCONV"))
-    assert sum(1 for ln in coll[0] if ln.startswith("EXCH_IN")) == n_bconv == sum(1 for ln in coll[0] if ln.startswith("EXCH_OUT"))
-    # SURVEY §8e: one all-to-all pair for ModUp (all digits) and one for ModDown (both keys), or 2 beta + 2 pipelined per digit
-    assert n_bconv == (beta + 1 if pipeline else 2)
-    if pipeline:   # marks: every exchange sets one, in issue order; a conversion waits for its own exchange-in, a transform for its digit's exchange-out
-        marks = [int(re.search(r"mark=(\d+)", ln).group(1)) for ln in plans[0] if " mark=" in ln]
-        assert sorted(marks) == list(range(len(marks)))
-        xin = {re.match(r"EXCH_IN (\S+):", ln).group(1): int(re.search(r"mark=(\d+)", ln).group(1)) for ln in plans[0] if ln.startswith("EXCH_IN")}
-        xout = {re.match(r"EXCH_OUT (\S+):", ln).group(1): int(re.search(r"mark=(\d+)", ln).group(1)) for ln in plans[0] if ln.startswith("EXCH_OUT")}
-        for ln in plans[0]:
-            if ln.startswith("BCONV"):
-                assert re.search(r"wait=([\d,]+)", ln).group(1).strip(",") == str(xin[ln.split()[1]])
-        for j in range(beta):
+    kind = lambda ln: ln.split()[0]
+    cnt = lambda pl, k: sum(1 for ln in pl if kind(ln) == k)
+    if fused:
+        # ModUp: one column exchange pair and one BCONV_COL per digit on EVERY rank, one NTT_IP on every rank that owns an extended limb;
+        # ModDown: the contiguous-slice conversion as before
+        for pl in plans:
+            assert cnt(pl, "EXCH_IN_COL") == cnt(pl, "BCONV_COL") == cnt(pl, "EXCH_OUT_COL") == beta
+            assert cnt(pl, "EXCH_IN") == cnt(pl, "BCONV") == cnt(pl, "EXCH_OUT") == 1
+            assert cnt(pl, "NTT_IP") == 1 and cnt(pl, "NTT") == 0 and cnt(pl, "IP") == 0
+        if pipeline:
+            marks = [int(re.search(r"mark=(\d+)", ln).group(1)) for ln in plans[0] if " mark=" in ln]
+            assert sorted(marks) == list(range(len(marks)))
+            xin = {re.match(r"EXCH_IN_COL (\S+):", ln).group(1): int(re.search(r"mark=(\d+)", ln).group(1)) for ln in plans[0] if kind(ln) == "EXCH_IN_COL"}
+            xout = [int(re.search(r"mark=(\d+)", ln).group(1)) for ln in plans[0] if kind(ln) == "EXCH_OUT_COL"]
             for pl in plans:
                 for ln in pl:
-                    if ln.startswith(f"NTT ModUp_NTT_({j})"):
-                        assert re.search(r"wait=([\d,]+)", ln).group(1).strip(",") == str(xout[f"ModUp_BCONV_({j})"])
-        first_bconv = next(i for i, ln in enumerate(plans[0]) if ln.startswith("BCONV"))
-        assert sum(1 for ln in plans[0][:first_bconv] if ln.startswith("EXCH_IN")) == beta   # all digits' exchange-in are in flight before the first conversion
+                    if kind(ln) == "BCONV_COL":   # a conversion waits for its own digit's exchange-in only
+                        assert re.search(r"wait=([\d,]+)", ln).group(1).strip(",") == str(xin[ln.split()[1]])
+                    if kind(ln) == "NTT_IP":      # the transform x key launch needs every digit's hand-off
+                        assert sorted(int(x) for x in re.search(r"wait=([\d,]+)", ln).group(1).strip(",").split(",")) == sorted(xout)
+            first_bc = next(i for i, ln in enumerate(plans[0]) if kind(ln) == "BCONV_COL")
+            assert sum(1 for ln in plans[0][:first_bc] if kind(ln) == "EXCH_IN_COL") == beta   # all digits' exchange-in are in flight before the first conversion
+    else:
+        n_bconv = sum(1 for ln in plans[0] if ln.startswith("BCONV"))
+        assert sum(1 for ln in coll[0] if ln.startswith("EXCH_IN")) == n_bconv == sum(1 for ln in coll[0] if ln.startswith("EXCH_OUT"))
+        # SURVEY §8e: one all-to-all pair for ModUp (all digits) and one for ModDown (both keys), or 2 beta + 2 pipelined per digit
+        assert n_bconv == (beta + 1 if pipeline else 2)
+        if pipeline:   # marks: every exchange sets one, in issue order; a conversion waits for its own exchange-in, a transform for its digit's exchange-out
+            marks = [int(re.search(r"mark=(\d+)", ln).group(1)) for ln in plans[0] if " mark=" in ln]
+            assert sorted(marks) == list(range(len(marks)))
+            xin = {re.match(r"EXCH_IN (\S+):", ln).group(1): int(re.search(r"mark=(\d+)", ln).group(1)) for ln in plans[0] if ln.startswith("EXCH_IN")}
+            xout = {re.match(r"EXCH_OUT (\S+):", ln).group(1): int(re.search(r"mark=(\d+)", ln).group(1)) for ln in plans[0] if ln.startswith("EXCH_OUT")}
+            for ln in plans[0]:
+                if ln.startswith("BCONV"):
+                    assert re.search(r"wait=([\d,]+)", ln).group(1).strip(",") == str(xin[ln.split()[1]])
+            for j in range(beta):
+                for pl in plans:
+                    for ln in pl:
+                        if ln.startswith(f"NTT ModUp_NTT_({j})"):
+                            assert re.search(r"wait=([\d,]+)", ln).group(1).strip(",") == str(xout[f"ModUp_BCONV_({j})"])
+            first_bconv = next(i for i, ln in enumerate(plans[0]) if ln.startswith("BCONV"))
+            assert sum(1 for ln in plans[0][:first_bconv] if ln.startswith("EXCH_IN")) == beta   # all digits' exchange-in are in flight before the first conversion
     if opname == "hmult":
         assert sum(1 for ln in coll[0] if ln.startswith("REPLICATE")) == 1   # rescale's r
     # owners follow limb % world on the exchanged limbs, and the element-wise work is partitioned exactly
+    EW = ("NTT", "INTT", "EWE", "AUTO", "NTT_SUBSCALE", "TENSOR", "IP", "NTT_IP")
     per_rank = []
     for pl in plans:
-        n = 0
-        for ln in pl:
-            kind = ln.split()[0]
-            if kind in ("NTT", "INTT", "EWE", "AUTO", "NTT_SUBSCALE", "TENSOR", "IP", "NTT_IP"):
-                n += int(re.search(r" n=(\d+)", ln).group(1))
-        per_rank.append(n)
+        per_rank.append(sum(int(re.search(r" n=(\d+)", ln).group(1)) for ln in pl if kind(ln) in EW))
     # (against the one-GPU plan with the conversions as launches of their own, as in every sharded plan: with fuse_bconv the residue's
     # element-wise step is the ModDown conversion's epilogue and is not a limb-poly of an EWE launch)
     single_conv = host.Op("config_4.cfg", opname, L, ell, alpha, backend=host.BACKEND_COUNT, overrides={**ov, "fuse_bconv": 0})
-    n_single = sum(int(re.search(r" n=(\d+)", ln).group(1)) for ln in single_conv.plan() if ln.split()[0] in ("NTT", "INTT", "EWE", "AUTO", "NTT_SUBSCALE", "TENSOR", "IP", "NTT_IP"))
+    n_single = sum(int(re.search(r" n=(\d+)", ln).group(1)) for ln in single_conv.plan() if kind(ln) in EW)
     assert sum(per_rank) == n_single
     assert max(per_rank) - min(per_rank) <= 12 * batch   # balanced up to the remainder limbs of each stage
-    assert total_ref > 0
+    # the instruction accounting of the sharded plans adds up to the one-GPU total
+    assert sum(int(re.search(r"ref=(\d+)", ln).group(1)) for pl in plans for ln in pl if kind(ln) not in ("BCONV",)) + \
+        sum(int(re.search(r"ref=(\d+)", ln).group(1)) for ln in plans[0] if kind(ln) == "BCONV") == total_ref
 
 
 def test_slice_rows_layout():
