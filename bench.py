@@ -147,6 +147,25 @@ def exchange_overlap(stage_rows, ops_per_launch, us_per_step, instances, pipelin
             "note": "estimate: step time minus the compute launches timed alone = exposed exchange time; exchanges run on the context's exchange stream, ordered against compute by marks"}
 
 
+def roofline_op(batched_rows, batch, rin):
+    """NTT_IP = k_bconv_col<n_in> (conversion + first pass) + k_ntt_row_ip (second pass + key MAC, both keys, all digits).  Algorithmic limb-polys
+    per op at 45/35/15 (SURVEY.md 8d conventions: every operand read once, every result written once; beta = 3, E = 50, l = 35): conversion
+    inputs 35 + hand-off written and read 2 x 115 + own-digit limbs 35 + outputs 2 x 50 = 400 per op, + the key 2 x 3 x 50 = 300 ONCE per launch."""
+    if not batched_rows:
+        return None
+    us = [ns * 1e-3 / batch for kind, _, ns in batched_rows if kind == "NTT_IP"]
+    if not us:
+        return None
+    alg = (400 + 300 / batch) * LP
+    pmc = rin.get("ntt_ip_bytes_per_op") if rin.get("whole_op_batch") == batch else None
+    return {"kernel": "NTT_IP launch = k_bconv_col<15> + k_bconv_col<5> + k_ntt_row_ip<2> (ModUp conversion + transforms + key MAC)", "bound": "valu",
+            "us_per_op": us[0], "algorithmic_bytes_per_op_evk_once": alg, "achieved": alg / (us[0] * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": alg / (us[0] * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": pmc,
+            "traffic_frac_of_peak": None if not pmc else pmc / (us[0] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+            "valu_wave_instructions_per_op": rin.get("ntt_ip_valu_per_op"), "source": rin.get("whole_op_source"),
+            "note": "timed alone on the chip (stage_us_per_op_batched); `bound`: 83-93 % VALU issue (profiles/r03_pmc_kernels_batch10.txt)"}
+
+
 DEFAULT_BATCH = 10
 
 
@@ -354,7 +373,7 @@ def main():
             "stage_us_per_op_batched": None if not batched_rows else [[kind, name, round(ns * 1e-3 / batch, 2)] for kind, name, ns in batched_rows],
             "exchange_us_per_op": round(sum(ns for kind, _, ns in stage_rows if kind in ("EXCH_IN", "EXCH_OUT", "REPLICATE")) * 1e-3 / (batch if world > 1 else 1), 2),
             "exchange_overlap": exchange_overlap(stage_rows, batch if world > 1 else 1, ms * 1e3, streams if world > 1 else 1,
-                                                 world > 1 and os.environ.get("HOMULATOR_PIPELINE_DIGITS", "1") != "0"),
+                                                 world > 1 and any(" mark=" in ln for ln in op.plan())),   # the op's own plan says whether its exchanges are pipelined
             "hmult_hbm_gbs_algorithmic": alg_bytes / (ms * 1e-3) / 1e9,
             "hmult_frac_of_hbm_peak": alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             # the same with the evaluation key (2 beta E = 300 limb-polys) charged ONCE per launch of `batch` ops instead of once per
@@ -367,7 +386,11 @@ def main():
                 "frac_of_peak": rin["whole_op_bytes"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "batch": rin["whole_op_batch"], "instances": rin["whole_op_instances"], "source": rin.get("whole_op_source"),
                 "note": "bytes from the committed rocprofv3 counter passes of the same launch shape, time from this run"},
-            "roofline": {"bound": "hbm",
+            # the op's dominant launch (ModUp conversion + transforms + key MAC in one C-ABI call): algorithmic bytes with the key charged once per
+            # launch of `batch` ops, HBM bytes of its kernels from the committed counter passes, time from this run's per-launch events
+            "roofline_op": roofline_op(batched_rows, batch, rin) if world == 1 and opn == "hmult" else None,
+            "roofline": {"bound": "valu" if valu_floor_ns and valu_floor_ns > hbm_floor_ns else "hbm",   # the ceiling with the larger floor for this launch, measured
+                         "contract_bound": "hbm",   # ... `achieved` / `peak` / `frac` / `traffic` are the HBM figures the task's contract asks for, whatever binds
                          "binding_ceiling": "valu" if valu_floor_ns and valu_floor_ns > hbm_floor_ns else "hbm",
                          "kernel": "forward NTT sweep, 50 limbs = k_ntt_col + k_ntt_row",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -386,10 +409,12 @@ def main():
                              "valu_frac": None if not wb_ns else wb_ns * BFLY_PER_LIMB_NTT / 64 * inop_limbs / inop_ns},
                          "real_traffic": {
                              "floor_bytes_per_limb_ntt": 4 * LP,
-                             "note": "a limb-poly (512 KiB) does not fit one CU's LDS (160 KiB), so a transform is two passes through global memory; the MI355X L2 writes "
-                                     "every store through and does not allocate on it (profiles/r03_fused_ntt.txt), so the hand-off crosses the fabric twice: 4 limb-polys "
-                                     "per limb-NTT + row twiddles is the floor of `traffic`, twice the algorithmic figure"},
-                         "note": "`achieved`/`peak`/`frac`/`bound` are the HBM figures of the task's contract; `binding_ceiling` names the ceiling "
+                             "note": "a limb-poly (512 KiB) does not fit one CU's LDS (160 KiB), so a transform is two passes through global memory with a hand-off between "
+                                     "them; as two kernels the hand-off crosses the fabric twice (4 limb-polys per limb-NTT + row twiddles = `traffic`).  Round 4's counters "
+                                     "(profiles/r04_l2_handoff.txt, r04_ntt_queue.txt) withdraw round 3's claim: the L2 is write-back and a hand-off kept inside one launch with <= 3 MiB live "
+                                     "per XCD saves its write, and in place also its read (50-limb sweep 116 -> 79 MB) — but the persistent kernels that do so run slower than the two "
+                                     "kernels (dependency waits, per-item control latency), so the shipped sweep keeps the two-kernel traffic"},
+                         "note": "`achieved`/`peak`/`frac`/`traffic` are the HBM figures of the task's contract (`contract_bound`); `bound` names the ceiling "
                                  "with the larger floor for this launch (the 64-bit modular butterflies are integer VALU work)"},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -23,6 +23,8 @@ struct G16 {
   template <int LOGR> static constexpr int rounds() { return hm16::HmRounds<LOGR>::n; }
   template <int TL, int LOGR, bool STRIDED> static constexpr int ldsWords() { return hm16::HmLds<TL, LOGR, STRIDED>::WORDS; }
   template <int TL, int LOGR, bool STRIDED, bool INV, int MODE, int P, class... A> static void phase(A &&...a) { hm16::hm_ntt_phase<TL, LOGR, STRIDED, INV, MODE, P>(a...); }
+  template <int TL, int LOGR, bool STRIDED, bool INV, int MODE, int P, class... A> static void phase_src1(A &&...a) { hm16::hm_ntt_phase<TL, LOGR, STRIDED, INV, MODE, P, 0, 0, HM_EPI_CHUNK, 1>(a...); }
+  template <int TL, int LOGR, bool STRIDED, bool INV, int MODE, class... A> static void lds0(A &&...a) { hm16::hm_ntt_phase_lds0<TL, LOGR, STRIDED, INV, MODE>(a...); }
 };
 struct G8 {
   typedef hm8::HmNttState State;
@@ -30,6 +32,8 @@ struct G8 {
   template <int LOGR> static constexpr int rounds() { return hm8::HmRounds<LOGR>::n; }
   template <int TL, int LOGR, bool STRIDED> static constexpr int ldsWords() { return hm8::HmLds<TL, LOGR, STRIDED>::WORDS; }
   template <int TL, int LOGR, bool STRIDED, bool INV, int MODE, int P, class... A> static void phase(A &&...a) { hm8::hm_ntt_phase<TL, LOGR, STRIDED, INV, MODE, P>(a...); }
+  template <int TL, int LOGR, bool STRIDED, bool INV, int MODE, int P, class... A> static void phase_src1(A &&...a) { hm8::hm_ntt_phase<TL, LOGR, STRIDED, INV, MODE, P, 0, 0, HM_EPI_CHUNK, 1>(a...); }
+  template <int TL, int LOGR, bool STRIDED, bool INV, int MODE, class... A> static void lds0(A &&...a) { hm8::hm_ntt_phase_lds0<TL, LOGR, STRIDED, INV, MODE>(a...); }
 };
 
 // phase P of every thread of the workgroup, then phase P + 1, ... (a barrier on the GPU = the end of a phase loop here)
@@ -66,6 +70,52 @@ static void run_ntt(const Emu &e, uint32_t mod, const uint64_t *in, uint64_t *ou
   } else {
     run_pass<G, HM_ROW_LOG, false, true, 0>(e, mod, in, out, sc);
     run_pass<G, LOG1, true, true, 2>(e, mod, out, out, sc);
+  }
+}
+
+// ---- the persistent double-buffered passes (k_ntt_*_dma): the tile is put into its LDS image the way the LDS-DMA does it — 16-byte unit
+// at (even) word w of the image <- the coefficients hm_lds_unidx names, the staged twiddles linearly behind it — and the pass runs its
+// first round from the image (phase SRC = 1: global requests, [the kernel issues the next tile's DMA here], LDS reads, rounds)
+template <class G, int TL, int LOGR, bool STRIDED, bool INV, int MODE, int P>
+static void run_phases_src1(std::vector<typename G::State> &st, uint64_t *lds, uint64_t *dst, uint32_t tile, const HmTw *twl, const HmTw *twt, uint32_t s0,
+                            uint32_t prefix0, uint64_t q, HmTw sc, HmEpi ep) {
+  for (int t = 0; t < (int)st.size(); ++t) G::template phase_src1<TL, LOGR, STRIDED, INV, MODE, P>(st[t], t, lds, nullptr, dst, tile, twl, twt, s0, prefix0, q, sc, ep, lds + (1 << TL));
+  if constexpr (P == 0)
+    for (int t = 0; t < (int)st.size(); ++t) G::template lds0<TL, LOGR, STRIDED, INV, MODE>(st[t], t, lds, lds + (1 << TL), s0, prefix0, q, ep);
+  if constexpr (P < G::template rounds<LOGR>()) run_phases_src1<G, TL, LOGR, STRIDED, INV, MODE, P + 1>(st, lds, dst, tile, twl, twt, s0, prefix0, q, sc, ep);
+}
+template <class G, int LOGR, bool STRIDED, bool INV, int MODE>
+static void run_pass_dma(const Emu &e, uint32_t mod, const uint64_t *src, uint64_t *dst, HmTw sc, HmEpi ep = hm_epi_none()) {
+  constexpr int TL = HM_TL(STRIDED), TILE = 1 << TL, THREADS = TILE / G::EPT, LOGC = TL - LOGR;
+  constexpr int NTW = STRIDED ? (1 << LOGR) : 128;
+  const uint32_t tiles = e.P.N >> TL;
+  const uint64_t q = e.P.mod[mod];
+  const HmTw *twl = (INV ? e.inv : e.fwd)[mod].data();
+  const uint32_t s0 = STRIDED ? 0u : (e.P.logN - HM_ROW_LOG);
+  std::vector<uint64_t> lds(TILE + 2 * NTW);
+  std::vector<typename G::State> st(THREADS);
+  const HmTw *twist = (INV ? e.twi : e.twf)[mod].data();
+  std::vector<uint64_t> in(src, src + e.P.N);   // (a pass may run in place: the kernel's DMA reads a tile before anybody stores to it)
+  for (uint32_t tile = 0; tile < tiles; ++tile) {
+    for (int w = 0; w < TILE; w += 2) {
+      int x, c;
+      if (G::EPT == 16) hm16::hm_lds_unidx<TL, LOGR, STRIDED>(w, x, c); else hm8::hm_lds_unidx<TL, LOGR, STRIDED>(w, x, c);
+      const uint32_t g = STRIDED ? ((uint32_t)x << HM_ROW_LOG) + (tile << LOGC) + (uint32_t)c : (tile << TL) + ((uint32_t)c << LOGR) + (uint32_t)x;
+      lds[w] = in[g]; lds[w + 1] = in[g + 1];
+    }
+    for (int k = 0; k < NTW; ++k) { lds[TILE + 2 * k] = twl[k].w; lds[TILE + 2 * k + 1] = twl[k].ws; }
+    const uint32_t prefix0 = STRIDED ? 0u : (tile << (TL - LOGR));
+    run_phases_src1<G, TL, LOGR, STRIDED, INV, MODE, 0>(st, lds.data(), dst, tile, twl, twist + (size_t)prefix0 * 3, s0, prefix0, q, sc, ep);
+  }
+}
+template <class G, int LOG1>
+static void run_ntt_dma(const Emu &e, uint32_t mod, const uint64_t *in, uint64_t *out, int inverse, HmTw sc) {
+  if (!inverse) {
+    run_pass_dma<G, LOG1, true, false, 0>(e, mod, in, out, sc);
+    run_pass_dma<G, HM_ROW_LOG, false, false, 1>(e, mod, out, out, sc);
+  } else {
+    run_pass_dma<G, HM_ROW_LOG, false, true, 0>(e, mod, in, out, sc);
+    run_pass_dma<G, LOG1, true, true, 2>(e, mod, out, out, sc);
   }
 }
 
@@ -122,6 +172,27 @@ int emu_ntt(void *h, uint32_t mod, const uint64_t *in, uint64_t *out, int invers
   case 7: run_ntt<G16, 7>(e, mod, in, out, inverse, sc); break;
   case 8: run_ntt<G16, 8>(e, mod, in, out, inverse, sc); break;
   case 9: run_ntt<G16, 9>(e, mod, in, out, inverse, sc); break;
+  default: return 1;
+  }
+  return 0;
+}
+
+// the same transform through the persistent double-buffered passes' code path (tile image by DMA address map, first round from LDS)
+int emu_ntt_dma(void *h, uint32_t mod, const uint64_t *in, uint64_t *out, int inverse, int geo8) {
+  Emu &e = *(Emu *)h;
+  const uint64_t q = e.P.mod[mod], k = e.P.modc[mod].ninv;
+  HmTw sc = {k, hm::shoup(k, q)};
+  if (geo8) {
+    if (e.P.logN != 16) return 1;
+    run_ntt_dma<G8, 8>(e, mod, in, out, inverse, sc);
+    return 0;
+  }
+  switch (e.P.logN - HM_ROW_LOG) {
+  case 5: run_ntt_dma<G16, 5>(e, mod, in, out, inverse, sc); break;
+  case 6: run_ntt_dma<G16, 6>(e, mod, in, out, inverse, sc); break;
+  case 7: run_ntt_dma<G16, 7>(e, mod, in, out, inverse, sc); break;
+  case 8: run_ntt_dma<G16, 8>(e, mod, in, out, inverse, sc); break;
+  case 9: run_ntt_dma<G16, 9>(e, mod, in, out, inverse, sc); break;
   default: return 1;
   }
   return 0;

@@ -235,6 +235,32 @@ def test_emu_ntt_eight_coefficients_per_thread(emu):
         emu.emu_destroy(h)
 
 
+@pytest.mark.parametrize("logN,geo8", [(13, 0), (14, 0), (15, 0), (16, 0), (16, 1), (17, 0)])
+def test_emu_ntt_through_the_dma_tile_image(emu, logN, geo8):
+    """the persistent double-buffered passes (round 4) on the CPU emulator: the tile image is filled through the LDS-DMA's source-address
+    map (hm_lds_unidx: the inverse of the image's XOR swizzle), the staged twiddles sit behind it, and the first round reads the image
+    (phase SRC = 1 + hm_ntt_phase_lds0); forward, inverse in place, worst-case operands, every ring size, both geometries"""
+    emu.emu_ntt_dma.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    L, K = 2, 1
+    o = Oracle(logN, L, K)
+    h = emu.emu_create(logN, L, K)
+    try:
+        for m in (0, L + K - 1):
+            x = o.fill_uniform([m], 7 + m)[0]
+            x[0], x[1], x[-1] = 0, o.moduli[m] - 1, o.moduli[m] - 1
+            out = np.empty_like(x)
+            assert emu.emu_ntt_dma(h, m, p(x), p(out), 0, geo8) == 0
+            assert np.array_equal(out, o.ntt([m], x[None])[0]), f"forward mod={m}"
+            assert emu.emu_ntt_dma(h, m, p(out), p(out), 1, geo8) == 0
+            assert np.array_equal(out, x), f"inverse in place mod={m}"
+        worst = np.full(1 << logN, o.moduli[1] - 1, dtype=np.uint64)
+        out = np.empty_like(worst)
+        emu.emu_ntt_dma(h, 1, p(worst), p(out), 0, geo8)
+        assert np.array_equal(out, o.ntt([1], worst[None])[0])
+    finally:
+        emu.emu_destroy(h)
+
+
 def test_emu_key_mac_lazy_ranges(emu):
     """the fused transform x key kernel's multiply-accumulate (hm_mac_add): Barrett's quotient from two approximate high products.
     For x anywhere below 8q (the transform's lazy output), y below q: every product adds x*y mod q plus at most 6q, two terms stay

@@ -21,6 +21,24 @@ if os.path.exists(wp):   # "<COUNTER> total <KiB> KiB per op = ... ; shape: batc
                  "whole_op_fetch_kib": float(f.group(1)), "whole_op_write_kib": float(w.group(1)),
                  "whole_op_batch": int(sh.group(1)), "whole_op_instances": int(sh.group(2)),
                  "whole_op_source": f"profiles/{r}_pmc_whole_op.txt: (2 x FETCH_SIZE + WRITE_SIZE) KiB over every kernel of hmult at the timed region's launch shape, per op, separate --pmc passes"}
+if os.path.exists(wp):   # per-kernel lines "<kernel> <KiB> KiB per op" under each counter: the NTT_IP launch = k_bconv_col* + k_ntt_row_ip
+    t = open(wp).read()
+    def kernel_sum(counter):
+        tot, seen = 0.0, False
+        for ln in t.splitlines():
+            if ln.startswith(f"{counter} total"):
+                return tot
+            m = re.match(r"(k_\S+)\s+([0-9.]+) (KiB )?per op", ln)
+            if m:
+                if m.group(1).startswith("k_bconv_col") or m.group(1).startswith("k_ntt_row_ip"):
+                    tot += float(m.group(2))
+            if "total" in ln and not ln.startswith(counter):
+                tot = 0.0   # the next counter's block starts behind a total line
+        return tot
+    f, w, v = kernel_sum("FETCH_SIZE"), kernel_sum("WRITE_SIZE"), kernel_sum("SQ_INSTS_VALU")
+    if f and w:
+        whole["ntt_ip_bytes_per_op"] = int((2 * f + w) * 1024)
+        whole["ntt_ip_valu_per_op"] = int(v)
 out = {**whole, "ntt_sweep50_traffic_bytes": traffic,
        "ntt_sweep50_traffic_source": f"profiles/{r}_pmc_ntt_sweep.txt: (2 x FETCH_SIZE + WRITE_SIZE) KiB summed over the two pass kernels, separate --pmc passes",
        "wave_butterfly_ns": wb,

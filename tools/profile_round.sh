@@ -6,7 +6,7 @@
 # Every figure of the bench line that comes from a profiler is derived from THIS run; the whole-op passes use the timed
 # region's launch shape (batch 10, 2 instances), the sweep passes the same 6 rotating buffer pairs as bench.py.
 set -e
-R=${1:-r03}
+R=${1:-r04}
 BATCH=${BATCH:-10}; INST=${INST:-2}; ROUNDS=${ROUNDS:-3}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$R
