@@ -158,7 +158,7 @@ def roofline_op(batched_rows, batch, rin):
         return None
     alg = (400 + 300 / batch) * LP
     pmc = rin.get("ntt_ip_bytes_per_op") if rin.get("whole_op_batch") == batch else None
-    return {"kernel": "NTT_IP launch = k_bconv_col<15> + k_bconv_col<5> + k_ntt_row_ip<2> (ModUp conversion + transforms + key MAC)", "bound": "valu",
+    return {"kernel": "NTT_IP launch = k_bconv_col2<15> + k_bconv_col2<5> + k_ntt_row_ip<2> (ModUp conversion + transforms + key MAC in one C-ABI call)", "bound": "valu",
             "us_per_op": us[0], "algorithmic_bytes_per_op_evk_once": alg, "achieved": alg / (us[0] * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": alg / (us[0] * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": pmc,
             "traffic_frac_of_peak": None if not pmc else pmc / (us[0] * 1e-6) / 1e9 / HBM_PEAK_GBS,
