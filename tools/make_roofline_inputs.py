@@ -28,7 +28,7 @@ if os.path.exists(wp):   # per-kernel lines "<kernel> <KiB> KiB per op" under ea
         for ln in t.splitlines():
             if ln.startswith(f"{counter} total"):
                 return tot
-            m = re.match(r"(k_\S+)\s+([0-9.]+) (KiB )?per op", ln)
+            m = re.match(r"(k_.*?)\s+([0-9.]+) (KiB )?per op$", ln)   # (kernel names hold ", ")
             if m:
                 if m.group(1).startswith("k_bconv_col") or m.group(1).startswith("k_ntt_row_ip"):
                     tot += float(m.group(2))
