@@ -5,8 +5,9 @@
 // close to full rate on CDNA4, so everything here is written as 64x64->128 products that hipcc lowers
 // to v_mad_u64_u32 chains; v_mul_hi_u32 is avoided.
 //
-// Conventions: every modulus q satisfies 2^(k-1) < q < 2^k with k <= 60.
-//   * Shoup form for known constants w: ws = floor(w * 2^64 / q); lazy product in [0, 2q).
+// Conventions: every modulus q satisfies 2^(k-1) < q < 2^k with k <= 60 and q = 1 mod 2^32.
+//   * Montgomery form for the transform's twiddles (round 4): wt = w 2^64 mod q, word-wise reduction, one multiply per step.
+//   * Shoup form for the other known constants w: ws = floor(w * 2^64 / q); lazy product in [0, 2q).
 //   * Barrett for variable x variable: mu = floor(2^(k+63) / q), valid for z < 2^(k+63).
 // The same header compiles with g++ (HM_EMULATE) for the host-side kernel emulator in tests/emu.
 #pragma once
@@ -106,21 +107,26 @@ HM_HD uint64_t hm_opaque_zero() {
   return z;
 }
 
-// Per-modulus constants of the lazy butterflies (wave-uniform, SGPRs): 4q and the two's complements of q and 4q.
+// Per-modulus constants of the lazy butterflies and products (wave-uniform, SGPRs)
 struct HmBflyMod {
-  uint64_t q4, nq, nq4, nq8, z;
+  uint64_t q2, q4, nq, nq2, nq4, nq8, cc, z;
+  uint32_t h;
 };
 HM_HD HmBflyMod hm_bfly_mod(uint64_t q) {
   HmBflyMod m;
   m.z = hm_opaque_zero();
+  m.q2 = 2 * q;
   m.q4 = 4 * q;
   m.nq = m.z - q;
+  m.nq2 = m.z - 2 * q;
   m.nq4 = m.z - 4 * q;
   m.nq8 = m.z - 8 * q;
+  m.h = (uint32_t)(q >> 32);
+  m.cc = ((uint64_t)m.h + 1) * ((1ull << 32) + 1);
   return m;
 }
 
-// Approximate Shoup quotient for the butterflies: floor(x ws / 2^64) = x1 s1 + floor((x1 s0 + x0 s1 +
+// Approximate Shoup quotient (the key multiply-accumulate's Barrett steps): floor(x ws / 2^64) = x1 s1 + floor((x1 s0 + x0 s1 +
 // floor(x0 s0 / 2^32)) / 2^32); the estimate truncates the two cross terms separately and drops x0 s0 (three
 // v_mad_u64_u32, no v_mul_hi_u32), so it is at most 2 below the true quotient and the lazy product
 // w x - h q lies in [0, 4q) instead of [0, 2q) — still w x mod q exactly, for ANY 64-bit x.
@@ -140,35 +146,53 @@ HM_HD uint64_t hm_csub_neg(uint64_t x, uint64_t nm) {
   return t < x ? t : x;
 }
 
-// Harvey butterflies with the approximate product (q < 2^60, so 8q < 2^63): 23 VALU instructions each
-// (5 v_mad_u64_u32, 4 v_mul_lo_u32), 87 cycles per wave against 109 for the subtract-with-borrow form
-// (tools/bflyrate.hip, profiles/r01_bflyrate.txt).
-// forward (Cooley-Tukey): X, Y in [0, 8q) -> X', Y' in [0, 8q)
-HM_HD void hm_bfly_fwd(uint64_t &X, uint64_t &Y, const HmTw &t, const HmBflyMod &m) {
-  const uint64_t x = hm_csub_neg(X, m.nq4);                 // [0, 4q)
-  const uint64_t xn = hm_shoup_lazy4_acc(x, Y, t, m);       // x + v, v = w Y mod q in [0, 4q)
-  Y = ((x << 1) + m.q4) - xn;                               // x - v + 4q
-  X = xn;
+// ---------------------------------------------------------------------------------------------------
+// Round 4: word-wise Montgomery products for moduli q = h 2^32 + 1 (every modulus of a context is 1 mod 2^32: DESIGN.md §2).
+// q^-1 = 1 mod 2^32, so a reduction step T -> (T - T0 q) / 2^32 = (T >> 32) - T0 h needs ONE multiply; written with the complement,
+// (T + (~T0) q + q) / 2^32 = (T >> 32) + (~T0) h + (h + 1) (the low words always carry exactly 1; adding q more leaves the class).
+// Two steps take the 124-bit product x wt to x wt 2^-64 mod q: SIX multiplies (four of the product, one per step) where the Shoup form
+// needs nine (3 + 3 + 3), and no companion word per constant.  wt = w 2^64 mod q (tables are stored in this form).
+//   c + v,  v = x w mod q + {0, q},  0 <= v < q (1 + x / 2^64) + 1 <= 1.5 q + 1       for x < 2^63 (no 64-bit sum overflows:
+//   b1 w0 < 2^63, b0 w1 < 2^60, (~P0) h < 2^60, cc < 2^60 + 2^33), c + v < 2^64.
+// cc = (h + 1)(2^32 + 1): the constants of both steps in one addend (the second step's sits 32 bits up, where the first step's low word
+// cannot see it).  15 VALU instructions per forward butterfly against 17, 65.9 against 79.0 cycles per wave
+// (tools/bflyrate.hip, profiles/r04_bflyrate.txt).
+// ---------------------------------------------------------------------------------------------------
+HM_HD uint64_t hm_mont_acc(uint64_t c, uint64_t x, uint64_t wt, const HmBflyMod &m) {
+  const uint32_t b0 = (uint32_t)x, b1 = (uint32_t)(x >> 32), w0 = (uint32_t)wt, w1 = (uint32_t)(wt >> 32);
+  const uint64_t P = (uint64_t)b0 * w0 + m.z;
+  const uint32_t n0 = ~(uint32_t)P;
+  uint64_t A = (uint64_t)b0 * w1 + m.cc;
+  A = (uint64_t)b1 * w0 + A;
+  A = (uint64_t)n0 * m.h + A;
+  const uint64_t S = A + (uint32_t)(P >> 32);
+  const uint32_t n1 = ~(uint32_t)S;
+  uint64_t B = (uint64_t)b1 * w1 + c;
+  B = (uint64_t)n1 * m.h + B;
+  return B + (uint32_t)(S >> 32);
 }
-// The same with the conditional subtraction SCHEDULED over the stages (q < 2^60: 16q fits a word).  Y goes through the
-// product, which takes any 64-bit value; only X needs a bound, and the outputs are at most (bound of X) + 4q:
-//   kind 0: no subtraction        X < 12q        ->  X', Y' < 16q
-//   kind 1: X -= 8q if X >= 8q    X < 16q        ->  X', Y' < 12q
-//   kind 2: both 8q and 4q        X < 16q        ->  X', Y' <  8q   (last stage of a transform: hm_reduce8 follows)
-// Alternating 0 / 1 halves the subtractions (4 of the 23 instructions of a butterfly).  2X + 4q may wrap around 2^64;
-// the difference with X' = X + v is exact all the same, the true value X + 4q - v being below 16q.
+// w 2^64 mod q on the host (table generation)
+HM_HD uint64_t hm_to_mont(uint64_t w, uint64_t q) { return (uint64_t)(((hm_u128)w << 64) % q); }
+
+// Harvey-lazy butterflies on the Montgomery product (q < 2^60, so 8q <= 2^63).  The multiplied operand must stay below 2^63 and a
+// butterfly's outputs are at most (bound of X) + 2q, so every value is kept below 8q and the conditional subtraction is SCHEDULED over
+// the stages (hm_fwd_kind):
+//   kind 0: no subtraction        X < 6q, Y < 8q  ->  X', Y' < 8q
+//   kind 1: X -= 4q if X >= 4q    X < 8q, Y < 8q  ->  X', Y' < 6q
+//   kind 2: both 4q and 2q        X < 8q, Y < 8q  ->  X', Y' < 4q   (last stage of a transform: hm_reduce4 follows)
+// Y' = X - v + 2q is computed as (2X + 2q) - X' (2X + 2q < 2^64).
 template <int KIND>
 HM_HD void hm_bfly_fwd_k(uint64_t &X, uint64_t &Y, const HmTw &t, const HmBflyMod &m) {
   uint64_t x = X;
 #if !defined(HM_ABL_NOCSUB)   // (timing-only ablation: butterflies without their conditional subtractions)
-  if (KIND >= 1) x = hm_csub_neg(x, m.nq8);
-  if (KIND == 2) x = hm_csub_neg(x, m.nq4);
+  if (KIND >= 1) x = hm_csub_neg(x, m.nq4);
+  if (KIND == 2) x = hm_csub_neg(x, m.nq2);
 #endif
-  const uint64_t xn = hm_shoup_lazy4_acc(x, Y, t, m);
-  Y = ((x << 1) + m.q4) - xn;
+  const uint64_t xn = hm_mont_acc(x, Y, t.w, m);
+  Y = ((x << 1) + m.q2) - xn;
   X = xn;
 }
-// inverse (Gentleman-Sande): X, Y in [0, 4q) -> X', Y' in [0, 4q)
+// inverse (Gentleman-Sande): X, Y in [0, 4q) -> X' in [0, 4q), Y' in [0, 1.5q + 1]   (X + 4q - Y < 8q <= 2^63)
 HM_HD void hm_bfly_inv(uint64_t &X, uint64_t &Y, const HmTw &t, const HmBflyMod &m) {
   const uint64_t d = (X + m.q4) - Y;
 #if defined(HM_ABL_NOCSUB)
@@ -176,8 +200,10 @@ HM_HD void hm_bfly_inv(uint64_t &X, uint64_t &Y, const HmTw &t, const HmBflyMod 
 #else
   X = hm_csub_neg(X + Y, m.nq4);
 #endif
-  Y = hm_shoup_lazy4_acc(0, d, t, m);
+  Y = hm_mont_acc(0, d, t.w, m);
 }
+// [0, 4q) -> [0, q)
+HM_HD uint64_t hm_reduce4(uint64_t x, uint64_t q) { return hm_csub(hm_csub(x, 2 * q), q); }
 // [0, 8q) -> [0, q)
 HM_HD uint64_t hm_reduce8(uint64_t x, uint64_t q) {
   return hm_csub(hm_csub(hm_csub(x, 4 * q), 2 * q), q);

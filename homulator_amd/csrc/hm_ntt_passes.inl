@@ -113,26 +113,27 @@ struct HmRound {
   }
 };
 
-// Forward transform: which kind of butterfly (hm_bfly_fwd_k) local stage sigma of a pass runs.  Bounds in units of q:
-// the COL pass starts from reduced data (1), its first two stages need no subtraction (5, 9); from there on the stages
-// alternate so that the pass ENDS on a subtracting stage (12 out); the ROW pass (8 stages, 12 in) alternates 0 / 1 and
-// ends with kind 2 (8 out).  hm_fwd_bound replays the bounds at compile time: every stage is checked below.
+// Forward transform: which kind of butterfly (hm_bfly_fwd_k) local stage sigma of a pass runs.  Bounds in units of q (every value
+// stays below 8q <= 2^63: the Montgomery product's operand range): the COL pass starts from reduced data (1), its first two stages need
+// no subtraction (3, 5); from there on the stages alternate so that the pass ENDS on a subtracting stage (6 out); the ROW pass
+// (8 stages, 6 in) alternates 0 / 1 and ends with kind 2 (4 out).  hm_fwd_bound replays the bounds at compile time: every stage is
+// checked below.
 constexpr int hm_fwd_kind(bool strided, int logr, int sigma) {
   if (strided) return sigma <= 1 ? 0 : (((logr - 1 - sigma) & 1) == 0 ? 1 : 0);
   return sigma == logr - 1 ? 2 : (sigma & 1);
 }
 constexpr int hm_fwd_bound(bool strided, int logr, int upto) {  // bound (in q) of the values entering local stage `upto`
-  int b = strided ? 1 : 12;
+  int b = strided ? 1 : 6;
   for (int s = 0; s < upto; ++s) {
     const int k = hm_fwd_kind(strided, logr, s);
-    if (k == 0 ? b > 12 : b > 16) return 1000;                  // the stage's input condition
-    b = (k == 0 ? b : k == 1 ? 8 : 4) + 4;
+    if (k == 0 ? b > 6 : b > 8) return 1000;                    // the stage's input condition
+    b = (k == 0 ? b : k == 1 ? 4 : 2) + 2;
   }
   return b;
 }
-static_assert(hm_fwd_bound(true, 5, 5) == 12 && hm_fwd_bound(true, 6, 6) == 12 && hm_fwd_bound(true, 7, 7) == 12 &&
-              hm_fwd_bound(true, 8, 8) == 12 && hm_fwd_bound(true, 9, 9) == 12, "COL pass hands over values below 12q");
-static_assert(hm_fwd_bound(false, 8, 8) == 8, "ROW pass ends below 8q");
+static_assert(hm_fwd_bound(true, 5, 5) == 6 && hm_fwd_bound(true, 6, 6) == 6 && hm_fwd_bound(true, 7, 7) == 6 &&
+              hm_fwd_bound(true, 8, 8) == 6 && hm_fwd_bound(true, 9, 9) == 6, "COL pass hands over values below 6q");
+static_assert(hm_fwd_bound(false, 8, 8) == 4, "ROW pass ends below 4q");
 
 // Where the twiddles of a pass come from.  exec(i) = the i-th round executed.
 template <int LOGR, bool STRIDED, bool INV>
@@ -228,16 +229,16 @@ HM_HD void hm_ph_load_global_mix(HmNttState &st, int tid, const uint64_t *g, uin
   }
 }
 
-// MODE 5 (ROW pass of the fused transform x key inner product): the last pass keeps its results in registers (lazy, below 8q)
+// MODE 5 (ROW pass of the fused transform x key inner product): the last pass keeps its results in registers (lazy, below 4q)
 // and stores nothing; hm_ph_mac consumes them.
 // the epilogue of one coefficient.  MODE 0 / 4: store as is (lazy values, hand-off between the two passes; 4 = first
-// pass with the mix prologue); 1: forward final, reduce [0,8q) -> [0,q); 2: inverse final, multiply by the per-limb
+// pass with the mix prologue); 1: forward final, reduce [0,4q) -> [0,q); 2: inverse final, multiply by the per-limb
 // constant and reduce to [0,q); 3: forward final fused with out = (minuend - x) * k [+ addend [* ak]]
 template <int MODE>
 HM_HD uint64_t hm_epilogue(uint64_t a, uint64_t va, uint64_t vd, uint64_t q, HmTw sc, const HmEpi &ep) {
-  if (MODE == 1) return hm_reduce8(a, q);
+  if (MODE == 1) return hm_reduce4(a, q);
   if (MODE == 2) return hm_shoup(a, sc.w, sc.ws, q);
-  if (MODE == 3) {  // a in [0, 8q): minuend - a + 8q stays positive and below 2^64; the product reduces it
+  if (MODE == 3) {  // a in [0, 4q): minuend - a + 8q stays positive and below 2^64; the product reduces it
     a = hm_shoup(va + 8 * q - a, sc.w, sc.ws, q);
     if (ep.d) a = hm_addmod(a, ep.dk.w ? hm_shoup(vd, ep.dk.w, ep.dk.ws, q) : vd, q);
   }
@@ -326,7 +327,7 @@ HM_HD void hm_ph_compute(HmNttState &st, uint64_t q) {
   st.v[0] ^= st.tw[R][0].w;  // keeps the twiddle loads alive
   return;
 #endif
-  const HmBflyMod m = hm_bfly_mod(q);  // lazy ranges: forward [0, 8q), inverse [0, 4q)
+  const HmBflyMod m = hm_bfly_mod(q);  // lazy ranges: forward [0, 8q) inside a pass, inverse [0, 4q)
 #pragma unroll
   for (int jj = 0; jj < G::NB; ++jj) {
     const int j = INV ? (G::NB - 1 - jj) : jj;  // sub-stage j combines e-bit (NB-1-j)
@@ -347,7 +348,8 @@ HM_HD void hm_ph_compute(HmNttState &st, uint64_t q) {
   }
 }
 // multiply element j of the row by tws[(j mod 4) - 1] (the K == 0, NB == 2 ROW round: v[4 u + e] is element 4 hi + e).
-// Lazy product: any 64-bit input, result in [0, 4q) — inside the input range of both butterfly forms.
+// Lazy Montgomery product (constants in Montgomery form): input below 2^63 (every value of a pass is below 8q), result in
+// [0, 1.5q + 1] — inside the input range of both butterfly forms.
 HM_HD void hm_ph_twist(HmNttState &st, uint64_t q) {
 #if defined(HM_ABL_NOCOMPUTE)
   st.v[1] ^= st.tws[0].w ^ st.tws[1].w ^ st.tws[2].w;
@@ -357,7 +359,7 @@ HM_HD void hm_ph_twist(HmNttState &st, uint64_t q) {
 #pragma unroll
   for (int u = 0; u < HM_EPT / 4; ++u)
 #pragma unroll
-    for (int k = 1; k < 4; ++k) st.v[4 * u + k] = hm_shoup_lazy4_acc(0, st.v[4 * u + k], st.tws[k - 1], m);
+    for (int k = 1; k < 4; ++k) st.v[4 * u + k] = hm_mont_acc(0, st.v[4 * u + k], st.tws[k - 1].w, m);
 }
 
 // The whole pass of one thread, phase by phase.  `sync` is __syncthreads() on the GPU; the emulator calls the
@@ -561,11 +563,11 @@ HM_HD void hm_mac_add(uint64_t &acc, uint64_t x, uint64_t y, const HmMod &m, con
 HM_HD void hm_mac_add(hm_u128 &acc, uint64_t x, uint64_t y, const HmMod &, const HmMacMod &, bool) { acc += (hm_u128)x * y; }
 HM_HD uint64_t hm_mac_final(uint64_t acc, const HmMod &m) { return hm_reduce16(acc, m.q); }
 HM_HD uint64_t hm_mac_final(hm_u128 acc, const HmMod &m) { return hm_barrett(acc, m); }   // 4 terms x (x < 2q) x (y < q) < 2^123
-// [0, 8q) -> [0, 2q): the wide accumulators take transform outputs below 2q, so that the sum stays inside hm_barrett's range
+// [0, 4q) -> [0, 2q): the wide accumulators take transform outputs below 2q, so that the sum stays inside hm_barrett's range
 HM_HD void hm_ph_below_2q(HmNttState &st, uint64_t q) {
   const HmBflyMod m = hm_bfly_mod(q);
 #pragma unroll
-  for (int i = 0; i < HM_EPT; ++i) st.v[i] = hm_csub_neg(hm_csub_neg(st.v[i], m.nq4), m.z - 2 * q);
+  for (int i = 0; i < HM_EPT; ++i) st.v[i] = hm_csub_neg(st.v[i], m.nq2);
 }
 template <int TL, int LOGR, int R, int OUTS, int CH = 2, class ACC = uint64_t>
 HM_HD void hm_ph_mac(const HmNttState &st, ACC (&acc)[OUTS][HM_EPT], int tid, const uint64_t *const (&y)[OUTS], uint32_t tile, const HmMod &m, uint32_t term) {

@@ -75,14 +75,15 @@ void Params::init(uint32_t logN_, uint32_t L_, uint32_t K_, const uint64_t *q, c
   } else {
     uint64_t cand = (1ull << 60) + 1;
     for (uint32_t m = 0; m < M;) {
-      cand -= 2ull * N;
+      cand -= 1ull << 32;   // q = h 2^32 + 1: one multiply per Montgomery reduction step (hm_modarith.h), and 1 mod 2N for every N
       if (is_prime(cand)) mod[m++] = cand;
     }
   }
   for (uint32_t m = 0; m < M; ++m) {
     const uint64_t qm = mod[m];
-    if (qm >> 60 || qm < (1ull << 20) || (qm - 1) % (2ull * N) != 0 || !is_prime(qm))
-      throw std::invalid_argument("modulus " + std::to_string(qm) + " is not a prime = 1 mod 2N below 2^60");
+    if (qm >> 60 || (qm & 0xffffffffull) != 1 || (qm >> 32) == 0 || !is_prime(qm))
+      throw std::invalid_argument("modulus " + std::to_string(qm) + " is not a prime = 1 mod 2^32 below 2^60 (the transform's word-wise "
+                                  "Montgomery reduction needs q = h 2^32 + 1)");
     for (uint32_t j = 0; j < m; ++j)
       if (mod[j] == qm) throw std::invalid_argument("duplicate modulus");
     psi[m] = psi_in ? psi_in[m] : smallest_primitive_root(qm, N);
@@ -110,8 +111,8 @@ void Params::make_table(uint32_t m, bool inverse, HmTw *out) const {
   uint64_t p = 1;
   for (uint32_t i = 0; i < N; ++i) {
     HmTw &t = out[bitrev(i, logN)];
-    t.w = p;
-    t.ws = shoup(p, q);
+    t.w = hm_to_mont(p, q);   // Montgomery form: the butterflies' product is x wt 2^-64 (hm_mont_acc)
+    t.ws = 0;
     p = mulmod(p, base, q);
   }
 }
@@ -125,7 +126,7 @@ void Params::make_twist(uint32_t m, bool inverse, HmTw *out) const {
     uint64_t p = 1;
     for (uint32_t k = 0; k < 3; ++k) {
       p = mulmod(p, a, q);
-      out[3 * r + k] = HmTw{p, shoup(p, q)};
+      out[3 * r + k] = HmTw{hm_to_mont(p, q), 0};
     }
   }
 }

@@ -120,7 +120,7 @@ ho_ctx *ho_create(uint32_t logN, uint32_t L, uint32_t K) {
   c->mod = calloc(M, 8); c->psi = calloc(M, 8); c->ninv = calloc(M, 8);
   c->w = calloc(M, sizeof(void *)); c->ws = calloc(M, sizeof(void *));
   c->wi = calloc(M, sizeof(void *)); c->wis = calloc(M, sizeof(void *));
-  uint64_t step = 2ull * N, cand = (1ull << 60) + 1;
+  uint64_t step = 1ull << 32, cand = (1ull << 60) + 1;   /* q = 1 mod 2^32 (hence 1 mod 2N): DESIGN.md section 2 */
   for (uint32_t m = 0; m < M;) {
     cand -= step;
     if (is_prime_u64(cand)) c->mod[m++] = cand;

@@ -266,7 +266,7 @@ def test_emu_key_mac_lazy_ranges(emu):
     For x anywhere below 8q (the transform's lazy output), y below q: every product adds x*y mod q plus at most 6q, two terms stay
     below 14q, with the fold from the third term on any number of terms stays below 15q, and the final reduction is x.y mod q —
     with the extreme operands (0, 1, q-1, 8q-1, values next to powers of two) and random ones, for the default chain (60-bit moduli)
-    and for 59-, 45- and 31-bit moduli (the operand shift 64 - k and the quotient constant depend on the width k)"""
+    and for 59-, 45- and 40-bit moduli (the operand shift 64 - k and the quotient constant depend on the width k)"""
     emu.emu_mac.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]
     emu.emu_mac_final.restype = C.c_uint64
     emu.emu_mac_final.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64]
@@ -274,10 +274,11 @@ def test_emu_key_mac_lazy_ranges(emu):
     emu.emu_create_mods.restype = C.c_void_p
     emu.emu_create_mods.argtypes = [C.c_uint32] * 3 + [C.c_void_p] * 2
     small = []
-    for bits in (59, 45, 31, 59, 45, 31):
-        c = (1 << bits) - (1 << 14) + 1 - (len(small) << 20)
+    for bits in (59, 45, 40, 59, 45, 40):   # (every modulus of a context is 1 mod 2^32)
+        c = (1 << bits) + 1 - (1 << 32)
         while not isprime(c) or c in small:
-            c -= 1 << 14
+            c -= 1 << 32
+            assert c > 1 << (bits - 1)
         small.append(c)
     chain = np.array(small, dtype=np.uint64)
     rng = np.random.default_rng(5)

@@ -435,17 +435,18 @@ def test_mix_sub_scale_with_conversion_inside(logN, n_in, outs_per_wg):
 
 
 def test_inner_product_with_narrow_moduli():
-    """the key multiply-accumulate of hm_ntt_inner_product over a caller-chosen chain of 59-, 45- and 31-bit moduli (the lazy product's
+    """the key multiply-accumulate of hm_ntt_inner_product over a caller-chosen chain of 59-, 45- and 40-bit moduli (the lazy product's
     operand shift and quotient constant depend on the modulus width): evaluation-form operands only (no transform, so no oracle is
     needed), 4 terms, both keys, extreme operands; expected values from Python integers"""
     from sympy import isprime
     from homulator_amd import hip
     logN, N = 13, 1 << 13
     chain = []
-    for bits in (59, 45, 31, 59, 45, 31):
-        c = (1 << bits) - (1 << 14) + 1 - (len(chain) << 20)
+    for bits in (59, 45, 40, 59, 45, 40):   # (every modulus of a context is 1 mod 2^32)
+        c = (1 << bits) + 1 - (1 << 32)
         while not isprime(c) or c in chain:
-            c -= 1 << 14
+            c -= 1 << 32
+            assert c > 1 << (bits - 1)
         chain.append(c)
     ctx = hip.Context(logN, 4, 2, q=chain[:4], p=chain[4:])
     try:

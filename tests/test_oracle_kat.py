@@ -18,10 +18,10 @@ def test_prime_chain_and_roots():
     N = o.N
     mods = o.moduli
     assert len(set(mods)) == 8 and mods == sorted(mods, reverse=True)
-    # exactly the largest primes = 1 mod 2N below 2^60
+    # exactly the largest primes = 1 mod 2^32 below 2^60 (q = h 2^32 + 1 makes a Montgomery step one multiply)
     cand, found = (1 << 60) + 1, []
     while len(found) < 8:
-        cand -= 2 * N
+        cand -= 1 << 32
         if sympy.isprime(cand):
             found.append(cand)
     assert found == mods
@@ -39,7 +39,7 @@ def test_prime_chain_and_roots():
 def test_prime_chain_n16_matches_spec():
     o = Oracle(16, 3, 1)
     for q in o.moduli:
-        assert sympy.isprime(q) and q % (1 << 17) == 1 and q < (1 << 60)
+        assert sympy.isprime(q) and q % (1 << 32) == 1 and q % (1 << 17) == 1 and (1 << 59) < q < (1 << 60)
     assert o.moduli[0] == max(o.moduli)
 
 
