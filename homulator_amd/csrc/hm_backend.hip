@@ -80,10 +80,10 @@ __device__ __forceinline__ void hm_ntt_pass_run(const HmNttArgs &a, uint64_t *ld
   const uint32_t mod = lb.mod;
   const size_t N = (size_t)1 << a.logN;
   const uint64_t q = HM_CONST_MODS(a.mods)[mod].q;   // through the scalar cache (read-only for the lifetime of the context)
-  const HmTw *twl = a.tw + (size_t)mod * N;
+  const HmW *twl = a.tw + (size_t)mod * N;
   const uint32_t s0 = STRIDED ? 0u : (a.logN - HM_ROW_LOG);
   const uint32_t prefix0 = STRIDED ? 0u : (tile << (TL - LOGR));
-  const HmTw *twt = STRIDED ? nullptr : a.twist + ((size_t)mod * (N >> HM_ROW_LOG) + prefix0) * 3;  // the tile's first row
+  const HmW *twt = STRIDED ? nullptr : a.twist + ((size_t)mod * (N >> HM_ROW_LOG) + prefix0) * 3;  // the tile's first row
   // the first pass of a transform reads `in`, the second works in place on `out`
   constexpr bool FIRST = (STRIDED != INV);
   const uint64_t *src = FIRST ? a.in + (size_t)lb.in * N : a.out + (size_t)lb.out * N;
@@ -457,8 +457,8 @@ __global__ void __launch_bounds__((1 << HM_TL_ROW) / 8) k_ntt_queue8(HmNttArgs a
 // frees the other image; the barriers between the rounds are raw too (`__syncthreads()` would wait for vmcnt(0) and drain the DMA).
 // The first round reads its elements from the image (phase SRC = 1) instead of from global memory.
 template <int TL, int LOGR, bool STRIDED, bool INV, int MODE, class GEO, class ISSUE>
-__device__ __forceinline__ void hm_dma_tile(uint64_t *__restrict__ cur, uint64_t *__restrict__ nxt, int tid, uint64_t *dst, uint32_t tile, const HmTw *twl,
-                                            const HmTw *twt, uint32_t s0, uint32_t prefix0, uint64_t q, HmTw sc, HmEpi ep, ISSUE issue_next) {
+__device__ __forceinline__ void hm_dma_tile(uint64_t *__restrict__ cur, uint64_t *__restrict__ nxt, int tid, uint64_t *dst, uint32_t tile, const HmW *twl,
+                                            const HmW *twt, uint32_t s0, uint32_t prefix0, uint64_t q, HmTw sc, HmEpi ep, ISSUE issue_next) {
   typename GEO::State st;
   GEO::template phases_dma<TL, LOGR, STRIDED, INV, MODE>(st, tid, cur, nullptr, dst, tile, twl, twt, s0, prefix0, q, sc, ep,
                                                         [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }, cur + (1 << TL),
@@ -468,7 +468,7 @@ template <int LOGR, bool STRIDED, bool INV, int MODE, class GEO, int TL = HM_TL(
 __device__ __forceinline__ void hm_ntt_pass_dma_body(const HmNttArgs &a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // (buffer descriptors and the LDS-DMA builtins exist in the device pass only)
   constexpr int TILE = 1 << TL, THREADS = TILE / GEO::EPT, WAVES = THREADS / 64;
-  constexpr int NTWW = (STRIDED ? (1 << LOGR) : 128) * 2;          // staged twiddle words behind a tile image
+  constexpr int NTWW = STRIDED ? (1 << LOGR) : 128;                // staged twiddle words behind a tile image (one per entry)
   constexpr int CH_TILE = TILE * 8 / 1024, CH_TW = (NTWW * 8 + 1023) / 1024;  // 1 KiB pieces (a short twiddle list is copied with what follows it in the table)
   constexpr int IMG = TILE + CH_TW * 128;                           // words per buffer
   constexpr int NDMA = (CH_TILE + CH_TW + WAVES - 1) / WAVES;
@@ -520,7 +520,7 @@ __device__ __forceinline__ void hm_ntt_pass_dma_body(const HmNttArgs &a) {
     const HmLimb lb = unpack(rec);
     const uint64_t *src = FIRST ? a.in + (size_t)lb.in * N : a.out + (size_t)lb.out * N;
     const uint32_t soff = STRIDED ? tile << (LOGC + 3) : tile << (TL + 3);
-    const __amdgpu_buffer_rsrc_t rs = hm_rsrc(src), rt = hm_rsrc(reinterpret_cast<const uint64_t *>(a.tw + (size_t)lb.mod * N));
+    const __amdgpu_buffer_rsrc_t rs = hm_rsrc(src), rt = hm_rsrc(a.tw + (size_t)lb.mod * N);
 #pragma unroll
     for (int k = 0; k < NDMA; ++k) {
       const int c = k * WAVES + wave;
@@ -545,10 +545,10 @@ __device__ __forceinline__ void hm_ntt_pass_dma_body(const HmNttArgs &a) {
       const HmLimb lb = unpack(rec);
       const uint32_t mod = lb.mod;
       const uint64_t q = HM_CONST_MODS(a.mods)[mod].q;
-      const HmTw *twl = a.tw + (size_t)mod * N;
+      const HmW *twl = a.tw + (size_t)mod * N;
       const uint32_t s0 = STRIDED ? 0u : (a.logN - HM_ROW_LOG);
       const uint32_t prefix0 = STRIDED ? 0u : (tile << (TL - LOGR));
-      const HmTw *twt = STRIDED ? nullptr : a.twist + ((size_t)mod * (N >> HM_ROW_LOG) + prefix0) * 3;
+      const HmW *twt = STRIDED ? nullptr : a.twist + ((size_t)mod * (N >> HM_ROW_LOG) + prefix0) * 3;
       uint64_t *dst = a.out + (size_t)lb.out * N;
       HmTw sc = {0, 0};
       HmEpi ep = hm_epi_none();
@@ -613,7 +613,7 @@ struct HmNipArgs {
   const uint64_t *x;      // evaluation-form operands (a digit's own limbs)
   const uint64_t *y;      // evaluation key
   uint64_t *out;
-  const HmTw *tw, *twist;
+  const HmW *tw, *twist;
   const HmMod *mods;
   uint32_t logN, n_limbs, logG, n_terms;
   const HmNipLimb *limb;  // device, [n_limbs]
@@ -650,9 +650,9 @@ __global__ void __launch_bounds__((1 << HM_TL_ROW) / HM_EPT) __attribute__((amdg
   if (mod == HM_NTT_NONE) return;
   const size_t N = (size_t)1 << a.logN;
   const HmMod m = HM_CONST_MODS(a.mods)[mod];
-  const HmTw *twl = a.tw + (size_t)mod * N;
+  const HmW *twl = a.tw + (size_t)mod * N;
   const uint32_t s0 = a.logN - LOGR, prefix0 = tile << (TL - LOGR);
-  const HmTw *twt = a.twist + ((size_t)mod * (N >> LOGR) + prefix0) * 3;
+  const HmW *twt = a.twist + ((size_t)mod * (N >> LOGR) + prefix0) * 3;
   const uint32_t mask = rec->coeff_mask;
 #if HM_NIP_WIDE
   typedef hm_u128 Acc;
@@ -895,8 +895,8 @@ struct hm_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_done = nullptr;
-  HmTw *d_tw_fwd = nullptr, *d_tw_inv = nullptr;
-  HmTw *d_twist_fwd = nullptr, *d_twist_inv = nullptr;  // [L+K][N/256][3], hm::Params::make_twist
+  HmW *d_tw_fwd = nullptr, *d_tw_inv = nullptr;     // [L+K][N], Montgomery form (one word per entry)
+  HmW *d_twist_fwd = nullptr, *d_twist_inv = nullptr;  // [L+K][N/256][3], hm::Params::make_twist
   HmMod *d_mods = nullptr;
   std::map<std::vector<uint32_t>, uint64_t *> bconv_tables;  // key: n_in, in_ids..., out_ids...
   std::map<std::string, void *> ntt_tables;                  // launch tables (device_table), key: their bytes
@@ -1027,22 +1027,22 @@ extern "C" hm_status hm_create(hm_ctx **out, const hm_params *p) {
   HM_HIP(nullptr, hipEventCreate(&cc->ev0));
   HM_HIP(nullptr, hipEventCreate(&cc->ev1));
   const uint32_t M = cc->P.L + cc->P.K, N = cc->P.N;
-  HM_HIP(nullptr, hipMalloc(&cc->d_tw_fwd, sizeof(HmTw) * (size_t)M * N));
-  HM_HIP(nullptr, hipMalloc(&cc->d_tw_inv, sizeof(HmTw) * (size_t)M * N));
+  HM_HIP(nullptr, hipMalloc(&cc->d_tw_fwd, sizeof(HmW) * (size_t)M * N));
+  HM_HIP(nullptr, hipMalloc(&cc->d_tw_inv, sizeof(HmW) * (size_t)M * N));
   HM_HIP(nullptr, hipMalloc(&cc->d_mods, sizeof(HmMod) * M));
   const size_t twistRow = (size_t)(N >> HM_ROW_LOG) * 3;
-  HM_HIP(nullptr, hipMalloc(&cc->d_twist_fwd, sizeof(HmTw) * M * twistRow));
-  HM_HIP(nullptr, hipMalloc(&cc->d_twist_inv, sizeof(HmTw) * M * twistRow));
-  std::vector<HmTw> tmp(N);
+  HM_HIP(nullptr, hipMalloc(&cc->d_twist_fwd, sizeof(HmW) * M * twistRow));
+  HM_HIP(nullptr, hipMalloc(&cc->d_twist_inv, sizeof(HmW) * M * twistRow));
+  std::vector<HmW> tmp(N);
   for (uint32_t m = 0; m < M; ++m) {
     cc->P.make_twist(m, false, tmp.data());
-    HM_HIP(nullptr, hipMemcpy(cc->d_twist_fwd + m * twistRow, tmp.data(), sizeof(HmTw) * twistRow, hipMemcpyHostToDevice));
+    HM_HIP(nullptr, hipMemcpy(cc->d_twist_fwd + m * twistRow, tmp.data(), sizeof(HmW) * twistRow, hipMemcpyHostToDevice));
     cc->P.make_twist(m, true, tmp.data());
-    HM_HIP(nullptr, hipMemcpy(cc->d_twist_inv + m * twistRow, tmp.data(), sizeof(HmTw) * twistRow, hipMemcpyHostToDevice));
+    HM_HIP(nullptr, hipMemcpy(cc->d_twist_inv + m * twistRow, tmp.data(), sizeof(HmW) * twistRow, hipMemcpyHostToDevice));
     cc->P.make_table(m, false, tmp.data());
-    HM_HIP(nullptr, hipMemcpy(cc->d_tw_fwd + (size_t)m * N, tmp.data(), sizeof(HmTw) * N, hipMemcpyHostToDevice));
+    HM_HIP(nullptr, hipMemcpy(cc->d_tw_fwd + (size_t)m * N, tmp.data(), sizeof(HmW) * N, hipMemcpyHostToDevice));
     cc->P.make_table(m, true, tmp.data());
-    HM_HIP(nullptr, hipMemcpy(cc->d_tw_inv + (size_t)m * N, tmp.data(), sizeof(HmTw) * N, hipMemcpyHostToDevice));
+    HM_HIP(nullptr, hipMemcpy(cc->d_tw_inv + (size_t)m * N, tmp.data(), sizeof(HmW) * N, hipMemcpyHostToDevice));
   }
   HM_HIP(nullptr, hipMemcpy(cc->d_mods, cc->P.modc.data(), sizeof(HmMod) * M, hipMemcpyHostToDevice));
   HM_HIP(nullptr, hipMalloc(&cc->ntt_ws, sizeof(HmNttSync)));

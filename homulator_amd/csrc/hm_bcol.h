@@ -26,7 +26,7 @@ struct HmBcolProb {
 struct HmBcolArgs {
   const HmBcolProb *prob;   // device
   uint64_t *out;
-  const HmTw *tw;
+  const HmW *tw;
   uint32_t logN, n_prob, max_out;   // max_out: output GROUPS (of NOUT limbs) per (conversion, tile)
   const uint64_t *mix;
   uint32_t tile0, logTiles;         // the column tiles this launch works on: [tile0, tile0 + 2^logTiles) (all of them, or a rank's column slice)
@@ -62,10 +62,10 @@ __device__ __forceinline__ void hm_bcol_convert(const uint32_t (&yl)[2][N_IN], c
   }
 }
 template <int TL, int LOG1>
-__device__ __forceinline__ void hm_bcol_rounds(HmNttState &st, int tid, uint64_t *lds, uint64_t q, const HmTw *twl, uint64_t *dst, uint32_t tile) {
+__device__ __forceinline__ void hm_bcol_rounds(HmNttState &st, int tid, uint64_t *lds, uint64_t q, const HmW *twl, uint64_t *dst, uint32_t tile) {
   using PS = HmPass<LOG1, true, false>;
   constexpr int n = PS::n, r0 = PS::exec(0);
-  const HmTw *ltw = reinterpret_cast<const HmTw *>(lds + (1 << TL));
+  const HmW *ltw = lds + (1 << TL);
   const HmTw sc = {0, 0};
   const HmEpi ep = hm_epi_none();
   hm_ph_load_tw<TL, LOG1, true, r0, true>(st, tid, ltw, 0, 0);

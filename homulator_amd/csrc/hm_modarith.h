@@ -35,9 +35,10 @@ struct HmMod {
   uint64_t nqinv;   // -q^-1 mod 2^64 (Montgomery reduction of the base-conversion accumulators)
 };
 
-struct HmTw {  // one twiddle: value and its Shoup companion (16 B -> one dwordx4 load)
+struct HmTw {  // a constant in Shoup form: value and companion (epilogue / prologue / element-wise constants)
   uint64_t w, ws;
 };
+typedef uint64_t HmW;   // a transform twiddle or twist constant in Montgomery form, w 2^64 mod q: ONE word per table entry (round 4)
 
 HM_HD uint64_t hm_mulhi(uint64_t a, uint64_t b) { return (uint64_t)(((hm_u128)a * b) >> 64); }
 
@@ -182,25 +183,25 @@ HM_HD uint64_t hm_to_mont(uint64_t w, uint64_t q) { return (uint64_t)(((hm_u128)
 //   kind 2: both 4q and 2q        X < 8q, Y < 8q  ->  X', Y' < 4q   (last stage of a transform: hm_reduce4 follows)
 // Y' = X - v + 2q is computed as (2X + 2q) - X' (2X + 2q < 2^64).
 template <int KIND>
-HM_HD void hm_bfly_fwd_k(uint64_t &X, uint64_t &Y, const HmTw &t, const HmBflyMod &m) {
+HM_HD void hm_bfly_fwd_k(uint64_t &X, uint64_t &Y, HmW wt, const HmBflyMod &m) {
   uint64_t x = X;
 #if !defined(HM_ABL_NOCSUB)   // (timing-only ablation: butterflies without their conditional subtractions)
   if (KIND >= 1) x = hm_csub_neg(x, m.nq4);
   if (KIND == 2) x = hm_csub_neg(x, m.nq2);
 #endif
-  const uint64_t xn = hm_mont_acc(x, Y, t.w, m);
+  const uint64_t xn = hm_mont_acc(x, Y, wt, m);
   Y = ((x << 1) + m.q2) - xn;
   X = xn;
 }
 // inverse (Gentleman-Sande): X, Y in [0, 4q) -> X' in [0, 4q), Y' in [0, 1.5q + 1]   (X + 4q - Y < 8q <= 2^63)
-HM_HD void hm_bfly_inv(uint64_t &X, uint64_t &Y, const HmTw &t, const HmBflyMod &m) {
+HM_HD void hm_bfly_inv(uint64_t &X, uint64_t &Y, HmW wt, const HmBflyMod &m) {
   const uint64_t d = (X + m.q4) - Y;
 #if defined(HM_ABL_NOCSUB)
   X = X + Y;
 #else
   X = hm_csub_neg(X + Y, m.nq4);
 #endif
-  Y = hm_mont_acc(0, d, t.w, m);
+  Y = hm_mont_acc(0, d, wt, m);
 }
 // [0, 4q) -> [0, q)
 HM_HD uint64_t hm_reduce4(uint64_t x, uint64_t q) { return hm_csub(hm_csub(x, 2 * q), q); }

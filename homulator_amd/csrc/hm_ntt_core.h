@@ -95,8 +95,8 @@ struct HmNttEntry {                  // the part of a record that is not needed 
 struct HmNttArgs {
   const uint64_t *in;
   uint64_t *out;
-  const HmTw *tw;      // [n_mod][N] forward or inverse table (chosen by the host)
-  const HmTw *twist;   // [n_mod][N / 256][3] per-row constants alpha_r^k (forward) or alpha_r^-k (inverse), k = 1..3
+  const HmW *tw;       // [n_mod][N] forward or inverse table (chosen by the host), Montgomery form
+  const HmW *twist;    // [n_mod][N / 256][3] per-row constants alpha_r^k (forward) or alpha_r^-k (inverse), k = 1..3
   const HmMod *mods;   // [n_mod]
   const HmNttEntry *entry;                // [n_limbs], device
   const uint64_t *minuend, *addend, *mix; // bases of the MODE 3 / MODE 4 operands (addend may be null)

@@ -1,11 +1,12 @@
 // hm_ntt_passes.inl — the per-thread phases of a transform pass for ONE geometry (HM_EPT coefficients per thread); included by
 // hm_ntt_core.h once per geometry, inside that geometry's namespace.  No include guard on purpose.
-// LDS words of a pass: the tile, then the staged shared twiddles (2 words each)
+// LDS words of a pass: the tile, then the staged shared twiddles (one word each: Montgomery form)
 template <int TL, int LOGR, bool STRIDED>
 struct HmLds {
   static constexpr int TILE = 1 << TL, THREADS = TILE / HM_EPT;
   static constexpr int NTW = STRIDED ? (1 << LOGR) : 128;  // staged entries: w[0 .. NTW) of the modulus
-  static constexpr int WORDS = TILE + (HM_TW_IN_LDS(STRIDED) ? 2 * NTW : 0);
+  static constexpr int WORDS = TILE + (HM_TW_IN_LDS(STRIDED) ? NTW : 0);
+  static_assert(NTW % 2 == 0, "staged in 16-byte units");
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -19,8 +20,8 @@ struct HmLds {
 #define HM_MAX_TW 14  // twiddles of one round of one thread: a pair of radix-8 groups 7, four radix-4 groups 12
 struct HmNttState {
   uint64_t v[HM_EPT];
-  HmTw tw[4][HM_MAX_TW];
-  HmTw tws[3];  // twist constants of the thread's row (ROW pass)
+  HmW tw[4][HM_MAX_TW];
+  HmW tws[3];  // twist constants of the thread's row (ROW pass)
 };
 
 // Round schedule per sub-transform length: bits are consumed from the top for the forward transform
@@ -154,7 +155,7 @@ struct HmPass {
 // request the twiddles of round R: sub-stage j needs 2^j of them, indexed by the top j bits of e.
 // SHARED ROW round: the row-independent factor w[h]; otherwise the full table entry.
 template <int TL, int LOGR, bool STRIDED, int R, bool SHARED>
-HM_HD void hm_ph_load_tw(HmNttState &st, int tid, const HmTw *twl, uint32_t s0, uint32_t prefix0) {
+HM_HD void hm_ph_load_tw(HmNttState &st, int tid, const HmW *twl, uint32_t s0, uint32_t prefix0) {
   using G = HmRound<TL, LOGR, STRIDED, R>;
 #pragma unroll
   for (int v = 0; v < G::SETS; ++v) {
@@ -168,7 +169,7 @@ HM_HD void hm_ph_load_tw(HmNttState &st, int tid, const HmTw *twl, uint32_t s0, 
 #pragma unroll
       for (int t = 0; t < (1 << j); ++t) {
 #if defined(HM_ABL_NOTW)
-        st.tw[R][v * (G::E - 1) + (1 << j) - 1 + t] = HmTw{(uint64_t)(twbase + t) * 0x9E3779B97F4A7C15ull >> 5, (uint64_t)(twbase + t) * 0xD1342543DE82EF95ull};
+        st.tw[R][v * (G::E - 1) + (1 << j) - 1 + t] = (uint64_t)(twbase + t) * 0x9E3779B97F4A7C15ull >> 5;
 #else
         st.tw[R][v * (G::E - 1) + (1 << j) - 1 + t] = twl[twbase + (uint32_t)t];
 #endif
@@ -178,7 +179,7 @@ HM_HD void hm_ph_load_tw(HmNttState &st, int tid, const HmTw *twl, uint32_t s0, 
 }
 // the three twist constants of the thread's row (the K == 0 ROW round: all groups of a thread lie in one row)
 template <int TL, int LOGR, bool STRIDED, int R>
-HM_HD void hm_ph_load_twist(HmNttState &st, int tid, const HmTw *twist_tile) {
+HM_HD void hm_ph_load_twist(HmNttState &st, int tid, const HmW *twist_tile) {
   using G = HmRound<TL, LOGR, STRIDED, R>;
   int c, xr;
   G::group(tid, 0, c, xr);
@@ -187,15 +188,12 @@ HM_HD void hm_ph_load_twist(HmNttState &st, int tid, const HmTw *twist_tile) {
 }
 // copy the shared twiddles w[0 .. NTW) of the modulus into LDS (visible after the next barrier)
 template <int TL, int LOGR, bool STRIDED>
-HM_HD void hm_ph_stage_tw(int tid, uint64_t *lds, const HmTw *twl) {
+HM_HD void hm_ph_stage_tw(int tid, uint64_t *lds, const HmW *twl) {
   using LD = HmLds<TL, LOGR, STRIDED>;
 #pragma unroll
-  for (int i = 0; i < (LD::NTW + LD::THREADS - 1) / LD::THREADS; ++i) {
+  for (int i = 0; i < (LD::NTW / 2 + LD::THREADS - 1) / LD::THREADS; ++i) {   // two entries (16 bytes) per thread and step
     const int k = tid + LD::THREADS * i;
-    if (k < LD::NTW) {
-      const HmTw t = twl[k];
-      hm_st2(lds + LD::TILE + 2 * k, t.w, t.ws);
-    }
+    if (k < LD::NTW / 2) hm_st2(lds + LD::TILE + 2 * k, twl[2 * k], twl[2 * k + 1]);
   }
 }
 
@@ -324,7 +322,7 @@ template <int TL, int LOGR, bool STRIDED, int R, bool INV>
 HM_HD void hm_ph_compute(HmNttState &st, uint64_t q) {
   using G = HmRound<TL, LOGR, STRIDED, R>;
 #if defined(HM_ABL_NOCOMPUTE)
-  st.v[0] ^= st.tw[R][0].w;  // keeps the twiddle loads alive
+  st.v[0] ^= st.tw[R][0];  // keeps the twiddle loads alive
   return;
 #endif
   const HmBflyMod m = hm_bfly_mod(q);  // lazy ranges: forward [0, 8q) inside a pass, inverse [0, 4q)
@@ -337,7 +335,7 @@ HM_HD void hm_ph_compute(HmNttState &st, uint64_t q) {
 #pragma unroll
       for (int e = 0; e < G::E; ++e) {
         if (e & (1 << pb)) continue;
-        const HmTw t = st.tw[R][G::twslot(u) + (1 << j) - 1 + (e >> (G::NB - j))];
+        const HmW t = st.tw[R][G::twslot(u) + (1 << j) - 1 + (e >> (G::NB - j))];
         constexpr int sigma = LOGR - G::K - G::NB;  // + j: the local stage (j is a constant once unrolled)
         if (INV) hm_bfly_inv(st.v[u * G::E + e], st.v[u * G::E + (e | (1 << pb))], t, m);
         else if (hm_fwd_kind(STRIDED, LOGR, sigma + j) == 0) hm_bfly_fwd_k<0>(st.v[u * G::E + e], st.v[u * G::E + (e | (1 << pb))], t, m);
@@ -352,14 +350,14 @@ HM_HD void hm_ph_compute(HmNttState &st, uint64_t q) {
 // [0, 1.5q + 1] — inside the input range of both butterfly forms.
 HM_HD void hm_ph_twist(HmNttState &st, uint64_t q) {
 #if defined(HM_ABL_NOCOMPUTE)
-  st.v[1] ^= st.tws[0].w ^ st.tws[1].w ^ st.tws[2].w;
+  st.v[1] ^= st.tws[0] ^ st.tws[1] ^ st.tws[2];
   return;
 #endif
   const HmBflyMod m = hm_bfly_mod(q);
 #pragma unroll
   for (int u = 0; u < HM_EPT / 4; ++u)
 #pragma unroll
-    for (int k = 1; k < 4; ++k) st.v[4 * u + k] = hm_mont_acc(0, st.v[4 * u + k], st.tws[k - 1].w, m);
+    for (int k = 1; k < 4; ++k) st.v[4 * u + k] = hm_mont_acc(0, st.v[4 * u + k], st.tws[k - 1], m);
 }
 
 // The whole pass of one thread, phase by phase.  `sync` is __syncthreads() on the GPU; the emulator calls the
@@ -378,14 +376,14 @@ HM_HD void hm_ph_twist(HmNttState &st, uint64_t q) {
 // twiddles were staged by the caller at `lds_tw` (a pass over several tiles stages them once per modulus).
 template <int TL, int LOGR, bool STRIDED, bool INV, int MODE, int PHASE, int LDAUX = 0, int STAUX = 0, int EPICH = HM_EPI_CHUNK, int SRC = 0>
 HM_HD void hm_ntt_phase(HmNttState &st, int tid, uint64_t *lds, const uint64_t *src, uint64_t *dst, uint32_t tile,
-                        const HmTw *twl, const HmTw *twist_tile, uint32_t s0, uint32_t prefix0, uint64_t q, HmTw sc, HmEpi ep,
+                        const HmW *twl, const HmW *twist_tile, uint32_t s0, uint32_t prefix0, uint64_t q, HmTw sc, HmEpi ep,
                         const uint64_t *lds_tw = nullptr) {
   using PS = HmPass<LOGR, STRIDED, INV>;
   constexpr int n = PS::n;
   static_assert(PHASE >= 0 && PHASE <= n, "a pass of n rounds has phases 0 .. n");
   constexpr int TWR = PS::twistRound;
   constexpr int iTW = TWR < 0 ? -1 : (INV ? n - 1 - TWR : TWR);   // execution index of the twisted round
-  const HmTw *ltw = reinterpret_cast<const HmTw *>(SRC ? lds_tw : lds + (1 << TL));
+  const HmW *ltw = SRC ? lds_tw : lds + (1 << TL);
   // register pressure: the inverse ROW pass has 120 registers of loads in flight in its first phase (data, the first
   // round's shared twiddles, the twist constants and the NEXT round's private twiddles); inside the one-launch transform
   // that no longer fits 128.  The next round's twiddles are then requested after the first round's butterflies instead
@@ -453,7 +451,7 @@ HM_HD void hm_ntt_phase_lds0(HmNttState &st, int tid, const uint64_t *lds, const
   using PS = HmPass<LOGR, STRIDED, INV>;
   constexpr int r0 = PS::exec(0);
   using G = HmRound<TL, LOGR, STRIDED, r0>;
-  if (HM_TW_IN_LDS(STRIDED) && PS::shared(r0)) hm_ph_load_tw<TL, LOGR, STRIDED, r0, true>(st, tid, reinterpret_cast<const HmTw *>(lds_tw), s0, prefix0);
+  if (HM_TW_IN_LDS(STRIDED) && PS::shared(r0)) hm_ph_load_tw<TL, LOGR, STRIDED, r0, true>(st, tid, lds_tw, s0, prefix0);
 #pragma unroll
   for (int a = 0; a < HM_UNITS; ++a) {
     int i0, i1, x, c;
@@ -472,7 +470,7 @@ struct HmNoMid { HM_HD void operator()() const {} };
 // there: requests behind the DMA would wait for it, vmcnt retires in order)
 template <int TL, int LOGR, bool STRIDED, bool INV, int MODE, int LDAUX = 0, int STAUX = 0, int EPICH = HM_EPI_CHUNK, int SRC = 0, class SYNC, class MID = HmNoMid>
 HM_HD void hm_ntt_pass_phases(HmNttState &st, int tid, uint64_t *lds, const uint64_t *src, uint64_t *dst, uint32_t tile,
-                              const HmTw *twl, const HmTw *twist_tile, uint32_t s0, uint32_t prefix0, uint64_t q, HmTw sc, HmEpi ep, SYNC sync,
+                              const HmW *twl, const HmW *twist_tile, uint32_t s0, uint32_t prefix0, uint64_t q, HmTw sc, HmEpi ep, SYNC sync,
                               const uint64_t *lds_tw = nullptr, MID mid = MID()) {
   constexpr int n = HmRounds<LOGR>::n;
   hm_ntt_phase<TL, LOGR, STRIDED, INV, MODE, 0, LDAUX, STAUX, EPICH, SRC>(st, tid, lds, src, dst, tile, twl, twist_tile, s0, prefix0, q, sc, ep, lds_tw);

@@ -105,19 +105,17 @@ void Params::init(uint32_t logN_, uint32_t L_, uint32_t K_, const uint64_t *q, c
   }
 }
 
-void Params::make_table(uint32_t m, bool inverse, HmTw *out) const {
+void Params::make_table(uint32_t m, bool inverse, HmW *out) const {
   const uint64_t q = mod[m];
   const uint64_t base = inverse ? invmod(psi[m], q) : psi[m];
   uint64_t p = 1;
   for (uint32_t i = 0; i < N; ++i) {
-    HmTw &t = out[bitrev(i, logN)];
-    t.w = hm_to_mont(p, q);   // Montgomery form: the butterflies' product is x wt 2^-64 (hm_mont_acc)
-    t.ws = 0;
+    out[bitrev(i, logN)] = hm_to_mont(p, q);   // Montgomery form: the butterflies' product is x wt 2^-64 (hm_mont_acc)
     p = mulmod(p, base, q);
   }
 }
 
-void Params::make_twist(uint32_t m, bool inverse, HmTw *out) const {
+void Params::make_twist(uint32_t m, bool inverse, HmW *out) const {
   const uint64_t q = mod[m];
   const uint64_t base = inverse ? invmod(psi[m], q) : psi[m];
   const uint32_t rows = N >> 8, bits = logN - 8;
@@ -126,7 +124,7 @@ void Params::make_twist(uint32_t m, bool inverse, HmTw *out) const {
     uint64_t p = 1;
     for (uint32_t k = 0; k < 3; ++k) {
       p = mulmod(p, a, q);
-      out[3 * r + k] = HmTw{hm_to_mont(p, q), 0};
+      out[3 * r + k] = hm_to_mont(p, q);
     }
   }
 }

@@ -1,7 +1,7 @@
 // hm_params.h — host-side parameter generation for the HIP backend: prime chain, roots of unity,
-// twiddle tables (value + Shoup companion), per-modulus Barrett constants, base-conversion tables.
+// twiddle tables (Montgomery form, one word per entry), per-modulus Barrett constants, base-conversion tables.
 // The reference defines none of these; the rules are SURVEY.md §8d / Appendix A:
-// the L+K largest primes below 2^60 congruent to 1 mod 2N (descending; first L = Q, next K = P),
+// the L+K largest primes below 2^60 congruent to 1 mod 2^32 (descending; first L = Q, next K = P),
 // psi = smallest primitive 2N-th root of unity, tables in bit-reversed order.
 #pragma once
 #include <cstdint>
@@ -25,11 +25,11 @@ struct Params {
 
   // default chain (q == nullptr) or caller-supplied moduli / roots (psi may be nullptr)
   void init(uint32_t logN, uint32_t L, uint32_t K, const uint64_t *q, const uint64_t *p, const uint64_t *psi);
-  // forward (inverse=false) or inverse twiddle table of one modulus, N entries, bit-reversed order
-  void make_table(uint32_t mod_id, bool inverse, HmTw *out) const;
+  // forward (inverse=false) or inverse twiddle table of one modulus, N entries w 2^64 mod q, bit-reversed order
+  void make_table(uint32_t mod_id, bool inverse, HmW *out) const;
   // per-row constants of the ROW pass (hm_ntt_core.h): out[3 r + k - 1] = alpha_r^k (inverse: alpha_r^-k), k = 1..3,
   // alpha_r = psi^(1 + 2 brev(r)), r < N / 256
-  void make_twist(uint32_t mod_id, bool inverse, HmTw *out) const;
+  void make_twist(uint32_t mod_id, bool inverse, HmW *out) const;
   // base conversion constants for an input basis -> output basis
   void bconv_consts(const uint32_t *in_ids, uint32_t n_in, const uint32_t *out_ids, uint32_t n_out,
                     uint64_t *qhat_inv, uint64_t *table) const;

@@ -13,7 +13,7 @@
 
 struct Emu {
   hm::Params P;
-  std::vector<std::vector<HmTw>> fwd, inv, twf, twi;
+  std::vector<std::vector<HmW>> fwd, inv, twf, twi;
 };
 
 // the two geometries of the passes (hm_ntt_core.h): 16 coefficients per thread (hm16) and 8 (hm8, N = 2^16 only)
@@ -38,8 +38,8 @@ struct G8 {
 
 // phase P of every thread of the workgroup, then phase P + 1, ... (a barrier on the GPU = the end of a phase loop here)
 template <class G, int TL, int LOGR, bool STRIDED, bool INV, int MODE, int P>
-static void run_phases(std::vector<typename G::State> &st, uint64_t *lds, const uint64_t *src, uint64_t *dst, uint32_t tile, const HmTw *twl,
-                       const HmTw *twt, uint32_t s0, uint32_t prefix0, uint64_t q, HmTw sc, HmEpi ep) {
+static void run_phases(std::vector<typename G::State> &st, uint64_t *lds, const uint64_t *src, uint64_t *dst, uint32_t tile, const HmW *twl,
+                       const HmW *twt, uint32_t s0, uint32_t prefix0, uint64_t q, HmTw sc, HmEpi ep) {
   for (int t = 0; t < (int)st.size(); ++t) G::template phase<TL, LOGR, STRIDED, INV, MODE, P>(st[t], t, lds, src, dst, tile, twl, twt, s0, prefix0, q, sc, ep);
   if constexpr (P < G::template rounds<LOGR>()) run_phases<G, TL, LOGR, STRIDED, INV, MODE, P + 1>(st, lds, src, dst, tile, twl, twt, s0, prefix0, q, sc, ep);
 }
@@ -49,15 +49,15 @@ static void run_pass(const Emu &e, uint32_t mod, const uint64_t *src, uint64_t *
   constexpr int TL = HM_TL(STRIDED), THREADS = (1 << TL) / G::EPT;
   const uint32_t tiles = e.P.N >> TL;
   const uint64_t q = e.P.mod[mod];
-  const HmTw *twl = (INV ? e.inv : e.fwd)[mod].data();
+  const HmW *twl = (INV ? e.inv : e.fwd)[mod].data();
   const uint32_t s0 = STRIDED ? 0u : (e.P.logN - HM_ROW_LOG);
   std::vector<uint64_t> lds(G::template ldsWords<TL, LOGR, STRIDED>());
   std::vector<typename G::State> st(THREADS);
-  const HmTw *twist = (INV ? e.twi : e.twf)[mod].data();
+  const HmW *twist = (INV ? e.twi : e.twf)[mod].data();
   // a pass may run in place (src == dst): every thread reads its elements before any thread writes its own
   for (uint32_t tile = 0; tile < tiles; ++tile) {
     const uint32_t prefix0 = STRIDED ? 0u : (tile << (TL - LOGR));
-    const HmTw *twt = twist + (size_t)prefix0 * 3;
+    const HmW *twt = twist + (size_t)prefix0 * 3;
     run_phases<G, TL, LOGR, STRIDED, INV, MODE, 0>(st, lds.data(), src, dst, tile, twl, twt, s0, prefix0, q, sc, ep);
   }
 }
@@ -77,7 +77,7 @@ static void run_ntt(const Emu &e, uint32_t mod, const uint64_t *in, uint64_t *ou
 // at (even) word w of the image <- the coefficients hm_lds_unidx names, the staged twiddles linearly behind it — and the pass runs its
 // first round from the image (phase SRC = 1: global requests, [the kernel issues the next tile's DMA here], LDS reads, rounds)
 template <class G, int TL, int LOGR, bool STRIDED, bool INV, int MODE, int P>
-static void run_phases_src1(std::vector<typename G::State> &st, uint64_t *lds, uint64_t *dst, uint32_t tile, const HmTw *twl, const HmTw *twt, uint32_t s0,
+static void run_phases_src1(std::vector<typename G::State> &st, uint64_t *lds, uint64_t *dst, uint32_t tile, const HmW *twl, const HmW *twt, uint32_t s0,
                             uint32_t prefix0, uint64_t q, HmTw sc, HmEpi ep) {
   for (int t = 0; t < (int)st.size(); ++t) G::template phase_src1<TL, LOGR, STRIDED, INV, MODE, P>(st[t], t, lds, nullptr, dst, tile, twl, twt, s0, prefix0, q, sc, ep, lds + (1 << TL));
   if constexpr (P == 0)
@@ -90,11 +90,11 @@ static void run_pass_dma(const Emu &e, uint32_t mod, const uint64_t *src, uint64
   constexpr int NTW = STRIDED ? (1 << LOGR) : 128;
   const uint32_t tiles = e.P.N >> TL;
   const uint64_t q = e.P.mod[mod];
-  const HmTw *twl = (INV ? e.inv : e.fwd)[mod].data();
+  const HmW *twl = (INV ? e.inv : e.fwd)[mod].data();
   const uint32_t s0 = STRIDED ? 0u : (e.P.logN - HM_ROW_LOG);
-  std::vector<uint64_t> lds(TILE + 2 * NTW);
+  std::vector<uint64_t> lds(TILE + NTW);
   std::vector<typename G::State> st(THREADS);
-  const HmTw *twist = (INV ? e.twi : e.twf)[mod].data();
+  const HmW *twist = (INV ? e.twi : e.twf)[mod].data();
   std::vector<uint64_t> in(src, src + e.P.N);   // (a pass may run in place: the kernel's DMA reads a tile before anybody stores to it)
   for (uint32_t tile = 0; tile < tiles; ++tile) {
     for (int w = 0; w < TILE; w += 2) {
@@ -103,7 +103,7 @@ static void run_pass_dma(const Emu &e, uint32_t mod, const uint64_t *src, uint64
       const uint32_t g = STRIDED ? ((uint32_t)x << HM_ROW_LOG) + (tile << LOGC) + (uint32_t)c : (tile << TL) + ((uint32_t)c << LOGR) + (uint32_t)x;
       lds[w] = in[g]; lds[w + 1] = in[g + 1];
     }
-    for (int k = 0; k < NTW; ++k) { lds[TILE + 2 * k] = twl[k].w; lds[TILE + 2 * k + 1] = twl[k].ws; }
+    for (int k = 0; k < NTW; ++k) lds[TILE + k] = twl[k];
     const uint32_t prefix0 = STRIDED ? 0u : (tile << (TL - LOGR));
     run_phases_src1<G, TL, LOGR, STRIDED, INV, MODE, 0>(st, lds.data(), dst, tile, twl, twist + (size_t)prefix0 * 3, s0, prefix0, q, sc, ep);
   }

@@ -61,12 +61,13 @@ template <class V> __global__ void __launch_bounds__(512) k(uint64_t *out, const
   out[tid] = s;
 }
 
-// ---- V3: the shipped forward butterflies (hm_modarith.h hm_bfly_fwd_k): conditional subtraction every other stage
+// ---- V3: the shipped forward butterflies (hm_modarith.h hm_bfly_fwd_k: word-wise Montgomery product, q = h 2^32 + 1, conditional
+// subtraction every other stage)
 __global__ void __launch_bounds__(512) k3(uint64_t *out, const uint64_t *in, uint64_t q) {
-  uint64_t v[8]; HmTw tw[7];
+  uint64_t v[8]; HmW tw[7];
   const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-  for (int i = 0; i < 8; ++i) v[i] = in[tid * 8 + i] % (4 * q);
-  for (int i = 0; i < 7; ++i) { tw[i].w = in[tid + i] % q; tw[i].ws = (uint64_t)(((unsigned __int128)tw[i].w << 64) / q); }
+  for (int i = 0; i < 8; ++i) v[i] = in[tid * 8 + i] % (2 * q);
+  for (int i = 0; i < 7; ++i) tw[i] = in[tid + i] % q;
   const HmBflyMod m = hm_bfly_mod(q);
   for (int it = 0; it < ITERS / 2; ++it) {
 #pragma unroll
@@ -83,59 +84,21 @@ __global__ void __launch_bounds__(512) k3(uint64_t *out, const uint64_t *in, uin
   uint64_t s = 0; for (int i = 0; i < 8; ++i) s ^= v[i] % q;
   out[tid] = s;
 }
-static int run3() {
-  const int blocks = 256 * 4, threads = 512;
-  const uint64_t q = 1152921504606584833ull;
-  uint64_t *d, *in; CK(hipMalloc(&d, (size_t)blocks * threads * 8)); CK(hipMalloc(&in, (size_t)blocks * threads * 8 * 8 + 64));
-  CK(hipMemset(in, 0x5a, (size_t)blocks * threads * 8 * 8 + 64));
-  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int w = 0; w < 40; ++w) hipLaunchKernelGGL(k3, dim3(blocks), dim3(threads), 0, 0, d, in, q);  // ~70 ms: clocks settle under load
-  CK(hipDeviceSynchronize());
-  float best = 1e30f, sum = 0;
-  for (int r = 0; r < 5; ++r) {
-    CK(hipEventRecord(e0));
-    hipLaunchKernelGGL(k3, dim3(blocks), dim3(threads), 0, 0, d, in, q);
-    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
-    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms; sum += ms;
-  }
-  const double wbfly_per_simd = (double)blocks * threads * ITERS * 12 / 64.0 / 1024.0;
-  printf("%-40s %8.3f ms (mean %.3f)  %7.2f cyc@2.4GHz/wave-butterfly/SIMD  wave_butterfly_ns (full chip, sustained) = %.5f  -> %.3f us per 2^16 limb NTT\n",
-         "V3 shipped: csub every other stage", best, sum / 5, best * 1e-3 * 2.4e9 / wbfly_per_simd, sum / 5 * 1e6 / wbfly_per_simd / 1024.0,
-         sum / 5 * 1e6 / wbfly_per_simd / 1024.0 * (32768.0 * 16 / 64) * 1e-3);
-  CK(hipFree(d)); CK(hipFree(in));
-  return 0;
-}
-
-// ---- V4: word-wise Montgomery for q = h 2^32 + 1 (q^-1 = 1 mod 2^32: a reduction step is ONE multiply): 6 multiplies per butterfly
-// instead of 9, no Shoup companion.  wt = w 2^64 mod q; Y < 2^63; v = Y w mod q + {0, q} in (0, 1.5q + 1).
-struct HmMontMod { uint64_t h, cc, q2, nq4, z; };
-__device__ __forceinline__ HmMontMod mont_mod(uint64_t q) {
-  HmMontMod m; m.z = hm_opaque_zero(); m.h = q >> 32; m.cc = (m.h + 1) * ((1ull << 32) + 1); m.q2 = 2 * q; m.nq4 = m.z - 4 * q; return m;
-}
+// ---- V2s: round 3's shipped form for comparison (Shoup product with the approximate quotient, 9 multiplies, subtraction of 8q every other stage)
 template <int KIND>
-__device__ __forceinline__ void mont_bfly_fwd(uint64_t &X, uint64_t &Y, uint64_t wt, const HmMontMod &m) {
+__device__ __forceinline__ void shoup_bfly_fwd_k(uint64_t &X, uint64_t &Y, const HmTw &t, const HmBflyMod &m) {
   uint64_t x = X;
-  if (KIND >= 1) x = hm_csub_neg(x, m.nq4);
-  const uint32_t b0 = (uint32_t)Y, b1 = (uint32_t)(Y >> 32), w0 = (uint32_t)wt, w1 = (uint32_t)(wt >> 32), h = (uint32_t)m.h;
-  const uint64_t P = (uint64_t)b0 * w0 + m.z;
-  const uint32_t n0 = ~(uint32_t)P;
-  uint64_t A = (uint64_t)b0 * w1 + m.cc;
-  A = (uint64_t)b1 * w0 + A;
-  A = (uint64_t)n0 * h + A;
-  const uint64_t S = A + (uint32_t)(P >> 32);
-  const uint32_t n1 = ~(uint32_t)S;
-  uint64_t B = (uint64_t)b1 * w1 + x;
-  B = (uint64_t)n1 * h + B;
-  const uint64_t Xn = B + (uint32_t)(S >> 32);
-  Y = ((x << 1) + m.q2) - Xn;
-  X = Xn;
+  if (KIND >= 1) x = hm_csub_neg(x, m.nq8);
+  const uint64_t xn = hm_shoup_lazy4_acc(x, Y, t, m);
+  Y = ((x << 1) + m.q4) - xn;
+  X = xn;
 }
-__global__ void __launch_bounds__(512) k4(uint64_t *out, const uint64_t *in, uint64_t q) {
-  uint64_t v[8]; uint64_t tw[7];
+__global__ void __launch_bounds__(512) k2s(uint64_t *out, const uint64_t *in, uint64_t q) {
+  uint64_t v[8]; HmTw tw[7];
   const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-  for (int i = 0; i < 8; ++i) v[i] = in[tid * 8 + i] % (2 * q);
-  for (int i = 0; i < 7; ++i) tw[i] = in[tid + i] % q;
-  const HmMontMod m = mont_mod(q);
+  for (int i = 0; i < 8; ++i) v[i] = in[tid * 8 + i] % (4 * q);
+  for (int i = 0; i < 7; ++i) { tw[i].w = in[tid + i] % q; tw[i].ws = (uint64_t)(((unsigned __int128)tw[i].w << 64) / q); }
+  const HmBflyMod m = hm_bfly_mod(q);
   for (int it = 0; it < ITERS / 2; ++it) {
 #pragma unroll
     for (int jj = 0; jj < 6; ++jj) {
@@ -143,32 +106,32 @@ __global__ void __launch_bounds__(512) k4(uint64_t *out, const uint64_t *in, uin
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         if (e & (1 << pb)) continue;
-        if (jj & 1) mont_bfly_fwd<1>(v[e], v[e | (1 << pb)], tw[(1 << j) - 1 + (e >> (3 - j))], m);
-        else        mont_bfly_fwd<0>(v[e], v[e | (1 << pb)], tw[(1 << j) - 1 + (e >> (3 - j))], m);
+        if (jj & 1) shoup_bfly_fwd_k<1>(v[e], v[e | (1 << pb)], tw[(1 << j) - 1 + (e >> (3 - j))], m);
+        else        shoup_bfly_fwd_k<0>(v[e], v[e | (1 << pb)], tw[(1 << j) - 1 + (e >> (3 - j))], m);
       }
     }
   }
   uint64_t s = 0; for (int i = 0; i < 8; ++i) s ^= v[i] % q;
   out[tid] = s;
 }
-static int run4() {
+template <class K> static int run3(K kern, const char *name, const char *key) {
   const int blocks = 256 * 4, threads = 512;
   const uint64_t q = 1152921092289986561ull;   // (2^28 - 97) 2^32 + 1
   uint64_t *d, *in; CK(hipMalloc(&d, (size_t)blocks * threads * 8)); CK(hipMalloc(&in, (size_t)blocks * threads * 8 * 8 + 64));
   CK(hipMemset(in, 0x5a, (size_t)blocks * threads * 8 * 8 + 64));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int w = 0; w < 40; ++w) hipLaunchKernelGGL(k4, dim3(blocks), dim3(threads), 0, 0, d, in, q);
+  for (int w = 0; w < 40; ++w) hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), 0, 0, d, in, q);  // ~70 ms: clocks settle under load
   CK(hipDeviceSynchronize());
   float best = 1e30f, sum = 0;
   for (int r = 0; r < 5; ++r) {
     CK(hipEventRecord(e0));
-    hipLaunchKernelGGL(k4, dim3(blocks), dim3(threads), 0, 0, d, in, q);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), 0, 0, d, in, q);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms; sum += ms;
   }
   const double wbfly_per_simd = (double)blocks * threads * ITERS * 12 / 64.0 / 1024.0;
-  printf("%-40s %8.3f ms (mean %.3f)  %7.2f cyc@2.4GHz/wave-butterfly/SIMD  mont_wave_butterfly_ns = %.5f  -> %.3f us per 2^16 limb NTT\n",
-         "V4 Montgomery, q = h 2^32 + 1", best, sum / 5, best * 1e-3 * 2.4e9 / wbfly_per_simd, sum / 5 * 1e6 / wbfly_per_simd / 1024.0,
+  printf("%-40s %8.3f ms (mean %.3f)  %7.2f cyc@2.4GHz/wave-butterfly/SIMD  %s (full chip, sustained) = %.5f  -> %.3f us per 2^16 limb NTT\n",
+         name, best, sum / 5, best * 1e-3 * 2.4e9 / wbfly_per_simd, key, sum / 5 * 1e6 / wbfly_per_simd / 1024.0,
          sum / 5 * 1e6 / wbfly_per_simd / 1024.0 * (32768.0 * 16 / 64) * 1e-3);
   CK(hipFree(d)); CK(hipFree(in));
   return 0;
@@ -204,7 +167,7 @@ int main() {
   run<V2<0>>("V2 chain, csub by compare", &s);
   run<V2<1>>("V2 chain, csub by unsigned min", &s);
   run<V2<2>>("V2 chain, csub every other stage", &s);
-  run4();
-  run3();
+  run3(k2s, "V2s round 3: Shoup, csub every other stage", "shoup_wave_butterfly_ns");
+  run3(k3, "V3 shipped: Montgomery, q = h 2^32 + 1", "wave_butterfly_ns");
   return 0;
 }
