@@ -29,10 +29,10 @@ struct HmMod {
   uint64_t r64;     // 2^64 mod q (folds the top word of a 128-bit accumulator)
   uint64_t r64s;    // Shoup companion of r64
   uint64_t ninv;    // N^-1 mod q
-  uint64_t ninvs;   // Shoup companion of ninv
+  uint64_t r128;    // 2^128 mod q: takes a sum of Montgomery products (x y 2^-64) back to x y in one more product
   uint32_t sh;      // k - 1
   uint32_t pad0;
-  uint64_t nqinv;   // -q^-1 mod 2^64 (Montgomery reduction of the base-conversion accumulators)
+  uint64_t nqinv;   // -q^-1 mod 2^64 (kept for callers' tables; the word-wise reductions need only h = q >> 32)
 };
 
 struct HmTw {  // a constant in Shoup form: value and companion (epilogue / prologue / element-wise constants)
@@ -78,17 +78,20 @@ HM_HD uint64_t hm_barrett_wide(hm_u128 z, const HmMod &m) {
   return hm_barrett(f, m);
 }
 
-// Montgomery reduction of a wide accumulator: z -> z * 2^-64 mod q, fully reduced.  m = z_lo * (-q^-1) makes
-// z + m q divisible by 2^64.  About half the instructions of hm_barrett_wide; the 2^-64 is absorbed by constants
+// Montgomery reduction of a wide accumulator: z -> z * 2^-64 mod q, fully reduced.  Two word-wise steps (q = h 2^32 + 1: q^-1 = 1 mod
+// 2^32, a step is one multiply: see hm_mont_acc below): t = (z + m1 q + m2 q 2^32) / 2^64 with m1, m2 <= 2^32, so
+// t < (z >> 64) + q + 2.  About a third of the instructions of hm_barrett_wide; the 2^-64 is absorbed by constants
 // stored as c * 2^64 mod q (base-conversion tables).
-// TERMS = number of products y * w summed into z with y < 2^60 (any input modulus) and w < q: z >> 64 < TERMS * q / 16,
-// i.e. below q for up to 16 terms and below 2q for up to 32; the Montgomery quotient adds less than q + 1: one
-// conditional subtraction for TERMS <= 16, two for <= 32.
+// TERMS = number of products y * w summed into z with y < 2^60 - 2^32 (any input modulus) and w < q: z >> 64 < TERMS * q (1 - 2^-28) / 16,
+// i.e. below q - 2 for up to 16 terms and below 2q - 2 for up to 32: one conditional subtraction for TERMS <= 16, two for <= 32.
 template <int TERMS = 32>
 HM_HD uint64_t hm_redc_wide(hm_u128 z, const HmMod &m) {
   static_assert(TERMS <= 32, "accumulator bound");
   const uint64_t lo = (uint64_t)z, hi = (uint64_t)(z >> 64);
-  uint64_t t = hi + hm_mulhi(lo * m.nqinv, m.q) + (lo != 0);  // the low words cancel; they carry iff lo != 0
+  const uint32_t h = (uint32_t)(m.q >> 32);
+  const uint64_t c = (uint64_t)h + 1;
+  const uint64_t S = (uint64_t)(~(uint32_t)lo) * h + (c + (uint32_t)(lo >> 32));
+  uint64_t t = (uint64_t)(~(uint32_t)S) * h + (hi + c) + (uint32_t)(S >> 32);
   if (TERMS > 16) t = hm_csub(t, 2 * m.q);
   return hm_csub(t, m.q);
 }

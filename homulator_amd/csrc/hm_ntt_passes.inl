@@ -512,54 +512,34 @@ HM_HD void hm_lds_unidx(int w, int &x, int &c) {
 // evk MAC: HPIP src/Components.cpp:571-668, InsGen::GenHPIP src/InsGen.cpp:356-406, KeySwitch::InnerProduceOperation
 // src/Operation.cpp:294-414).  After the ROW pass of digit j (MODE 5) a thread holds 16 coefficients of ext_j in the layout
 // of the pass's last round; hm_ph_mac adds ext_j * evk_{j,k} for both keys to the thread's accumulators, which live in
-// registers across the digits: the extended digit never exists in HBM.  Accumulators are lazy (below 16q, x may be any value below
-// 8q); hm_ph_mac_store reduces once.
+// registers across the digits: the extended digit never exists in HBM.  Accumulators are lazy (below 8q, x may be any value below
+// 2^63); hm_ph_mac_store reduces once.
 // ---------------------------------------------------------------------------------------------------
 // Accumulator forms: uint64_t — every product reduced lazily before it is added (64 registers for both keys); hm_u128 — the raw 128-bit
 // products are summed (12 instructions per product: x < 2q and y < q keep 4 terms below 2^123 once x is brought below 2q) and reduced
 // once per output by hm_barrett, at the price of 128 accumulator registers (two waves per SIMD).
 //
-// The lazy product (HM_NIP_BARRETT = 1, default): Barrett's quotient from two APPROXIMATE high products and no 128-bit shift.  With
-// X = 2x (x < 8q < 2^63) and Y = y 2^(64-k) (y < q < 2^k) the high word of X Y IS floor(x y / 2^(k-1)); hm_shoup_quot gives it and then
-// floor(zh mu / 2^64) from three v_mad_u64_u32 each, at most 2 below the true value.  The estimate never exceeds floor(x y / q) and is
-// at most 2 (Barrett) + 2 (zh) + 2 (second product) = 6 below it, so x y - qe q lies in [0, 7q): about 19 instructions per product
-// against 31 for the exact form (hm_barrett_lazy: full 128-bit product, variable shift, exact high product; [0, 3q)).  Two products fit
-// a word (14q < 16q <= 2^64); from the third term on the accumulator is first brought below 8q (one conditional subtraction per
-// accumulator and digit), so any number of terms stays below 15q; hm_mac_final reduces from below 16q.
-#ifndef HM_NIP_BARRETT
-#define HM_NIP_BARRETT 1
-#endif
+// The lazy product (round 4): the transform's word-wise Montgomery product (hm_mont_acc, q = h 2^32 + 1) with the key word as the
+// constant: acc += x y 2^-64 mod q + {0, q}, six multiplies and 11 instructions where Barrett's quotient from two approximate high
+// products took twelve and 19.  x < 4q (the transform's lazy output; any x below 2^63 is allowed), y < q: a term adds less than
+// 1.5q + 1, so up to five terms stay below 8q <= 2^63 with no folding.  hm_mac_final multiplies the sum by 2^128 mod q the same way
+// (sum 2^-64 2^128 2^-64 = sum) and subtracts q once: 16 instructions per output.
 struct HmMacMod {
-  uint64_t mu, nq, nq8, z;
-  uint32_t ysh;
+  HmBflyMod b;
+  uint64_t r128;
 };
 HM_HD HmMacMod hm_mac_mod(const HmMod &m) {
   HmMacMod r;
-  r.z = hm_opaque_zero();
-  r.mu = m.mu;
-  r.nq = r.z - m.q;
-  r.nq8 = r.z - 8 * m.q;
-  r.ysh = 63 - m.sh;
+  r.b = hm_bfly_mod(m.q);
+  r.r128 = m.r128;
   return r;
 }
-#if defined(HM_ABL_NIP_FAKE_SHOUP)   // timing-only ablation (tools/ablate.sh): the instruction count of a Shoup product, wrong values
-HM_HD void hm_mac_add(uint64_t &acc, uint64_t x, uint64_t y, const HmMod &m, const HmMacMod &mm, bool) {
-  const HmTw t = {y, y * 3 + 1};
-  HmBflyMod b; b.z = mm.z; b.nq = mm.nq;
-  acc = hm_shoup_lazy4_acc(acc, x, t, b);
-}
-#elif HM_NIP_BARRETT == 1
-HM_HD void hm_mac_add(uint64_t &acc, uint64_t x, uint64_t y, const HmMod &, const HmMacMod &mm, bool fold) {
-  if (fold) acc = hm_csub_neg(acc, mm.nq8);                        // [0, 15q) -> [0, 8q)
-  const uint64_t zh = hm_shoup_quot(x << 1, y << mm.ysh, mm.z);    // floor(x y / 2^(k-1)) - {0, 1, 2}
-  const uint64_t qe = hm_shoup_quot(zh, mm.mu, mm.z);              // floor(x y / q) - {0 .. 6}
-  acc = acc + x * y + qe * mm.nq;                                  // + (x y mod q) + {0 .. 6} q, exact in the low word
-}
-#else
-HM_HD void hm_mac_add(uint64_t &acc, uint64_t x, uint64_t y, const HmMod &m, const HmMacMod &, bool) { acc += hm_barrett_lazy((hm_u128)x * y, m); }   // [0, 3q): 4 terms below 12q
-#endif
+HM_HD void hm_mac_add(uint64_t &acc, uint64_t x, uint64_t y, const HmMod &, const HmMacMod &mm, bool) { acc = hm_mont_acc(acc, x, y, mm.b); }
 HM_HD void hm_mac_add(hm_u128 &acc, uint64_t x, uint64_t y, const HmMod &, const HmMacMod &, bool) { acc += (hm_u128)x * y; }
-HM_HD uint64_t hm_mac_final(uint64_t acc, const HmMod &m) { return hm_reduce16(acc, m.q); }
+HM_HD uint64_t hm_mac_final(uint64_t acc, const HmMod &m) {   // acc < 8q
+  const HmBflyMod b = hm_bfly_mod(m.q);
+  return hm_csub_neg(hm_mont_acc(0, acc, m.r128, b), b.nq);   // [0, 1.5q + 1] -> [0, q)
+}
 HM_HD uint64_t hm_mac_final(hm_u128 acc, const HmMod &m) { return hm_barrett(acc, m); }   // 4 terms x (x < 2q) x (y < q) < 2^123
 // [0, 4q) -> [0, 2q): the wide accumulators take transform outputs below 2q, so that the sum stays inside hm_barrett's range
 HM_HD void hm_ph_below_2q(HmNttState &st, uint64_t q) {

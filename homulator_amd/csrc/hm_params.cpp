@@ -101,7 +101,7 @@ void Params::init(uint32_t logN_, uint32_t L_, uint32_t K_, const uint64_t *q, c
       c.nqinv = 0 - x;
     }
     c.ninv = invmod(N, qm);
-    c.ninvs = shoup(c.ninv, qm);
+    c.r128 = mulmod(c.r64, c.r64, qm);
   }
 }
 
