@@ -111,6 +111,14 @@ HM_HD uint64_t hm_opaque_zero() {
   return z;
 }
 
+// keeps a value as computed: the optimiser cannot look through the empty statement (no instruction is emitted)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(HM_NO_PIN)
+#define HM_PIN(x) asm("" : "+v"(x))
+#define HM_PIN64(x) asm("" : "+v"(x))
+#else
+#define HM_PIN(x) ((void)0)
+#define HM_PIN64(x) ((void)0)
+#endif
 // Per-modulus constants of the lazy butterflies and products (wave-uniform, SGPRs)
 struct HmBflyMod {
   uint64_t q2, q4, nq, nq2, nq4, nq8, cc, z;
@@ -119,7 +127,7 @@ struct HmBflyMod {
 HM_HD HmBflyMod hm_bfly_mod(uint64_t q) {
   HmBflyMod m;
   m.z = hm_opaque_zero();
-  m.q2 = 2 * q;
+  m.q2 = m.z + 2 * q;   // (opaque: (x << 1) + 2q stays ONE v_lshl_add_u64 instead of (x + q) << 1)
   m.q4 = 4 * q;
   m.nq = m.z - q;
   m.nq2 = m.z - 2 * q;
@@ -165,12 +173,14 @@ HM_HD uint64_t hm_csub_neg(uint64_t x, uint64_t nm) {
 HM_HD uint64_t hm_mont_acc(uint64_t c, uint64_t x, uint64_t wt, const HmBflyMod &m) {
   const uint32_t b0 = (uint32_t)x, b1 = (uint32_t)(x >> 32), w0 = (uint32_t)wt, w1 = (uint32_t)(wt >> 32);
   const uint64_t P = (uint64_t)b0 * w0 + m.z;
-  const uint32_t n0 = ~(uint32_t)P;
+  uint32_t n0 = ~(uint32_t)P;
   uint64_t A = (uint64_t)b0 * w1 + m.cc;
+  HM_PIN(n0); HM_PIN64(A);   // (hipcc otherwise re-associates the complement and the constant into a longer sequence: 19 instead of 15 instructions)
   A = (uint64_t)b1 * w0 + A;
   A = (uint64_t)n0 * m.h + A;
   const uint64_t S = A + (uint32_t)(P >> 32);
-  const uint32_t n1 = ~(uint32_t)S;
+  uint32_t n1 = ~(uint32_t)S;
+  HM_PIN(n1);
   uint64_t B = (uint64_t)b1 * w1 + c;
   B = (uint64_t)n1 * m.h + B;
   return B + (uint32_t)(S >> 32);

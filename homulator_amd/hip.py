@@ -147,7 +147,7 @@ class Context:
     """One GPU, one parameter set.  Thin, 1:1 with the C ABI."""
 
     def __init__(self, logN, L, K, device=0, q=None, p=None):
-        """q / p: the L chain moduli and the K special moduli (primes = 1 mod 2N below 2^60); default: the library's own chain"""
+        """q / p: the L chain moduli and the K special moduli (primes = 1 mod 2^32 below 2^60); default: the library's own chain"""
         self.L = load()
         self.h = C.c_void_p()
         qa = None if q is None else np.ascontiguousarray(np.asarray(q, dtype=np.uint64))

@@ -25,8 +25,11 @@ enum { HM_OK = 0, HM_ERR_ARG = 1, HM_ERR_HIP = 2, HM_ERR_UNSUPPORTED = 3, HM_ERR
 
 /* Parameter set.  N = 2^logN (13..17), L Q-primes, K special primes (the reference sizes the special
  * basis as exactly alpha limbs, src/Operation.cpp:160,193,297-304).  q == NULL selects the default
- * chain: the L+K largest primes below 2^60 that are 1 mod 2N, descending, first L = Q, next K = P;
- * psi == NULL selects the smallest primitive 2N-th root of each prime.  "mod id" m: m < L -> q[m],
+ * chain: the L+K largest primes below 2^60 that are 1 mod 2^32 (hence 1 mod 2N), descending, first L = Q,
+ * next K = P; psi == NULL selects the smallest primitive 2N-th root of each prime.  Explicit moduli must be
+ * distinct primes q = h 2^32 + 1 below 2^60 as well: the transforms reduce word-wise in Montgomery form, and
+ * q^-1 = 1 mod 2^32 makes a reduction step one multiply (six 32-bit multiplies per butterfly instead of nine);
+ * hm_create fails with the modulus in hm_last_error otherwise.  "mod id" m: m < L -> q[m],
  * m >= L -> p[m-L].  Replaces: Arch::Arch(Config*) include/Arch.h:154 / src/Arch.cpp:8-168 (the
  * construction of the execution resources from N / cluster). */
 typedef struct hm_params {

@@ -27,7 +27,7 @@ typedef struct ho_ctx ho_ctx;
 
 /* Parameter set: N = 2^logN, L Q-primes q_0..q_{L-1}, K special primes p_0..p_{K-1} (the reference
  * sizes the special basis as exactly alpha limbs: src/Operation.cpp:160,193,297-304).
- * Primes: the L+K largest primes below 2^60 that are 1 mod 2N, in descending order; the first L
+ * Primes: the L+K largest primes below 2^60 that are 1 mod 2^32 (hence 1 mod 2N), in descending order; the first L
  * are Q, the next K are P.  psi = smallest primitive 2N-th root of unity of each prime.
  * "mod id" m: m < L -> q_m ; m >= L -> p_{m-L}. */
 ho_ctx *ho_create(uint32_t logN, uint32_t L, uint32_t K);
