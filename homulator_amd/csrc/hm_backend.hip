@@ -1522,15 +1522,15 @@ static hm_status ntt_common(hm_ctx *c, const char *what, const uint64_t *in, con
         if (inverse) {
           uint64_t v = c->P.modc[m].ninv;
           if (k) v = hm::mulmod(v, k[g], q);
-          t.sc = HmTw{v, hm::shoup(v, q)};
+          t.sc = HmTw{hm_to_mont(v, q), 0};
         } else if (fused) {
-          t.sc = HmTw{k[g], hm::shoup(k[g], q)};
+          t.sc = HmTw{hm_to_mont(k[g], q), 0};
           a.limb[e].aux = (uint16_t)limb_at(f.minuend_limbs, g);
           t.alimb = f.addend_limbs && f.addend_limbs[g] == HM_NO_LIMB ? (uint16_t)HM_NTT_NONE : (uint16_t)limb_at(f.addend_limbs, g);
-          if (f.addend_k) t.ak = HmTw{f.addend_k[g], hm::shoup(f.addend_k[g], q)};
+          if (f.addend_k) t.ak = HmTw{hm_to_mont(f.addend_k[g], q), 0};
           if (f.mix) {
             t.mixlimb = (uint16_t)limb_at(f.mix_limbs, g);
-            t.mixk = HmTw{f.mix_k[g], hm::shoup(f.mix_k[g], q)};
+            t.mixk = HmTw{hm_to_mont(f.mix_k[g], q), 0};
           }
         }
       }
@@ -1637,15 +1637,15 @@ static hm_status ntt_common(hm_ctx *c, const char *what, const uint64_t *in, con
         if (inverse) {
           uint64_t v = c->P.modc[m].ninv;
           if (k) v = hm::mulmod(v, k[g], q);
-          t.sc = HmTw{v, hm::shoup(v, q)};
+          t.sc = HmTw{hm_to_mont(v, q), 0};
         } else if (fused) {
-          t.sc = HmTw{k[g], hm::shoup(k[g], q)};
+          t.sc = HmTw{hm_to_mont(k[g], q), 0};
           a.limb[e].aux = (uint16_t)limb_at(f.minuend_limbs, g);
           t.alimb = f.addend_limbs && f.addend_limbs[g] == HM_NO_LIMB ? (uint16_t)HM_NTT_NONE : (uint16_t)limb_at(f.addend_limbs, g);
-          if (f.addend_k) t.ak = HmTw{f.addend_k[g], hm::shoup(f.addend_k[g], q)};
+          if (f.addend_k) t.ak = HmTw{hm_to_mont(f.addend_k[g], q), 0};
           if (f.mix) {
             t.mixlimb = (uint16_t)limb_at(f.mix_limbs, g);
-            t.mixk = HmTw{f.mix_k[g], hm::shoup(f.mix_k[g], q)};
+            t.mixk = HmTw{hm_to_mont(f.mix_k[g], q), 0};
           }
         }
       }
@@ -2234,7 +2234,7 @@ static hm_status bconv_col_launch(hm_ctx *c, const hm_bconv_desc *descs, uint32_
         const uint64_t q = c->P.mod[d.out_ids[t]], k = mix->mix_k[pi][t];
         if (k >= q) return fail(c, HM_ERR_ARG, "fused conversion: mix constant [%u][%u] is not reduced", pi, t);
         if (mix->mix_limbs[pi][t] > 0xFFFFu) return fail(c, HM_ERR_ARG, "fused conversion: limb index exceeds 65535");
-        mk[t] = HmTw{k, hm::shoup(k, q)};
+        mk[t] = HmTw{hm_to_mont(k, q), 0};
         p.mix_limb[t] = mix->mix_limbs[pi][t];
       }
       const void *dk = nullptr;

@@ -57,8 +57,8 @@ __device__ __forceinline__ void hm_bcol_convert(const uint32_t (&yl)[2][N_IN], c
 #endif
     uint64_t b0, b1;
     hm_gld2<G0>(mixp, tile, tid, u, b0, b1);
-    r0v = hm_addmod(r0v, hm_shoup(b0, mk.w, mk.ws, m.q), m.q);
-    r1v = hm_addmod(r1v, hm_shoup(b1, mk.w, mk.ws, m.q), m.q);
+    r0v = hm_addmod(r0v, hm_mont_const_mul(b0, mk.w, m.q), m.q);
+    r1v = hm_addmod(r1v, hm_mont_const_mul(b1, mk.w, m.q), m.q);
   }
 }
 template <int TL, int LOG1>

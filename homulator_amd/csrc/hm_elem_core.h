@@ -71,10 +71,17 @@ struct HmTensorArgs {
   uint32_t logN, n_limbs;
   HmTensorLimb limb[HM_MAX_LIMBS];
 };
+// Round 4: on the word-wise Montgomery product (hm_mont_acc, q = h 2^32 + 1).  b and d are taken to Montgomery form once (a product
+// with 2^128 mod q: b 2^64 mod q + {0, q}, below 1.5q + 1), then the four products are exact: x wt 2^-64 with wt = b 2^64 is x b.  Six
+// products of 11 instructions + four subtractions where three Barrett reductions of full 128-bit products took about twice as many.
+// A product with an operand below q and a constant below 1.5q + 1 comes out below 1.1q + 1.
 HM_HD void hm_tensor_one(uint64_t a, uint64_t b, uint64_t c, uint64_t d, const HmMod &m, uint64_t &d0, uint64_t &d1, uint64_t &d2) {
-  d0 = hm_mulmod(a, b, m);
-  d1 = hm_barrett((hm_u128)a * d + (hm_u128)c * b, m);
-  d2 = hm_mulmod(c, d, m);
+  const HmBflyMod bm = hm_bfly_mod(m.q);
+  const uint64_t bt = hm_mont_acc(0, b, m.r128, bm), dt = hm_mont_acc(0, d, m.r128, bm);
+  d0 = hm_csub_neg(hm_mont_acc(0, a, bt, bm), bm.nq);
+  d2 = hm_csub_neg(hm_mont_acc(0, c, dt, bm), bm.nq);
+  d1 = hm_mont_acc(hm_mont_acc(0, a, dt, bm), c, bt, bm);   // below 2.2q + 2
+  d1 = hm_csub_neg(hm_csub_neg(d1, bm.nq2), bm.nq);
 }
 
 // ---- K5 inner product with the evaluation key (the reference's HPIP unit: InsGen::GenHPIP src/InsGen.cpp:356-406,

@@ -185,6 +185,12 @@ HM_HD uint64_t hm_mont_acc(uint64_t c, uint64_t x, uint64_t wt, const HmBflyMod 
   B = (uint64_t)n1 * m.h + B;
   return B + (uint32_t)(S >> 32);
 }
+// x k mod q, fully reduced, for a constant held in Montgomery form kt = k 2^64 mod q and any x below 2^63 (the per-launch constants of the
+// transforms' prologues and epilogues: 15 instructions where the exact Shoup product took about 20, one of them a quarter-rate v_mul_hi_u32)
+HM_HD uint64_t hm_mont_const_mul(uint64_t x, uint64_t kt, uint64_t q) {
+  const HmBflyMod m = hm_bfly_mod(q);
+  return hm_csub_neg(hm_mont_acc(0, x, kt, m), m.nq);
+}
 // w 2^64 mod q on the host (table generation)
 HM_HD uint64_t hm_to_mont(uint64_t w, uint64_t q) { return (uint64_t)(((hm_u128)w << 64) % q); }
 

@@ -222,8 +222,8 @@ HM_HD void hm_ph_load_global_mix(HmNttState &st, int tid, const uint64_t *g, uin
     uint64_t p0, p1, b0, b1;
     hm_gld2<G, AUX>(g, tile, tid, a, p0, p1);
     hm_gld2<G, AUX>(ep.b, tile, tid, a, b0, b1);
-    st.v[i0] = hm_addmod(p0, hm_shoup(b0, ep.bk.w, ep.bk.ws, q), q);
-    st.v[i1] = hm_addmod(p1, hm_shoup(b1, ep.bk.w, ep.bk.ws, q), q);
+    st.v[i0] = hm_addmod(p0, hm_mont_const_mul(b0, ep.bk.w, q), q);
+    st.v[i1] = hm_addmod(p1, hm_mont_const_mul(b1, ep.bk.w, q), q);
   }
 }
 
@@ -232,13 +232,14 @@ HM_HD void hm_ph_load_global_mix(HmNttState &st, int tid, const uint64_t *g, uin
 // the epilogue of one coefficient.  MODE 0 / 4: store as is (lazy values, hand-off between the two passes; 4 = first
 // pass with the mix prologue); 1: forward final, reduce [0,4q) -> [0,q); 2: inverse final, multiply by the per-limb
 // constant and reduce to [0,q); 3: forward final fused with out = (minuend - x) * k [+ addend [* ak]]
+// (sc, ep.dk, ep.bk: HmTw records whose .w holds the constant in MONTGOMERY form, k 2^64 mod q: hm_mont_const_mul; .ws is unused)
 template <int MODE>
 HM_HD uint64_t hm_epilogue(uint64_t a, uint64_t va, uint64_t vd, uint64_t q, HmTw sc, const HmEpi &ep) {
   if (MODE == 1) return hm_reduce4(a, q);
-  if (MODE == 2) return hm_shoup(a, sc.w, sc.ws, q);
-  if (MODE == 3) {  // a in [0, 4q): minuend - a + 8q stays positive and below 2^64; the product reduces it
-    a = hm_shoup(va + 8 * q - a, sc.w, sc.ws, q);
-    if (ep.d) a = hm_addmod(a, ep.dk.w ? hm_shoup(vd, ep.dk.w, ep.dk.ws, q) : vd, q);
+  if (MODE == 2) return hm_mont_const_mul(a, sc.w, q);
+  if (MODE == 3) {  // a in [0, 4q): minuend - a + 4q stays positive and below 5q < 2^63; the product reduces it
+    a = hm_mont_const_mul(va + 4 * q - a, sc.w, q);
+    if (ep.d) a = hm_addmod(a, ep.dk.w ? hm_mont_const_mul(vd, ep.dk.w, q) : vd, q);
   }
   return a;
 }
@@ -303,8 +304,8 @@ HM_HD void hm_ph_load_lds_mix(HmNttState &st, int tid, const uint64_t *lds, uint
     uint64_t p0, p1, b0, b1;
     hm_gld2<G, AUX>(ep.b, tile, tid, a, b0, b1);
     hm_ld2(lds + hm_lds_idx<TL, LOGR, STRIDED>(x, c), p0, p1);
-    st.v[i0] = hm_addmod(p0, hm_shoup(b0, ep.bk.w, ep.bk.ws, q), q);
-    st.v[i1] = hm_addmod(p1, hm_shoup(b1, ep.bk.w, ep.bk.ws, q), q);
+    st.v[i0] = hm_addmod(p0, hm_mont_const_mul(b0, ep.bk.w, q), q);
+    st.v[i1] = hm_addmod(p1, hm_mont_const_mul(b1, ep.bk.w, q), q);
   }
 }
 template <int TL, int LOGR, bool STRIDED, int R>
@@ -459,8 +460,8 @@ HM_HD void hm_ntt_phase_lds0(HmNttState &st, int tid, const uint64_t *lds, const
     uint64_t p0, p1;
     hm_ld2(lds + hm_lds_idx<TL, LOGR, STRIDED>(x, c), p0, p1);
     if (MODE == 4) {
-      st.v[i0] = hm_addmod(p0, hm_shoup(st.v[i0], ep.bk.w, ep.bk.ws, q), q);
-      st.v[i1] = hm_addmod(p1, hm_shoup(st.v[i1], ep.bk.w, ep.bk.ws, q), q);
+      st.v[i0] = hm_addmod(p0, hm_mont_const_mul(st.v[i0], ep.bk.w, q), q);
+      st.v[i1] = hm_addmod(p1, hm_mont_const_mul(st.v[i1], ep.bk.w, q), q);
     } else { st.v[i0] = p0; st.v[i1] = p1; }
   }
 }

@@ -165,7 +165,7 @@ int emu_ntt(void *h, uint32_t mod, const uint64_t *in, uint64_t *out, int invers
   Emu &e = *(Emu *)h;
   uint64_t q = e.P.mod[mod], k = e.P.modc[mod].ninv;
   if (has_scale) k = hm::mulmod(k, scale, q);
-  HmTw sc = {k, hm::shoup(k, q)};
+  HmTw sc = {hm_to_mont(k, q), 0};
   switch (e.P.logN - HM_ROW_LOG) {
   case 5: run_ntt<G16, 5>(e, mod, in, out, inverse, sc); break;
   case 6: run_ntt<G16, 6>(e, mod, in, out, inverse, sc); break;
@@ -181,7 +181,7 @@ int emu_ntt(void *h, uint32_t mod, const uint64_t *in, uint64_t *out, int invers
 int emu_ntt_dma(void *h, uint32_t mod, const uint64_t *in, uint64_t *out, int inverse, int geo8) {
   Emu &e = *(Emu *)h;
   const uint64_t q = e.P.mod[mod], k = e.P.modc[mod].ninv;
-  HmTw sc = {k, hm::shoup(k, q)};
+  HmTw sc = {hm_to_mont(k, q), 0};
   if (geo8) {
     if (e.P.logN != 16) return 1;
     run_ntt_dma<G8, 8>(e, mod, in, out, inverse, sc);
@@ -203,11 +203,11 @@ int emu_ntt_sub_scale(void *h, uint32_t mod, const uint64_t *in, const uint64_t 
                       uint64_t k, const uint64_t *mix, uint64_t mix_k, uint64_t addend_k) {
   Emu &e = *(Emu *)h;
   const uint64_t q = e.P.mod[mod];
-  HmTw sc = {k, hm::shoup(k, q)};
+  HmTw sc = {hm_to_mont(k, q), 0};
   HmEpi ep = hm_epi_none();
   ep.a = minuend; ep.d = addend;
-  if (addend_k) ep.dk = HmTw{addend_k, hm::shoup(addend_k, q)};
-  if (mix) { ep.b = mix; ep.bk = HmTw{mix_k, hm::shoup(mix_k, q)}; }
+  if (addend_k) ep.dk = HmTw{hm_to_mont(addend_k, q), 0};
+  if (mix) { ep.b = mix; ep.bk = HmTw{hm_to_mont(mix_k, q), 0}; }
   switch (e.P.logN - HM_ROW_LOG) {
 #define HM_CASE(n) case n: if (mix) run_pass<G16, n, true, false, 4>(e, mod, in, out, sc, ep); else run_pass<G16, n, true, false, 0>(e, mod, in, out, sc); break;
     HM_CASE(5) HM_CASE(6) HM_CASE(7) HM_CASE(8) HM_CASE(9)
@@ -223,7 +223,7 @@ int emu_ntt8(void *h, uint32_t mod, const uint64_t *in, uint64_t *out, int inver
   if (e.P.logN != 16) return 1;
   uint64_t q = e.P.mod[mod], k = e.P.modc[mod].ninv;
   if (has_scale) k = hm::mulmod(k, scale, q);
-  run_ntt<G8, 8>(e, mod, in, out, inverse, HmTw{k, hm::shoup(k, q)});
+  run_ntt<G8, 8>(e, mod, in, out, inverse, HmTw{hm_to_mont(k, q), 0});
   return 0;
 }
 int emu_ntt_sub_scale8(void *h, uint32_t mod, const uint64_t *in, const uint64_t *minuend, const uint64_t *addend, uint64_t *out,
@@ -231,11 +231,11 @@ int emu_ntt_sub_scale8(void *h, uint32_t mod, const uint64_t *in, const uint64_t
   Emu &e = *(Emu *)h;
   if (e.P.logN != 16) return 1;
   const uint64_t q = e.P.mod[mod];
-  HmTw sc = {k, hm::shoup(k, q)};
+  HmTw sc = {hm_to_mont(k, q), 0};
   HmEpi ep = hm_epi_none();
   ep.a = minuend; ep.d = addend;
-  if (addend_k) ep.dk = HmTw{addend_k, hm::shoup(addend_k, q)};
-  if (mix) { ep.b = mix; ep.bk = HmTw{mix_k, hm::shoup(mix_k, q)}; }
+  if (addend_k) ep.dk = HmTw{hm_to_mont(addend_k, q), 0};
+  if (mix) { ep.b = mix; ep.bk = HmTw{hm_to_mont(mix_k, q), 0}; }
   if (mix) run_pass<G8, 8, true, false, 4>(e, mod, in, out, sc, ep); else run_pass<G8, 8, true, false, 0>(e, mod, in, out, sc);
   run_pass<G8, HM_ROW_LOG, false, false, 3>(e, mod, out, out, sc, ep);
   return 0;

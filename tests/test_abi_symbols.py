@@ -33,6 +33,28 @@ def test_create_fails_loudly_without_gpu():
     assert "no HIP device" in str(e.value) or "hip" in str(e.value).lower()
 
 
+def test_create_refuses_moduli_that_are_not_1_mod_2_32():
+    """hm_create validates the chain before it touches the device: a prime that is 1 mod 2N but not 1 mod 2^32 (the chain rule of rounds
+    1-3) is refused with HM_ERR_ARG and named in the message; a chain of the required form passes the check (and then fails on the
+    missing device here, or builds a context on a GPU box)"""
+    import pytest
+    from homulator_amd import hip
+    old_rule = 1152921504606584833          # 2^60 - 2^18 + 1: prime, 1 mod 2^17, not 1 mod 2^32
+    with pytest.raises(hip.HmError) as e:
+        hip.Context(13, 1, 1, q=[old_rule], p=[0xfffffa000000001])
+    assert "2^32" in str(e.value) and str(old_rule) in str(e.value)
+    with pytest.raises(hip.HmError) as e:   # composite of the right form
+        hip.Context(13, 1, 1, q=[(1 << 32) + 1], p=[0xfffffa000000001])
+    assert "2^32" in str(e.value)
+    try:
+        ctx = hip.Context(13, 1, 1, q=[0xfffff8800000001], p=[0xfffffa000000001])
+    except hip.HmError as ex:
+        assert "no HIP device" in str(ex) or "hip" in str(ex).lower()
+    else:
+        assert ctx.moduli == [0xfffff8800000001, 0xfffffa000000001]
+        ctx.close()
+
+
 def test_fat_binary_targets_gfx950():
     """The hipcc wrapper silently falls back to gfx906 under some flag combinations: check the embedded code object."""
     from homulator_amd import hip
