@@ -121,6 +121,9 @@ __device__ __forceinline__ void hm_ntt_pass_body(const HmNttArgs &a) {
   uint32_t entry, tile;
   if (!hm_block_map(1u << (a.logN - TL), a.n_limbs, a.logG, entry, tile)) return;
   if (a.limb[entry].mod == HM_NTT_NONE) return;
+#if defined(HM_ABL_EMPTY)   // timing-only ablation: launch, dispatch and the block map only
+  return;
+#endif
   hm_ntt_pass_run<LOGR, STRIDED, INV, MODE, 0, 0, HM_EPI_CHUNK, GEO>(a, lds, entry, tile, threadIdx.x);
 }
 
