@@ -82,7 +82,8 @@ def measure_ntt_inop(batch, iters=12, sets=2):
 
 def measure_ntt_sweep(n_limbs, iters=48, sets=6):
     """forward NTT sweep over the extended basis (l + alpha limbs): device time per sweep, HIP events on the
-    backend stream.  One sweep = one hm_ntt call = the two pass kernels k_ntt_col + k_ntt_row.
+    backend stream.  One sweep = one hm_ntt call = ONE launch (k_ntt_fused8: both passes, the hand-off through the XCD's L2 behind a
+    rendezvous on XCD-local atomics; launches above 96 limb-polys run the two pass kernels k_ntt_col + k_ntt_row).
     The sweeps rotate over `sets` input/output buffer pairs (6 x 2 x 26 MB = 315 MB > the 256 MiB Infinity Cache), so
     that every sweep reads its input from HBM rather than from a cache the previous replay left warm."""
     from homulator_amd import hip
@@ -392,7 +393,7 @@ def main():
             "roofline": {"bound": "valu" if valu_floor_ns and valu_floor_ns > hbm_floor_ns else "hbm",   # the ceiling with the larger floor for this launch, measured
                          "contract_bound": "hbm",   # ... `achieved` / `peak` / `frac` / `traffic` are the HBM figures the task's contract asks for, whatever binds
                          "binding_ceiling": "valu" if valu_floor_ns and valu_floor_ns > hbm_floor_ns else "hbm",
-                         "kernel": "forward NTT sweep, 50 limbs = k_ntt_col + k_ntt_row",
+                         "kernel": "forward NTT sweep, 50 limbs = ONE launch, k_ntt_fused8<false, 0, 1> (COL pass, per-limb rendezvous on XCD-local atomics, ROW pass)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": rin.get("ntt_sweep50_traffic_bytes") if sweep_limbs == 50 else None, "us_per_launch": ntt_ns * 1e-3,
                          "algorithmic_bytes_per_launch": NTT_ALG_BYTES * sweep_limbs,
@@ -410,10 +411,9 @@ def main():
                          "real_traffic": {
                              "floor_bytes_per_limb_ntt": 4 * LP,
                              "note": "a limb-poly (512 KiB) does not fit one CU's LDS (160 KiB), so a transform is two passes through global memory with a hand-off between "
-                                     "them; as two kernels the hand-off crosses the fabric twice (4 limb-polys per limb-NTT + row twiddles = `traffic`).  Round 4's counters "
-                                     "(profiles/r04_l2_handoff.txt, r04_ntt_queue.txt) withdraw round 3's claim: the L2 is write-back and a hand-off kept inside one launch with <= 3 MiB live "
-                                     "per XCD saves its write, and in place also its read (50-limb sweep 116 -> 79 MB) — but the persistent kernels that do so run slower than the two "
-                                     "kernels (dependency waits, per-item control latency), so the shipped sweep keeps the two-kernel traffic"},
+                                     "them (4 limb-polys per limb-NTT + row twiddles = the floor above).  Since round 4 launches of up to 96 limb-polys run both passes in ONE kernel: the "
+                                     "workgroups of a limb-poly share an XCD, meet at a counter in that XCD's L2 (returning atomics without the agent-scope bit) and read the hand-off "
+                                     "from the L2 that holds it (write-back: profiles/r04_l2_handoff.txt); larger launches stay two kernels, where the rendezvous costs more than it saves"},
                          "note": "`achieved`/`peak`/`frac`/`traffic` are the HBM figures of the task's contract (`contract_bound`); `bound` names the ceiling "
                                  "with the larger floor for this launch (the 64-bit modular butterflies are integer VALU work)"},
         }

@@ -176,10 +176,24 @@ __global__ void __launch_bounds__((1 << HM_TL_ROW) / 8) k_ntt_row8(HmNttArgs a) 
 // co-resident: they are neighbours in dispatch order (consecutive slots of one XCD hold a group of limb-polys), so with
 // workgroups dispatched in order the oldest unfinished limb of an XCD is always fully dispatched; the spin is bounded all
 // the same, and a timeout is reported through the context (hm_sync fails) instead of hanging the GPU.
+// Round 4 (second half): the rendezvous runs on XCD-LOCAL atomics.  An agent-scope atomic or load is a round trip to memory (the L2s of
+// the eight XCDs are not coherent with each other): arrival + polls cost the one-launch transform 16 us at 50 limb-polys (51 against 35 us
+// for two kernels).  All workgroups of a limb-poly run on ONE XCD (hm_block_map; checked per workgroup against HW_REG_XCC_ID), so their
+// counter can live in that XCD's L2: returning atomics WITHOUT the agent-scope bit (`global_atomic_add_x2 ... sc0`) execute there.  One
+// 128-byte line per limb-poly (a line shared with a limb-poly of another XCD would be modified in two L2s at once): low word = arrivals,
+// high word = leavers; the last leaver swaps it back to zero.  Should the dispatcher ever spread a limb-poly's workgroups over XCDs (it
+// promises nothing), no copy of the counter reaches the member count; the waiting workgroups find out through an agent-scope mask of XCC
+// ids and everybody takes the agent-scope path: release (L2 write-back), a second rendezvous on an agent-scope counter, acquire — slow,
+// still right (never seen: counter `ntt_cross_xcd`).
+struct HmLimbSync {
+  unsigned long long w;        // XCD-local atomics only
+  unsigned long long pad[15];
+};
 struct HmNttSync {
-  unsigned long long arrive[HM_NTT_MAX_ENTRIES];   // bits 0..7 arrivals, 6 bits per XCD above: arrivals from that XCD
-  unsigned long long arrive2[HM_NTT_MAX_ENTRIES];  // second rendezvous of the agent-scope path
-  unsigned done[HM_NTT_MAX_ENTRIES];               // workgroups that left the limb-poly: the last one zeroes its three words
+  HmLimbSync fast[HM_NTT_MAX_ENTRIES];
+  unsigned long long arrive2[HM_NTT_MAX_ENTRIES];  // rendezvous of the agent-scope path
+  unsigned done[HM_NTT_MAX_ENTRIES];               // agent-scope path: workgroups that left the limb-poly; the last one zeroes the agent-scope words
+  unsigned xccmask[HM_NTT_MAX_ENTRIES];            // agent-scope: XCC ids of the workgroups that had to wait (two bits set: the limb-poly is spread over XCDs)
   unsigned stats[4];                               // [0] limb-polys that took the agent-scope path (diagnostic)
 };
 #define HM_SPIN_LIMIT (1u << 22)
@@ -193,30 +207,50 @@ struct HmNttSync {
 #define HM_FUSED_OUT_AUX 0   // cache policy of the second pass's output stores (2 = nt)
 #endif
 #ifndef HM_FUSED_MID_AUX
-#define HM_FUSED_MID_AUX 16  // the hand-off loads: sc1
+#define HM_FUSED_MID_AUX 16  // the hand-off loads: sc1 (past the CU's vector L1, which another CU's stores never refresh)
 #endif
 __device__ __forceinline__ unsigned hm_xcc_id() {
   unsigned v;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(v));
   return v & 7u;
 }
-// all `members` workgroups of limb-poly `entry` have stored their hand-off.  Returns true if they all run on this XCD.
-__device__ __forceinline__ bool hm_limb_rendezvous(HmNttSync *ws, unsigned *err, uint32_t entry, uint32_t members, uint32_t *lds_flag) {
+// returning atomics executed in the L2 of the XCD the wave runs on (no sc1: not agent scope)
+__device__ __forceinline__ unsigned long long hm_l2_add(unsigned long long *p, unsigned long long v) {
+  unsigned long long old;
+  asm volatile("global_atomic_add_x2 %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(old) : "v"(p), "v"(v) : "memory");
+  return old;
+}
+__device__ __forceinline__ void hm_l2_zero(unsigned long long *p) {
+  unsigned long long old, z = 0;
+  asm volatile("global_atomic_swap_x2 %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(old) : "v"(p), "v"(z) : "memory");
+}
+// all `members` workgroups of limb-poly `entry` have stored their hand-off.  Returns 1 if they all run on this XCD and met on the
+// XCD-local counter, 0 if the limb-poly is spread over several XCDs (then no copy of the counter ever reaches `members`).  Which XCD a
+// block id lands on is the dispatcher's business (blocks b and b + 8 share one, but not necessarily XCD b mod 8), so a spread is found
+// by publication: a workgroup whose first poll fails ORs its XCC id into the limb-poly's agent-scope mask (not returning: no round trip
+// for the workgroup, which is waiting anyway; the last arriver never gets that far) and looks at the mask every 16th spin.
+__device__ __forceinline__ uint32_t hm_limb_rendezvous(HmNttSync *ws, unsigned *err, uint32_t entry, uint32_t members, uint32_t *lds_flag) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave: its stores have reached L2
   __syncthreads();
   if (threadIdx.x == 0) {
-    const unsigned xcc = hm_xcc_id();
-    __hip_atomic_fetch_add(&ws->arrive[entry], 1ull | (1ull << (8 + 6 * xcc)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned long long v;
+    unsigned long long *w = &ws->fast[entry].w;
+    uint32_t fast = 0;
+    (void)hm_l2_add(w, 1ull);
     unsigned spins = 0;
-    while (((v = __hip_atomic_load(&ws->arrive[entry], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0xFFull) < members) {
-      __builtin_amdgcn_s_sleep(4);
+    for (;;) {
+      if ((uint32_t)hm_l2_add(w, 0ull) == members) { fast = 1; break; }
+      if (spins == 0) (void)__hip_atomic_fetch_or(&ws->xccmask[entry], 1u << hm_xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else if ((spins & 15u) == 15u) {
+        const unsigned m = __hip_atomic_load(&ws->xccmask[entry], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (m & (m - 1u)) break;   // two XCDs: everybody takes the agent-scope path
+      }
+      __builtin_amdgcn_s_sleep(1);
       if (++spins > HM_SPIN_LIMIT) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
     }
-    *lds_flag = ((v >> (8 + 6 * xcc)) & 0x3Full) == members;
+    *lds_flag = fast;
   }
   __syncthreads();
-  return *lds_flag != 0;
+  return *lds_flag;
 }
 // the agent-scope path: make the hand-off visible to every XCD
 __device__ __forceinline__ void hm_limb_publish_everywhere(HmNttSync *ws, unsigned *err, uint32_t entry, uint32_t members) {
@@ -234,14 +268,22 @@ __device__ __forceinline__ void hm_limb_publish_everywhere(HmNttSync *ws, unsign
   }
   __syncthreads();
 }
-// leave the limb-poly: the last workgroup out zeroes the words for the next launch (everybody has finished polling)
-__device__ __forceinline__ void hm_limb_leave(HmNttSync *ws, uint32_t entry, uint32_t members, bool slow) {
+// leave the limb-poly: the last leaver of an XCD-local counter zeroes it (arrivals are final by then: in either mode every workgroup has
+// passed a rendezvous) and, when everybody met there, the agent-scope mask; on the agent-scope path the last workgroup out zeroes the
+// agent-scope words for the next launch
+__device__ __forceinline__ void hm_limb_leave(HmNttSync *ws, uint32_t entry, uint32_t members, uint32_t fast) {
   if (threadIdx.x == 0) {
-    if (__hip_atomic_fetch_add(&ws->done[entry], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1) {
-      __hip_atomic_store(&ws->arrive[entry], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long *w = &ws->fast[entry].w;
+    const unsigned long long old = hm_l2_add(w, 1ull << 32);
+    if ((uint32_t)(old >> 32) + 1u == (uint32_t)old) {
+      hm_l2_zero(w);
+      if (fast) __hip_atomic_store(&ws->xccmask[entry], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (!fast && __hip_atomic_fetch_add(&ws->done[entry], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1) {
       __hip_atomic_store(&ws->arrive2[entry], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&ws->xccmask[entry], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(&ws->done[entry], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (slow) __hip_atomic_fetch_add(&ws->stats[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(&ws->stats[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -250,29 +292,39 @@ struct HmNttFusedArgs {
   unsigned *err;   // host-visible word: 0 = fine, 1 / 2 = a rendezvous timed out
 };
 // MODE_A: first pass (0, or 4 = mix prologue); MODE_B: last pass (1 forward, 3 fused epilogue, 2 inverse)
-template <int LOG1, bool INV, int MODE_A, int MODE_B>
-__global__ void __launch_bounds__((1 << HM_TL_ROW) / HM_EPT) __attribute__((amdgpu_waves_per_eu(HM_NTT_MIN_WAVES))) k_ntt_fused(HmNttArgs a, HmNttFusedArgs f) {
+template <int LOG1, bool INV, int MODE_A, int MODE_B, class GEO>
+__device__ __forceinline__ void hm_ntt_fused_body(const HmNttArgs &a, const HmNttFusedArgs &f) {
   static_assert(HM_TL_COL == HM_TL_ROW, "the one-launch transform keeps a workgroup on tile t of both passes");
   constexpr int TL = HM_TL_ROW;
-  constexpr int W1 = HmLds<TL, LOG1, true>::WORDS, W2 = HmLds<TL, HM_ROW_LOG, false>::WORDS;
+  constexpr int W1 = GEO::template ldsWords<TL, LOG1, true>(), W2 = GEO::template ldsWords<TL, HM_ROW_LOG, false>();
   __shared__ __attribute__((aligned(16))) uint64_t lds[(W1 > W2 ? W1 : W2) + 2];
   uint32_t entry, tile;
   const uint32_t members = 1u << (a.logN - TL);
   if (!hm_block_map(members, a.n_limbs, a.logG, entry, tile)) return;
   if (a.limb[entry].mod == HM_NTT_NONE) return;
   uint32_t *flag = reinterpret_cast<uint32_t *>(lds + (W1 > W2 ? W1 : W2));
-  if (!INV) hm_ntt_pass_run<LOG1, true, false, MODE_A, HM_FUSED_IN_AUX, 0>(a, lds, entry, tile, threadIdx.x);
-  else hm_ntt_pass_run<HM_ROW_LOG, false, true, MODE_A, HM_FUSED_IN_AUX, 0>(a, lds, entry, tile, threadIdx.x);
-  const bool same = hm_limb_rendezvous(f.ws, f.err, entry, members, flag);
-  if (!same) hm_limb_publish_everywhere(f.ws, f.err, entry, members);
+  if (!INV) hm_ntt_pass_run<LOG1, true, false, MODE_A, HM_FUSED_IN_AUX, 0, HM_EPI_CHUNK, GEO>(a, lds, entry, tile, threadIdx.x);
+  else hm_ntt_pass_run<HM_ROW_LOG, false, true, MODE_A, HM_FUSED_IN_AUX, 0, HM_EPI_CHUNK, GEO>(a, lds, entry, tile, threadIdx.x);
+  const uint32_t fast = hm_limb_rendezvous(f.ws, f.err, entry, members, flag);
+  if (!fast) hm_limb_publish_everywhere(f.ws, f.err, entry, members);
   // a thread id the compiler cannot connect with the first pass's: otherwise lane offsets of the second pass are computed
   // up front and kept (spilled) through the first
   int tid2 = threadIdx.x;
   if (HM_OPAQUE_TID2) asm volatile("" : "+v"(tid2));
-  __builtin_assume(tid2 >= 0 && tid2 < (1 << HM_TL_ROW) / HM_EPT);
-  if (!INV) hm_ntt_pass_run<HM_ROW_LOG, false, false, MODE_B, HM_FUSED_MID_AUX, HM_FUSED_OUT_AUX, 1>(a, lds, entry, tile, tid2);
-  else hm_ntt_pass_run<LOG1, true, true, MODE_B, HM_FUSED_MID_AUX, HM_FUSED_OUT_AUX>(a, lds, entry, tile, tid2);
-  hm_limb_leave(f.ws, entry, members, !same);
+  __builtin_assume(tid2 >= 0 && tid2 < (1 << HM_TL_ROW) / GEO::EPT);
+  if (!INV) hm_ntt_pass_run<HM_ROW_LOG, false, false, MODE_B, HM_FUSED_MID_AUX, HM_FUSED_OUT_AUX, 1, GEO>(a, lds, entry, tile, tid2);
+  else hm_ntt_pass_run<LOG1, true, true, MODE_B, HM_FUSED_MID_AUX, HM_FUSED_OUT_AUX, HM_EPI_CHUNK, GEO>(a, lds, entry, tile, tid2);
+  hm_limb_leave(f.ws, entry, members, fast);
+}
+template <int LOG1, bool INV, int MODE_A, int MODE_B>
+__global__ void __launch_bounds__((1 << HM_TL_ROW) / HM_EPT) __attribute__((amdgpu_waves_per_eu(HM_NTT_MIN_WAVES))) k_ntt_fused(HmNttArgs a, HmNttFusedArgs f) {
+  hm_ntt_fused_body<LOG1, INV, MODE_A, MODE_B, Geo16>(a, f);
+}
+// the same in the small-launch geometry (512-thread workgroups, 8 coefficients per thread; N = 2^16): the form that launches of up to
+// `ntt_fused_small` limb-polys take by default
+template <bool INV, int MODE_A, int MODE_B>
+__global__ void __launch_bounds__((1 << HM_TL_ROW) / 8) k_ntt_fused8(HmNttArgs a, HmNttFusedArgs f) {
+  hm_ntt_fused_body<8, INV, MODE_A, MODE_B, Geo8>(a, f);
 }
 
 // ---- both passes of a transform in ONE persistent launch, fed from per-XCD work queues (round 4) ----------------------------------
@@ -916,7 +968,8 @@ struct hm_ctx {
   bool side_launches = false;   // independent small launches of one call side by side (hm_set_option "side_launches"): measured SLOWER, see bconv_col_launch
   uint32_t side_max_wgs = 4096;   // ... when together they are at most this many workgroups (4 rounds of the chip)
   uint32_t small_limbs = 64;   // measured (tools/ntt_small_ab.py): 2-3 us per launch faster up to ~64 entries, equal at 115, slower from 128
-  bool fused_ntt = false;  // measured slower and no lighter on HBM: opt-in
+  bool fused_ntt = false;  // every transform as one launch (k_ntt_fused): slower for launches that fill the chip more than once, opt-in
+  uint32_t fused_small = 96;  // launches of up to this many entries (N = 2^16) run as ONE launch in the small-launch geometry (k_ntt_fused8): 2-5 us faster than two kernels up to ~100 limb-polys, slower from 128 (tools/ntt_fused_small_ab.py); 0 = off
   uint32_t fused_extra_lds = 0;   // dynamic LDS added to every k_ntt_fused workgroup: occupancy throttle of the L2 hand-off experiment
   // persistent two-pass transform fed from per-XCD queues (k_ntt_queue): 0 off, 1 = 8-coefficient geometry (N = 2^16), 2 = 16-coefficient
   uint32_t queue_ntt = 0, queue_wgs = 0 /* workgroups of the grid; 0 = 2 (geometry 8) or 4 (16) per CU */, queue_la = 2, queue_gc = 0 /* 0 = auto */;
@@ -1073,6 +1126,7 @@ extern "C" hm_status hm_create(hm_ctx **out, const hm_params *p) {
   memset(cc->err_host, 0, 64);
   HM_HIP(nullptr, hipHostGetDevicePointer(reinterpret_cast<void **>(&cc->err_dev), cc->err_host, 0));
   if (const char *e = getenv("HOMULATOR_NTT_FUSED")) cc->fused_ntt = std::string(e) != "0";
+  if (const char *e = getenv("HOMULATOR_NTT_FUSED_SMALL")) cc->fused_small = (uint32_t)std::min(HM_NTT_MAX_ENTRIES, std::max(0, atoi(e)));
   if (const char *e = getenv("HOMULATOR_NTT_FUSED_LDS")) cc->fused_extra_lds = (uint32_t)std::min(120 * 1024, std::max(0, atoi(e)));
   if (const char *e = getenv("HOMULATOR_NTT_SMALL_LIMBS")) { cc->small_limbs = (uint32_t)atoi(e); cc->small_ept8 = cc->small_limbs != 0; }
   if (const char *e = getenv("HOMULATOR_SIDE_LAUNCHES")) cc->side_launches = std::string(e) != "0";
@@ -1219,6 +1273,7 @@ extern "C" hm_status hm_wait_for(hm_ctx *c, hm_ctx *producer) {
 extern "C" hm_status hm_set_option(hm_ctx *c, const char *name, uint64_t value) {
   if (!c || !name) return HM_ERR_ARG;
   if (!strcmp(name, "ntt_fused")) { c->fused_ntt = value != 0; return HM_OK; }
+  if (!strcmp(name, "ntt_fused_small")) { if (value > HM_NTT_MAX_ENTRIES) return fail(c, HM_ERR_ARG, "hm_set_option: ntt_fused_small above %d", HM_NTT_MAX_ENTRIES); c->fused_small = (uint32_t)value; return HM_OK; }
   if (!strcmp(name, "ntt_fused_lds")) { if (value > 120 * 1024) return fail(c, HM_ERR_ARG, "hm_set_option: ntt_fused_lds above 120 KiB"); c->fused_extra_lds = (uint32_t)value; return HM_OK; }
   if (!strcmp(name, "bconv_col_outs")) { if (value > 2) return fail(c, HM_ERR_ARG, "hm_set_option: bconv_col_outs is 0 (by launch size), 1 or 2"); c->bcol_outs = (uint32_t)value; return HM_OK; }
   if (!strcmp(name, "ntt_dma")) { if (value > 3) return fail(c, HM_ERR_ARG, "hm_set_option: ntt_dma is 0 .. 3"); c->dma_ntt = (uint32_t)value; return HM_OK; }
@@ -1365,6 +1420,15 @@ static void launch_ntt(hm_ctx *c, const HmNttArgs &a, bool fusedEpilogue, bool m
   }
   // small launches (one round of workgroups on the chip): the 8-coefficient geometry halves the serial work per wave
   if constexpr (LOG1 == 8) {
+    if (!firstPassOnly && !c->fused_ntt && !c->dma_ntt && a.n_limbs <= c->fused_small) {   // ... and both passes in one launch behind an XCD-local rendezvous
+      const HmNttFusedArgs f = {c->ntt_ws, c->err_dev};
+      const dim3 grid8(a.n_limbs * (c->P.N >> HM_TL_ROW)), block8((1 << HM_TL_ROW) / 8);
+      if (inverse) hipLaunchKernelGGL((k_ntt_fused8<true, 0, 2>), grid8, block8, 0, c->stream, a, f);
+      else if (mixPrologue) hipLaunchKernelGGL((k_ntt_fused8<false, 4, 3>), grid8, block8, 0, c->stream, a, f);
+      else if (fusedEpilogue) hipLaunchKernelGGL((k_ntt_fused8<false, 0, 3>), grid8, block8, 0, c->stream, a, f);
+      else hipLaunchKernelGGL((k_ntt_fused8<false, 0, 1>), grid8, block8, 0, c->stream, a, f);
+      return;
+    }
     if (c->small_ept8 && !firstPassOnly && !c->fused_ntt && !c->dma_ntt && a.n_limbs <= c->small_limbs) {
       // small_mode: bit 0 = COL pass in the 8-coefficient geometry, bit 1 = ROW pass (the hand-off between the passes is the same)
       const dim3 grid8(a.n_limbs * (c->P.N >> HM_TL_ROW)), block8((1 << HM_TL_ROW) / 8);

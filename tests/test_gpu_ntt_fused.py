@@ -154,3 +154,46 @@ def test_small_launch_geometry_equals_wide_and_oracle():
         ctx.set_option("ntt_small_limbs", 128)
     finally:
         ctx.close()
+
+
+def test_one_launch_small_geometry_equals_two_kernels_and_oracle():
+    """launches of up to `ntt_fused_small` limb-polys at N = 2^16 run both passes in ONE launch of the 8-coefficient geometry
+    (k_ntt_fused8: the hand-off through the XCD's L2 behind a rendezvous on XCD-local atomics).  The same calls as two kernels
+    (option 0) and the oracle must agree bit for bit: forward, inverse in place with a scale, fused epilogue with and without the
+    mix prologue, worst-case operands, 1 .. 64 limb-polys, launches repeated back to back (the rendezvous words return to zero),
+    out of place and in place; no limb-poly may have taken the agent-scope path"""
+    ctx, o = _ctx(16, 6, 3)
+    try:
+        for n in (1, 9, 35, 50, 64):
+            ids = [(i * 5 + 2) % 9 for i in range(n)]
+            x = o.fill_uniform(ids, 131 + n)
+            x[0, :] = o.moduli[ids[0]] - 1
+            d, a, b = ctx.from_host(x), ctx.alloc(n), ctx.alloc(n)
+            mn, ad, mx = (ctx.alloc(n) for _ in range(3))
+            for buf, s in ((mn, 5), (ad, 6), (mx, 7)):
+                ctx.fill_uniform(buf, ids, s)
+            k = [o.moduli[m] - 2 - r for r, m in enumerate(ids)]
+            mk = [(kk * 3 + 1) % o.moduli[m] for kk, m in zip(k, ids)]
+            ak = [(kk * 5 + 1) % o.moduli[m] for kk, m in zip(k, ids)]
+            res = {}
+            for one in (64, 0):
+                ctx.set_option("ntt_fused_small", one)
+                for _ in range(3):
+                    ctx.ntt(d, a, ids)
+                fwd = a.download()
+                ctx.ntt(a, a, ids, inverse=True, scale=k)
+                inv = a.download()
+                ctx.ntt_sub_scale(d, mn, b, ids, k)
+                ss = b.download()
+                ctx.ntt_mix_sub_scale(d, mn, b, ids, k, addend=ad, addend_k=ak, mix=mx, mix_k=mk)
+                mss = b.download()
+                res[one] = (fwd, inv, ss, mss)
+            for u, v in zip(res[64], res[0]):
+                assert np.array_equal(u, v), n
+            assert np.array_equal(res[64][0], o.ntt(ids, x)), n
+            assert np.array_equal(res[64][1], o.ewe(5, ids, x, k=k)), n     # INTT(NTT(x)) * k
+            for buf in (d, a, b, mn, ad, mx):
+                buf.free()
+        assert ctx.counter("ntt_cross_xcd") == 0
+    finally:
+        ctx.close()
