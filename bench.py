@@ -393,7 +393,7 @@ def main():
             "roofline": {"bound": "valu" if valu_floor_ns and valu_floor_ns > hbm_floor_ns else "hbm",   # the ceiling with the larger floor for this launch, measured
                          "contract_bound": "hbm",   # ... `achieved` / `peak` / `frac` / `traffic` are the HBM figures the task's contract asks for, whatever binds
                          "binding_ceiling": "valu" if valu_floor_ns and valu_floor_ns > hbm_floor_ns else "hbm",
-                         "kernel": "forward NTT sweep, 50 limbs = ONE launch, k_ntt_fused8<false, 0, 1> (COL pass, per-limb rendezvous on XCD-local atomics, ROW pass)",
+                         "kernel": "forward NTT sweep, 50 limbs = ONE launch, k_ntt_fused8<false, 0, 1, true> (COL pass on non-temporal input loads, per-limb rendezvous on XCD-local atomics, ROW pass)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": rin.get("ntt_sweep50_traffic_bytes") if sweep_limbs == 50 else None, "us_per_launch": ntt_ns * 1e-3,
                          "algorithmic_bytes_per_launch": NTT_ALG_BYTES * sweep_limbs,

@@ -58,6 +58,7 @@ __device__ __forceinline__ void hm_pass_sync(int nth) {
 struct Geo16 {
   static constexpr int EPT = 16;
   typedef hm16::HmNttState State;
+  typedef hm16::HmNoMid NoMid;
   template <int TL, int LOGR, bool STRIDED> static constexpr int ldsWords() { return hm16::HmLds<TL, LOGR, STRIDED>::WORDS; }
   template <int TL, int LOGR, bool STRIDED, bool INV, int MODE, int LDAUX, int STAUX, int EPICH, class... A>
   static __device__ __forceinline__ void phases(A &&...a) { hm16::hm_ntt_pass_phases<TL, LOGR, STRIDED, INV, MODE, LDAUX, STAUX, EPICH>(a...); }
@@ -67,14 +68,15 @@ struct Geo16 {
 struct Geo8 {
   static constexpr int EPT = 8;
   typedef hm8::HmNttState State;
+  typedef hm8::HmNoMid NoMid;
   template <int TL, int LOGR, bool STRIDED> static constexpr int ldsWords() { return hm8::HmLds<TL, LOGR, STRIDED>::WORDS; }
   template <int TL, int LOGR, bool STRIDED, bool INV, int MODE, int LDAUX, int STAUX, int EPICH, class... A>
   static __device__ __forceinline__ void phases(A &&...a) { hm8::hm_ntt_pass_phases<TL, LOGR, STRIDED, INV, MODE, LDAUX, STAUX, EPICH>(a...); }
   template <int TL, int LOGR, bool STRIDED, bool INV, int MODE, class... A>
   static __device__ __forceinline__ void phases_dma(A &&...a) { hm8::hm_ntt_pass_phases<TL, LOGR, STRIDED, INV, MODE, 0, 0, HM_EPI_CHUNK, 1>(a...); }
 };
-template <int LOGR, bool STRIDED, bool INV, int MODE, int LDAUX = 0, int STAUX = 0, int EPICH = HM_EPI_CHUNK, class GEO = Geo16>
-__device__ __forceinline__ void hm_ntt_pass_run(const HmNttArgs &a, uint64_t *lds, uint32_t entry, uint32_t tile, int tid) {
+template <int LOGR, bool STRIDED, bool INV, int MODE, int LDAUX = 0, int STAUX = 0, int EPICH = HM_EPI_CHUNK, class GEO = Geo16, class PRE = HmNoPre>
+__device__ __forceinline__ void hm_ntt_pass_run(const HmNttArgs &a, uint64_t *lds, uint32_t entry, uint32_t tile, int tid, PRE pre = PRE()) {
   constexpr int TL = HM_TL(STRIDED);
   const HmLimb lb = a.limb[entry];
   const uint32_t mod = lb.mod;
@@ -111,7 +113,7 @@ __device__ __forceinline__ void hm_ntt_pass_run(const HmNttArgs &a, uint64_t *ld
   typename GEO::State st;
   int nsync = 0;
   GEO::template phases<TL, LOGR, STRIDED, INV, MODE, LDAUX, STAUX, EPICH>(st, tid, lds, src, dst, tile, twl, twt, s0, prefix0, q, sc, ep,
-                                                                           [&] { hm_pass_sync<STRIDED>(nsync++); });
+                                                                           [&] { hm_pass_sync<STRIDED>(nsync++); }, nullptr, typename GEO::NoMid(), pre);
 }
 
 template <int LOGR, bool STRIDED, bool INV, int MODE, class GEO = Geo16>
@@ -292,7 +294,10 @@ struct HmNttFusedArgs {
   unsigned *err;   // host-visible word: 0 = fine, 1 / 2 = a rendezvous timed out
 };
 // MODE_A: first pass (0, or 4 = mix prologue); MODE_B: last pass (1 forward, 3 fused epilogue, 2 inverse)
-template <int LOG1, bool INV, int MODE_A, int MODE_B, class GEO>
+// IN_AUX: cache policy of the first pass's input loads.  Out of place they are read once and only crowd the L2 that should keep the
+// hand-off: non-temporal loads (2) take 2-4 us off a 50-64 limb-poly launch; in place the hand-off lands on the very lines the input
+// loads brought in, and plain loads (0) are 2 us faster (tools/ntt_fused_small_ab.py)
+template <int LOG1, bool INV, int MODE_A, int MODE_B, class GEO, int IN_AUX = HM_FUSED_IN_AUX>
 __device__ __forceinline__ void hm_ntt_fused_body(const HmNttArgs &a, const HmNttFusedArgs &f) {
   static_assert(HM_TL_COL == HM_TL_ROW, "the one-launch transform keeps a workgroup on tile t of both passes");
   constexpr int TL = HM_TL_ROW;
@@ -303,17 +308,28 @@ __device__ __forceinline__ void hm_ntt_fused_body(const HmNttArgs &a, const HmNt
   if (!hm_block_map(members, a.n_limbs, a.logG, entry, tile)) return;
   if (a.limb[entry].mod == HM_NTT_NONE) return;
   uint32_t *flag = reinterpret_cast<uint32_t *>(lds + (W1 > W2 ? W1 : W2));
-  if (!INV) hm_ntt_pass_run<LOG1, true, false, MODE_A, HM_FUSED_IN_AUX, 0, HM_EPI_CHUNK, GEO>(a, lds, entry, tile, threadIdx.x);
-  else hm_ntt_pass_run<HM_ROW_LOG, false, true, MODE_A, HM_FUSED_IN_AUX, 0, HM_EPI_CHUNK, GEO>(a, lds, entry, tile, threadIdx.x);
-  const uint32_t fast = hm_limb_rendezvous(f.ws, f.err, entry, members, flag);
-  if (!fast) hm_limb_publish_everywhere(f.ws, f.err, entry, members);
+  if (!INV) hm_ntt_pass_run<LOG1, true, false, MODE_A, IN_AUX, 0, HM_EPI_CHUNK, GEO>(a, lds, entry, tile, threadIdx.x);
+  else hm_ntt_pass_run<HM_ROW_LOG, false, true, MODE_A, IN_AUX, 0, HM_EPI_CHUNK, GEO>(a, lds, entry, tile, threadIdx.x);
   // a thread id the compiler cannot connect with the first pass's: otherwise lane offsets of the second pass are computed
   // up front and kept (spilled) through the first
   int tid2 = threadIdx.x;
   if (HM_OPAQUE_TID2) asm volatile("" : "+v"(tid2));
   __builtin_assume(tid2 >= 0 && tid2 < (1 << HM_TL_ROW) / GEO::EPT);
+  // the rendezvous sits INSIDE the second pass's first phase, behind the requests for its first round's twiddles (they do not depend on
+  // the hand-off and arrive while the workgroup waits) and in front of everything that touches LDS or the hand-off
+  uint32_t fast = 0;
+  auto meet = [&] {
+    fast = hm_limb_rendezvous(f.ws, f.err, entry, members, flag);
+    if (!fast) hm_limb_publish_everywhere(f.ws, f.err, entry, members);
+  };
+#if defined(HM_FUSED_MEET_FIRST)   // (A/B: the rendezvous in front of the second pass instead of inside its first phase)
+  meet();
   if (!INV) hm_ntt_pass_run<HM_ROW_LOG, false, false, MODE_B, HM_FUSED_MID_AUX, HM_FUSED_OUT_AUX, 1, GEO>(a, lds, entry, tile, tid2);
   else hm_ntt_pass_run<LOG1, true, true, MODE_B, HM_FUSED_MID_AUX, HM_FUSED_OUT_AUX, HM_EPI_CHUNK, GEO>(a, lds, entry, tile, tid2);
+#else
+  if (!INV) hm_ntt_pass_run<HM_ROW_LOG, false, false, MODE_B, HM_FUSED_MID_AUX, HM_FUSED_OUT_AUX, 1, GEO>(a, lds, entry, tile, tid2, meet);
+  else hm_ntt_pass_run<LOG1, true, true, MODE_B, HM_FUSED_MID_AUX, HM_FUSED_OUT_AUX, HM_EPI_CHUNK, GEO>(a, lds, entry, tile, tid2, meet);
+#endif
   hm_limb_leave(f.ws, entry, members, fast);
 }
 template <int LOG1, bool INV, int MODE_A, int MODE_B>
@@ -322,9 +338,9 @@ __global__ void __launch_bounds__((1 << HM_TL_ROW) / HM_EPT) __attribute__((amdg
 }
 // the same in the small-launch geometry (512-thread workgroups, 8 coefficients per thread; N = 2^16): the form that launches of up to
 // `ntt_fused_small` limb-polys take by default
-template <bool INV, int MODE_A, int MODE_B>
+template <bool INV, int MODE_A, int MODE_B, bool NTIN>
 __global__ void __launch_bounds__((1 << HM_TL_ROW) / 8) k_ntt_fused8(HmNttArgs a, HmNttFusedArgs f) {
-  hm_ntt_fused_body<8, INV, MODE_A, MODE_B, Geo8>(a, f);
+  hm_ntt_fused_body<8, INV, MODE_A, MODE_B, Geo8, NTIN ? 2 : 0>(a, f);
 }
 
 // ---- both passes of a transform in ONE persistent launch, fed from per-XCD work queues (round 4) ----------------------------------
@@ -1423,10 +1439,15 @@ static void launch_ntt(hm_ctx *c, const HmNttArgs &a, bool fusedEpilogue, bool m
     if (!firstPassOnly && !c->fused_ntt && !c->dma_ntt && a.n_limbs <= c->fused_small) {   // ... and both passes in one launch behind an XCD-local rendezvous
       const HmNttFusedArgs f = {c->ntt_ws, c->err_dev};
       const dim3 grid8(a.n_limbs * (c->P.N >> HM_TL_ROW)), block8((1 << HM_TL_ROW) / 8);
-      if (inverse) hipLaunchKernelGGL((k_ntt_fused8<true, 0, 2>), grid8, block8, 0, c->stream, a, f);
-      else if (mixPrologue) hipLaunchKernelGGL((k_ntt_fused8<false, 4, 3>), grid8, block8, 0, c->stream, a, f);
-      else if (fusedEpilogue) hipLaunchKernelGGL((k_ntt_fused8<false, 0, 3>), grid8, block8, 0, c->stream, a, f);
-      else hipLaunchKernelGGL((k_ntt_fused8<false, 0, 1>), grid8, block8, 0, c->stream, a, f);
+      bool inPlace = a.in == a.out;   // every limb-poly transformed onto itself: the input loads keep their lines for the hand-off
+      for (uint32_t e = 0; inPlace && e < a.n_limbs; ++e) inPlace = a.limb[e].mod == HM_NTT_NONE || a.limb[e].in == a.limb[e].out;
+#define HM_F8GO(INV_, A_, B_) do { if (inPlace) hipLaunchKernelGGL((k_ntt_fused8<INV_, A_, B_, false>), grid8, block8, 0, c->stream, a, f); \
+                                   else hipLaunchKernelGGL((k_ntt_fused8<INV_, A_, B_, true>), grid8, block8, 0, c->stream, a, f); } while (0)
+      if (inverse) HM_F8GO(true, 0, 2);
+      else if (mixPrologue) HM_F8GO(false, 4, 3);
+      else if (fusedEpilogue) HM_F8GO(false, 0, 3);
+      else HM_F8GO(false, 0, 1);
+#undef HM_F8GO
       return;
     }
     if (c->small_ept8 && !firstPassOnly && !c->fused_ntt && !c->dma_ntt && a.n_limbs <= c->small_limbs) {

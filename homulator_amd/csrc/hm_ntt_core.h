@@ -221,6 +221,7 @@ HM_HD int hm_lds_idx(int x, int c) {
 // ---------------------------------------------------------------------------------------------------
 #define HM_EPT 16                      // coefficients per thread
 #define HM_UNITS (HM_EPT / 2)          // 16-byte access units per thread
+struct HmNoPre { HM_HD void operator()() const {} };
 namespace hm16 {
 #include "hm_ntt_passes.inl"
 }

@@ -375,10 +375,12 @@ HM_HD void hm_ph_twist(HmNttState &st, uint64_t q) {
 // SRC = 1 (the persistent double-buffered passes, hm_ntt_dma.inl / k_ntt_*_dma): the tile already sits in `lds` in the image of
 // hm_lds_idx (an LDS-DMA put it there while the previous tile was being transformed), the first round reads it from there; the shared
 // twiddles were staged by the caller at `lds_tw` (a pass over several tiles stages them once per modulus).
-template <int TL, int LOGR, bool STRIDED, bool INV, int MODE, int PHASE, int LDAUX = 0, int STAUX = 0, int EPICH = HM_EPI_CHUNK, int SRC = 0>
+// pre() (phase 0 only): called between the first round's twiddle requests and everything that touches LDS or the pass's input — the
+// one-launch transform waits there for the other workgroups' hand-off, with the second pass's first twiddles already on their way
+template <int TL, int LOGR, bool STRIDED, bool INV, int MODE, int PHASE, int LDAUX = 0, int STAUX = 0, int EPICH = HM_EPI_CHUNK, int SRC = 0, class PRE = HmNoPre>
 HM_HD void hm_ntt_phase(HmNttState &st, int tid, uint64_t *lds, const uint64_t *src, uint64_t *dst, uint32_t tile,
                         const HmW *twl, const HmW *twist_tile, uint32_t s0, uint32_t prefix0, uint64_t q, HmTw sc, HmEpi ep,
-                        const uint64_t *lds_tw = nullptr) {
+                        const uint64_t *lds_tw = nullptr, PRE pre = PRE()) {
   using PS = HmPass<LOGR, STRIDED, INV>;
   constexpr int n = PS::n;
   static_assert(PHASE >= 0 && PHASE <= n, "a pass of n rounds has phases 0 .. n");
@@ -392,10 +394,11 @@ HM_HD void hm_ntt_phase(HmNttState &st, int tid, uint64_t *lds, const uint64_t *
   constexpr bool LATE_TW1 = ((INV && HM_LATE_TW1) || MODE == 5) && !STRIDED;   // MODE 5: 64 accumulator registers are live beside the pass
   if constexpr (PHASE == 0) {
     constexpr int r0 = PS::exec(0), r1 = PS::exec(1);
-    if (PS::anyLds() && !SRC) hm_ph_stage_tw<TL, LOGR, STRIDED>(tid, lds, twl);
     // SRC = 1: every shared round reads the staged copy, the first one included (it was staged for an earlier tile)
     if (SRC && HM_TW_IN_LDS(STRIDED) && PS::shared(r0)) { /* from the staged copy: hm_ntt_phase_lds0 */ }
     else hm_ph_load_tw<TL, LOGR, STRIDED, r0, PS::shared(r0)>(st, tid, twl, s0, prefix0);
+    pre();
+    if (PS::anyLds() && !SRC) hm_ph_stage_tw<TL, LOGR, STRIDED>(tid, lds, twl);
     if (SRC) {   // the tile is read from its LDS image by hm_ntt_phase_lds0 (after the caller has issued the next tile's DMA);
       // here only what comes from global memory is requested: the MODE 4 operand lands in st.v for the time being
       if (MODE == 4) hm_ph_load_global<TL, LOGR, STRIDED, r0, LDAUX>(st, tid, ep.b, tile);
@@ -469,12 +472,12 @@ struct HmNoMid { HM_HD void operator()() const {} };
 // all phases of a pass with `sync()` between them (the GPU passes __syncthreads, the emulator runs the phases itself)
 // SRC = 1: mid() runs between the global requests of phase 0 and the LDS reads of the tile image (the caller issues the next tile's DMA
 // there: requests behind the DMA would wait for it, vmcnt retires in order)
-template <int TL, int LOGR, bool STRIDED, bool INV, int MODE, int LDAUX = 0, int STAUX = 0, int EPICH = HM_EPI_CHUNK, int SRC = 0, class SYNC, class MID = HmNoMid>
+template <int TL, int LOGR, bool STRIDED, bool INV, int MODE, int LDAUX = 0, int STAUX = 0, int EPICH = HM_EPI_CHUNK, int SRC = 0, class SYNC, class MID = HmNoMid, class PRE = HmNoPre>
 HM_HD void hm_ntt_pass_phases(HmNttState &st, int tid, uint64_t *lds, const uint64_t *src, uint64_t *dst, uint32_t tile,
                               const HmW *twl, const HmW *twist_tile, uint32_t s0, uint32_t prefix0, uint64_t q, HmTw sc, HmEpi ep, SYNC sync,
-                              const uint64_t *lds_tw = nullptr, MID mid = MID()) {
+                              const uint64_t *lds_tw = nullptr, MID mid = MID(), PRE pre = PRE()) {
   constexpr int n = HmRounds<LOGR>::n;
-  hm_ntt_phase<TL, LOGR, STRIDED, INV, MODE, 0, LDAUX, STAUX, EPICH, SRC>(st, tid, lds, src, dst, tile, twl, twist_tile, s0, prefix0, q, sc, ep, lds_tw);
+  hm_ntt_phase<TL, LOGR, STRIDED, INV, MODE, 0, LDAUX, STAUX, EPICH, SRC>(st, tid, lds, src, dst, tile, twl, twist_tile, s0, prefix0, q, sc, ep, lds_tw, pre);
   if constexpr (SRC != 0) {
     mid();
     hm_ntt_phase_lds0<TL, LOGR, STRIDED, INV, MODE>(st, tid, lds, lds_tw, s0, prefix0, q, ep);
