@@ -1436,7 +1436,11 @@ static void launch_ntt(hm_ctx *c, const HmNttArgs &a, bool fusedEpilogue, bool m
   }
   // small launches (one round of workgroups on the chip): the 8-coefficient geometry halves the serial work per wave
   if constexpr (LOG1 == 8) {
-    if (!firstPassOnly && !c->fused_ntt && !c->dma_ntt && a.n_limbs <= c->fused_small) {   // ... and both passes in one launch behind an XCD-local rendezvous
+    // ... and both passes in one launch behind an XCD-local rendezvous.  Progress: a kernel's workgroups are dispatched in order, so it has at
+    // most ONE partially dispatched group of 2^logG limb-polys per XCD whose workgroups wait for siblings that have no slot yet (logG <= 1:
+    // at most 31 of an XCD's 128 slots); every other resident workgroup belongs to a complete limb-poly and finishes.  Up to four such
+    // kernels in flight on one GPU (contexts, instances) cannot starve one another; the spins are bounded all the same.
+    if (!firstPassOnly && !c->fused_ntt && !c->dma_ntt && a.n_limbs <= c->fused_small && a.logG <= 1) {
       const HmNttFusedArgs f = {c->ntt_ws, c->err_dev};
       const dim3 grid8(a.n_limbs * (c->P.N >> HM_TL_ROW)), block8((1 << HM_TL_ROW) / 8);
       bool inPlace = a.in == a.out;   // every limb-poly transformed onto itself: the input loads keep their lines for the hand-off

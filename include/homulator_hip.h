@@ -292,11 +292,15 @@ hm_status hm_graph_launch(hm_ctx *ctx, hm_graph *graph);
 void hm_graph_destroy(hm_graph *graph);
 
 /* Execution options of a context (A/B measurements, tests; every option has a working default):
- *   "ntt_fused"  0 (default): two kernels per transform; 1: both passes of a transform in ONE launch behind a per-limb
- *                rendezvous (measured slower on MI355X and no lighter on HBM: the L2 writes through and does not
- *                allocate on a store).  Env HOMULATOR_NTT_FUSED sets the default.
- *   "ntt_small_limbs"  transform launches of at most this many limb-poly entries (default 64, N = 2^16) use the small-launch
- *                geometry (512-thread workgroups, 8 coefficients per thread); 0 switches it off.  Env HOMULATOR_NTT_SMALL_LIMBS.
+ *   "ntt_fused_small"  transform launches of at most this many limb-poly entries (default 96, N = 2^16) run both passes in
+ *                ONE launch: the workgroups of a limb-poly meet at a counter in their XCD's L2 between the passes
+ *                (k_ntt_fused8; 2-5 us faster than two kernels up to ~100 limb-polys); 0 switches it off.
+ *                Env HOMULATOR_NTT_FUSED_SMALL.
+ *   "ntt_fused"  0 (default); 1: EVERY transform as one launch, in the wide geometry (slower than two kernels for launches
+ *                that fill the chip more than once).  Env HOMULATOR_NTT_FUSED sets the default.
+ *   "ntt_small_limbs"  two-kernel transform launches (single passes; "ntt_fused_small" 0) of at most this many limb-poly entries
+ *                (default 64, N = 2^16) use the small-launch geometry (512-thread workgroups, 8 coefficients per thread);
+ *                0 switches it off.  Env HOMULATOR_NTT_SMALL_LIMBS.
  *   "ntt_small_mode"   which passes of such a launch use it: bit 0 = COL, bit 1 = ROW (default 3; the hand-off is the same).
  *   "side_launches"    0 (default); 1: independent small kernels of one call (the conversion sizes of a ModUp inside
  *                hm_ntt_inner_product) run side by side, the later ones on a side stream between a fork and a join event;
@@ -304,8 +308,8 @@ void hm_graph_destroy(hm_graph *graph);
  *                workgroups (4096).
  *                Env HOMULATOR_SIDE_LAUNCHES sets the default.
  * Counters:
- *   "ntt_cross_xcd"  limb-polys whose workgroups were NOT all placed on one XCD and took the agent-scope hand-off
- *                    (slow, still correct); expected 0 under the dispatcher's observed round-robin placement.
+ *   "ntt_cross_xcd"  limb-polys of one-launch transforms whose workgroups were NOT all placed on one XCD and took the
+ *                    agent-scope hand-off (slow, still correct); expected 0 under the dispatcher's observed round-robin placement.
  * No reference counterpart: the reference's Arch has no tunables besides the .cfg keys (src/Arch.cpp:8-168). */
 hm_status hm_set_option(hm_ctx *ctx, const char *name, uint64_t value);
 hm_status hm_get_counter(hm_ctx *ctx, const char *name, uint64_t *value); /* synchronises */
