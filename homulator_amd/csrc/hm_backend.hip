@@ -1437,10 +1437,10 @@ static void launch_ntt(hm_ctx *c, const HmNttArgs &a, bool fusedEpilogue, bool m
   // small launches (one round of workgroups on the chip): the 8-coefficient geometry halves the serial work per wave
   if constexpr (LOG1 == 8) {
     // ... and both passes in one launch behind an XCD-local rendezvous.  Progress: a kernel's workgroups are dispatched in order, so it has at
-    // most ONE partially dispatched group of 2^logG limb-polys per XCD whose workgroups wait for siblings that have no slot yet (logG <= 1:
-    // at most 31 of an XCD's 128 slots); every other resident workgroup belongs to a complete limb-poly and finishes.  Up to four such
-    // kernels in flight on one GPU (contexts, instances) cannot starve one another; the spins are bounded all the same.
-    if (!firstPassOnly && !c->fused_ntt && !c->dma_ntt && a.n_limbs <= c->fused_small && a.logG <= 1) {
+    // most ONE partially dispatched limb-poly per XCD whose workgroups wait for siblings that have no slot yet (logG == 0: at most 15 of an
+    // XCD's 128 slots); every other resident workgroup belongs to a complete limb-poly and finishes.  Up to eight such kernels in flight on
+    // one GPU (contexts, instances; HIP drives four hardware queues by default) cannot starve one another; the spins are bounded all the same.
+    if (!firstPassOnly && !c->fused_ntt && !c->dma_ntt && a.n_limbs <= c->fused_small && a.logG == 0) {
       const HmNttFusedArgs f = {c->ntt_ws, c->err_dev};
       const dim3 grid8(a.n_limbs * (c->P.N >> HM_TL_ROW)), block8((1 << HM_TL_ROW) / 8);
       bool inPlace = a.in == a.out;   // every limb-poly transformed onto itself: the input loads keep their lines for the hand-off
@@ -1679,6 +1679,10 @@ static hm_status ntt_common(hm_ctx *c, const char *what, const uint64_t *in, con
   std::map<uint32_t, std::vector<int>> byMod;
   for (uint32_t i = 0; i < n; ++i) byMod[mod_ids[i]].push_back((int)i);
   uint32_t logG = 1;
+  // a call that will run as ONE launch (k_ntt_fused8) takes single limb-polys as groups: a kernel then has at most 15 workgroups per XCD
+  // waiting for siblings that have no slot yet (launch_ntt), and the 50-limb sweep 56 entries instead of 64
+  if (c->P.logN == 16 && c->fused_small && !c->fused_ntt && !c->dma_ntt && !c->queue_ntt && !f.firstPassOnly && !f.secondPassOnly &&
+      (n + 7) / 8 * 8 <= c->fused_small) logG = 0;
 #ifndef HM_NTT_MAX_LOGG
 #define HM_NTT_MAX_LOGG 3
 #endif
