@@ -670,7 +670,7 @@ __global__ void __launch_bounds__(256) k_ntt_row8_dma11(HmNttArgs a) { hm_ntt_pa
 
 // ---- K1 x K5: last transform pass x evaluation key, both keys, all digits of one extended limb in one workgroup ---------
 #define HM_NIP_MAX_TERMS 4
-static_assert(HM_NIP_MAX_TERMS <= 5, "lazy key products: five terms of less than 1.5q + 1 stay below 8q (hm_mac_add)");
+static_assert(HM_NIP_MAX_TERMS <= 5, "lazy key products: five terms of less than 1.5q + 2^28 stay below 8q (hm_mac_add)");
 #define HM_NIP_MAX_OUT 2
 #define HM_NIP_MAX_LIMBS 4096   // per launch: the records live in a device table (cached by content), read through the scalar cache
 struct HmNipLimb {                       // 32 bytes

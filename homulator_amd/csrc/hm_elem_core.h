@@ -72,9 +72,9 @@ struct HmTensorArgs {
   HmTensorLimb limb[HM_MAX_LIMBS];
 };
 // Round 4: on the word-wise Montgomery product (hm_mont_acc, q = h 2^32 + 1).  b and d are taken to Montgomery form once (a product
-// with 2^128 mod q: b 2^64 mod q + {0, q}, below 1.5q + 1), then the four products are exact: x wt 2^-64 with wt = b 2^64 is x b.  Six
+// with 2^128 mod q: b 2^64 mod q + {0, q}, below 1.5q + 2^28), then the four products are exact: x wt 2^-64 with wt = b 2^64 is x b.  Six
 // products of 11 instructions + four subtractions where three Barrett reductions of full 128-bit products took about twice as many.
-// A product with an operand below q and a constant below 1.5q + 1 comes out below 1.1q + 1.
+// A product with an operand below q and a constant below 1.5q + 2^28 comes out below 1.1q + 1.
 HM_HD void hm_tensor_one(uint64_t a, uint64_t b, uint64_t c, uint64_t d, const HmMod &m, uint64_t &d0, uint64_t &d1, uint64_t &d2) {
   const HmBflyMod bm = hm_bfly_mod(m.q);
   const uint64_t bt = hm_mont_acc(0, b, m.r128, bm), dt = hm_mont_acc(0, d, m.r128, bm);

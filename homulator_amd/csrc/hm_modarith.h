@@ -80,10 +80,10 @@ HM_HD uint64_t hm_barrett_wide(hm_u128 z, const HmMod &m) {
 
 // Montgomery reduction of a wide accumulator: z -> z * 2^-64 mod q, fully reduced.  Two word-wise steps (q = h 2^32 + 1: q^-1 = 1 mod
 // 2^32, a step is one multiply: see hm_mont_acc below): t = (z + m1 q + m2 q 2^32) / 2^64 with m1, m2 <= 2^32, so
-// t < (z >> 64) + q + 2.  About a third of the instructions of hm_barrett_wide; the 2^-64 is absorbed by constants
+// t < (z >> 64) + q + h + 2.  About a third of the instructions of hm_barrett_wide; the 2^-64 is absorbed by constants
 // stored as c * 2^64 mod q (base-conversion tables).
 // TERMS = number of products y * w summed into z with y < 2^60 - 2^32 (any input modulus) and w < q: z >> 64 < TERMS * q (1 - 2^-28) / 16,
-// i.e. below q - 2 for up to 16 terms and below 2q - 2 for up to 32: one conditional subtraction for TERMS <= 16, two for <= 32.
+// i.e. below q - 16 h for up to 16 terms and below 2q - 32 h for up to 32: one conditional subtraction for TERMS <= 16, two for <= 32.
 template <int TERMS = 32>
 HM_HD uint64_t hm_redc_wide(hm_u128 z, const HmMod &m) {
   static_assert(TERMS <= 32, "accumulator bound");
@@ -164,8 +164,9 @@ HM_HD uint64_t hm_csub_neg(uint64_t x, uint64_t nm) {
 // (T + (~T0) q + q) / 2^32 = (T >> 32) + (~T0) h + (h + 1) (the low words always carry exactly 1; adding q more leaves the class).
 // Two steps take the 124-bit product x wt to x wt 2^-64 mod q: SIX multiplies (four of the product, one per step) where the Shoup form
 // needs nine (3 + 3 + 3), and no companion word per constant.  wt = w 2^64 mod q (tables are stored in this form).
-//   c + v,  v = x w mod q + {0, q},  0 <= v < q (1 + x / 2^64) + 1 <= 1.5 q + 1       for x < 2^63 (no 64-bit sum overflows:
-//   b1 w0 < 2^63, b0 w1 < 2^60, (~P0) h < 2^60, cc < 2^60 + 2^33), c + v < 2^64.
+//   c + v,  v = x w mod q + {0, q},  0 <= v = (x wt + m1 q + m2 q 2^32) / 2^64 with m1, m2 <= 2^32, so v <= floor(x wt / 2^64) + q + h + 1
+//   < 1.5 q + 2^28 for x < 2^63 (no 64-bit sum overflows: b1 w0 < 2^63, b0 w1 < 2^60, (~P0) h < 2^60, cc < 2^60 + 2^33), c + v < 2^64.
+//   (The 2^28 is the first step's m1 q / 2^64; every range below has half a q of slack.)
 // cc = (h + 1)(2^32 + 1): the constants of both steps in one addend (the second step's sits 32 bits up, where the first step's low word
 // cannot see it).  15 VALU instructions per forward butterfly against 17, 65.9 against 79.0 cycles per wave
 // (tools/bflyrate.hip, profiles/r04_bflyrate.txt).
@@ -212,7 +213,7 @@ HM_HD void hm_bfly_fwd_k(uint64_t &X, uint64_t &Y, HmW wt, const HmBflyMod &m) {
   Y = ((x << 1) + m.q2) - xn;
   X = xn;
 }
-// inverse (Gentleman-Sande): X, Y in [0, 4q) -> X' in [0, 4q), Y' in [0, 1.5q + 1]   (X + 4q - Y < 8q <= 2^63)
+// inverse (Gentleman-Sande): X, Y in [0, 4q) -> X' in [0, 4q), Y' in [0, 1.5q + 2^28)   (X + 4q - Y < 8q <= 2^63)
 HM_HD void hm_bfly_inv(uint64_t &X, uint64_t &Y, HmW wt, const HmBflyMod &m) {
   const uint64_t d = (X + m.q4) - Y;
 #if defined(HM_ABL_NOCSUB)

@@ -348,7 +348,7 @@ HM_HD void hm_ph_compute(HmNttState &st, uint64_t q) {
 }
 // multiply element j of the row by tws[(j mod 4) - 1] (the K == 0, NB == 2 ROW round: v[4 u + e] is element 4 hi + e).
 // Lazy Montgomery product (constants in Montgomery form): input below 2^63 (every value of a pass is below 8q), result in
-// [0, 1.5q + 1] — inside the input range of both butterfly forms.
+// [0, 1.5q + 2^28) — inside the input range of both butterfly forms.
 HM_HD void hm_ph_twist(HmNttState &st, uint64_t q) {
 #if defined(HM_ABL_NOCOMPUTE)
   st.v[1] ^= st.tws[0] ^ st.tws[1] ^ st.tws[2];
@@ -526,7 +526,7 @@ HM_HD void hm_lds_unidx(int w, int &x, int &c) {
 // The lazy product (round 4): the transform's word-wise Montgomery product (hm_mont_acc, q = h 2^32 + 1) with the key word as the
 // constant: acc += x y 2^-64 mod q + {0, q}, six multiplies and 11 instructions where Barrett's quotient from two approximate high
 // products took twelve and 19.  x < 4q (the transform's lazy output; any x below 2^63 is allowed), y < q: a term adds less than
-// 1.5q + 1, so up to five terms stay below 8q <= 2^63 with no folding.  hm_mac_final multiplies the sum by 2^128 mod q the same way
+// 1.5q + 2^28, so up to five terms stay below 8q <= 2^63 with no folding.  hm_mac_final multiplies the sum by 2^128 mod q the same way
 // (sum 2^-64 2^128 2^-64 = sum) and subtracts q once: 16 instructions per output.
 struct HmMacMod {
   HmBflyMod b;
@@ -542,7 +542,7 @@ HM_HD void hm_mac_add(uint64_t &acc, uint64_t x, uint64_t y, const HmMod &, cons
 HM_HD void hm_mac_add(hm_u128 &acc, uint64_t x, uint64_t y, const HmMod &, const HmMacMod &, bool) { acc += (hm_u128)x * y; }
 HM_HD uint64_t hm_mac_final(uint64_t acc, const HmMod &m) {   // acc < 8q
   const HmBflyMod b = hm_bfly_mod(m.q);
-  return hm_csub_neg(hm_mont_acc(0, acc, m.r128, b), b.nq);   // [0, 1.5q + 1] -> [0, q)
+  return hm_csub_neg(hm_mont_acc(0, acc, m.r128, b), b.nq);   // [0, 1.5q + 2^28) -> [0, q)
 }
 HM_HD uint64_t hm_mac_final(hm_u128 acc, const HmMod &m) { return hm_barrett(acc, m); }   // 4 terms x (x < 2q) x (y < q) < 2^123
 // [0, 4q) -> [0, 2q): the wide accumulators take transform outputs below 2q, so that the sum stays inside hm_barrett's range

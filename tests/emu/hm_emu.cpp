@@ -309,4 +309,28 @@ int emu_mac(void *h, uint32_t mod, uint64_t *acc, const uint64_t *x, const uint6
   return 0;
 }
 uint64_t emu_mac_final(void *h, uint32_t mod, uint64_t acc) { return hm16::hm_mac_final(acc, ((Emu *)h)->P.modc[mod]); }
+// the word-wise Montgomery product itself (hm_mont_acc): out[i] = c[i] + x[i] * wt[i] * 2^-64 mod q + {0, q}; and the per-launch constant
+// product (hm_mont_const_mul), the wide reduction (hm_redc_wide) and one forward / inverse butterfly of each kind
+void emu_mont_acc(void *h, uint32_t mod, const uint64_t *c, const uint64_t *x, const uint64_t *wt, uint64_t *out, uint32_t n) {
+  const HmBflyMod m = hm_bfly_mod(((Emu *)h)->P.mod[mod]);
+  for (uint32_t i = 0; i < n; ++i) out[i] = hm_mont_acc(c[i], x[i], wt[i], m);
+}
+uint64_t emu_mont_const_mul(void *h, uint32_t mod, uint64_t x, uint64_t k) {
+  const uint64_t q = ((Emu *)h)->P.mod[mod];
+  return hm_mont_const_mul(x, hm_to_mont(k, q), q);
+}
+uint64_t emu_redc_wide(void *h, uint32_t mod, uint64_t lo, uint64_t hi, int terms) {
+  const HmMod &m = ((Emu *)h)->P.modc[mod];
+  const hm_u128 z = ((hm_u128)hi << 64) | lo;
+  return terms <= 16 ? hm_redc_wide<16>(z, m) : hm_redc_wide<32>(z, m);
+}
+void emu_bfly(void *h, uint32_t mod, int kind, uint64_t *X, uint64_t *Y, uint64_t w) {   // kind 0..2: forward; 3: inverse
+  const uint64_t q = ((Emu *)h)->P.mod[mod];
+  const HmBflyMod m = hm_bfly_mod(q);
+  const HmW wt = hm_to_mont(w, q);
+  if (kind == 0) hm_bfly_fwd_k<0>(*X, *Y, wt, m);
+  else if (kind == 1) hm_bfly_fwd_k<1>(*X, *Y, wt, m);
+  else if (kind == 2) hm_bfly_fwd_k<2>(*X, *Y, wt, m);
+  else hm_bfly_inv(*X, *Y, wt, m);
+}
 }

@@ -264,7 +264,7 @@ def test_emu_ntt_through_the_dma_tile_image(emu, logN, geo8):
 def test_emu_key_mac_lazy_ranges(emu):
     """the fused transform x key kernel's multiply-accumulate (hm_mac_add): the word-wise Montgomery product with the key word as the
     constant.  For x anywhere below 8q (twice the transform's lazy output range), y below q: every product adds x*y*2^-64 mod q plus at
-    most q, less than 1.5q + 1, so five terms stay below 8q <= 2^63 (the kernel takes at most four); the final product with 2^128 mod q
+    most q, less than 1.5q + 2^28, so five terms stay below 8q <= 2^63 (the kernel takes at most four); the final product with 2^128 mod q
     and one subtraction give x.y mod q — with the extreme operands (0, 1, q-1, 8q-1, values next to powers of two) and random ones, for
     the default chain (60-bit moduli) and for 59-, 45- and 40-bit moduli"""
     emu.emu_mac.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]
@@ -301,7 +301,76 @@ def test_emu_key_mac_lazy_ranges(emu):
                 want[i] = (want[i] + int(Xt[i]) * int(Yt[i])) % q
                 a = int(acc[i])
                 assert (a << 64) % q == want[i], (mod, term, i)
-                assert a - int(before[i]) <= (3 * q) // 2 + 1 and a < 8 * q, (mod, term, i, a // q)
+                assert a - int(before[i]) < (3 * q) // 2 + (1 << 28) and a < 8 * q, (mod, term, i, a // q)
         for i in range(0, n, 97):
             assert emu.emu_mac_final(h, mod, int(acc[i])) == want[i]
+        emu.emu_destroy(h)
+
+
+def test_emu_montgomery_products_and_butterfly_ranges(emu):
+    """the word-wise Montgomery arithmetic on moduli q = h 2^32 + 1 (hm_modarith.h) against Python integers, at the edges of every stated range:
+    hm_mont_acc (c + x wt 2^-64 mod q + {0, q}, at most floor(x wt / 2^64) + q + h + 1 < 1.5q + 2^28 for x up to 2^63 - 1, wt up to q - 1, no 64-bit overflow with c up
+    to 8q), the per-launch constant product, the two-step reduction of the 128-bit conversion accumulator (16 and 32 terms at their bounds),
+    and the butterflies of each kind at the bounds hm_fwd_bound assumes (inputs below 6q / 8q, outputs below 8q / 6q / 4q; inverse 4q -> 4q);
+    60-, 59-, 45- and 40-bit moduli"""
+    from sympy import isprime
+    emu.emu_create_mods.restype = C.c_void_p
+    emu.emu_create_mods.argtypes = [C.c_uint32] * 3 + [C.c_void_p] * 2
+    emu.emu_mont_acc.argtypes = [C.c_void_p, C.c_uint32] + [C.c_void_p] * 4 + [C.c_uint32]
+    emu.emu_mont_const_mul.restype = C.c_uint64
+    emu.emu_mont_const_mul.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64]
+    emu.emu_redc_wide.restype = C.c_uint64
+    emu.emu_redc_wide.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_int]
+    emu.emu_bfly.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64]
+    small = []
+    for bits in (59, 45, 40, 59, 45, 40):
+        c = (1 << bits) + 1 - (1 << 32)
+        while not isprime(c) or c in small:
+            c -= 1 << 32
+            assert c > 1 << (bits - 1)
+        small.append(c)
+    chain = np.array(small, dtype=np.uint64)
+    rng = np.random.default_rng(17)
+    for h, mod in [(emu.emu_create(13, 4, 2), m) for m in (0, 5)] + [(emu.emu_create_mods(13, 4, 2, p(chain[:4]), p(chain[4:])), m) for m in range(3)]:
+        q = emu.emu_modulus(h, mod)
+        r64inv = pow(1 << 64, -1, q)
+        xs = [0, 1, q - 1, q, 4 * q - 1, 8 * q - 1, (1 << 63) - 1, (1 << 32) - 1, 1 << 32, (1 << 62) + 12345]
+        ws = [0, 1, q - 1, q - 2, (1 << 32) - 1, 1 << 32, q >> 1]
+        cs = [0, q, 6 * q - 1, 8 * q - 1]
+        ex = [(c, x, w) for c in cs for x in xs if x < (1 << 63) for w in ws if w < q]
+        n = 4096
+        Cc = np.concatenate([np.array([e[0] for e in ex], dtype=np.uint64), rng.integers(0, 1 << 62, n, dtype=np.uint64) % np.uint64(8 * q)])
+        X = np.concatenate([np.array([e[1] for e in ex], dtype=np.uint64), rng.integers(0, 1 << 63, n, dtype=np.uint64)])
+        W = np.concatenate([np.array([e[2] for e in ex], dtype=np.uint64), rng.integers(0, 1 << 62, n, dtype=np.uint64) % np.uint64(q)])
+        out = np.zeros(len(X), dtype=np.uint64)
+        emu.emu_mont_acc(h, mod, p(Cc), p(X), p(W), p(out), len(X))
+        for c, x, w, o in zip(Cc.tolist(), X.tolist(), W.tolist(), out.tolist()):
+            v = o - c
+            assert 0 <= v <= (x * w >> 64) + q + (q >> 32) + 1 and v < (3 * q) // 2 + (1 << 28) and o < (1 << 64), (mod, c, x, w)
+            assert v % q == x * w * r64inv % q, (mod, c, x, w)
+        for x in xs:
+            if x >= (1 << 63):
+                continue
+            for k in ws:
+                assert emu.emu_mont_const_mul(h, mod, x, k) == x * k % q, (mod, x, k)
+        # the conversion accumulator: TERMS products y w with y below 2^60 - 2^32 (any input modulus) and w below q, at the bound and random
+        for terms in (16, 32):
+            zmax = terms * ((1 << 60) - (1 << 32)) * (q - 1)
+            for z in [0, 1, q, zmax, zmax - 1, (1 << 64) - 1, 1 << 64, (zmax >> 1) + 977] + [int(rng.integers(0, 1 << 62)) * int(rng.integers(0, 1 << 62)) % (zmax + 1) for _ in range(2000)]:
+                assert emu.emu_redc_wide(h, mod, z & ((1 << 64) - 1), z >> 64, terms) == z * r64inv % q, (mod, terms, z)
+        # butterflies at the bounds of the stage schedule
+        Xb, Yb = (C.c_uint64 * 1)(), (C.c_uint64 * 1)()
+        for kind, xmax, ymax, omax in ((0, 6, 8, 8), (1, 8, 8, 6), (2, 8, 8, 4), (3, 4, 4, 4)):
+            vals = lambda m: [0, 1, q - 1, m * q - 1, m * q - 2, (m * q) >> 1] + [int(v) % (m * q) for v in rng.integers(0, 1 << 62, 200)]
+            for x in vals(xmax):
+                for y in vals(ymax)[::7] + [ymax * q - 1]:
+                    for w in (1, q - 1, 3 + (q >> 3)):
+                        Xb[0], Yb[0] = x, y
+                        emu.emu_bfly(h, mod, kind, Xb, Yb, w)
+                        a, b = int(Xb[0]), int(Yb[0])
+                        assert a < omax * q and b < omax * q, (mod, kind, x, y, w, a // q, b // q)
+                        if kind < 3:
+                            assert a % q == (x + w * y) % q and b % q == (x - w * y) % q, (mod, kind, x, y, w)
+                        else:
+                            assert a % q == (x + y) % q and b % q == (x - y) * w % q, (mod, kind, x, y, w)
         emu.emu_destroy(h)
