@@ -1,19 +1,22 @@
 """soak: two batched hmult instances at full size interleaved for many iterations.  The plan recomputes the same
-deterministic outputs on every pass; all 8 outputs (2 instances x batch 4) are compared with the oracle at EVERY periodic
+deterministic outputs on every pass; all outputs (2 instances x batch B) are compared with the oracle at EVERY periodic
 synchronisation (every 2000 enqueues) and at the end, so a corruption at any point of the run is seen at the next check.
-usage: python tools/soak.py [iterations]"""
+B = 4: the batched launches (two-kernel transforms); B = 1: every transform of both instances is a one-launch transform
+(k_ntt_fused8: two kernels with rendezvous in flight on one GPU at a time).
+usage: python tools/soak.py [iterations] [batch]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from homulator_amd import host
 from oracle.homoracle import Oracle
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 o = Oracle(16, 45, 15); o.set_threads(16)
 evk = {i: o.synth_evk(35, host.SEED + 7 * i + 10000) for i in range(2)}
-ops = [host.Op("config_4.cfg", "hmult", 45, 35, 15, overrides={"seed": host.SEED + 7 * i, "batch": 4}) for i in range(2)]
+ops = [host.Op("config_4.cfg", "hmult", 45, 35, 15, overrides={"seed": host.SEED + 7 * i, "batch": B}) for i in range(2)]
 exp = {}
 for i in range(2):
-    for c in range(4):
+    for c in range(B):
         s = host.SEED + 7 * i + c * 100000
         exp[i, c] = o.hmult(35, o.synth_ct(35, s), o.synth_ct(35, s + 2000), evk[i])
 
@@ -21,7 +24,7 @@ for i in range(2):
 def check():
     n = 0
     for i, op in enumerate(ops):
-        for c in range(4):
+        for c in range(B):
             n += not (np.array_equal(op.read("out.c0", copy=c), exp[i, c][0]) and np.array_equal(op.read("out.c1", copy=c), exp[i, c][1]))
     return n
 
@@ -33,8 +36,8 @@ for it in range(iters):
     if it % 2000 == 1999:
         for op in ops: op.sync()
         bad += check()
-        print(f"{it + 1} enqueues ({(it + 1) * 4} hmults), {time.time() - t0:.1f} s, mismatching outputs so far: {bad}", flush=True)
+        print(f"{it + 1} enqueues ({(it + 1) * B} hmults), {time.time() - t0:.1f} s, mismatching outputs so far: {bad}", flush=True)
 for op in ops: op.sync()
 bad += check()
-print("soak", "OK" if not bad else f"MISMATCH in {bad} outputs", f"{iters * 4 / (time.time() - t0):.0f} hmult/s incl. syncs")
+print("soak", "OK" if not bad else f"MISMATCH in {bad} outputs", f"{iters * B / (time.time() - t0):.0f} hmult/s incl. syncs")
 sys.exit(1 if bad else 0)
