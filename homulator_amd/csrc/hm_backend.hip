@@ -231,7 +231,7 @@ __device__ __forceinline__ void hm_l2_zero(unsigned long long *p) {
 // block id lands on is the dispatcher's business (blocks b and b + 8 share one, but not necessarily XCD b mod 8), so a spread is found
 // by publication: a workgroup whose first poll fails ORs its XCC id into the limb-poly's agent-scope mask (not returning: no round trip
 // for the workgroup, which is waiting anyway; the last arriver never gets that far) and looks at the mask every 16th spin.
-__device__ __forceinline__ uint32_t hm_limb_rendezvous(HmNttSync *ws, unsigned *err, uint32_t entry, uint32_t members, uint32_t *lds_flag) {
+__device__ __forceinline__ uint32_t hm_limb_rendezvous(HmNttSync *ws, unsigned *err, uint32_t entry, uint32_t members, uint32_t *lds_flag, uint32_t pretend_spread = 0, uint32_t tile = 0) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave: its stores have reached L2
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -240,8 +240,10 @@ __device__ __forceinline__ uint32_t hm_limb_rendezvous(HmNttSync *ws, unsigned *
     (void)hm_l2_add(w, 1ull);
     unsigned spins = 0;
     for (;;) {
-      if ((uint32_t)hm_l2_add(w, 0ull) == members) { fast = 1; break; }
-      if (spins == 0) (void)__hip_atomic_fetch_or(&ws->xccmask[entry], 1u << hm_xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // (pretend_spread: test hook — the workgroups behave as if those of odd tiles ran on another XCD, whose copy of the counter this one
+      // never sees complete: exercises the agent-scope path on hardware that never spreads a limb-poly)
+      if ((uint32_t)hm_l2_add(w, 0ull) == members && !pretend_spread) { fast = 1; break; }
+      if (spins == 0) (void)__hip_atomic_fetch_or(&ws->xccmask[entry], pretend_spread ? 1u << (tile & 1u) : 1u << hm_xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       else if ((spins & 15u) == 15u) {
         const unsigned m = __hip_atomic_load(&ws->xccmask[entry], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (m & (m - 1u)) break;   // two XCDs: everybody takes the agent-scope path
@@ -292,6 +294,7 @@ __device__ __forceinline__ void hm_limb_leave(HmNttSync *ws, uint32_t entry, uin
 struct HmNttFusedArgs {
   HmNttSync *ws;
   unsigned *err;   // host-visible word: 0 = fine, 1 / 2 = a rendezvous timed out
+  uint32_t pretend_spread;   // test hook (hm_set_option "ntt_fused_test_spread"): take the agent-scope path as if the limb-poly were spread over XCDs
 };
 // MODE_A: first pass (0, or 4 = mix prologue); MODE_B: last pass (1 forward, 3 fused epilogue, 2 inverse)
 // IN_AUX: cache policy of the first pass's input loads.  Out of place they are read once and only crowd the L2 that should keep the
@@ -319,7 +322,7 @@ __device__ __forceinline__ void hm_ntt_fused_body(const HmNttArgs &a, const HmNt
   // the hand-off and arrive while the workgroup waits) and in front of everything that touches LDS or the hand-off
   uint32_t fast = 0;
   auto meet = [&] {
-    fast = hm_limb_rendezvous(f.ws, f.err, entry, members, flag);
+    fast = hm_limb_rendezvous(f.ws, f.err, entry, members, flag, f.pretend_spread, tile);
     if (!fast) hm_limb_publish_everywhere(f.ws, f.err, entry, members);
   };
 #if defined(HM_FUSED_MEET_FIRST)   // (A/B: the rendezvous in front of the second pass instead of inside its first phase)
@@ -985,6 +988,7 @@ struct hm_ctx {
   uint32_t side_max_wgs = 4096;   // ... when together they are at most this many workgroups (4 rounds of the chip)
   uint32_t small_limbs = 64;   // measured (tools/ntt_small_ab.py): 2-3 us per launch faster up to ~64 entries, equal at 115, slower from 128
   bool fused_ntt = false;  // every transform as one launch (k_ntt_fused): slower for launches that fill the chip more than once, opt-in
+  uint32_t fused_test_spread = 0;   // test hook: one-launch transforms take the agent-scope path
   uint32_t fused_small = 96;  // launches of up to this many entries (N = 2^16) run as ONE launch in the small-launch geometry (k_ntt_fused8): 2-5 us faster than two kernels up to ~100 limb-polys, slower from 128 (tools/ntt_fused_small_ab.py); 0 = off
   uint32_t fused_extra_lds = 0;   // dynamic LDS added to every k_ntt_fused workgroup: occupancy throttle of the L2 hand-off experiment
   // persistent two-pass transform fed from per-XCD queues (k_ntt_queue): 0 off, 1 = 8-coefficient geometry (N = 2^16), 2 = 16-coefficient
@@ -1289,6 +1293,7 @@ extern "C" hm_status hm_wait_for(hm_ctx *c, hm_ctx *producer) {
 extern "C" hm_status hm_set_option(hm_ctx *c, const char *name, uint64_t value) {
   if (!c || !name) return HM_ERR_ARG;
   if (!strcmp(name, "ntt_fused")) { c->fused_ntt = value != 0; return HM_OK; }
+  if (!strcmp(name, "ntt_fused_test_spread")) { c->fused_test_spread = value != 0; return HM_OK; }
   if (!strcmp(name, "ntt_fused_small")) { if (value > HM_NTT_MAX_ENTRIES) return fail(c, HM_ERR_ARG, "hm_set_option: ntt_fused_small above %d", HM_NTT_MAX_ENTRIES); c->fused_small = (uint32_t)value; return HM_OK; }
   if (!strcmp(name, "ntt_fused_lds")) { if (value > 120 * 1024) return fail(c, HM_ERR_ARG, "hm_set_option: ntt_fused_lds above 120 KiB"); c->fused_extra_lds = (uint32_t)value; return HM_OK; }
   if (!strcmp(name, "bconv_col_outs")) { if (value > 2) return fail(c, HM_ERR_ARG, "hm_set_option: bconv_col_outs is 0 (by launch size), 1 or 2"); c->bcol_outs = (uint32_t)value; return HM_OK; }
@@ -1441,7 +1446,7 @@ static void launch_ntt(hm_ctx *c, const HmNttArgs &a, bool fusedEpilogue, bool m
     // XCD's 128 slots); every other resident workgroup belongs to a complete limb-poly and finishes.  Up to eight such kernels in flight on
     // one GPU (contexts, instances; HIP drives four hardware queues by default) cannot starve one another; the spins are bounded all the same.
     if (!firstPassOnly && !c->fused_ntt && !c->dma_ntt && a.n_limbs <= c->fused_small && a.logG == 0) {
-      const HmNttFusedArgs f = {c->ntt_ws, c->err_dev};
+      const HmNttFusedArgs f = {c->ntt_ws, c->err_dev, c->fused_test_spread};
       const dim3 grid8(a.n_limbs * (c->P.N >> HM_TL_ROW)), block8((1 << HM_TL_ROW) / 8);
       bool inPlace = a.in == a.out;   // every limb-poly transformed onto itself: the input loads keep their lines for the hand-off
       for (uint32_t e = 0; inPlace && e < a.n_limbs; ++e) inPlace = a.limb[e].mod == HM_NTT_NONE || a.limb[e].in == a.limb[e].out;
@@ -1496,7 +1501,7 @@ static void launch_ntt(hm_ctx *c, const HmNttArgs &a, bool fusedEpilogue, bool m
     return;
   }
   if (c->fused_ntt) {   // both passes in one launch, hand-off through the XCD's L2
-    const HmNttFusedArgs f = {c->ntt_ws, c->err_dev};
+    const HmNttFusedArgs f = {c->ntt_ws, c->err_dev, c->fused_test_spread};
     // "ntt_fused_lds": extra dynamic LDS per workgroup = an occupancy throttle (100 KiB: one workgroup per CU = 32 per XCD = two
     // limb-polys in flight per XCD, 3 MiB live per 4 MiB L2): the capacity-controlled form of the hand-off experiment
     const uint32_t xl = c->fused_extra_lds;

@@ -296,6 +296,8 @@ void hm_graph_destroy(hm_graph *graph);
  *                ONE launch: the workgroups of a limb-poly meet at a counter in their XCD's L2 between the passes
  *                (k_ntt_fused8; 2-5 us faster than two kernels up to ~100 limb-polys); 0 switches it off.
  *                Env HOMULATOR_NTT_FUSED_SMALL.
+ *   "ntt_fused_test_spread"  test hook: one-launch transforms take the agent-scope path of their rendezvous, as if the
+ *                dispatcher had spread every limb-poly over two XCDs (slow; results unchanged; counted by "ntt_cross_xcd").
  *   "ntt_fused"  0 (default); 1: EVERY transform as one launch, in the wide geometry (slower than two kernels for launches
  *                that fill the chip more than once).  Env HOMULATOR_NTT_FUSED sets the default.
  *   "ntt_small_limbs"  two-kernel transform launches (single passes; "ntt_fused_small" 0) of at most this many limb-poly entries

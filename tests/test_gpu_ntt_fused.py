@@ -197,3 +197,32 @@ def test_one_launch_small_geometry_equals_two_kernels_and_oracle():
         assert ctx.counter("ntt_cross_xcd") == 0
     finally:
         ctx.close()
+
+
+def test_agent_scope_path_of_the_rendezvous():
+    """the dispatcher has never spread a limb-poly's workgroups over XCDs, so the agent-scope path of the rendezvous (found through the
+    XCC-id mask: L2 write-back, second rendezvous on an agent-scope counter, acquire) would never run: the test hook makes the workgroups
+    of odd tiles publish another XCC id and nobody accept the XCD-local count.  Results must not change, every limb-poly must be counted
+    as spread, and the words must be back at rest for the next (ordinary) launch — in both geometries"""
+    ctx, o = _ctx(16, 6, 3)
+    try:
+        n = 21
+        ids = [(i * 5 + 1) % 9 for i in range(n)]
+        x = o.fill_uniform(ids, 991)
+        d, a = ctx.from_host(x), ctx.alloc(n)
+        exp = o.ntt(ids, x)
+        for wide in (0, 1):
+            ctx.set_option("ntt_fused", wide)
+            before = ctx.counter("ntt_cross_xcd")
+            ctx.set_option("ntt_fused_test_spread", 1)
+            for _ in range(2):
+                ctx.ntt(d, a, ids)
+            assert np.array_equal(a.download(), exp)
+            assert ctx.counter("ntt_cross_xcd") - before == 2 * n
+            ctx.set_option("ntt_fused_test_spread", 0)
+            ctx.ntt(d, a, ids)
+            ctx.ntt(a, a, ids, inverse=True)
+            assert np.array_equal(a.download(), x)
+            assert ctx.counter("ntt_cross_xcd") - before == 2 * n
+    finally:
+        ctx.close()
