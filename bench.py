@@ -98,10 +98,56 @@ def measure_ntt_sweep(n_limbs, iters=48, sets=6):
         a, b = bufs[i % sets]
         ctx.ntt(a, b, ids)
     ns = ctx.timer_stop() / iters
+    cross = ctx.counter("ntt_cross_xcd")   # limb-polys whose workgroups were spread over XCDs (agent-scope path of the rendezvous): 0 expected
+    one_launch = ctx.counter("ntt_fused_small")
     for a, b in bufs:
         a.free(); b.free()
     ctx.close()
-    return ns
+    return ns, cross, one_launch
+
+
+def measure_second_op(opn, streams, batch, steps, device):
+    """BASELINE configs[3] beside the headline: `steps` hrotates at 45/35/15 through the same instances x batch x HIP-graph shape as the
+    timed region of the headline op, timed the same way (wall clock around enqueue + sync); own instances, closed afterwards"""
+    from homulator_amd import host
+    ops = [host.Op(CFG, opn, L, ELL, ALPHA, device=device,
+                   overrides={"seed": host.SEED + 31 * (i + 1), **({"batch": batch} if batch > 1 else {}), "graph": 1}) for i in range(streams)]
+    tail = host.Op(CFG, opn, L, ELL, ALPHA, device=device, overrides={"seed": host.SEED + 998}) if batch > 1 else None
+
+    def run(n):
+        for i in range(n // batch):
+            ops[i % streams].enqueue(1)
+        if n % batch:
+            (tail if tail is not None else ops[0]).enqueue(n % batch if tail is not None else 1)
+
+    def sync_all():
+        for o in ops:
+            o.sync()
+        if tail is not None:
+            tail.sync()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.3:   # plan, graph capture, clock ramp
+        run(streams * batch)
+        sync_all()
+    if tail is not None:
+        tail.enqueue(1)
+    sync_all()
+    t0 = time.perf_counter()
+    run(steps)
+    sync_all()
+    dt = time.perf_counter() - t0
+    cross = sum(o.backend_counter("ntt_cross_xcd") for o in ops + ([tail] if tail is not None else []))
+    launches = ops[0].launch_count()
+    for o in ops:
+        o.close()
+    if tail is not None:
+        tail.close()
+    ms = dt / steps * 1e3
+    evk_once = HROTATE_ALG_BYTES - EVK_BYTES * (1 - 1 / batch)
+    return {"workload": f"{CFG} {opn} L={L} l={ELL} alpha={ALPHA} (BASELINE configs[3]: automorphism + full hybrid key switch)",
+            "ops_per_s": steps / dt, "ms_per_step": ms, "steps": steps, "streams": streams, "batch": batch, "launches_per_op": launches,
+            "frac_of_hbm_peak": HROTATE_ALG_BYTES / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "frac_evk_once": evk_once / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "ntt_cross_xcd": cross}
 
 
 def cpu_baseline(opn="hmult", runs=5):
@@ -168,6 +214,11 @@ def roofline_op(batched_rows, batch, rin):
 
 
 DEFAULT_BATCH = 10
+# which arithmetic back-end the context chose for the chain it was given (hm_get_counter "arith")
+MODULI_NOTE = {
+    0: "mont32: the default chain, 45 + 15 largest primes h*2^32 + 1 below 2^60 (word-wise Montgomery reduction, q^-1 = 1 mod 2^32: six 32-bit multiplies per butterfly, one-word twiddles)",
+    1: "generic: any distinct NTT-friendly primes below 2^60 (Shoup / Barrett arithmetic, nine multiplies per butterfly, two-word twiddles)",
+}
 
 
 def pick_batch(steps, streams, default=DEFAULT_BATCH):
@@ -347,7 +398,10 @@ def main():
         ms = dt / args.steps * 1e3
         value = args.steps / dt   # whole-job rate: the N GPUs complete `steps` sharded hmults together
         sweep_limbs = ELL + ALPHA
-        ntt_ns = measure_ntt_sweep(sweep_limbs)
+        ntt_ns, sweep_cross, sweep_one_launch = measure_ntt_sweep(sweep_limbs)
+        # limb-polys of one-launch transforms that took the agent-scope path of the rendezvous in the op instances (timed region, warm-up, stage timings)
+        op_cross = sum(o.backend_counter("ntt_cross_xcd") for o in ops + ([tail_op] if tail_op is not None else []))
+        arith = op.backend_counter("arith")
         inop_ns, inop_limbs = measure_ntt_inop(batch) if world == 1 else (None, None)
         achieved = NTT_ALG_BYTES * sweep_limbs / ntt_ns  # B/ns = GB/s
         rin = roofline_inputs()
@@ -364,9 +418,13 @@ def main():
                        "parallelism": "single GPU" if world == 1 else f"limbs sharded over {world} GPUs (limb e -> e % {world}); RCCL all-to-all around every digit's ModUp conversion and around the ModDown conversion (2 beta + 2 per key switch, digit j+1's exchange on the exchange stream beside digit j's conversion and transform) + replicate of the rescale residue; {batch} hmults per launch share the exchanges",
                        "launches_per_op": op.launch_count(), "streams": streams, "batch": batch, "transport": transport,
                        "hip_graph": bool(world == 1 and args.graph),
+                       "moduli": MODULI_NOTE[arith],
                        "evk_note": "the ops of a batch share ONE evaluation key: the 157 MB key stream that the algorithmic figure charges per op is read from HBM once per batch, the other readers hit cache",
                        "streams_note": "`streams` instances in flight (own HBM pool / HIP stream each), each carrying `batch` independent hmults per launch (own inputs, one evaluation key); a step is one hmult"},
             "hip_library": loaded_hip_library(),
+            # one-launch transforms: limb-polys whose workgroups were spread over XCDs (the rendezvous' slow agent-scope path; 0 expected) after
+            # the sweep and in the op instances, and whether the form was in force (0 = off: the guard of hm_create or a time-out)
+            "ntt_cross_xcd": {"after_sweep": sweep_cross, "after_timed_region": op_cross, "ntt_fused_small": sweep_one_launch},
             "single_stream_ops_per_s": single,
             "sustained_ops_per_s": sustained,
             "launches_in_timed_region_per_instance": args.steps // (batch * streams),
@@ -417,6 +475,8 @@ def main():
                          "note": "`achieved`/`peak`/`frac`/`traffic` are the HBM figures of the task's contract (`contract_bound`); `bound` names the ceiling "
                                  "with the larger floor for this launch (the 64-bit modular butterflies are integer VALU work)"},
         }
+        if world == 1 and opn == "hmult":   # configs[3] at the same launch shape, so that the driver's run times it too
+            out["hrotate"] = measure_second_op("hrotate", streams, batch, args.steps, local_rank)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(opn)
         try:  # the reference's own answer for the same command line, from the build's cycle model (backend = sim): host only

@@ -226,18 +226,28 @@ __device__ __forceinline__ void hm_l2_zero(unsigned long long *p) {
   unsigned long long old, z = 0;
   asm volatile("global_atomic_swap_x2 %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(old) : "v"(p), "v"(z) : "memory");
 }
-// all `members` workgroups of limb-poly `entry` have stored their hand-off.  Returns 1 if they all run on this XCD and met on the
-// XCD-local counter, 0 if the limb-poly is spread over several XCDs (then no copy of the counter ever reaches `members`).  Which XCD a
-// block id lands on is the dispatcher's business (blocks b and b + 8 share one, but not necessarily XCD b mod 8), so a spread is found
-// by publication: a workgroup whose first poll fails ORs its XCC id into the limb-poly's agent-scope mask (not returning: no round trip
-// for the workgroup, which is waiting anyway; the last arriver never gets that far) and looks at the mask every 16th spin.
-__device__ __forceinline__ uint32_t hm_limb_rendezvous(HmNttSync *ws, unsigned *err, uint32_t entry, uint32_t members, uint32_t *lds_flag, uint32_t pretend_spread = 0, uint32_t tile = 0) {
+// not returning: the issuing wave does not wait for it (same-address operations of one wave reach the L2 in order)
+__device__ __forceinline__ void hm_l2_add_noret(unsigned long long *p, unsigned long long v) {
+  asm volatile("global_atomic_add_x2 %0, %1, off" ::"v"(p), "v"(v) : "memory");
+}
+// The rendezvous of a limb-poly's workgroups, in two halves.  hm_limb_arrive: this workgroup's hand-off stores have reached the L2 (every
+// storing wave waits for its own, then the barrier), one lane adds to the limb-poly's XCD-local counter.  It runs BEFORE the second pass
+// requests anything, so nothing but the stores is waited for and the arrival is not held up by the twiddle loads (round 5; it used to sit
+// behind them).  hm_limb_wait (inside the second pass's first phase, behind its first twiddle requests, which travel while the workgroup
+// waits): all `members` workgroups have arrived.  Returns 1 if they all run on this XCD and met on the XCD-local counter, 0 if the
+// limb-poly is spread over several XCDs (then no copy of the counter ever reaches `members`).  Which XCD a block id lands on is the
+// dispatcher's business (blocks b and b + 8 share one, but not necessarily XCD b mod 8), so a spread is found by publication: a workgroup
+// whose first poll fails ORs its XCC id into the limb-poly's agent-scope mask (not returning: no round trip for the workgroup, which is
+// waiting anyway; the last arriver never gets that far) and looks at the mask every 16th spin.
+__device__ __forceinline__ void hm_limb_arrive(HmNttSync *ws, uint32_t entry, bool withhold) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave: its stores have reached L2
   __syncthreads();
+  if (threadIdx.x == 0 && !withhold) hm_l2_add_noret(&ws->fast[entry].w, 1ull);
+}
+__device__ __forceinline__ uint32_t hm_limb_wait(HmNttSync *ws, unsigned *err, uint32_t entry, uint32_t members, uint32_t *lds_flag, uint32_t spin_limit, uint32_t pretend_spread = 0, uint32_t tile = 0) {
   if (threadIdx.x == 0) {
     unsigned long long *w = &ws->fast[entry].w;
     uint32_t fast = 0;
-    (void)hm_l2_add(w, 1ull);
     unsigned spins = 0;
     for (;;) {
       // (pretend_spread: test hook — the workgroups behave as if those of odd tiles ran on another XCD, whose copy of the counter this one
@@ -249,7 +259,7 @@ __device__ __forceinline__ uint32_t hm_limb_rendezvous(HmNttSync *ws, unsigned *
         if (m & (m - 1u)) break;   // two XCDs: everybody takes the agent-scope path
       }
       __builtin_amdgcn_s_sleep(1);
-      if (++spins > HM_SPIN_LIMIT) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+      if (++spins > spin_limit) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); fast = 2; break; }   // 2: timed out, leave without a second wait
     }
     *lds_flag = fast;
   }
@@ -257,7 +267,7 @@ __device__ __forceinline__ uint32_t hm_limb_rendezvous(HmNttSync *ws, unsigned *
   return *lds_flag;
 }
 // the agent-scope path: make the hand-off visible to every XCD
-__device__ __forceinline__ void hm_limb_publish_everywhere(HmNttSync *ws, unsigned *err, uint32_t entry, uint32_t members) {
+__device__ __forceinline__ void hm_limb_publish_everywhere(HmNttSync *ws, unsigned *err, uint32_t entry, uint32_t members, uint32_t spin_limit) {
   if (threadIdx.x == 0) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -265,7 +275,7 @@ __device__ __forceinline__ void hm_limb_publish_everywhere(HmNttSync *ws, unsign
     unsigned spins = 0;
     while (__hip_atomic_load(&ws->arrive2[entry], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < members) {
       __builtin_amdgcn_s_sleep(4);
-      if (++spins > HM_SPIN_LIMIT) { __hip_atomic_store(err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+      if (++spins > spin_limit) { __hip_atomic_store(err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -295,6 +305,8 @@ struct HmNttFusedArgs {
   HmNttSync *ws;
   unsigned *err;   // host-visible word: 0 = fine, 1 / 2 = a rendezvous timed out
   uint32_t pretend_spread;   // test hook (hm_set_option "ntt_fused_test_spread"): take the agent-scope path as if the limb-poly were spread over XCDs
+  uint32_t spin_limit;       // HM_SPIN_LIMIT; the time-out test hook passes a short one
+  uint32_t withhold;         // test hook (hm_set_option "ntt_fused_test_timeout"): tile 0 of every limb-poly never arrives
 };
 // MODE_A: first pass (0, or 4 = mix prologue); MODE_B: last pass (1 forward, 3 fused epilogue, 2 inverse)
 // IN_AUX: cache policy of the first pass's input loads.  Out of place they are read once and only crowd the L2 that should keep the
@@ -318,21 +330,18 @@ __device__ __forceinline__ void hm_ntt_fused_body(const HmNttArgs &a, const HmNt
   int tid2 = threadIdx.x;
   if (HM_OPAQUE_TID2) asm volatile("" : "+v"(tid2));
   __builtin_assume(tid2 >= 0 && tid2 < (1 << HM_TL_ROW) / GEO::EPT);
-  // the rendezvous sits INSIDE the second pass's first phase, behind the requests for its first round's twiddles (they do not depend on
-  // the hand-off and arrive while the workgroup waits) and in front of everything that touches LDS or the hand-off
+  // the arrival is published as soon as the hand-off is stored; the wait sits INSIDE the second pass's first phase, behind the requests for
+  // its first round's twiddles (they do not depend on the hand-off and arrive while the workgroup waits) and in front of everything that
+  // touches LDS or the hand-off
+  hm_limb_arrive(f.ws, entry, f.withhold && tile == 0);
   uint32_t fast = 0;
   auto meet = [&] {
-    fast = hm_limb_rendezvous(f.ws, f.err, entry, members, flag, f.pretend_spread, tile);
-    if (!fast) hm_limb_publish_everywhere(f.ws, f.err, entry, members);
+    fast = hm_limb_wait(f.ws, f.err, entry, members, flag, f.spin_limit, f.pretend_spread, tile);
+    if (!fast) hm_limb_publish_everywhere(f.ws, f.err, entry, members, f.spin_limit);
   };
-#if defined(HM_FUSED_MEET_FIRST)   // (A/B: the rendezvous in front of the second pass instead of inside its first phase)
-  meet();
-  if (!INV) hm_ntt_pass_run<HM_ROW_LOG, false, false, MODE_B, HM_FUSED_MID_AUX, HM_FUSED_OUT_AUX, 1, GEO>(a, lds, entry, tile, tid2);
-  else hm_ntt_pass_run<LOG1, true, true, MODE_B, HM_FUSED_MID_AUX, HM_FUSED_OUT_AUX, HM_EPI_CHUNK, GEO>(a, lds, entry, tile, tid2);
-#else
   if (!INV) hm_ntt_pass_run<HM_ROW_LOG, false, false, MODE_B, HM_FUSED_MID_AUX, HM_FUSED_OUT_AUX, 1, GEO>(a, lds, entry, tile, tid2, meet);
   else hm_ntt_pass_run<LOG1, true, true, MODE_B, HM_FUSED_MID_AUX, HM_FUSED_OUT_AUX, HM_EPI_CHUNK, GEO>(a, lds, entry, tile, tid2, meet);
-#endif
+  if (fast == 2) return;   // timed out: the host zeroes the words (check_device_error)
   hm_limb_leave(f.ws, entry, members, fast);
 }
 template <int LOG1, bool INV, int MODE_A, int MODE_B>
@@ -989,6 +998,10 @@ struct hm_ctx {
   uint32_t small_limbs = 64;   // measured (tools/ntt_small_ab.py): 2-3 us per launch faster up to ~64 entries, equal at 115, slower from 128
   bool fused_ntt = false;  // every transform as one launch (k_ntt_fused): slower for launches that fill the chip more than once, opt-in
   uint32_t fused_test_spread = 0;   // test hook: one-launch transforms take the agent-scope path
+  uint32_t fused_test_timeout = 0;  // test hook: tile 0 of every limb-poly withholds its arrival and the spins are short: the rendezvous times out
+  uint32_t fused_slots_per_xcd = 0;  // workgroups of the one-launch transform an XCD holds at once (hm_create: occupancy x CUs per XCD)
+  bool fused_broken = false;        // a rendezvous timed out: no one-launch transforms any more, graphs that hold one refuse to replay
+  bool capture_has_fused = false;   // the capture in progress recorded a one-launch transform
   uint32_t fused_small = 96;  // launches of up to this many entries (N = 2^16) run as ONE launch in the small-launch geometry (k_ntt_fused8): 2-5 us faster than two kernels up to ~100 limb-polys, slower from 128 (tools/ntt_fused_small_ab.py); 0 = off
   uint32_t fused_extra_lds = 0;   // dynamic LDS added to every k_ntt_fused workgroup: occupancy throttle of the L2 hand-off experiment
   // persistent two-pass transform fed from per-XCD queues (k_ntt_queue): 0 off, 1 = 8-coefficient geometry (N = 2^16), 2 = 16-coefficient
@@ -1130,6 +1143,24 @@ extern "C" hm_status hm_create(hm_ctx **out, const hm_params *p) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, cc->device) == hipSuccess && prop.multiProcessorCount > 0) cc->n_cu = prop.multiProcessorCount;
   }
+  // Co-residency guard of the one-launch transform: its rendezvous needs the N / 4096 = 16 workgroups of a limb-poly resident on one XCD
+  // at a time.  The occupancy the runtime reports for the register-heaviest variant times the CUs of an XCD (an eighth of what the device
+  // shows: under a CU mask or a partition mode this is conservative) must cover that; otherwise the form is switched off for the context
+  // instead of degrading into time-outs (counter "ntt_fused_slots_per_xcd").
+  {
+    uint32_t slots = ~0u;
+    auto probe = [&](auto kern) {
+      int nb = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, (1 << HM_TL_ROW) / 8, 0) != hipSuccess) nb = 0;
+      slots = std::min(slots, (uint32_t)std::max(nb, 0) * (uint32_t)std::max(1, cc->n_cu / 8));
+    };
+    probe(k_ntt_fused8<false, 0, 1, true>); probe(k_ntt_fused8<false, 0, 1, false>);
+    probe(k_ntt_fused8<false, 0, 3, true>); probe(k_ntt_fused8<false, 0, 3, false>);
+    probe(k_ntt_fused8<false, 4, 3, true>); probe(k_ntt_fused8<false, 4, 3, false>);
+    probe(k_ntt_fused8<true, 0, 2, true>);  probe(k_ntt_fused8<true, 0, 2, false>);
+    cc->fused_slots_per_xcd = slots;
+    if (slots < (cc->P.N >> HM_TL_ROW)) cc->fused_small = 0;
+  }
   if (getenv("HOMULATOR_NTT_QUEUE_TRACE")) {
     HM_HIP(nullptr, hipHostMalloc(reinterpret_cast<void **>(&cc->q_trace_host), 64 * 256 * 4, hipHostMallocMapped));
     memset(cc->q_trace_host, 0, 64 * 256 * 4);
@@ -1147,6 +1178,7 @@ extern "C" hm_status hm_create(hm_ctx **out, const hm_params *p) {
   HM_HIP(nullptr, hipHostGetDevicePointer(reinterpret_cast<void **>(&cc->err_dev), cc->err_host, 0));
   if (const char *e = getenv("HOMULATOR_NTT_FUSED")) cc->fused_ntt = std::string(e) != "0";
   if (const char *e = getenv("HOMULATOR_NTT_FUSED_SMALL")) cc->fused_small = (uint32_t)std::min(HM_NTT_MAX_ENTRIES, std::max(0, atoi(e)));
+  if (cc->fused_slots_per_xcd < (cc->P.N >> HM_TL_ROW)) cc->fused_small = 0;   // the guard above wins over the environment
   if (const char *e = getenv("HOMULATOR_NTT_FUSED_LDS")) cc->fused_extra_lds = (uint32_t)std::min(120 * 1024, std::max(0, atoi(e)));
   if (const char *e = getenv("HOMULATOR_NTT_SMALL_LIMBS")) { cc->small_limbs = (uint32_t)atoi(e); cc->small_ept8 = cc->small_limbs != 0; }
   if (const char *e = getenv("HOMULATOR_SIDE_LAUNCHES")) cc->side_launches = std::string(e) != "0";
@@ -1209,6 +1241,7 @@ extern "C" hm_status hm_free(hm_ctx *c, void *dptr) {
   HM_HIP(c, hipFree(dptr));
   return HM_OK;
 }
+static hm_status check_device_error(hm_ctx *c);
 extern "C" hm_status hm_memcpy_h2d(hm_ctx *c, void *dst, const void *src, size_t bytes) {
   if (!c) return HM_ERR_ARG;
   HM_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
@@ -1219,7 +1252,7 @@ extern "C" hm_status hm_memcpy_d2h(hm_ctx *c, void *dst, const void *src, size_t
   if (!c) return HM_ERR_ARG;
   HM_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
   HM_HIP(c, hipStreamSynchronize(c->stream));
-  return HM_OK;
+  return check_device_error(c);   // a launch whose rendezvous timed out must not be read back as success
 }
 extern "C" hm_status hm_memcpy_d2d(hm_ctx *c, void *dst, const void *src, size_t bytes) {
   if (!c) return HM_ERR_ARG;
@@ -1233,11 +1266,17 @@ static hm_status check_device_error(hm_ctx *c) {
     const unsigned code = *c->err_host;
     *c->err_host = 0;
     c->fused_ntt = false;
+    c->fused_small = 0;       // the default one-launch form too: every later launch would stall and fail the same way
+    c->fused_broken = true;   // graphs captured with one-launch transforms inside refuse to replay (hm_graph_launch)
+    (void)hipStreamSynchronize(c->stream);
     (void)hipMemsetAsync(c->ntt_ws, 0, sizeof(HmNttSync), c->stream);
     (void)hipMemsetAsync(c->ntt_q, 0, sizeof(HmNttQueue), c->stream);
     c->queue_ntt = 0;
     (void)hipStreamSynchronize(c->stream);
-    return fail(c, HM_ERR_HIP, "one-launch transform: rendezvous %u timed out (workgroups of a limb-poly not co-resident); results of the last launches are invalid, the context now uses two-kernel transforms", code);
+    const char *why = code == 1 ? "XCD-local rendezvous: the workgroups of a limb-poly were not co-resident"
+                    : code == 2 ? "agent-scope rendezvous of a limb-poly spread over XCDs"
+                                : "work-queue wait";
+    return fail(c, HM_ERR_HIP, "one-launch transform: wait %u timed out (%s); results of the last launches are invalid, the context now uses two-kernel transforms and refuses to replay graphs that hold one-launch transforms", code, why);
   }
   return HM_OK;
 }
@@ -1294,7 +1333,14 @@ extern "C" hm_status hm_set_option(hm_ctx *c, const char *name, uint64_t value) 
   if (!c || !name) return HM_ERR_ARG;
   if (!strcmp(name, "ntt_fused")) { c->fused_ntt = value != 0; return HM_OK; }
   if (!strcmp(name, "ntt_fused_test_spread")) { c->fused_test_spread = value != 0; return HM_OK; }
-  if (!strcmp(name, "ntt_fused_small")) { if (value > HM_NTT_MAX_ENTRIES) return fail(c, HM_ERR_ARG, "hm_set_option: ntt_fused_small above %d", HM_NTT_MAX_ENTRIES); c->fused_small = (uint32_t)value; return HM_OK; }
+  if (!strcmp(name, "ntt_fused_test_timeout")) { c->fused_test_timeout = value != 0; return HM_OK; }
+  if (!strcmp(name, "ntt_fused_small")) {
+    if (value > HM_NTT_MAX_ENTRIES) return fail(c, HM_ERR_ARG, "hm_set_option: ntt_fused_small above %d", HM_NTT_MAX_ENTRIES);
+    if (value && c->fused_broken) return fail(c, HM_ERR_UNSUPPORTED, "hm_set_option: a rendezvous of this context has timed out: one-launch transforms stay off");
+    if (value && c->fused_slots_per_xcd < (c->P.N >> HM_TL_ROW)) return fail(c, HM_ERR_UNSUPPORTED, "hm_set_option: an XCD holds %u workgroups of the one-launch transform, a limb-poly needs %u", c->fused_slots_per_xcd, c->P.N >> HM_TL_ROW);
+    c->fused_small = (uint32_t)value;
+    return HM_OK;
+  }
   if (!strcmp(name, "ntt_fused_lds")) { if (value > 120 * 1024) return fail(c, HM_ERR_ARG, "hm_set_option: ntt_fused_lds above 120 KiB"); c->fused_extra_lds = (uint32_t)value; return HM_OK; }
   if (!strcmp(name, "bconv_col_outs")) { if (value > 2) return fail(c, HM_ERR_ARG, "hm_set_option: bconv_col_outs is 0 (by launch size), 1 or 2"); c->bcol_outs = (uint32_t)value; return HM_OK; }
   if (!strcmp(name, "ntt_dma")) { if (value > 3) return fail(c, HM_ERR_ARG, "hm_set_option: ntt_dma is 0 .. 3"); c->dma_ntt = (uint32_t)value; return HM_OK; }
@@ -1325,6 +1371,9 @@ extern "C" hm_status hm_get_counter(hm_ctx *c, const char *name, uint64_t *value
     fprintf(stderr, "err word: %u\n", c->err_host ? *c->err_host : 0);
     return HM_OK;
   }
+  if (!strcmp(name, "arith")) { *value = 0; return HM_OK; }   // arithmetic back-end of this context: 0 = word-wise Montgomery on q = h 2^32 + 1
+  if (!strcmp(name, "ntt_fused_slots_per_xcd")) { *value = c->fused_slots_per_xcd; return HM_OK; }
+  if (!strcmp(name, "ntt_fused_small")) { *value = c->fused_small; return HM_OK; }   // 0: the one-launch form is off (option, guard, or after a time-out)
   if (!strcmp(name, "ntt_cross_xcd")) {
     HM_HIP(c, hipStreamSynchronize(c->stream));
     unsigned v = 0;
@@ -1338,6 +1387,7 @@ extern "C" hm_status hm_get_counter(hm_ctx *c, const char *name, uint64_t *value
 struct hm_graph {
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
+  bool has_fused = false;    // holds one-launch transforms: unusable once a rendezvous of the owner has timed out
   hm_ctx *owner = nullptr;   // its kernel nodes keep device addresses of the owner's launch tables: destroy graphs before their context
 };
 static void detach_graphs(hm_ctx *c) {
@@ -1349,6 +1399,7 @@ extern "C" hm_status hm_capture_begin(hm_ctx *c) {
   if (c->ext_fn) return fail(c, HM_ERR_UNSUPPORTED, "hm_capture_begin: an external exchange transport cannot be captured");
   HM_HIP(c, hipSetDevice(c->device));
   c->capturing = true;  // kernel nodes of the graph keep the device addresses of the launch tables
+  c->capture_has_fused = false;
   hipError_t e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal);
   if (e != hipSuccess) { c->capturing = false; return fail(c, HM_ERR_HIP, "hipStreamBeginCapture: %s", hipGetErrorString(e)); }
   return HM_OK;
@@ -1365,6 +1416,7 @@ extern "C" hm_status hm_capture_end(hm_ctx *c, hm_graph **out) {
     return fail(c, HM_ERR_HIP, "hm_capture_end: %s", hipGetErrorString(e));
   }
   g->owner = c;
+  g->has_fused = c->capture_has_fused;
   c->graphs.push_back(g);
   c->live_graphs++;   // the launch-table cache is pinned while this graph lives (released in hm_graph_destroy)
   *out = g;
@@ -1373,6 +1425,7 @@ extern "C" hm_status hm_capture_end(hm_ctx *c, hm_graph **out) {
 extern "C" hm_status hm_graph_launch(hm_ctx *c, hm_graph *g) {
   if (!c || !g) return HM_ERR_ARG;
   if (g->owner != c) return fail(c, HM_ERR_ARG, "hm_graph_launch: the graph was captured from another (or a destroyed) context");
+  if (g->has_fused && c->fused_broken) return fail(c, HM_ERR_UNSUPPORTED, "hm_graph_launch: the graph holds one-launch transforms and a rendezvous of this context has timed out: capture the plan again (it now uses two-kernel transforms)");
   HM_HIP(c, hipGraphLaunch(g->exec, c->stream));
   return HM_OK;
 }
@@ -1446,7 +1499,8 @@ static void launch_ntt(hm_ctx *c, const HmNttArgs &a, bool fusedEpilogue, bool m
     // XCD's 128 slots); every other resident workgroup belongs to a complete limb-poly and finishes.  Up to eight such kernels in flight on
     // one GPU (contexts, instances; HIP drives four hardware queues by default) cannot starve one another; the spins are bounded all the same.
     if (!firstPassOnly && !c->fused_ntt && !c->dma_ntt && a.n_limbs <= c->fused_small && a.logG == 0) {
-      const HmNttFusedArgs f = {c->ntt_ws, c->err_dev, c->fused_test_spread};
+      const HmNttFusedArgs f = {c->ntt_ws, c->err_dev, c->fused_test_spread, c->fused_test_timeout ? 1u << 10 : HM_SPIN_LIMIT, c->fused_test_timeout};
+      if (c->capturing) c->capture_has_fused = true;
       const dim3 grid8(a.n_limbs * (c->P.N >> HM_TL_ROW)), block8((1 << HM_TL_ROW) / 8);
       bool inPlace = a.in == a.out;   // every limb-poly transformed onto itself: the input loads keep their lines for the hand-off
       for (uint32_t e = 0; inPlace && e < a.n_limbs; ++e) inPlace = a.limb[e].mod == HM_NTT_NONE || a.limb[e].in == a.limb[e].out;
@@ -1501,7 +1555,8 @@ static void launch_ntt(hm_ctx *c, const HmNttArgs &a, bool fusedEpilogue, bool m
     return;
   }
   if (c->fused_ntt) {   // both passes in one launch, hand-off through the XCD's L2
-    const HmNttFusedArgs f = {c->ntt_ws, c->err_dev, c->fused_test_spread};
+    const HmNttFusedArgs f = {c->ntt_ws, c->err_dev, c->fused_test_spread, c->fused_test_timeout ? 1u << 10 : HM_SPIN_LIMIT, c->fused_test_timeout};
+      if (c->capturing) c->capture_has_fused = true;
     // "ntt_fused_lds": extra dynamic LDS per workgroup = an occupancy throttle (100 KiB: one workgroup per CU = 32 per XCD = two
     // limb-polys in flight per XCD, 3 MiB live per 4 MiB L2): the capacity-controlled form of the hand-off experiment
     const uint32_t xl = c->fused_extra_lds;

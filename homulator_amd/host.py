@@ -50,6 +50,7 @@ def load():
         L.hh_op_N.argtypes = [vp]
         L.hh_op_plan.argtypes = [vp, C.c_char_p, u32]
         L.hh_op_stage_times.argtypes = [vp, u32, C.c_char_p, u32]
+        L.hh_op_backend_counter.argtypes = [vp, C.c_char_p, u64p]
         L.hh_op_bind_input.argtypes = [vp, C.c_char_p, vp]
         L.hh_chain_create.argtypes = [C.POINTER(vp), C.c_char_p, C.c_char_p, u32, u32, u32, C.c_char_p, C.c_int]
         L.hh_chain_destroy.argtypes = [vp]
@@ -186,6 +187,11 @@ class Op:
         buf = C.create_string_buffer(1 << 20)
         self._ck(self.L.hh_op_plan(self.h, buf, len(buf)))
         return [s for s in buf.value.decode().split("\n") if s]
+
+    def backend_counter(self, name):
+        """hm_get_counter of the op's HIP context (synchronises): e.g. "ntt_cross_xcd" = limb-polys of one-launch transforms whose
+        workgroups were spread over XCDs (slow path), "ntt_fused_small" = the one-launch threshold in force (0 = off)"""
+        return self._u64(lambda h, p: self.L.hh_op_backend_counter(h, name.encode(), p))
 
     def stage_times(self, iters=5):
         """[(kind, stage names, ns)] per launch of the plan, each launch bracketed by its own HIP event pair (collective

@@ -44,6 +44,8 @@ int hh_op_read_buffer_copy(hh_op *op, const char *name, uint32_t copy, uint64_t 
 int hh_op_write_buffer(hh_op *op, const char *name, uint32_t copy, const uint64_t *host);
 uint32_t hh_op_batch(hh_op *op);
 int hh_op_plan(hh_op *op, char *out, uint32_t cap);          /* launch plan, one line per launch */
+/* hm_get_counter of the op's backend context (hip backend; e.g. "ntt_cross_xcd", "ntt_fused_small", "arith"): synchronises */
+int hh_op_backend_counter(hh_op *op, const char *name, uint64_t *value);
 int hh_op_stage_times(hh_op *op, uint32_t iters, char *out, uint32_t cap); /* "<kind> <stages> <ns>" per launch, each timed alone */
 /* continuous execution: `dst`'s input ciphertext `input` ("ct1" / "ct2") becomes `src`'s output ciphertext,
  * copied device to device before every run of `dst`, stream-ordered after `src`; call before the first execute of `dst` and after `src` was

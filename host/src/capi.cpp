@@ -110,6 +110,12 @@ int hh_op_stage_times(hh_op *h, uint32_t iters, char *out, uint32_t cap) {
   HH_TRY(h->op->prepare(); std::string s = h->arch->stageTimes(iters); if (s.size() + 1 > cap) throw std::runtime_error("buffer too small");
          memcpy(out, s.c_str(), s.size() + 1))
 }
+extern "C" int hm_get_counter(hm_ctx *, const char *, uint64_t *);
+extern "C" const char *hm_last_error(const hm_ctx *);
+int hh_op_backend_counter(hh_op *h, const char *name, uint64_t *value) {
+  HH_TRY(h->op->prepare(); if (!h->arch->context()) throw std::runtime_error("no backend context (not the hip backend)");
+         if (hm_get_counter(h->arch->context(), name, value)) throw std::runtime_error(hm_last_error(h->arch->context())))
+}
 int hh_op_bind_input(hh_op *dst, const char *input, hh_op *src) { HH_TRY(dst->op->bindInput(input, src->op)) }
 
 struct hh_chain {

@@ -110,6 +110,15 @@ def test_two_contexts_share_the_chip():
             c.ntt(s, r, ids)
         for c, ids, s, f, r in jobs:
             assert np.array_equal(f.download(), r.download())
+        # the default one-launch form (k_ntt_fused8) under the same concurrency: two contexts, alternating launches of <= 96 limb-polys
+        small = [j for j in jobs if len(j[1]) <= 96]
+        for rep in range(6):
+            for c, ids, s, f, r in small:
+                c.ntt(s, f, ids)
+        for c, ids, s, f, r in small:
+            assert np.array_equal(f.download(), r.download())
+        for c in (c1, c2):
+            assert c.counter("ntt_cross_xcd") == 0, "a limb-poly was spread over XCDs under concurrency: the slow path ran"
     finally:
         c1.close(); c2.close()
 
@@ -160,11 +169,13 @@ def test_one_launch_small_geometry_equals_two_kernels_and_oracle():
     """launches of up to `ntt_fused_small` limb-polys at N = 2^16 run both passes in ONE launch of the 8-coefficient geometry
     (k_ntt_fused8: the hand-off through the XCD's L2 behind a rendezvous on XCD-local atomics).  The same calls as two kernels
     (option 0) and the oracle must agree bit for bit: forward, inverse in place with a scale, fused epilogue with and without the
-    mix prologue, worst-case operands, 1 .. 64 limb-polys, launches repeated back to back (the rendezvous words return to zero),
-    out of place and in place; no limb-poly may have taken the agent-scope path"""
+    mix prologue, worst-case operands, 1 .. 96 limb-polys (96 = the shipped threshold: 1 536 workgroups, past one round of the chip),
+    launches repeated back to back (the rendezvous words return to zero), out of place and in place; no limb-poly may have taken
+    the agent-scope path"""
     ctx, o = _ctx(16, 6, 3)
     try:
-        for n in (1, 9, 35, 50, 64):
+        assert ctx.counter("ntt_fused_small") == 96, "the shipped default"
+        for n in (1, 9, 35, 50, 64, 72, 96):
             ids = [(i * 5 + 2) % 9 for i in range(n)]
             x = o.fill_uniform(ids, 131 + n)
             x[0, :] = o.moduli[ids[0]] - 1
@@ -176,7 +187,7 @@ def test_one_launch_small_geometry_equals_two_kernels_and_oracle():
             mk = [(kk * 3 + 1) % o.moduli[m] for kk, m in zip(k, ids)]
             ak = [(kk * 5 + 1) % o.moduli[m] for kk, m in zip(k, ids)]
             res = {}
-            for one in (64, 0):
+            for one in (96, 0):
                 ctx.set_option("ntt_fused_small", one)
                 for _ in range(3):
                     ctx.ntt(d, a, ids)
@@ -188,10 +199,11 @@ def test_one_launch_small_geometry_equals_two_kernels_and_oracle():
                 ctx.ntt_mix_sub_scale(d, mn, b, ids, k, addend=ad, addend_k=ak, mix=mx, mix_k=mk)
                 mss = b.download()
                 res[one] = (fwd, inv, ss, mss)
-            for u, v in zip(res[64], res[0]):
+            for u, v in zip(res[96], res[0]):
                 assert np.array_equal(u, v), n
-            assert np.array_equal(res[64][0], o.ntt(ids, x)), n
-            assert np.array_equal(res[64][1], o.ewe(5, ids, x, k=k)), n     # INTT(NTT(x)) * k
+            assert np.array_equal(res[96][0], o.ntt(ids, x)), n
+            assert np.array_equal(res[96][1], o.ewe(5, ids, x, k=k)), n     # INTT(NTT(x)) * k
+            assert ctx.counter("ntt_cross_xcd") == 0, n
             for buf in (d, a, b, mn, ad, mx):
                 buf.free()
         assert ctx.counter("ntt_cross_xcd") == 0
@@ -224,5 +236,52 @@ def test_agent_scope_path_of_the_rendezvous():
             ctx.ntt(a, a, ids, inverse=True)
             assert np.array_equal(a.download(), x)
             assert ctx.counter("ntt_cross_xcd") - before == 2 * n
+    finally:
+        ctx.close()
+
+
+def test_rendezvous_timeout_is_reported_everywhere_and_switches_the_form_off():
+    """a rendezvous that times out (test hook: tile 0 of every limb-poly withholds its arrival, the spins are short) leaves invalid
+    output.  It must be reported by the next synchronising call whatever that is (a download, not only hm_sync), switch off EVERY
+    one-launch form of the context (the default k_ntt_fused8 included), leave the rendezvous words at rest, and make graphs that
+    hold one-launch transforms refuse to replay; later launches run as two kernels and are right"""
+    import ctypes as C
+    from homulator_amd import hip
+    ctx, o = _ctx(16, 4, 2)
+    try:
+        L = ctx.L
+        n = 9
+        ids = [(i * 5 + 1) % 6 for i in range(n)]
+        x = o.fill_uniform(ids, 17)
+        d, a = ctx.from_host(x), ctx.alloc(n)
+        exp = o.ntt(ids, x)
+        assert ctx.counter("ntt_fused_slots_per_xcd") >= 16
+        ctx.ntt(d, a, ids)                       # warm: the launch tables exist before the capture
+        assert np.array_equal(a.download(), exp)
+        g = C.c_void_p()
+        L.hm_capture_begin.argtypes = [C.c_void_p]
+        L.hm_capture_end.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        L.hm_graph_launch.argtypes = [C.c_void_p, C.c_void_p]
+        L.hm_graph_destroy.argtypes = [C.c_void_p]
+        ctx._ck(L.hm_capture_begin(ctx.h))
+        ctx.ntt(d, a, ids)
+        ctx._ck(L.hm_capture_end(ctx.h, C.byref(g)))
+        ctx._ck(L.hm_graph_launch(ctx.h, g))
+        assert np.array_equal(a.download(), exp)
+        ctx.set_option("ntt_fused_test_timeout", 1)
+        ctx.ntt(d, a, ids)
+        with pytest.raises(hip.HmError, match="timed out"):
+            a.download()
+        ctx.set_option("ntt_fused_test_timeout", 0)
+        assert ctx.counter("ntt_fused_small") == 0
+        assert L.hm_graph_launch(ctx.h, g) != 0 and b"one-launch" in L.hm_last_error(ctx.h)
+        with pytest.raises(hip.HmError):
+            ctx.set_option("ntt_fused_small", 64)
+        for _ in range(2):
+            ctx.ntt(d, a, ids)                   # two kernels now
+            assert np.array_equal(a.download(), exp)
+        ctx.ntt(a, a, ids, inverse=True)
+        assert np.array_equal(a.download(), x)
+        L.hm_graph_destroy(g)
     finally:
         ctx.close()
