@@ -106,13 +106,15 @@ def measure_ntt_sweep(n_limbs, iters=48, sets=6):
     return ns, cross, one_launch
 
 
-def measure_second_op(opn, streams, batch, steps, device):
-    """BASELINE configs[3] beside the headline: `steps` hrotates at 45/35/15 through the same instances x batch x HIP-graph shape as the
-    timed region of the headline op, timed the same way (wall clock around enqueue + sync); own instances, closed afterwards"""
+def measure_second_op(opn, streams, batch, steps, device, extra=None):
+    """a second figure beside the headline, through the same instances x batch x HIP-graph shape as the timed region of the headline op and
+    timed the same way (wall clock around enqueue + sync); own instances, closed afterwards.  opn = "hrotate": BASELINE configs[3];
+    extra = {"chain_bits": 60}: the headline op on SURVEY.md 8(d)'s chain as written (the generic arithmetic back-end)"""
     from homulator_amd import host
+    extra = dict(extra or {})
     ops = [host.Op(CFG, opn, L, ELL, ALPHA, device=device,
-                   overrides={"seed": host.SEED + 31 * (i + 1), **({"batch": batch} if batch > 1 else {}), "graph": 1}) for i in range(streams)]
-    tail = host.Op(CFG, opn, L, ELL, ALPHA, device=device, overrides={"seed": host.SEED + 998}) if batch > 1 else None
+                   overrides={"seed": host.SEED + 31 * (i + 1), **({"batch": batch} if batch > 1 else {}), "graph": 1, **extra}) for i in range(streams)]
+    tail = host.Op(CFG, opn, L, ELL, ALPHA, device=device, overrides={"seed": host.SEED + 998, **extra}) if batch > 1 else None
 
     def run(n):
         for i in range(n // batch):
@@ -137,16 +139,18 @@ def measure_second_op(opn, streams, batch, steps, device):
     sync_all()
     dt = time.perf_counter() - t0
     cross = sum(o.backend_counter("ntt_cross_xcd") for o in ops + ([tail] if tail is not None else []))
+    arith = ops[0].backend_counter("arith")
     launches = ops[0].launch_count()
     for o in ops:
         o.close()
     if tail is not None:
         tail.close()
     ms = dt / steps * 1e3
-    evk_once = HROTATE_ALG_BYTES - EVK_BYTES * (1 - 1 / batch)
-    return {"workload": f"{CFG} {opn} L={L} l={ELL} alpha={ALPHA} (BASELINE configs[3]: automorphism + full hybrid key switch)",
-            "ops_per_s": steps / dt, "ms_per_step": ms, "steps": steps, "streams": streams, "batch": batch, "launches_per_op": launches,
-            "frac_of_hbm_peak": HROTATE_ALG_BYTES / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+    alg = HMULT_ALG_BYTES if opn == "hmult" else HROTATE_ALG_BYTES
+    evk_once = alg - EVK_BYTES * (1 - 1 / batch)
+    return {"workload": f"{CFG} {opn} L={L} l={ELL} alpha={ALPHA}" + (" (BASELINE configs[3]: automorphism + full hybrid key switch)" if opn == "hrotate" else ""),
+            "moduli": MODULI_NOTE[arith], "ops_per_s": steps / dt, "ms_per_step": ms, "steps": steps, "streams": streams, "batch": batch, "launches_per_op": launches,
+            "frac_of_hbm_peak": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "frac_evk_once": evk_once / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "ntt_cross_xcd": cross}
 
 
@@ -216,8 +220,8 @@ def roofline_op(batched_rows, batch, rin):
 DEFAULT_BATCH = 10
 # which arithmetic back-end the context chose for the chain it was given (hm_get_counter "arith")
 MODULI_NOTE = {
-    0: "mont32: the default chain, 45 + 15 largest primes h*2^32 + 1 below 2^60 (word-wise Montgomery reduction, q^-1 = 1 mod 2^32: six 32-bit multiplies per butterfly, one-word twiddles)",
-    1: "generic: any distinct NTT-friendly primes below 2^60 (Shoup / Barrett arithmetic, nine multiplies per butterfly, two-word twiddles)",
+    0: "mont32: the default chain, 45 + 15 largest primes h*2^32 + 1 below 2^60 (word-wise Montgomery reduction, q^-1 = 1 mod 2^32: six 32-bit multiplies per butterfly, one-word twiddles; libhm_m32.so)",
+    1: "generic: SURVEY.md 8(d)'s chain as written, the 45 + 15 largest primes = 1 mod 2N below 2^60 (Shoup / Barrett arithmetic for any NTT-friendly chain below 2^60: nine multiplies per butterfly, two-word twiddles; libhm_gen.so)",
 }
 
 
@@ -477,6 +481,13 @@ def main():
         }
         if world == 1 and opn == "hmult":   # configs[3] at the same launch shape, so that the driver's run times it too
             out["hrotate"] = measure_second_op("hrotate", streams, batch, args.steps, local_rank)
+            # ... and the headline op on SURVEY.md 8(d)'s chain as written (largest primes = 1 mod 2N below 2^60): the generic arithmetic
+            # back-end behind the same ABI (`value` is the default chain of primes h 2^32 + 1: config.moduli)
+            if arith == 0:
+                g = measure_second_op("hmult", streams, batch, args.steps, local_rank, {"chain_bits": 60})
+                out["generic_chain"] = g
+                out["generic_chain_ops_per_s"] = g["ops_per_s"]
+                out["generic_chain_frac_evk_once"] = g["frac_evk_once"]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(opn)
         try:  # the reference's own answer for the same command line, from the build's cycle model (backend = sim): host only

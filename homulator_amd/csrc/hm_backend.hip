@@ -58,22 +58,16 @@ __device__ __forceinline__ void hm_pass_sync(int nth) {
 struct Geo16 {
   static constexpr int EPT = 16;
   typedef hm16::HmNttState State;
-  typedef hm16::HmNoMid NoMid;
   template <int TL, int LOGR, bool STRIDED> static constexpr int ldsWords() { return hm16::HmLds<TL, LOGR, STRIDED>::WORDS; }
   template <int TL, int LOGR, bool STRIDED, bool INV, int MODE, int LDAUX, int STAUX, int EPICH, class... A>
   static __device__ __forceinline__ void phases(A &&...a) { hm16::hm_ntt_pass_phases<TL, LOGR, STRIDED, INV, MODE, LDAUX, STAUX, EPICH>(a...); }
-  template <int TL, int LOGR, bool STRIDED, bool INV, int MODE, class... A>
-  static __device__ __forceinline__ void phases_dma(A &&...a) { hm16::hm_ntt_pass_phases<TL, LOGR, STRIDED, INV, MODE, 0, 0, HM_EPI_CHUNK, 1>(a...); }
 };
 struct Geo8 {
   static constexpr int EPT = 8;
   typedef hm8::HmNttState State;
-  typedef hm8::HmNoMid NoMid;
   template <int TL, int LOGR, bool STRIDED> static constexpr int ldsWords() { return hm8::HmLds<TL, LOGR, STRIDED>::WORDS; }
   template <int TL, int LOGR, bool STRIDED, bool INV, int MODE, int LDAUX, int STAUX, int EPICH, class... A>
   static __device__ __forceinline__ void phases(A &&...a) { hm8::hm_ntt_pass_phases<TL, LOGR, STRIDED, INV, MODE, LDAUX, STAUX, EPICH>(a...); }
-  template <int TL, int LOGR, bool STRIDED, bool INV, int MODE, class... A>
-  static __device__ __forceinline__ void phases_dma(A &&...a) { hm8::hm_ntt_pass_phases<TL, LOGR, STRIDED, INV, MODE, 0, 0, HM_EPI_CHUNK, 1>(a...); }
 };
 template <int LOGR, bool STRIDED, bool INV, int MODE, int LDAUX = 0, int STAUX = 0, int EPICH = HM_EPI_CHUNK, class GEO = Geo16, class PRE = HmNoPre>
 __device__ __forceinline__ void hm_ntt_pass_run(const HmNttArgs &a, uint64_t *lds, uint32_t entry, uint32_t tile, int tid, PRE pre = PRE()) {
@@ -113,7 +107,7 @@ __device__ __forceinline__ void hm_ntt_pass_run(const HmNttArgs &a, uint64_t *ld
   typename GEO::State st;
   int nsync = 0;
   GEO::template phases<TL, LOGR, STRIDED, INV, MODE, LDAUX, STAUX, EPICH>(st, tid, lds, src, dst, tile, twl, twt, s0, prefix0, q, sc, ep,
-                                                                           [&] { hm_pass_sync<STRIDED>(nsync++); }, nullptr, typename GEO::NoMid(), pre);
+                                                                           [&] { hm_pass_sync<STRIDED>(nsync++); }, pre);
 }
 
 template <int LOGR, bool STRIDED, bool INV, int MODE, class GEO = Geo16>
@@ -161,32 +155,33 @@ __global__ void __launch_bounds__((1 << HM_TL_ROW) / 8) k_ntt_row8(HmNttArgs a) 
   hm_ntt_pass_body<HM_ROW_LOG, false, INV, MODE, Geo8>(a);
 }
 
-// ---- both passes of a transform in ONE launch (opt-in: hm_set_option "ntt_fused"; measured, not the default) ------------
-// Built to keep the hand-off between the passes in the XCD's L2: the workgroups of one limb-poly (N / 4096 of them, all dealt
-// to one XCD by hm_block_map) run the first pass on their tile, store the hand-off, meet at a per-limb counter and run the
-// second pass on what the others stored.  What the MI355X does with it (profiles/r03_fused_ntt.txt): WRITE_SIZE and
-// FETCH_SIZE of the 50-limb sweep are the SAME as for two kernels (51.2 MB written, 65 MB fetched) with plain stores and
-// plain, sc1 or nt loads alike — the L2 writes every store through to the fabric and a later load of the line by another CU
-// of the XCD misses (no write-allocate), so a hand-off through global memory costs two fabric crossings however it is
-// synchronised; and the rendezvous makes it slower (0.82-0.95 us per limb-NTT against 0.48-0.52): the workgroups of a
-// limb-poly start whenever slots free up, and the first ones hold their slots idle until the last one has arrived.
-// Kept as a tested code path (tests/test_gpu_ntt_fused.py) because the rendezvous is placement-independent and reusable.
+// ---- both passes of a transform in ONE launch (k_ntt_fused8: the default for launches of up to `ntt_fused_small` limb-polys, N = 2^16) ----
+// The workgroups of one limb-poly (N / 4096 of them, all dealt to one XCD by hm_block_map) run the first pass on their tile, store the
+// hand-off, meet at a per-limb counter and run the second pass on what the others stored.  What the MI355X does with the hand-off
+// (profiles/r04_l2_handoff.txt; round 3's reading of the same counters — "write-through, no allocation on a store" — was an eviction
+// result and is withdrawn): the XCD's L2 is WRITE-BACK for plain stores and the second pass's loads of the hand-off HIT as long as at most
+// ~3 MiB are live per XCD; a line that a store allocated is still filled from the fabric once when it is first read, unless it was
+// resident before the store, i.e. the transform runs IN PLACE (50-limb sweep: 104.5 MB of fabric traffic out of place, 79 MB in place).
+// The gain of the one-launch form is launch and latency (28-32 us against 34-36 us for the 50-limb sweep as two kernels); from ~128
+// limb-polys the rendezvous costs more than it saves (it idles a limb-poly's slots until its slowest workgroup has arrived), so larger
+// launches stay two kernels.  The wide-geometry form of rounds 3 / 4 (k_ntt_fused: 256-thread workgroups, any ring size) lost every
+// A/B against this one and left the tree in round 5 (profiles/r04_fused_small.txt keeps its numbers).
 //
-// Correct for ANY placement: every workgroup adds its XCC id (HW_REG_XCC_ID) to the counter word; if the limb's workgroups
+// Correct for ANY placement: every workgroup that has to wait publishes its XCC id (HW_REG_XCC_ID); if the limb's workgroups
 // turn out to sit on several XCDs (hipcc / the dispatcher promise nothing), all of them take the agent-scope path instead:
 // release (L2 write-back), a second rendezvous, acquire — slow, still right.  The rendezvous needs the limb's workgroups
-// co-resident: they are neighbours in dispatch order (consecutive slots of one XCD hold a group of limb-polys), so with
-// workgroups dispatched in order the oldest unfinished limb of an XCD is always fully dispatched; the spin is bounded all
-// the same, and a timeout is reported through the context (hm_sync fails) instead of hanging the GPU.
-// Round 4 (second half): the rendezvous runs on XCD-LOCAL atomics.  An agent-scope atomic or load is a round trip to memory (the L2s of
-// the eight XCDs are not coherent with each other): arrival + polls cost the one-launch transform 16 us at 50 limb-polys (51 against 35 us
-// for two kernels).  All workgroups of a limb-poly run on ONE XCD (hm_block_map; checked per workgroup against HW_REG_XCC_ID), so their
+// co-resident: they are neighbours in dispatch order (consecutive slots of one XCD hold a limb-poly), so with
+// workgroups dispatched in order the oldest unfinished limb of an XCD is always fully dispatched (hm_create checks that an XCD holds
+// at least one limb-poly's workgroups at the kernel's occupancy); the spin is bounded all the same, and a timeout is reported through
+// the context (the next synchronising call fails, the form is switched off) instead of hanging the GPU.
+// The rendezvous runs on XCD-LOCAL atomics.  An agent-scope atomic or load is a round trip to memory (the L2s of
+// the eight XCDs are not coherent with each other): arrival + polls cost round 3's one-launch transform 16 us at 50 limb-polys.
+// All workgroups of a limb-poly run on ONE XCD (hm_block_map; checked per workgroup against HW_REG_XCC_ID), so their
 // counter can live in that XCD's L2: returning atomics WITHOUT the agent-scope bit (`global_atomic_add_x2 ... sc0`) execute there.  One
 // 128-byte line per limb-poly (a line shared with a limb-poly of another XCD would be modified in two L2s at once): low word = arrivals,
-// high word = leavers; the last leaver swaps it back to zero.  Should the dispatcher ever spread a limb-poly's workgroups over XCDs (it
-// promises nothing), no copy of the counter reaches the member count; the waiting workgroups find out through an agent-scope mask of XCC
-// ids and everybody takes the agent-scope path: release (L2 write-back), a second rendezvous on an agent-scope counter, acquire — slow,
-// still right (never seen: counter `ntt_cross_xcd`).
+// high word = leavers; the last leaver swaps it back to zero.  Should the dispatcher ever spread a limb-poly's workgroups over XCDs, no
+// copy of the counter reaches the member count; the waiting workgroups find out through an agent-scope mask of XCC
+// ids and everybody takes the agent-scope path (never seen outside the test hook: counter `ntt_cross_xcd`).
 struct HmLimbSync {
   unsigned long long w;        // XCD-local atomics only
   unsigned long long pad[15];
@@ -344,12 +339,7 @@ __device__ __forceinline__ void hm_ntt_fused_body(const HmNttArgs &a, const HmNt
   if (fast == 2) return;   // timed out: the host zeroes the words (check_device_error)
   hm_limb_leave(f.ws, entry, members, fast);
 }
-template <int LOG1, bool INV, int MODE_A, int MODE_B>
-__global__ void __launch_bounds__((1 << HM_TL_ROW) / HM_EPT) __attribute__((amdgpu_waves_per_eu(HM_NTT_MIN_WAVES))) k_ntt_fused(HmNttArgs a, HmNttFusedArgs f) {
-  hm_ntt_fused_body<LOG1, INV, MODE_A, MODE_B, Geo16>(a, f);
-}
-// the same in the small-launch geometry (512-thread workgroups, 8 coefficients per thread; N = 2^16): the form that launches of up to
-// `ntt_fused_small` limb-polys take by default
+// the small-launch geometry (512-thread workgroups, 8 coefficients per thread; N = 2^16)
 template <bool INV, int MODE_A, int MODE_B, bool NTIN>
 __global__ void __launch_bounds__((1 << HM_TL_ROW) / 8) k_ntt_fused8(HmNttArgs a, HmNttFusedArgs f) {
   hm_ntt_fused_body<8, INV, MODE_A, MODE_B, Geo8, NTIN ? 2 : 0>(a, f);
@@ -377,24 +367,33 @@ __global__ void __launch_bounds__((1 << HM_TL_ROW) / 8) k_ntt_fused8(HmNttArgs a
 // Hand-off protocol (same as k_ntt_fused's same-XCD path): plain stores, every storing wave s_waitcnt vmcnt(0), workgroup barrier, one lane
 // adds to the limb-poly's counter; the consumer polls that counter (agent-scope relaxed load), barrier, then reads the hand-off with loads
 // that bypass its CU's vector L1 (sc1 / nt), which another CU's stores never refresh.
+// Round 5: the queue's control words live in the owning XCD's L2 too.  Round 4's form pulled, claimed and polled at agent scope — two
+// dependent round trips to memory in front of every item's first load (the L2s of the eight XCDs are not coherent with each other) — and
+// measured 0.59-0.65 us per limb-NTT against 0.47-0.51 for two kernels.  All items of a queue run on ONE XCD by construction, so every word
+// of a queue (the item counter, the slot -> group words, the per-limb-poly "first pass stored" counters) is touched by that XCD only and
+// can be served by its L2: returning atomics without the agent-scope bit.  Only the counter that deals groups to XCDs is shared
+// (agent scope, once per group and XCD).  Words of different XCDs never share a 128-byte line.  The NEXT item is pulled while the
+// current one is being transformed (the pull's latency hides behind the pass).  Nobody resets the words in the kernel (the XCD that owns
+// a line would have to): the host zeroes the structure with a memset node in front of every launch.
 #define HM_Q_MAX_SLOTS (HM_NTT_MAX_ENTRIES + 32)
 #define HM_Q_NONE 0xFFFFFFFFu
-#define HM_Q_SPIN_LIMIT (1u << 17)   // ~0.2 s of polling: a queue wait that long is a bug, reported through the context
-struct HmNttQueue {                  // device; all zero between launches (the last workgroup out resets what the launch touched)
-  unsigned next_group, exited, pad0[14];
+#define HM_Q_SPIN_LIMIT (1u << 20)   // a queue wait that long is a bug, reported through the context
+struct HmNttQueue {                  // device; zeroed by the host before every launch
+  unsigned next_group, pad0[31];           // agent scope: deals groups to the XCDs on demand (own line)
   struct Xcd {
-    unsigned next_item, pad[15];
-    unsigned slot_group[HM_Q_MAX_SLOTS];   // 0 = unclaimed, 1 = being claimed, else group + 2 (HM_Q_NONE: no group left)
+    unsigned next_item, pad[31];           // XCD-local (own line)
+    unsigned slot_group[HM_Q_MAX_SLOTS];   // XCD-local: 0 = unclaimed, 1 = being claimed, else group + 2 (HM_Q_NONE: no group left)
+    unsigned pad2[32 - HM_Q_MAX_SLOTS % 32];
   } xcd[8];
-  unsigned first_done[HM_NTT_MAX_ENTRIES];  // per limb-poly: tiles whose first pass has been stored
+  struct Done { unsigned n, pad[31]; } first_done[HM_NTT_MAX_ENTRIES];   // XCD-local, a line per limb-poly: tiles whose first pass has been stored
 };
+static_assert(sizeof(HmNttQueue::Xcd) % 128 == 0, "queue words of different XCDs never share a line");
 struct HmNttQueueArgs {
   HmNttQueue *q;
   unsigned *err;          // host-visible: 3 = a queue wait timed out
   uint32_t n_groups;      // groups of `gc` consecutive entries of HmNttArgs::limb (dense: entry = group * gc + member)
   uint32_t gc;            // limb-polys per group (same modulus: their tiles are handed out side by side and share the row twiddles in L2)
   uint32_t lookahead;     // LA >= 1
-  unsigned *trace;        // bring-up aid (HOMULATOR_NTT_QUEUE_TRACE=1): host-mapped, 256 words per workgroup: [0] count, then (item, slot value, entry, pass) per pull
 };
 #ifndef HM_Q_IN_AUX
 #define HM_Q_IN_AUX 0     // cache policy of the first pass's input loads (2 = nt: streamed once)
@@ -405,29 +404,47 @@ struct HmNttQueueArgs {
 #ifndef HM_Q_MID_AUX
 #define HM_Q_MID_AUX 16   // the hand-off loads: sc1 (L1 bypass, served by the XCD's L2)
 #endif
-__device__ __forceinline__ unsigned hm_q_load(unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// 32-bit atomics executed in the L2 of the XCD the wave runs on (no sc1: not agent scope); the loads are atomic ORs of zero (a plain
+// load with workgroup scope may be served by the CU's vector L1, which another CU's atomics never refresh)
+__device__ __forceinline__ unsigned hm_l2_add32(unsigned *p, unsigned v) {
+  unsigned old;
+  asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(old) : "v"(p), "v"(v) : "memory");
+  return old;
+}
+__device__ __forceinline__ void hm_l2_add32_noret(unsigned *p, unsigned v) { asm volatile("global_atomic_add %0, %1, off" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ unsigned hm_l2_load32(unsigned *p) { return hm_l2_add32(p, 0u); }
+__device__ __forceinline__ unsigned hm_l2_swap32(unsigned *p, unsigned v) {
+  unsigned old;
+  asm volatile("global_atomic_swap %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(old) : "v"(p), "v"(v) : "memory");
+  return old;
+}
+__device__ __forceinline__ unsigned hm_l2_cas32(unsigned *p, unsigned expect, unsigned desired) {   // returns the old value
+  unsigned old;
+  unsigned long long pair = ((unsigned long long)expect << 32) | desired;   // data = {new, compare}
+  asm volatile("global_atomic_cmpswap %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(old) : "v"(p), "v"(pair) : "memory");
+  return old;
+}
 // group of slot s on this XCD's queue (claimed from the global counter by whoever needs it first; claims are made in slot order, so the
 // groups of a queue increase with s and "no group left" is final)
 __device__ __forceinline__ unsigned hm_q_slot_group(HmNttQueue *Q, HmNttQueue::Xcd *x, unsigned s, unsigned n_groups, unsigned *err) {
   if (s >= HM_Q_MAX_SLOTS) return HM_Q_NONE;
-  unsigned v = hm_q_load(&x->slot_group[s]);
+  unsigned v = hm_l2_load32(&x->slot_group[s]);
   unsigned spins = 0;
   while (v < 2) {
     if (v == 0) {
       if (s > 0) {   // in slot order
-        while (hm_q_load(&x->slot_group[s - 1]) < 2) { __builtin_amdgcn_s_sleep(2); if (++spins > HM_Q_SPIN_LIMIT) { __hip_atomic_store(err, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return HM_Q_NONE; } }
+        while (hm_l2_load32(&x->slot_group[s - 1]) < 2) { __builtin_amdgcn_s_sleep(1); if (++spins > HM_Q_SPIN_LIMIT) { __hip_atomic_store(err, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return HM_Q_NONE; } }
       }
-      unsigned expect = 0;
-      if (__hip_atomic_compare_exchange_strong(&x->slot_group[s], &expect, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+      if (hm_l2_cas32(&x->slot_group[s], 0u, 1u) == 0u) {
         const unsigned g = __hip_atomic_fetch_add(&Q->next_group, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         v = g < n_groups ? g + 2 : HM_Q_NONE;
-        __hip_atomic_store(&x->slot_group[s], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        (void)hm_l2_swap32(&x->slot_group[s], v);
         return v;
       }
     }
-    __builtin_amdgcn_s_sleep(2);
+    __builtin_amdgcn_s_sleep(1);
     if (++spins > HM_Q_SPIN_LIMIT) { __hip_atomic_store(err, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return HM_Q_NONE; }
-    v = hm_q_load(&x->slot_group[s]);
+    v = hm_l2_load32(&x->slot_group[s]);
   }
   return v;
 }
@@ -443,246 +460,71 @@ __device__ __forceinline__ void hm_ntt_queue_body(const HmNttArgs &a, const HmNt
   const uint32_t per_block = tiles * f.gc;
   HmNttQueue *Q = f.q;
   HmNttQueue::Xcd *x = &Q->xcd[hm_xcc_id()];
+  // item index -> (slot, pass, member, tile); published through LDS by lane 0
+  auto decode = [&](unsigned i) {
+    const unsigned j = i / per_block, w = i % per_block;
+    unsigned second, s;
+    if (j < f.lookahead) { second = 0; s = j; }
+    else { const unsigned m = j - f.lookahead; second = (m & 1u) ^ 1u; s = second ? m / 2 : f.lookahead + m / 2; }
+    const unsigned v = hm_q_slot_group(Q, x, s, f.n_groups, f.err);
+    unsigned entry = HM_Q_NONE;
+    if (v != HM_Q_NONE) {
+      entry = (v - 2) * f.gc + w % f.gc;
+      if (entry >= a.n_limbs || a.limb[entry].mod == HM_NTT_NONE) entry = HM_Q_NONE - 1;   // padding of the last group
+    } else if (!second) entry = HM_Q_NONE - 1;   // a first-pass block beyond the last group: later blocks may still hold second passes
+    ctl[0] = entry; ctl[1] = w / f.gc; ctl[2] = second;
+  };
+  unsigned pulled = 0;   // lane 0: the item pulled ahead
+  if (threadIdx.x == 0) decode(hm_l2_add32(&x->next_item, 1u));
 #pragma unroll 1
   for (;;) {
-    if (threadIdx.x == 0) {
-      const unsigned i = __hip_atomic_fetch_add(&x->next_item, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned j = i / per_block, w = i % per_block;
-      unsigned second, s;
-      if (j < f.lookahead) { second = 0; s = j; }
-      else { const unsigned m = j - f.lookahead; second = (m & 1u) ^ 1u; s = second ? m / 2 : f.lookahead + m / 2; }
-      const unsigned v = hm_q_slot_group(Q, x, s, f.n_groups, f.err);
-      unsigned entry = HM_Q_NONE;
-      if (v != HM_Q_NONE) {
-        entry = (v - 2) * f.gc + w % f.gc;
-        if (entry >= a.n_limbs || a.limb[entry].mod == HM_NTT_NONE) entry = HM_Q_NONE - 1;   // padding of the last group
-        else if (second) {
-          unsigned spins = 0;
-          while (hm_q_load(&Q->first_done[entry]) < tiles) {
-            __builtin_amdgcn_s_sleep(4);
-            if (++spins > HM_Q_SPIN_LIMIT) { __hip_atomic_store(f.err, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
-          }
-        }
-      } else if (!second) entry = HM_Q_NONE - 1;   // a first-pass block beyond the last group: later blocks may still hold second passes
-      ctl[0] = entry; ctl[1] = w / f.gc; ctl[2] = second;
-      if (f.trace && blockIdx.x < 64) {
-        unsigned *t = f.trace + blockIdx.x * 256;
-        const unsigned k = t[0];
-        if (k < 63) {
-          __hip_atomic_store(&t[1 + 4 * k], i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          __hip_atomic_store(&t[2 + 4 * k], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          __hip_atomic_store(&t[3 + 4 * k], entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          __hip_atomic_store(&t[4 + 4 * k], second | (hm_xcc_id() << 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          __hip_atomic_store(&t[0], k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-      }
-    }
     __syncthreads();
     // wave-uniform by construction: scalar registers (as VGPR values they made every descriptor and branch below look divergent)
     const uint32_t entry = __builtin_amdgcn_readfirstlane(ctl[0]), tile = __builtin_amdgcn_readfirstlane(ctl[1]), second = __builtin_amdgcn_readfirstlane(ctl[2]);
-#define HM_Q_MARK(code) do { if (f.trace && blockIdx.x < 64 && threadIdx.x == 0) __hip_atomic_store(&f.trace[blockIdx.x * 256 + 255], (unsigned)(code), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } while (0)
-    HM_Q_MARK(1);
-    __syncthreads();   // ctl is rewritten by the next pull; the passes below start with their own LDS traffic
+    __syncthreads();   // ctl is rewritten below; the passes start with their own LDS traffic
     if (entry == HM_Q_NONE) break;
-    if (entry == HM_Q_NONE - 1) continue;
-    // a thread id the compiler cannot connect across the items (see k_ntt_fused)
-    int tid = threadIdx.x;
-    asm volatile("" : "+v"(tid));
-    __builtin_assume(tid >= 0 && tid < (1 << TL) / GEO::EPT);
-    if (!second) {
-      if (!INV) hm_ntt_pass_run<LOG1, true, false, MODE_A, HM_Q_IN_AUX, 0, HM_EPI_CHUNK, GEO>(a, lds, entry, tile, tid);
-      else hm_ntt_pass_run<HM_ROW_LOG, false, true, MODE_A, HM_Q_IN_AUX, 0, HM_EPI_CHUNK, GEO>(a, lds, entry, tile, tid);
-      HM_Q_MARK(2);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave: its stores have reached the L2
-      __syncthreads();
-      HM_Q_MARK(3);
-      if (threadIdx.x == 0) __hip_atomic_fetch_add(&Q->first_done[entry], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      HM_Q_MARK(4);
-    } else {
-      if (!INV) hm_ntt_pass_run<HM_ROW_LOG, false, false, MODE_B, HM_Q_MID_AUX, HM_Q_OUT_AUX, 1, GEO>(a, lds, entry, tile, tid);
-      else hm_ntt_pass_run<LOG1, true, true, MODE_B, HM_Q_MID_AUX, HM_Q_OUT_AUX, HM_EPI_CHUNK, GEO>(a, lds, entry, tile, tid);
-    }   // (the barriers at the top of the loop keep the next item's LDS writes behind this item's last reads)
-  }
-  // the last workgroup out resets the words this launch touched (everybody else has made its last access)
-  __shared__ unsigned last;
-  if (threadIdx.x == 0) last = __hip_atomic_fetch_add(&Q->exited, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
-  __syncthreads();
-  if (last) {
-    for (uint32_t k = 0; k < 8; ++k) {
-      const unsigned used = min((unsigned)HM_Q_MAX_SLOTS, hm_q_load(&Q->xcd[k].next_item) / per_block + 2u);
-      for (uint32_t s = threadIdx.x; s < used; s += blockDim.x) Q->xcd[k].slot_group[s] = 0;
+    // the next item is pulled now: the round trip hides behind this item's pass (workgroup-scope atomic = no agent-scope bit: served by
+    // the XCD's L2; the compiler places the wait where the value is first used, at the bottom of the loop)
+    if (threadIdx.x == 0) pulled = __hip_atomic_fetch_add(&x->next_item, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (entry != HM_Q_NONE - 1) {
+      // a thread id the compiler cannot connect across the items (see hm_ntt_fused_body)
+      int tid = threadIdx.x;
+      asm volatile("" : "+v"(tid));
+      __builtin_assume(tid >= 0 && tid < (1 << TL) / GEO::EPT);
+      if (!second) {
+        if (!INV) hm_ntt_pass_run<LOG1, true, false, MODE_A, HM_Q_IN_AUX, 0, HM_EPI_CHUNK, GEO>(a, lds, entry, tile, tid);
+        else hm_ntt_pass_run<HM_ROW_LOG, false, true, MODE_A, HM_Q_IN_AUX, 0, HM_EPI_CHUNK, GEO>(a, lds, entry, tile, tid);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave: its stores have reached the L2
+        __syncthreads();
+        if (threadIdx.x == 0) hm_l2_add32_noret(&Q->first_done[entry].n, 1u);
+      } else {
+        // all first passes of the limb-poly are stored: waited for inside the pass, behind its first twiddle requests
+        auto wait = [&] {
+          if (threadIdx.x == 0) {
+            unsigned spins = 0;
+            while (hm_l2_load32(&Q->first_done[entry].n) < tiles) {
+              __builtin_amdgcn_s_sleep(1);
+              if (++spins > HM_Q_SPIN_LIMIT) { __hip_atomic_store(f.err, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+            }
+          }
+          __syncthreads();
+        };
+        if (!INV) hm_ntt_pass_run<HM_ROW_LOG, false, false, MODE_B, HM_Q_MID_AUX, HM_Q_OUT_AUX, 1, GEO>(a, lds, entry, tile, tid, wait);
+        else hm_ntt_pass_run<LOG1, true, true, MODE_B, HM_Q_MID_AUX, HM_Q_OUT_AUX, HM_EPI_CHUNK, GEO>(a, lds, entry, tile, tid, wait);
+      }
     }
-    for (uint32_t e = threadIdx.x; e < a.n_limbs; e += blockDim.x) Q->first_done[e] = 0;
-    __syncthreads();
-    if (threadIdx.x < 8) Q->xcd[threadIdx.x].next_item = 0;
-    if (threadIdx.x == 0) { Q->next_group = 0; Q->exited = 0; }
-  }
+    if (threadIdx.x == 0) decode(pulled);
+  }   // (the barriers at the top of the loop keep the next item's LDS writes behind this item's last reads)
 }
-template <int LOG1, bool INV, int MODE_A, int MODE_B>
-__global__ void __launch_bounds__((1 << HM_TL_ROW) / HM_EPT) __attribute__((amdgpu_waves_per_eu(HM_NTT_MIN_WAVES))) k_ntt_queue(HmNttArgs a, HmNttQueueArgs f) {
-  hm_ntt_queue_body<LOG1, INV, MODE_A, MODE_B, Geo16>(a, f);
-}
+// (8-coefficient geometry, N = 2^16; the 16-coefficient form of round 4 was slower in every measurement and is gone)
 template <bool INV, int MODE_A, int MODE_B>
 __global__ void __launch_bounds__((1 << HM_TL_ROW) / 8) k_ntt_queue8(HmNttArgs a, HmNttQueueArgs f) {
   hm_ntt_queue_body<8, INV, MODE_A, MODE_B, Geo8>(a, f);
 }
 
-#ifndef HM_DMA_IN_AUX
-#define HM_DMA_IN_AUX 0   // cache policy of the DMA'd tile loads (2 = nt)
-#endif
-// ---- persistent, double-buffered passes: the next tile arrives by LDS-DMA while the current one is transformed (round 4) -------------
-// A workgroup walks a run of tiles (virtual block ids blockIdx.x, + gridDim.x, ...: the same XCD-aware map as the one-tile kernels).  Its
-// LDS holds TWO tile images with the shared twiddles of each tile's modulus behind them.  While it runs the rounds of tile t in image
-// t & 1, `buffer_load_dwordx4 ... lds` instructions (no VGPR destination: the data never passes through registers) fill image (t + 1) & 1
-// with tile t + 1 and its twiddles: every wave-instruction writes 1 KiB of LDS linearly, and the XOR swizzle of the image is applied
-// through the per-lane SOURCE addresses.  At the top of an iteration a counted `s_waitcnt vmcnt(stores of the previous tile)` retires this
-// wave's DMA pieces of tile t while the previous tile's stores are still draining, and one raw s_barrier publishes all waves' pieces and
-// frees the other image; the barriers between the rounds are raw too (`__syncthreads()` would wait for vmcnt(0) and drain the DMA).
-// The first round reads its elements from the image (phase SRC = 1) instead of from global memory.
-template <int TL, int LOGR, bool STRIDED, bool INV, int MODE, class GEO, class ISSUE>
-__device__ __forceinline__ void hm_dma_tile(uint64_t *__restrict__ cur, uint64_t *__restrict__ nxt, int tid, uint64_t *dst, uint32_t tile, const HmW *twl,
-                                            const HmW *twt, uint32_t s0, uint32_t prefix0, uint64_t q, HmTw sc, HmEpi ep, ISSUE issue_next) {
-  typename GEO::State st;
-  GEO::template phases_dma<TL, LOGR, STRIDED, INV, MODE>(st, tid, cur, nullptr, dst, tile, twl, twt, s0, prefix0, q, sc, ep,
-                                                        [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }, cur + (1 << TL),
-                                                        [&] { issue_next(nxt); });   // behind this tile's own global requests: the next tile's DMA
-}
-template <int LOGR, bool STRIDED, bool INV, int MODE, class GEO, int TL = HM_TL(STRIDED)>
-__device__ __forceinline__ void hm_ntt_pass_dma_body(const HmNttArgs &a) {
-#if defined(__HIP_DEVICE_COMPILE__)   // (buffer descriptors and the LDS-DMA builtins exist in the device pass only)
-  constexpr int TILE = 1 << TL, THREADS = TILE / GEO::EPT, WAVES = THREADS / 64;
-  constexpr int NTWW = STRIDED ? (1 << LOGR) : 128;                // staged twiddle words behind a tile image (one per entry)
-  constexpr int CH_TILE = TILE * 8 / 1024, CH_TW = (NTWW * 8 + 1023) / 1024;  // 1 KiB pieces (a short twiddle list is copied with what follows it in the table)
-  constexpr int IMG = TILE + CH_TW * 128;                           // words per buffer
-  constexpr int NDMA = (CH_TILE + CH_TW + WAVES - 1) / WAVES;
-  constexpr int LOGC = TL - LOGR;
-  static_assert(!STRIDED || LOGC >= 3, "tile image swizzle");
-  static_assert(HM_TW_IN_LDS(STRIDED), "the passes read their shared twiddles from the staged copy");
-  __shared__ __attribute__((aligned(16))) uint64_t lds[2 * IMG];
-  typedef __attribute__((address_space(3))) void *LdsPtr;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const uint32_t tiles = 1u << (a.logN - TL);
-  const uint32_t total = a.n_limbs * tiles;
-  const size_t N = (size_t)1 << a.logN;
-  constexpr bool FIRST = (STRIDED != INV);
-  // per-lane source offsets (bytes inside the limb-poly, without the tile's part) of this wave's pieces: loop-invariant
-  uint32_t voff[NDMA];
-#pragma unroll
-  for (int k = 0; k < NDMA; ++k) {
-    const int c = k * WAVES + wave;                 // piece number; pieces >= CH_TILE carry the twiddles
-    int x, cc;
-    hm_lds_unidx<TL, LOGR, STRIDED>((c * 128 + lane * 2) & (TILE - 1), x, cc);
-    voff[k] = c < CH_TILE ? (STRIDED ? (((uint32_t)x << HM_ROW_LOG) + (uint32_t)cc) << 3 : (((uint32_t)cc << LOGR) + (uint32_t)x) << 3)
-                          : (uint32_t)((c - CH_TILE) * 1024 + lane * 16);
-  }
-  const uint32_t logPer = a.logN - TL + a.logG;   // tiles per limb-poly x group size: powers of two, shifts instead of a (vector-unit) division
-  // one 8-byte scalar load per record (a lone 16-bit field at a 2-byte offset has no scalar load: it became a vector load whose
-  // vmcnt(0) drained the DMA)
-  auto record = [&](uint32_t entry) -> uint64_t {
-    uint64_t raw;
-    __builtin_memcpy(&raw, &a.limb[entry], 8);
-    return raw;
-  };
-  auto decode = [&](uint32_t vb, uint32_t &entry, uint32_t &tile, uint64_t &rec) -> bool {   // hm_block_map for a virtual block id
-    vb = __builtin_amdgcn_readfirstlane(vb);
-    const uint32_t xcd = vb & 7u, slot = vb >> 3;
-    const uint32_t grp = slot >> logPer, within = slot & ((1u << logPer) - 1u);
-    tile = within >> a.logG;
-    entry = (grp << (3 + a.logG)) + (within & ((1u << a.logG) - 1u)) * 8u + xcd;
-    if (vb >= total || entry >= a.n_limbs) return false;
-    rec = record(entry);
-    return ((rec >> 32) & 0xFFFFu) != HM_NTT_NONE;
-  };
-  auto next_valid = [&](uint32_t vb, uint32_t &entry, uint32_t &tile, uint64_t &rec) -> uint32_t {
-    while (vb < total && !decode(vb, entry, tile, rec)) vb += gridDim.x;
-    return vb;
-  };
-  auto unpack = [](uint64_t rec) { return HmLimb{(uint16_t)rec, (uint16_t)(rec >> 16), (uint16_t)(rec >> 32), (uint16_t)(rec >> 48)}; };
-  auto issue = [&](uint64_t rec, uint32_t tile, uint64_t *img) {
-    const HmLimb lb = unpack(rec);
-    const uint64_t *src = FIRST ? a.in + (size_t)lb.in * N : a.out + (size_t)lb.out * N;
-    const uint32_t soff = STRIDED ? tile << (LOGC + 3) : tile << (TL + 3);
-    const __amdgpu_buffer_rsrc_t rs = hm_rsrc(src), rt = hm_rsrc(a.tw + (size_t)lb.mod * N);
-#pragma unroll
-    for (int k = 0; k < NDMA; ++k) {
-      const int c = k * WAVES + wave;
-      if (c < CH_TILE) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (LdsPtr)(img + c * 128), 16, voff[k], soff, 0, HM_DMA_IN_AUX);
-      else if (c < CH_TILE + CH_TW) __builtin_amdgcn_raw_ptr_buffer_load_lds(rt, (LdsPtr)(img + c * 128), 16, voff[k], 0, 0, 0);
-    }
-  };
-  uint32_t entry, tile, nentry = 0, ntile = 0;
-  uint64_t rec = 0, nrec = 0;
-  uint32_t vb = next_valid(blockIdx.x, entry, tile, rec);
-  if (vb >= total) return;
-  issue(rec, tile, lds);
-#pragma unroll 1
-  for (uint32_t it = 0; vb < total; ++it) {
-    uint64_t *cur = lds + (it & 1) * IMG, *nxt = lds + ((it + 1) & 1) * IMG;
-    const uint32_t nvb = next_valid(vb + gridDim.x, nentry, ntile, nrec);
-    // this wave's DMA pieces of tile `it` have landed (everything older than the previous tile's stores has retired: vmcnt counts in order);
-    // the barrier publishes every wave's pieces and says that all waves are done reading the other image
-    if (it == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // nothing was issued behind the first tile's pieces
-    else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(GEO::EPT / 2) : "memory");
-    {
-      const HmLimb lb = unpack(rec);
-      const uint32_t mod = lb.mod;
-      const uint64_t q = HM_CONST_MODS(a.mods)[mod].q;
-      const HmW *twl = a.tw + (size_t)mod * N;
-      const uint32_t s0 = STRIDED ? 0u : (a.logN - HM_ROW_LOG);
-      const uint32_t prefix0 = STRIDED ? 0u : (tile << (TL - LOGR));
-      const HmW *twt = STRIDED ? nullptr : a.twist + ((size_t)mod * (N >> HM_ROW_LOG) + prefix0) * 3;
-      uint64_t *dst = a.out + (size_t)lb.out * N;
-      HmTw sc = {0, 0};
-      HmEpi ep = hm_epi_none();
-      typedef const HmNttEntry __attribute__((address_space(4))) *ConstEntry;
-      const ConstEntry entries = (ConstEntry)(uintptr_t)a.entry;
-      if constexpr (MODE == 2) { sc.w = entries[entry].sc.w; sc.ws = entries[entry].sc.ws; }
-      if constexpr (MODE == 3) {
-        const auto &en = entries[entry];
-        sc.w = en.sc.w; sc.ws = en.sc.ws;
-        ep.a = a.minuend + (size_t)lb.aux * N;
-        ep.d = a.addend && en.alimb != HM_NTT_NONE ? a.addend + (size_t)en.alimb * N : nullptr;
-        ep.dk.w = en.ak.w; ep.dk.ws = en.ak.ws;
-      }
-      if constexpr (MODE == 4) {
-        const auto &en = entries[entry];
-        ep.b = a.mix + (size_t)en.mixlimb * N;
-        ep.bk.w = en.mixk.w; ep.bk.ws = en.mixk.ws;
-      }
-      int t2 = tid;
-      asm volatile("" : "+v"(t2));   // lane offsets are recomputed per tile instead of living (spilled) across the loop
-      __builtin_assume(t2 >= 0 && t2 < THREADS);
-      // `cur` and `nxt` as __restrict__ parameters of an inlined function: the inliner then tags the accesses of the two images with
-      // alias scopes, and the waitcnt pass no longer puts s_waitcnt vmcnt(0) in front of the first LDS read of `cur` on account of the
-      // DMA that is writing `nxt`
-      hm_dma_tile<TL, LOGR, STRIDED, INV, MODE, GEO>(cur, nxt, t2, dst, tile, twl, twt, s0, prefix0, q, sc, ep, [&](uint64_t *img) {
-        __builtin_amdgcn_sched_barrier(0);
-        if (nvb < total) issue(nrec, ntile, img);
-        __builtin_amdgcn_sched_barrier(0);
-      });
-    }
-    vb = nvb; entry = nentry; tile = ntile; rec = nrec;
-  }
-#endif
-}
-template <int LOGR, bool INV, int MODE>
-__global__ void __launch_bounds__((1 << HM_TL_COL) / HM_EPT) k_ntt_col_dma(HmNttArgs a) { hm_ntt_pass_dma_body<LOGR, true, INV, MODE, Geo16>(a); }
-template <bool INV, int MODE>
-__global__ void __launch_bounds__((1 << HM_TL_ROW) / HM_EPT) k_ntt_row_dma(HmNttArgs a) { hm_ntt_pass_dma_body<HM_ROW_LOG, false, INV, MODE, Geo16>(a); }
-template <bool INV, int MODE>
-__global__ void __launch_bounds__((1 << HM_TL_COL) / 8) k_ntt_col8_dma(HmNttArgs a) { hm_ntt_pass_dma_body<8, true, INV, MODE, Geo8>(a); }
-template <bool INV, int MODE>
-__global__ void __launch_bounds__((1 << HM_TL_ROW) / 8) k_ntt_row8_dma(HmNttArgs a) { hm_ntt_pass_dma_body<HM_ROW_LOG, false, INV, MODE, Geo8>(a); }
-// ... on 2048-coefficient tiles: 256-thread workgroups with 2 x 18 (20) KiB of LDS, four per CU as in the one-tile kernels
-template <bool INV, int MODE>
-__global__ void __launch_bounds__(256) k_ntt_col8_dma11(HmNttArgs a) { hm_ntt_pass_dma_body<8, true, INV, MODE, Geo8, 11>(a); }
-template <bool INV, int MODE>
-__global__ void __launch_bounds__(256) k_ntt_row8_dma11(HmNttArgs a) { hm_ntt_pass_dma_body<HM_ROW_LOG, false, INV, MODE, Geo8, 11>(a); }
-
 // ---- K1 x K5: last transform pass x evaluation key, both keys, all digits of one extended limb in one workgroup ---------
 #define HM_NIP_MAX_TERMS 4
-static_assert(HM_NIP_MAX_TERMS <= 5, "lazy key products: five terms of less than 1.5q + 2^28 stay below 8q (hm_mac_add)");
+static_assert(HM_GENERIC || HM_NIP_MAX_TERMS <= 5, "mont32 lazy key products: five terms of less than 1.5q + 2^28 stay below 8q (hm_mac_add)");
 #define HM_NIP_MAX_OUT 2
 #define HM_NIP_MAX_LIMBS 4096   // per launch: the records live in a device table (cached by content), read through the scalar cache
 struct HmNipLimb {                       // 32 bytes
@@ -979,7 +821,7 @@ struct hm_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_done = nullptr;
-  HmW *d_tw_fwd = nullptr, *d_tw_inv = nullptr;     // [L+K][N], Montgomery form (one word per entry)
+  HmW *d_tw_fwd = nullptr, *d_tw_inv = nullptr;     // [L+K][N] table entries (mont32: one word in Montgomery form; generic: value + Shoup companion)
   HmW *d_twist_fwd = nullptr, *d_twist_inv = nullptr;  // [L+K][N/256][3], hm::Params::make_twist
   HmMod *d_mods = nullptr;
   std::map<std::vector<uint32_t>, uint64_t *> bconv_tables;  // key: n_in, in_ids..., out_ids...
@@ -993,23 +835,17 @@ struct hm_ctx {
   unsigned *err_host = nullptr, *err_dev = nullptr;
   bool small_ept8 = true;      // launches of at most small_limbs entries use the 8-coefficient geometry (N = 2^16)
   uint32_t small_mode = 3;     // which passes of a small launch use it: bit 0 COL, bit 1 ROW
-  bool side_launches = false;   // independent small launches of one call side by side (hm_set_option "side_launches"): measured SLOWER, see bconv_col_launch
-  uint32_t side_max_wgs = 4096;   // ... when together they are at most this many workgroups (4 rounds of the chip)
   uint32_t small_limbs = 64;   // measured (tools/ntt_small_ab.py): 2-3 us per launch faster up to ~64 entries, equal at 115, slower from 128
-  bool fused_ntt = false;  // every transform as one launch (k_ntt_fused): slower for launches that fill the chip more than once, opt-in
   uint32_t fused_test_spread = 0;   // test hook: one-launch transforms take the agent-scope path
   uint32_t fused_test_timeout = 0;  // test hook: tile 0 of every limb-poly withholds its arrival and the spins are short: the rendezvous times out
   uint32_t fused_slots_per_xcd = 0;  // workgroups of the one-launch transform an XCD holds at once (hm_create: occupancy x CUs per XCD)
   bool fused_broken = false;        // a rendezvous timed out: no one-launch transforms any more, graphs that hold one refuse to replay
   bool capture_has_fused = false;   // the capture in progress recorded a one-launch transform
   uint32_t fused_small = 96;  // launches of up to this many entries (N = 2^16) run as ONE launch in the small-launch geometry (k_ntt_fused8): 2-5 us faster than two kernels up to ~100 limb-polys, slower from 128 (tools/ntt_fused_small_ab.py); 0 = off
-  uint32_t fused_extra_lds = 0;   // dynamic LDS added to every k_ntt_fused workgroup: occupancy throttle of the L2 hand-off experiment
   // persistent two-pass transform fed from per-XCD queues (k_ntt_queue): 0 off, 1 = 8-coefficient geometry (N = 2^16), 2 = 16-coefficient
   uint32_t queue_ntt = 0, queue_wgs = 0 /* workgroups of the grid; 0 = 2 (geometry 8) or 4 (16) per CU */, queue_la = 2, queue_gc = 0 /* 0 = auto */;
   uint32_t bcol_outs = 0;   // output limbs per workgroup of the fused conversion + first pass (1 | 2; 0 = by launch size)
-  uint32_t dma_ntt = 0, dma_wgs = 0;   // persistent double-buffered passes (k_ntt_*_dma): 0 off, 1 = 8-coefficient geometry (N = 2^16), 2 = 16-coefficient; workgroups per launch (0 = 2 per CU)
   HmNttQueue *ntt_q = nullptr;
-  unsigned *q_trace_host = nullptr, *q_trace_dev = nullptr;   // HOMULATOR_NTT_QUEUE_TRACE
   int n_cu = 256;
   // multi-GPU
   int rank = 0, world = 1;
@@ -1020,8 +856,6 @@ struct hm_ctx {
   size_t stage_words = 0;
   // exchange / compute overlap inside one op: the exchanges run on a stream of their own (hm_exchange_stream), ordered against the
   // compute stream by marks (events)
-  hipStream_t sstream = nullptr;   // side stream of small independent launches (the two conversion sizes of a ModUp): fork / join by events
-  hipEvent_t sfork = nullptr, sjoin = nullptr;
   hipStream_t xstream = nullptr;
   bool xasync = false;
   hipEvent_t xdep = nullptr;
@@ -1100,7 +934,7 @@ extern "C" hm_status hm_create(hm_ctx **out, const hm_params *p) {
   *out = nullptr;
   std::unique_ptr<hm_ctx> c(new hm_ctx);
   try {
-    c->P.init(p->logN, p->L, p->K, p->q, p->p, p->psi);
+    c->P.init(p->logN, p->L, p->K, p->q, p->p, p->psi, HM_GENERIC != 0);   // (the mont32 build refuses a chain with a modulus that is not h 2^32 + 1)
   } catch (const std::exception &e) {
     return fail(nullptr, HM_ERR_ARG, "hm_create: %s", e.what());
   }
@@ -1161,27 +995,17 @@ extern "C" hm_status hm_create(hm_ctx **out, const hm_params *p) {
     cc->fused_slots_per_xcd = slots;
     if (slots < (cc->P.N >> HM_TL_ROW)) cc->fused_small = 0;
   }
-  if (getenv("HOMULATOR_NTT_QUEUE_TRACE")) {
-    HM_HIP(nullptr, hipHostMalloc(reinterpret_cast<void **>(&cc->q_trace_host), 64 * 256 * 4, hipHostMallocMapped));
-    memset(cc->q_trace_host, 0, 64 * 256 * 4);
-    HM_HIP(nullptr, hipHostGetDevicePointer(reinterpret_cast<void **>(&cc->q_trace_dev), cc->q_trace_host, 0));
-  }
   if (const char *e = getenv("HOMULATOR_BCOL_OUTS")) cc->bcol_outs = (uint32_t)std::min(2, std::max(0, atoi(e)));
-  if (const char *e = getenv("HOMULATOR_NTT_DMA")) cc->dma_ntt = (uint32_t)std::min(3, std::max(0, atoi(e)));
-  if (const char *e = getenv("HOMULATOR_NTT_DMA_WGS")) cc->dma_wgs = (uint32_t)std::min(8192, std::max(0, atoi(e)));
-  if (const char *e = getenv("HOMULATOR_NTT_QUEUE")) cc->queue_ntt = (uint32_t)std::min(2, std::max(0, atoi(e)));
+  if (const char *e = getenv("HOMULATOR_NTT_QUEUE")) cc->queue_ntt = (uint32_t)std::min(1, std::max(0, atoi(e)));
   if (const char *e = getenv("HOMULATOR_NTT_QUEUE_WGS")) cc->queue_wgs = (uint32_t)std::min(8192, std::max(0, atoi(e)));
   if (const char *e = getenv("HOMULATOR_NTT_QUEUE_LA")) cc->queue_la = (uint32_t)std::min(16, std::max(1, atoi(e)));
   if (const char *e = getenv("HOMULATOR_NTT_QUEUE_GROUP")) cc->queue_gc = (uint32_t)std::min(8, std::max(0, atoi(e)));
   HM_HIP(nullptr, hipHostMalloc(reinterpret_cast<void **>(&cc->err_host), 64, hipHostMallocMapped));
   memset(cc->err_host, 0, 64);
   HM_HIP(nullptr, hipHostGetDevicePointer(reinterpret_cast<void **>(&cc->err_dev), cc->err_host, 0));
-  if (const char *e = getenv("HOMULATOR_NTT_FUSED")) cc->fused_ntt = std::string(e) != "0";
   if (const char *e = getenv("HOMULATOR_NTT_FUSED_SMALL")) cc->fused_small = (uint32_t)std::min(HM_NTT_MAX_ENTRIES, std::max(0, atoi(e)));
   if (cc->fused_slots_per_xcd < (cc->P.N >> HM_TL_ROW)) cc->fused_small = 0;   // the guard above wins over the environment
-  if (const char *e = getenv("HOMULATOR_NTT_FUSED_LDS")) cc->fused_extra_lds = (uint32_t)std::min(120 * 1024, std::max(0, atoi(e)));
   if (const char *e = getenv("HOMULATOR_NTT_SMALL_LIMBS")) { cc->small_limbs = (uint32_t)atoi(e); cc->small_ept8 = cc->small_limbs != 0; }
-  if (const char *e = getenv("HOMULATOR_SIDE_LAUNCHES")) cc->side_launches = std::string(e) != "0";
   *out = c.release();
   return HM_OK;
 }
@@ -1205,9 +1029,6 @@ extern "C" void hm_destroy(hm_ctx *c) {
   (void)hipFree(c->ntt_ws);
   (void)hipFree(c->ntt_q);
   (void)hipHostFree(c->err_host);
-  if (c->sstream) { (void)hipStreamSynchronize(c->sstream); (void)hipStreamDestroy(c->sstream); }
-  if (c->sfork) (void)hipEventDestroy(c->sfork);
-  if (c->sjoin) (void)hipEventDestroy(c->sjoin);
   if (c->xstream) { (void)hipStreamSynchronize(c->xstream); (void)hipStreamDestroy(c->xstream); }
   if (c->xdep) (void)hipEventDestroy(c->xdep);
   for (hipEvent_t e : c->xmarks) (void)hipEventDestroy(e);
@@ -1265,7 +1086,6 @@ static hm_status check_device_error(hm_ctx *c) {
   if (c->err_host && *c->err_host) {
     const unsigned code = *c->err_host;
     *c->err_host = 0;
-    c->fused_ntt = false;
     c->fused_small = 0;       // the default one-launch form too: every later launch would stall and fail the same way
     c->fused_broken = true;   // graphs captured with one-launch transforms inside refuse to replay (hm_graph_launch)
     (void)hipStreamSynchronize(c->stream);
@@ -1331,7 +1151,6 @@ extern "C" hm_status hm_wait_for(hm_ctx *c, hm_ctx *producer) {
 
 extern "C" hm_status hm_set_option(hm_ctx *c, const char *name, uint64_t value) {
   if (!c || !name) return HM_ERR_ARG;
-  if (!strcmp(name, "ntt_fused")) { c->fused_ntt = value != 0; return HM_OK; }
   if (!strcmp(name, "ntt_fused_test_spread")) { c->fused_test_spread = value != 0; return HM_OK; }
   if (!strcmp(name, "ntt_fused_test_timeout")) { c->fused_test_timeout = value != 0; return HM_OK; }
   if (!strcmp(name, "ntt_fused_small")) {
@@ -1341,37 +1160,18 @@ extern "C" hm_status hm_set_option(hm_ctx *c, const char *name, uint64_t value) 
     c->fused_small = (uint32_t)value;
     return HM_OK;
   }
-  if (!strcmp(name, "ntt_fused_lds")) { if (value > 120 * 1024) return fail(c, HM_ERR_ARG, "hm_set_option: ntt_fused_lds above 120 KiB"); c->fused_extra_lds = (uint32_t)value; return HM_OK; }
   if (!strcmp(name, "bconv_col_outs")) { if (value > 2) return fail(c, HM_ERR_ARG, "hm_set_option: bconv_col_outs is 0 (by launch size), 1 or 2"); c->bcol_outs = (uint32_t)value; return HM_OK; }
-  if (!strcmp(name, "ntt_dma")) { if (value > 3) return fail(c, HM_ERR_ARG, "hm_set_option: ntt_dma is 0 .. 3"); c->dma_ntt = (uint32_t)value; return HM_OK; }
-  if (!strcmp(name, "ntt_dma_wgs")) { if (value > 8192) return fail(c, HM_ERR_ARG, "hm_set_option: ntt_dma_wgs above 8192"); c->dma_wgs = (uint32_t)value; return HM_OK; }
-  if (!strcmp(name, "ntt_queue")) { if (value > 2) return fail(c, HM_ERR_ARG, "hm_set_option: ntt_queue is 0, 1 or 2"); c->queue_ntt = (uint32_t)value; return HM_OK; }
+  if (!strcmp(name, "ntt_queue")) { if (value > 1) return fail(c, HM_ERR_ARG, "hm_set_option: ntt_queue is 0 or 1"); c->queue_ntt = (uint32_t)value; return HM_OK; }
   if (!strcmp(name, "ntt_queue_wgs")) { if (value > 8192) return fail(c, HM_ERR_ARG, "hm_set_option: ntt_queue_wgs above 8192"); c->queue_wgs = (uint32_t)value; return HM_OK; }
   if (!strcmp(name, "ntt_queue_lookahead")) { if (value < 1 || value > 16) return fail(c, HM_ERR_ARG, "hm_set_option: ntt_queue_lookahead in [1,16]"); c->queue_la = (uint32_t)value; return HM_OK; }
   if (!strcmp(name, "ntt_queue_group")) { if (value > 8) return fail(c, HM_ERR_ARG, "hm_set_option: ntt_queue_group in [0,8]"); c->queue_gc = (uint32_t)value; return HM_OK; }
   if (!strcmp(name, "ntt_small_mode")) { c->small_mode = (uint32_t)value & 3u; return HM_OK; }
-  if (!strcmp(name, "side_launches")) { c->side_launches = value != 0; if (value > 1) c->side_max_wgs = (uint32_t)value; return HM_OK; }
   if (!strcmp(name, "ntt_small_limbs")) { c->small_ept8 = value != 0; c->small_limbs = (uint32_t)value; return HM_OK; }
   return fail(c, HM_ERR_ARG, "hm_set_option: unknown option %s", name);
 }
 extern "C" hm_status hm_get_counter(hm_ctx *c, const char *name, uint64_t *value) {
   if (!c || !name || !value) return HM_ERR_ARG;
-  if (!strcmp(name, "ntt_queue_trace")) {   // bring-up aid: prints the pull trace (host-mapped memory: readable while a kernel hangs); does NOT synchronise
-    *value = 0;
-    if (!c->q_trace_host) return HM_OK;
-    for (int b = 0; b < 64; ++b) {
-      const volatile unsigned *t = c->q_trace_host + b * 256;
-      const unsigned k = t[0];
-      if (!k) continue;
-      fprintf(stderr, "wg %2d (mark %u):", b, t[255]);
-      for (unsigned i = 0; i < k && i < 63; ++i) fprintf(stderr, " [i=%u v=%d e=%d p=%u x=%u]", t[1 + 4 * i], (int)t[2 + 4 * i], (int)t[3 + 4 * i], t[4 + 4 * i] & 1, t[4 + 4 * i] >> 8);
-      fprintf(stderr, "\n");
-      *value += k;
-    }
-    fprintf(stderr, "err word: %u\n", c->err_host ? *c->err_host : 0);
-    return HM_OK;
-  }
-  if (!strcmp(name, "arith")) { *value = 0; return HM_OK; }   // arithmetic back-end of this context: 0 = word-wise Montgomery on q = h 2^32 + 1
+  if (!strcmp(name, "arith")) { *value = HM_GENERIC; return HM_OK; }   // arithmetic back-end of this context: 0 = mont32 (word-wise Montgomery on q = h 2^32 + 1), 1 = generic
   if (!strcmp(name, "ntt_fused_slots_per_xcd")) { *value = c->fused_slots_per_xcd; return HM_OK; }
   if (!strcmp(name, "ntt_fused_small")) { *value = c->fused_small; return HM_OK; }   // 0: the one-launch form is off (option, guard, or after a time-out)
   if (!strcmp(name, "ntt_cross_xcd")) {
@@ -1474,111 +1274,68 @@ static hm_status check_mods(hm_ctx *c, const char *what, const uint32_t *m, uint
   return HM_OK;
 }
 
+// The kernels of a transform, by form: 0 = forward, 1 = forward with the fused epilogue (MODE 3), 2 = forward with the mix prologue and
+// the epilogue (MODE 4 + 3), 3 = inverse.  `first` / `second` = the two pass kernels in the order they run (forward: COL then ROW,
+// inverse: ROW then COL) in the 16-coefficient geometry; `first8` / `second8` = the same in the small-launch geometry and `one` = both
+// passes in one launch ([0] out of place: non-temporal input loads, [1] in place), N = 2^16 only.
+typedef void (*hm_ntt_kernel)(HmNttArgs);
+typedef void (*hm_ntt_one_kernel)(HmNttArgs, HmNttFusedArgs);
+struct HmNttKernels {
+  hm_ntt_kernel first, second, first8, second8;
+  hm_ntt_one_kernel one[2];
+};
+template <int LOG1>
+static const HmNttKernels &ntt_kernels(int form) {
+  static const HmNttKernels wide[4] = {
+      {k_ntt_col<LOG1, false, 0>, k_ntt_row<false, 1>, nullptr, nullptr, {nullptr, nullptr}},
+      {k_ntt_col<LOG1, false, 0>, k_ntt_row<false, 3>, nullptr, nullptr, {nullptr, nullptr}},
+      {k_ntt_col<LOG1, false, 4>, k_ntt_row<false, 3>, nullptr, nullptr, {nullptr, nullptr}},
+      {k_ntt_row<true, 0>, k_ntt_col<LOG1, true, 2>, nullptr, nullptr, {nullptr, nullptr}}};
+  return wide[form];
+}
+template <>
+const HmNttKernels &ntt_kernels<8>(int form) {
+  static const HmNttKernels both[4] = {
+      {k_ntt_col<8, false, 0>, k_ntt_row<false, 1>, k_ntt_col8<false, 0>, k_ntt_row8<false, 1>, {k_ntt_fused8<false, 0, 1, true>, k_ntt_fused8<false, 0, 1, false>}},
+      {k_ntt_col<8, false, 0>, k_ntt_row<false, 3>, k_ntt_col8<false, 0>, k_ntt_row8<false, 3>, {k_ntt_fused8<false, 0, 3, true>, k_ntt_fused8<false, 0, 3, false>}},
+      {k_ntt_col<8, false, 4>, k_ntt_row<false, 3>, k_ntt_col8<false, 4>, k_ntt_row8<false, 3>, {k_ntt_fused8<false, 4, 3, true>, k_ntt_fused8<false, 4, 3, false>}},
+      {k_ntt_row<true, 0>, k_ntt_col<8, true, 2>, k_ntt_row8<true, 0>, k_ntt_col8<true, 2>, {k_ntt_fused8<true, 0, 2, true>, k_ntt_fused8<true, 0, 2, false>}}};
+  return both[form];
+}
+
 template <int LOG1>
 static void launch_ntt(hm_ctx *c, const HmNttArgs &a, bool fusedEpilogue, bool mixPrologue, bool inverse, bool firstPassOnly, bool secondPassOnly = false) {
-  // n_limbs = entries, a multiple of 16 (pairs x 8 XCDs); one workgroup per tile of each pass
-  const dim3 gridC(a.n_limbs * (c->P.N >> HM_TL_COL)), blockC((1 << HM_TL_COL) / HM_EPT);
-  const dim3 gridR(a.n_limbs * (c->P.N >> HM_TL_ROW)), blockR((1 << HM_TL_ROW) / HM_EPT);
+  // n_limbs = entries, a multiple of 8 (one group per XCD); one workgroup per 4096-coefficient tile of each pass (HM_TL_COL == HM_TL_ROW)
+  const HmNttKernels &K = ntt_kernels<LOG1>(inverse ? 3 : mixPrologue ? 2 : fusedEpilogue ? 1 : 0);
+  const dim3 grid(a.n_limbs * (c->P.N >> HM_TL_ROW)), block16((1 << HM_TL_ROW) / HM_EPT), block8((1 << HM_TL_ROW) / 8);
+  // small launches (one round of workgroups on the chip): the 8-coefficient geometry halves the serial work per wave (small_mode:
+  // bit 0 = the COL pass, bit 1 = the ROW pass; the hand-off between the passes is the same in both geometries)
+  const bool small = K.first8 && c->small_ept8 && a.n_limbs <= c->small_limbs;
+  const bool col8 = small && (c->small_mode & 1), row8 = small && (c->small_mode & 2);
+  const bool first8 = inverse ? row8 : col8, second8 = inverse ? col8 : row8;
   if (secondPassOnly) {   // the hand-off was written by a fused conversion + first pass (bconv_col_launch)
-    if constexpr (LOG1 == 8) {
-      if (c->small_ept8 && (c->small_mode & 2) && a.n_limbs <= c->small_limbs) {
-        const dim3 grid8(a.n_limbs * (c->P.N >> HM_TL_ROW)), block8((1 << HM_TL_ROW) / 8);
-        if (fusedEpilogue) hipLaunchKernelGGL((k_ntt_row8<false, 3>), grid8, block8, 0, c->stream, a);
-        else hipLaunchKernelGGL((k_ntt_row8<false, 1>), grid8, block8, 0, c->stream, a);
-        return;
-      }
-    }
-    if (fusedEpilogue) hipLaunchKernelGGL((k_ntt_row<false, 3>), gridR, blockR, 0, c->stream, a);
-    else hipLaunchKernelGGL((k_ntt_row<false, 1>), gridR, blockR, 0, c->stream, a);
+    hipLaunchKernelGGL(second8 ? K.second8 : K.second, grid, second8 ? block8 : block16, 0, c->stream, a);
     return;
   }
-  // small launches (one round of workgroups on the chip): the 8-coefficient geometry halves the serial work per wave
-  if constexpr (LOG1 == 8) {
-    // ... and both passes in one launch behind an XCD-local rendezvous.  Progress: a kernel's workgroups are dispatched in order, so it has at
-    // most ONE partially dispatched limb-poly per XCD whose workgroups wait for siblings that have no slot yet (logG == 0: at most 15 of an
-    // XCD's 128 slots); every other resident workgroup belongs to a complete limb-poly and finishes.  Up to eight such kernels in flight on
-    // one GPU (contexts, instances; HIP drives four hardware queues by default) cannot starve one another; the spins are bounded all the same.
-    if (!firstPassOnly && !c->fused_ntt && !c->dma_ntt && a.n_limbs <= c->fused_small && a.logG == 0) {
-      const HmNttFusedArgs f = {c->ntt_ws, c->err_dev, c->fused_test_spread, c->fused_test_timeout ? 1u << 10 : HM_SPIN_LIMIT, c->fused_test_timeout};
-      if (c->capturing) c->capture_has_fused = true;
-      const dim3 grid8(a.n_limbs * (c->P.N >> HM_TL_ROW)), block8((1 << HM_TL_ROW) / 8);
-      bool inPlace = a.in == a.out;   // every limb-poly transformed onto itself: the input loads keep their lines for the hand-off
-      for (uint32_t e = 0; inPlace && e < a.n_limbs; ++e) inPlace = a.limb[e].mod == HM_NTT_NONE || a.limb[e].in == a.limb[e].out;
-#define HM_F8GO(INV_, A_, B_) do { if (inPlace) hipLaunchKernelGGL((k_ntt_fused8<INV_, A_, B_, false>), grid8, block8, 0, c->stream, a, f); \
-                                   else hipLaunchKernelGGL((k_ntt_fused8<INV_, A_, B_, true>), grid8, block8, 0, c->stream, a, f); } while (0)
-      if (inverse) HM_F8GO(true, 0, 2);
-      else if (mixPrologue) HM_F8GO(false, 4, 3);
-      else if (fusedEpilogue) HM_F8GO(false, 0, 3);
-      else HM_F8GO(false, 0, 1);
-#undef HM_F8GO
-      return;
-    }
-    if (c->small_ept8 && !firstPassOnly && !c->fused_ntt && !c->dma_ntt && a.n_limbs <= c->small_limbs) {
-      // small_mode: bit 0 = COL pass in the 8-coefficient geometry, bit 1 = ROW pass (the hand-off between the passes is the same)
-      const dim3 grid8(a.n_limbs * (c->P.N >> HM_TL_ROW)), block8((1 << HM_TL_ROW) / 8);
-      const dim3 grid16(a.n_limbs * (c->P.N >> HM_TL_ROW)), block16((1 << HM_TL_ROW) / HM_EPT);
-      const bool c8 = c->small_mode & 1, r8 = c->small_mode & 2;
-      if (!inverse) {
-        if (mixPrologue) { if (c8) hipLaunchKernelGGL((k_ntt_col8<false, 4>), grid8, block8, 0, c->stream, a); else hipLaunchKernelGGL((k_ntt_col<LOG1, false, 4>), grid16, block16, 0, c->stream, a); }
-        else { if (c8) hipLaunchKernelGGL((k_ntt_col8<false, 0>), grid8, block8, 0, c->stream, a); else hipLaunchKernelGGL((k_ntt_col<LOG1, false, 0>), grid16, block16, 0, c->stream, a); }
-        if (fusedEpilogue) { if (r8) hipLaunchKernelGGL((k_ntt_row8<false, 3>), grid8, block8, 0, c->stream, a); else hipLaunchKernelGGL((k_ntt_row<false, 3>), grid16, block16, 0, c->stream, a); }
-        else { if (r8) hipLaunchKernelGGL((k_ntt_row8<false, 1>), grid8, block8, 0, c->stream, a); else hipLaunchKernelGGL((k_ntt_row<false, 1>), grid16, block16, 0, c->stream, a); }
-      } else {
-        if (r8) hipLaunchKernelGGL((k_ntt_row8<true, 0>), grid8, block8, 0, c->stream, a); else hipLaunchKernelGGL((k_ntt_row<true, 0>), grid16, block16, 0, c->stream, a);
-        if (c8) hipLaunchKernelGGL((k_ntt_col8<true, 2>), grid8, block8, 0, c->stream, a); else hipLaunchKernelGGL((k_ntt_col<LOG1, true, 2>), grid16, block16, 0, c->stream, a);
-      }
-      return;
-    }
-  }
-  if (c->dma_ntt && !c->fused_ntt && (c->dma_ntt == 2 || LOG1 == 8)) {   // persistent double-buffered passes
-    const bool g8 = c->dma_ntt == 1, g11 = c->dma_ntt == 3;   // 3: 8-coefficient geometry on 2048-coefficient tiles (four workgroups per CU)
-    const uint32_t allTiles = g11 ? 2 * gridC.x : gridC.x;
-    uint32_t wgs = c->dma_wgs ? c->dma_wgs : (g11 ? 4u : 2u) * (uint32_t)c->n_cu;
-    wgs = std::max(8u, std::min(wgs, allTiles) / 8u * 8u);
-    const dim3 grid(wgs), block(g11 ? 256 : (1 << HM_TL_ROW) / (g8 ? 8 : HM_EPT));
-#define HM_DGO(K11, K8, K16) do { if constexpr (LOG1 == 8) { if (g11) hipLaunchKernelGGL(K11, grid, block, 0, c->stream, a); else if (g8) hipLaunchKernelGGL(K8, grid, block, 0, c->stream, a); else hipLaunchKernelGGL(K16, grid, block, 0, c->stream, a); } else hipLaunchKernelGGL(K16, grid, block, 0, c->stream, a); } while (0)
-    if (!inverse) {
-      if (mixPrologue) HM_DGO((k_ntt_col8_dma11<false, 4>), (k_ntt_col8_dma<false, 4>), (k_ntt_col_dma<LOG1, false, 4>));
-      else HM_DGO((k_ntt_col8_dma11<false, 0>), (k_ntt_col8_dma<false, 0>), (k_ntt_col_dma<LOG1, false, 0>));
-      if (firstPassOnly) return;
-      if (fusedEpilogue) HM_DGO((k_ntt_row8_dma11<false, 3>), (k_ntt_row8_dma<false, 3>), (k_ntt_row_dma<false, 3>));
-      else HM_DGO((k_ntt_row8_dma11<false, 1>), (k_ntt_row8_dma<false, 1>), (k_ntt_row_dma<false, 1>));
-    } else {
-      HM_DGO((k_ntt_row8_dma11<true, 0>), (k_ntt_row8_dma<true, 0>), (k_ntt_row_dma<true, 0>));
-      HM_DGO((k_ntt_col8_dma11<true, 2>), (k_ntt_col8_dma<true, 2>), (k_ntt_col_dma<LOG1, true, 2>));
-    }
-#undef HM_DGO
+  if (firstPassOnly) {    // forward COL pass alone: hm_ntt_inner_product runs the ROW pass inside its own kernel
+    hipLaunchKernelGGL(K.first, grid, block16, 0, c->stream, a);
     return;
   }
-  if (firstPassOnly) {  // forward COL pass alone: hm_ntt_inner_product runs the ROW pass inside its own kernel
-    hipLaunchKernelGGL((k_ntt_col<LOG1, false, 0>), gridC, blockC, 0, c->stream, a);
-    return;
-  }
-  if (c->fused_ntt) {   // both passes in one launch, hand-off through the XCD's L2
+  // Both passes in one launch behind an XCD-local rendezvous.  Progress: a kernel's workgroups are dispatched in order, so it has at
+  // most ONE partially dispatched limb-poly per XCD whose workgroups wait for siblings that have no slot yet (logG == 0: at most 15 of an
+  // XCD's slots; hm_create checked that an XCD holds at least 16); every other resident workgroup belongs to a complete limb-poly and
+  // finishes.  Up to eight such kernels in flight on one GPU (contexts, instances; HIP drives four hardware queues by default) cannot
+  // starve one another; the spins are bounded all the same.
+  if (K.one[0] && a.n_limbs <= c->fused_small && a.logG == 0) {
     const HmNttFusedArgs f = {c->ntt_ws, c->err_dev, c->fused_test_spread, c->fused_test_timeout ? 1u << 10 : HM_SPIN_LIMIT, c->fused_test_timeout};
-      if (c->capturing) c->capture_has_fused = true;
-    // "ntt_fused_lds": extra dynamic LDS per workgroup = an occupancy throttle (100 KiB: one workgroup per CU = 32 per XCD = two
-    // limb-polys in flight per XCD, 3 MiB live per 4 MiB L2): the capacity-controlled form of the hand-off experiment
-    const uint32_t xl = c->fused_extra_lds;
-    auto go = [&](auto kern) {
-      if (xl > 24 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)xl);
-      hipLaunchKernelGGL(kern, gridR, blockR, xl, c->stream, a, f);
-    };
-    if (inverse) go(k_ntt_fused<LOG1, true, 0, 2>);
-    else if (mixPrologue) go(k_ntt_fused<LOG1, false, 4, 3>);
-    else if (fusedEpilogue) go(k_ntt_fused<LOG1, false, 0, 3>);
-    else go(k_ntt_fused<LOG1, false, 0, 1>);
+    if (c->capturing) c->capture_has_fused = true;
+    bool inPlace = a.in == a.out;   // every limb-poly transformed onto itself: the input loads keep their lines for the hand-off
+    for (uint32_t e = 0; inPlace && e < a.n_limbs; ++e) inPlace = a.limb[e].mod == HM_NTT_NONE || a.limb[e].in == a.limb[e].out;
+    hipLaunchKernelGGL(K.one[inPlace ? 1 : 0], grid, block8, 0, c->stream, a, f);
     return;
   }
-  if (!inverse) {
-    if (mixPrologue) hipLaunchKernelGGL((k_ntt_col<LOG1, false, 4>), gridC, blockC, 0, c->stream, a);
-    else hipLaunchKernelGGL((k_ntt_col<LOG1, false, 0>), gridC, blockC, 0, c->stream, a);
-    if (fusedEpilogue) hipLaunchKernelGGL((k_ntt_row<false, 3>), gridR, blockR, 0, c->stream, a);
-    else hipLaunchKernelGGL((k_ntt_row<false, 1>), gridR, blockR, 0, c->stream, a);
-  } else {
-    hipLaunchKernelGGL((k_ntt_row<true, 0>), gridR, blockR, 0, c->stream, a);
-    hipLaunchKernelGGL((k_ntt_col<LOG1, true, 2>), gridC, blockC, 0, c->stream, a);
-  }
+  hipLaunchKernelGGL(first8 ? K.first8 : K.first, grid, first8 ? block8 : block16, 0, c->stream, a);
+  hipLaunchKernelGGL(second8 ? K.second8 : K.second, grid, second8 ? block8 : block16, 0, c->stream, a);
 }
 
 // Device copy of a launch's table (NTT entry constants, base-conversion problem records), cached by content; uploaded
@@ -1646,8 +1403,7 @@ static hm_status ntt_common(hm_ctx *c, const char *what, const uint64_t *in, con
   }
   HM_HIP(c, hipSetDevice(c->device));
   // persistent two-pass transform from per-XCD queues (k_ntt_queue); the 8-coefficient geometry exists for N = 2^16
-  if (c->queue_ntt && !f.firstPassOnly && !f.secondPassOnly) {
-    const bool geo8 = c->queue_ntt == 1 && c->P.logN == 16;
+  if (c->queue_ntt && c->P.logN == 16 && !f.firstPassOnly && !f.secondPassOnly) {
     // dense entry list, same-modulus limb-polys adjacent (their tiles are handed out side by side: one fetch of the row twiddles per group)
     std::vector<uint32_t> order(n);
     for (uint32_t i = 0; i < n; ++i) order[i] = i;
@@ -1674,15 +1430,15 @@ static hm_status ntt_common(hm_ctx *c, const char *what, const uint64_t *in, con
         if (inverse) {
           uint64_t v = c->P.modc[m].ninv;
           if (k) v = hm::mulmod(v, k[g], q);
-          t.sc = HmTw{hm_to_mont(v, q), 0};
+          t.sc = hm_kconst(v, q);
         } else if (fused) {
-          t.sc = HmTw{hm_to_mont(k[g], q), 0};
+          t.sc = hm_kconst(k[g], q);
           a.limb[e].aux = (uint16_t)limb_at(f.minuend_limbs, g);
           t.alimb = f.addend_limbs && f.addend_limbs[g] == HM_NO_LIMB ? (uint16_t)HM_NTT_NONE : (uint16_t)limb_at(f.addend_limbs, g);
-          if (f.addend_k) t.ak = HmTw{hm_to_mont(f.addend_k[g], q), 0};
+          if (f.addend_k) t.ak = hm_kconst(f.addend_k[g], q);
           if (f.mix) {
             t.mixlimb = (uint16_t)limb_at(f.mix_limbs, g);
-            t.mixk = HmTw{hm_to_mont(f.mix_k[g], q), 0};
+            t.mixk = hm_kconst(f.mix_k[g], q);
           }
         }
       }
@@ -1698,37 +1454,17 @@ static hm_status ntt_common(hm_ctx *c, const char *what, const uint64_t *in, con
       a.minuend = f.minuend; a.addend = f.addend; a.mix = f.mix;
       a.logN = c->P.logN; a.n_limbs = cnt; a.logG = 0;
       HmNttQueueArgs qa;
-      qa.trace = c->q_trace_dev;
-      if (c->q_trace_host) memset(c->q_trace_host, 0, 64 * 256 * 4);
       qa.q = c->ntt_q; qa.err = c->err_dev; qa.gc = gc; qa.n_groups = (cnt + gc - 1) / gc; qa.lookahead = c->queue_la;
       const uint32_t items = 2 * qa.n_groups * gc * (c->P.N >> HM_TL_ROW);
-      uint32_t wgs = c->queue_wgs ? c->queue_wgs : (uint32_t)c->n_cu * (geo8 ? 2u : 4u);
+      uint32_t wgs = c->queue_wgs ? c->queue_wgs : (uint32_t)c->n_cu * 2u;
       wgs = std::max(8u, std::min(wgs, items));
       const bool mixPro = fused && f.mix;
-      const dim3 grid(wgs), block((1 << HM_TL_ROW) / (geo8 ? 8 : HM_EPT));
-#define HM_QGO(L1) \
-      do { \
-        if (geo8) { \
-          if (inverse) hipLaunchKernelGGL((k_ntt_queue8<true, 0, 2>), grid, block, 0, c->stream, a, qa); \
-          else if (mixPro) hipLaunchKernelGGL((k_ntt_queue8<false, 4, 3>), grid, block, 0, c->stream, a, qa); \
-          else if (fused) hipLaunchKernelGGL((k_ntt_queue8<false, 0, 3>), grid, block, 0, c->stream, a, qa); \
-          else hipLaunchKernelGGL((k_ntt_queue8<false, 0, 1>), grid, block, 0, c->stream, a, qa); \
-        } else { \
-          if (inverse) hipLaunchKernelGGL((k_ntt_queue<L1, true, 0, 2>), grid, block, 0, c->stream, a, qa); \
-          else if (mixPro) hipLaunchKernelGGL((k_ntt_queue<L1, false, 4, 3>), grid, block, 0, c->stream, a, qa); \
-          else if (fused) hipLaunchKernelGGL((k_ntt_queue<L1, false, 0, 3>), grid, block, 0, c->stream, a, qa); \
-          else hipLaunchKernelGGL((k_ntt_queue<L1, false, 0, 1>), grid, block, 0, c->stream, a, qa); \
-        } \
-      } while (0)
-      switch (c->P.logN - HM_ROW_LOG) {
-      case 5: HM_QGO(5); break;
-      case 6: HM_QGO(6); break;
-      case 7: HM_QGO(7); break;
-      case 8: HM_QGO(8); break;
-      case 9: HM_QGO(9); break;
-      default: return fail(c, HM_ERR_UNSUPPORTED, "%s: logN %u", what, c->P.logN);
-      }
-#undef HM_QGO
+      const dim3 grid(wgs), block((1 << HM_TL_ROW) / 8);
+      HM_HIP(c, hipMemsetAsync(c->ntt_q, 0, sizeof(HmNttQueue), c->stream));   // every word is owned by one XCD's L2 during the launch: only the host resets them
+      if (inverse) hipLaunchKernelGGL((k_ntt_queue8<true, 0, 2>), grid, block, 0, c->stream, a, qa);
+      else if (mixPro) hipLaunchKernelGGL((k_ntt_queue8<false, 4, 3>), grid, block, 0, c->stream, a, qa);
+      else if (fused) hipLaunchKernelGGL((k_ntt_queue8<false, 0, 3>), grid, block, 0, c->stream, a, qa);
+      else hipLaunchKernelGGL((k_ntt_queue8<false, 0, 1>), grid, block, 0, c->stream, a, qa);
       HM_HIP(c, hipGetLastError());
     }
     return HM_OK;
@@ -1741,7 +1477,7 @@ static hm_status ntt_common(hm_ctx *c, const char *what, const uint64_t *in, con
   uint32_t logG = 1;
   // a call that will run as ONE launch (k_ntt_fused8) takes single limb-polys as groups: a kernel then has at most 15 workgroups per XCD
   // waiting for siblings that have no slot yet (launch_ntt), and the 50-limb sweep 56 entries instead of 64
-  if (c->P.logN == 16 && c->fused_small && !c->fused_ntt && !c->dma_ntt && !c->queue_ntt && !f.firstPassOnly && !f.secondPassOnly &&
+  if (c->P.logN == 16 && c->fused_small && !c->queue_ntt && !f.firstPassOnly && !f.secondPassOnly &&
       (n + 7) / 8 * 8 <= c->fused_small) logG = 0;
 #ifndef HM_NTT_MAX_LOGG
 #define HM_NTT_MAX_LOGG 3
@@ -1793,15 +1529,15 @@ static hm_status ntt_common(hm_ctx *c, const char *what, const uint64_t *in, con
         if (inverse) {
           uint64_t v = c->P.modc[m].ninv;
           if (k) v = hm::mulmod(v, k[g], q);
-          t.sc = HmTw{hm_to_mont(v, q), 0};
+          t.sc = hm_kconst(v, q);
         } else if (fused) {
-          t.sc = HmTw{hm_to_mont(k[g], q), 0};
+          t.sc = hm_kconst(k[g], q);
           a.limb[e].aux = (uint16_t)limb_at(f.minuend_limbs, g);
           t.alimb = f.addend_limbs && f.addend_limbs[g] == HM_NO_LIMB ? (uint16_t)HM_NTT_NONE : (uint16_t)limb_at(f.addend_limbs, g);
-          if (f.addend_k) t.ak = HmTw{hm_to_mont(f.addend_k[g], q), 0};
+          if (f.addend_k) t.ak = hm_kconst(f.addend_k[g], q);
           if (f.mix) {
             t.mixlimb = (uint16_t)limb_at(f.mix_limbs, g);
-            t.mixk = HmTw{hm_to_mont(f.mix_k[g], q), 0};
+            t.mixk = hm_kconst(f.mix_k[g], q);
           }
         }
       }
@@ -2390,7 +2126,7 @@ static hm_status bconv_col_launch(hm_ctx *c, const hm_bconv_desc *descs, uint32_
         const uint64_t q = c->P.mod[d.out_ids[t]], k = mix->mix_k[pi][t];
         if (k >= q) return fail(c, HM_ERR_ARG, "fused conversion: mix constant [%u][%u] is not reduced", pi, t);
         if (mix->mix_limbs[pi][t] > 0xFFFFu) return fail(c, HM_ERR_ARG, "fused conversion: limb index exceeds 65535");
-        mk[t] = HmTw{hm_to_mont(k, q), 0};
+        mk[t] = hm_kconst(k, q);
         p.mix_limb[t] = mix->mix_limbs[pi][t];
       }
       const void *dk = nullptr;
@@ -2402,7 +2138,6 @@ static hm_status bconv_col_launch(hm_ctx *c, const hm_bconv_desc *descs, uint32_
   }
   struct Lnch { uint32_t n_in; dim3 grid; HmBcolArgs a; };
   std::vector<Lnch> ls;
-  size_t totalWgs = 0;
   for (auto &kv : byIn) {
     auto &grp = kv.second;
     uint32_t max_out = 0;
@@ -2417,37 +2152,15 @@ static hm_status bconv_col_launch(hm_ctx *c, const hm_bconv_desc *descs, uint32_
     HmBcolArgs a = {static_cast<const HmBcolProb *>(dtab), out, c->d_tw_fwd, c->P.logN, (uint32_t)grp.size(), groups, mix ? mix->mix : nullptr, tile0, logTiles};
     const uint32_t pairs = ((uint32_t)grp.size() * n_tiles + 7) / 8 * 8;
     ls.push_back(Lnch{kv.first, dim3(pairs * groups), a});
-    totalWgs += (size_t)pairs * groups;
   }
-  // Digits of different size are launches of different kernels (N_IN is a template parameter) that depend on nothing of each other.
-  // When both are small — one op at a time: 1 120 + 720 workgroups on the chip's 1 024 slots — they run side by side: the later ones go to
-  // a side stream between a fork and a join event (inside a captured plan these become graph edges), so the partly filled last round of
-  // one kernel is filled by the other.  Opt-in: measured on MI355X the two cross-stream dependencies cost more than the overlap gains
-  // (ModUp of one hmult: 147 -> 168 us, 3 050 -> 2 890 hmult/s one at a time).
-  bool fork = c->side_launches && ls.size() > 1 && totalWgs <= (size_t)c->side_max_wgs;
-  if (fork && !c->sstream) {
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(c->stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) fork = false;   // created on an earlier, eager run
-    else {
-      HM_HIP(c, hipStreamCreateWithFlags(&c->sstream, hipStreamNonBlocking));
-      HM_HIP(c, hipEventCreateWithFlags(&c->sfork, hipEventDisableTiming));
-      HM_HIP(c, hipEventCreateWithFlags(&c->sjoin, hipEventDisableTiming));
-    }
-  }
+  // Digits of different size are launches of different kernels (N_IN is a template parameter).  (Running them side by side on a second
+  // stream between a fork and a join event was measured slower: +21 us per op, profiles/README.md "side launches"; removed in round 5.)
   const dim3 block((1 << HM_TL_COL) / HM_EPT);
-  if (fork) {
-    HM_HIP(c, hipEventRecord(c->sfork, c->stream));
-    HM_HIP(c, hipStreamWaitEvent(c->sstream, c->sfork, 0));
-  }
   for (size_t i = 0; i < ls.size(); ++i) {
     const hm_bcol_kernel kern = hm_bcol_kernel_for(ls[i].n_in, c->P.logN, NOUT, mix != nullptr);
     if (!kern) return fail(c, HM_ERR_UNSUPPORTED, "fused conversion: no kernel for n_in %u at N = 2^%u", ls[i].n_in, c->P.logN);
-    hipLaunchKernelGGL(kern, ls[i].grid, block, 0, fork && i > 0 ? c->sstream : c->stream, ls[i].a);
+    hipLaunchKernelGGL(kern, ls[i].grid, block, 0, c->stream, ls[i].a);
     HM_HIP(c, hipGetLastError());
-  }
-  if (fork) {
-    HM_HIP(c, hipEventRecord(c->sjoin, c->sstream));
-    HM_HIP(c, hipStreamWaitEvent(c->stream, c->sjoin, 0));
   }
   return HM_OK;
 }

@@ -57,15 +57,15 @@ __device__ __forceinline__ void hm_bcol_convert(const uint32_t (&yl)[2][N_IN], c
 #endif
     uint64_t b0, b1;
     hm_gld2<G0>(mixp, tile, tid, u, b0, b1);
-    r0v = hm_addmod(r0v, hm_mont_const_mul(b0, mk.w, m.q), m.q);
-    r1v = hm_addmod(r1v, hm_mont_const_mul(b1, mk.w, m.q), m.q);
+    r0v = hm_addmod(r0v, hm_kmul(b0, mk, m.q), m.q);
+    r1v = hm_addmod(r1v, hm_kmul(b1, mk, m.q), m.q);
   }
 }
 template <int TL, int LOG1>
 __device__ __forceinline__ void hm_bcol_rounds(HmNttState &st, int tid, uint64_t *lds, uint64_t q, const HmW *twl, uint64_t *dst, uint32_t tile) {
   using PS = HmPass<LOG1, true, false>;
   constexpr int n = PS::n, r0 = PS::exec(0);
-  const HmW *ltw = lds + (1 << TL);
+  const HmW *ltw = reinterpret_cast<const HmW *>(lds + (1 << TL));
   const HmTw sc = {0, 0};
   const HmEpi ep = hm_epi_none();
   hm_ph_load_tw<TL, LOG1, true, r0, true>(st, tid, ltw, 0, 0);

@@ -76,12 +76,18 @@ struct HmTensorArgs {
 // products of 11 instructions + four subtractions where three Barrett reductions of full 128-bit products took about twice as many.
 // A product with an operand below q and a constant below 1.5q + 2^28 comes out below 1.1q + 1.
 HM_HD void hm_tensor_one(uint64_t a, uint64_t b, uint64_t c, uint64_t d, const HmMod &m, uint64_t &d0, uint64_t &d1, uint64_t &d2) {
+#if HM_GENERIC
+  d0 = hm_mulmod(a, b, m);   // generic: three Barrett reductions of full 128-bit products
+  d1 = hm_barrett((hm_u128)a * d + (hm_u128)c * b, m);
+  d2 = hm_mulmod(c, d, m);
+#else
   const HmBflyMod bm = hm_bfly_mod(m.q);
   const uint64_t bt = hm_mont_acc(0, b, m.r128, bm), dt = hm_mont_acc(0, d, m.r128, bm);
   d0 = hm_csub_neg(hm_mont_acc(0, a, bt, bm), bm.nq);
   d2 = hm_csub_neg(hm_mont_acc(0, c, dt, bm), bm.nq);
   d1 = hm_mont_acc(hm_mont_acc(0, a, dt, bm), c, bt, bm);   // below 2.2q + 2
   d1 = hm_csub_neg(hm_csub_neg(d1, bm.nq2), bm.nq);
+#endif
 }
 
 // ---- K5 inner product with the evaluation key (the reference's HPIP unit: InsGen::GenHPIP src/InsGen.cpp:356-406,

@@ -1,11 +1,11 @@
 // hm_ntt_passes.inl — the per-thread phases of a transform pass for ONE geometry (HM_EPT coefficients per thread); included by
 // hm_ntt_core.h once per geometry, inside that geometry's namespace.  No include guard on purpose.
-// LDS words of a pass: the tile, then the staged shared twiddles (one word each: Montgomery form)
+// LDS words of a pass: the tile, then the staged shared twiddles (HM_TW_WORDS words each: one in Montgomery form, two with a Shoup companion)
 template <int TL, int LOGR, bool STRIDED>
 struct HmLds {
   static constexpr int TILE = 1 << TL, THREADS = TILE / HM_EPT;
   static constexpr int NTW = STRIDED ? (1 << LOGR) : 128;  // staged entries: w[0 .. NTW) of the modulus
-  static constexpr int WORDS = TILE + (HM_TW_IN_LDS(STRIDED) ? NTW : 0);
+  static constexpr int WORDS = TILE + (HM_TW_IN_LDS(STRIDED) ? HM_TW_WORDS * NTW : 0);
   static_assert(NTW % 2 == 0, "staged in 16-byte units");
 };
 
@@ -114,8 +114,9 @@ struct HmRound {
   }
 };
 
-// Forward transform: which kind of butterfly (hm_bfly_fwd_k) local stage sigma of a pass runs.  Bounds in units of q (every value
-// stays below 8q <= 2^63: the Montgomery product's operand range): the COL pass starts from reduced data (1), its first two stages need
+// Forward transform: which kind of butterfly (hm_bfly_fwd_k) local stage sigma of a pass runs.  Bounds in units of q, written for
+// mont32 (U = HM_LAZY_Q / 2 = 1; the generic back-end's lazy product is twice as wide and every figure doubles): every value
+// stays below 8q <= 2^63, the Montgomery product's operand range; the COL pass starts from reduced data (1), its first two stages need
 // no subtraction (3, 5); from there on the stages alternate so that the pass ENDS on a subtracting stage (6 out); the ROW pass
 // (8 stages, 6 in) alternates 0 / 1 and ends with kind 2 (4 out).  hm_fwd_bound replays the bounds at compile time: every stage is
 // checked below.
@@ -124,17 +125,18 @@ constexpr int hm_fwd_kind(bool strided, int logr, int sigma) {
   return sigma == logr - 1 ? 2 : (sigma & 1);
 }
 constexpr int hm_fwd_bound(bool strided, int logr, int upto) {  // bound (in q) of the values entering local stage `upto`
-  int b = strided ? 1 : 6;
+  constexpr int U = HM_LAZY_Q / 2;
+  int b = strided ? 1 : 6 * U;
   for (int s = 0; s < upto; ++s) {
     const int k = hm_fwd_kind(strided, logr, s);
-    if (k == 0 ? b > 6 : b > 8) return 1000;                    // the stage's input condition
-    b = (k == 0 ? b : k == 1 ? 4 : 2) + 2;
+    if (k == 0 ? b > 6 * U : b > 8 * U) return 1000;            // the stage's input condition
+    b = (k == 0 ? b : k == 1 ? 4 * U : 2 * U) + 2 * U;
   }
   return b;
 }
-static_assert(hm_fwd_bound(true, 5, 5) == 6 && hm_fwd_bound(true, 6, 6) == 6 && hm_fwd_bound(true, 7, 7) == 6 &&
-              hm_fwd_bound(true, 8, 8) == 6 && hm_fwd_bound(true, 9, 9) == 6, "COL pass hands over values below 6q");
-static_assert(hm_fwd_bound(false, 8, 8) == 4, "ROW pass ends below 4q");
+static_assert(hm_fwd_bound(true, 5, 5) == 3 * HM_LAZY_Q && hm_fwd_bound(true, 6, 6) == 3 * HM_LAZY_Q && hm_fwd_bound(true, 7, 7) == 3 * HM_LAZY_Q &&
+              hm_fwd_bound(true, 8, 8) == 3 * HM_LAZY_Q && hm_fwd_bound(true, 9, 9) == 3 * HM_LAZY_Q, "COL pass hands over values below 6q (generic: 12q)");
+static_assert(hm_fwd_bound(false, 8, 8) == 2 * HM_LAZY_Q, "ROW pass ends below 4q (generic: 8q)");
 
 // Where the twiddles of a pass come from.  exec(i) = the i-th round executed.
 template <int LOGR, bool STRIDED, bool INV>
@@ -169,7 +171,11 @@ HM_HD void hm_ph_load_tw(HmNttState &st, int tid, const HmW *twl, uint32_t s0, u
 #pragma unroll
       for (int t = 0; t < (1 << j); ++t) {
 #if defined(HM_ABL_NOTW)
+#if HM_GENERIC
+        st.tw[R][v * (G::E - 1) + (1 << j) - 1 + t] = HmTw{(uint64_t)(twbase + t) * 0x9E3779B97F4A7C15ull >> 5, (uint64_t)(twbase + t) * 0xD1342543DE82EF95ull};
+#else
         st.tw[R][v * (G::E - 1) + (1 << j) - 1 + t] = (uint64_t)(twbase + t) * 0x9E3779B97F4A7C15ull >> 5;
+#endif
 #else
         st.tw[R][v * (G::E - 1) + (1 << j) - 1 + t] = twl[twbase + (uint32_t)t];
 #endif
@@ -190,10 +196,12 @@ HM_HD void hm_ph_load_twist(HmNttState &st, int tid, const HmW *twist_tile) {
 template <int TL, int LOGR, bool STRIDED>
 HM_HD void hm_ph_stage_tw(int tid, uint64_t *lds, const HmW *twl) {
   using LD = HmLds<TL, LOGR, STRIDED>;
+  const uint64_t *tww = reinterpret_cast<const uint64_t *>(twl);   // the table as words: 16 bytes = two Montgomery entries or one Shoup pair
+  constexpr int UNITS = LD::NTW * HM_TW_WORDS / 2;
 #pragma unroll
-  for (int i = 0; i < (LD::NTW / 2 + LD::THREADS - 1) / LD::THREADS; ++i) {   // two entries (16 bytes) per thread and step
+  for (int i = 0; i < (UNITS + LD::THREADS - 1) / LD::THREADS; ++i) {   // 16 bytes per thread and step
     const int k = tid + LD::THREADS * i;
-    if (k < LD::NTW / 2) hm_st2(lds + LD::TILE + 2 * k, twl[2 * k], twl[2 * k + 1]);
+    if (k < UNITS) hm_st2(lds + LD::TILE + 2 * k, tww[2 * k], tww[2 * k + 1]);
   }
 }
 
@@ -222,24 +230,24 @@ HM_HD void hm_ph_load_global_mix(HmNttState &st, int tid, const uint64_t *g, uin
     uint64_t p0, p1, b0, b1;
     hm_gld2<G, AUX>(g, tile, tid, a, p0, p1);
     hm_gld2<G, AUX>(ep.b, tile, tid, a, b0, b1);
-    st.v[i0] = hm_addmod(p0, hm_mont_const_mul(b0, ep.bk.w, q), q);
-    st.v[i1] = hm_addmod(p1, hm_mont_const_mul(b1, ep.bk.w, q), q);
+    st.v[i0] = hm_addmod(p0, hm_kmul(b0, ep.bk, q), q);
+    st.v[i1] = hm_addmod(p1, hm_kmul(b1, ep.bk, q), q);
   }
 }
 
-// MODE 5 (ROW pass of the fused transform x key inner product): the last pass keeps its results in registers (lazy, below 4q)
-// and stores nothing; hm_ph_mac consumes them.
+// MODE 5 (ROW pass of the fused transform x key inner product): the last pass keeps its results in registers (lazy, below
+// 2 HM_LAZY_Q q) and stores nothing; hm_ph_mac consumes them.
 // the epilogue of one coefficient.  MODE 0 / 4: store as is (lazy values, hand-off between the two passes; 4 = first
-// pass with the mix prologue); 1: forward final, reduce [0,4q) -> [0,q); 2: inverse final, multiply by the per-limb
+// pass with the mix prologue); 1: forward final, reduce [0, 2 HM_LAZY_Q q) -> [0,q); 2: inverse final, multiply by the per-limb
 // constant and reduce to [0,q); 3: forward final fused with out = (minuend - x) * k [+ addend [* ak]]
-// (sc, ep.dk, ep.bk: HmTw records whose .w holds the constant in MONTGOMERY form, k 2^64 mod q: hm_mont_const_mul; .ws is unused)
+// (sc, ep.dk, ep.bk: constant records made by hm_kconst on the host; hm_kmul multiplies by them)
 template <int MODE>
 HM_HD uint64_t hm_epilogue(uint64_t a, uint64_t va, uint64_t vd, uint64_t q, HmTw sc, const HmEpi &ep) {
-  if (MODE == 1) return hm_reduce4(a, q);
-  if (MODE == 2) return hm_mont_const_mul(a, sc.w, q);
-  if (MODE == 3) {  // a in [0, 4q): minuend - a + 4q stays positive and below 5q < 2^63; the product reduces it
-    a = hm_mont_const_mul(va + 4 * q - a, sc.w, q);
-    if (ep.d) a = hm_addmod(a, ep.dk.w ? hm_mont_const_mul(vd, ep.dk.w, q) : vd, q);
+  if (MODE == 1) return hm_reduce_fwd(a, q);
+  if (MODE == 2) return hm_kmul(a, sc, q);
+  if (MODE == 3) {  // a in [0, 2 HM_LAZY_Q q): minuend - a + 2 HM_LAZY_Q q stays positive and below 9q < 2^64 (mont32: 5q < 2^63); the product reduces it
+    a = hm_kmul(va + 2 * HM_LAZY_Q * q - a, sc, q);
+    if (ep.d) a = hm_addmod(a, ep.dk.w ? hm_kmul(vd, ep.dk, q) : vd, q);
   }
   return a;
 }
@@ -304,8 +312,8 @@ HM_HD void hm_ph_load_lds_mix(HmNttState &st, int tid, const uint64_t *lds, uint
     uint64_t p0, p1, b0, b1;
     hm_gld2<G, AUX>(ep.b, tile, tid, a, b0, b1);
     hm_ld2(lds + hm_lds_idx<TL, LOGR, STRIDED>(x, c), p0, p1);
-    st.v[i0] = hm_addmod(p0, hm_mont_const_mul(b0, ep.bk.w, q), q);
-    st.v[i1] = hm_addmod(p1, hm_mont_const_mul(b1, ep.bk.w, q), q);
+    st.v[i0] = hm_addmod(p0, hm_kmul(b0, ep.bk, q), q);
+    st.v[i1] = hm_addmod(p1, hm_kmul(b1, ep.bk, q), q);
   }
 }
 template <int TL, int LOGR, bool STRIDED, int R>
@@ -323,7 +331,7 @@ template <int TL, int LOGR, bool STRIDED, int R, bool INV>
 HM_HD void hm_ph_compute(HmNttState &st, uint64_t q) {
   using G = HmRound<TL, LOGR, STRIDED, R>;
 #if defined(HM_ABL_NOCOMPUTE)
-  st.v[0] ^= st.tw[R][0];  // keeps the twiddle loads alive
+  st.v[0] ^= hm_tw_bits(st.tw[R][0]);  // keeps the twiddle loads alive
   return;
 #endif
   const HmBflyMod m = hm_bfly_mod(q);  // lazy ranges: forward [0, 8q) inside a pass, inverse [0, 4q)
@@ -351,14 +359,14 @@ HM_HD void hm_ph_compute(HmNttState &st, uint64_t q) {
 // [0, 1.5q + 2^28) — inside the input range of both butterfly forms.
 HM_HD void hm_ph_twist(HmNttState &st, uint64_t q) {
 #if defined(HM_ABL_NOCOMPUTE)
-  st.v[1] ^= st.tws[0] ^ st.tws[1] ^ st.tws[2];
+  st.v[1] ^= hm_tw_bits(st.tws[0]) ^ hm_tw_bits(st.tws[1]) ^ hm_tw_bits(st.tws[2]);
   return;
 #endif
   const HmBflyMod m = hm_bfly_mod(q);
 #pragma unroll
   for (int u = 0; u < HM_EPT / 4; ++u)
 #pragma unroll
-    for (int k = 1; k < 4; ++k) st.v[4 * u + k] = hm_mont_acc(0, st.v[4 * u + k], st.tws[k - 1], m);
+    for (int k = 1; k < 4; ++k) st.v[4 * u + k] = hm_tw_acc(0, st.v[4 * u + k], st.tws[k - 1], m);
 }
 
 // The whole pass of one thread, phase by phase.  `sync` is __syncthreads() on the GPU; the emulator calls the
@@ -372,21 +380,17 @@ HM_HD void hm_ph_twist(HmNttState &st, uint64_t q) {
 //   Pn:      tw[exec n-1] (if LDS), LDS -> v, [forward twist], compute exec n-1, v -> global (MODE 5: stays in registers)
 // twl = table of the modulus; twist_tile = twist constants of the tile's first row (ROW pass)
 // LDAUX / STAUX: cache-policy bits of the pass's data loads / stores (hm_gld2)
-// SRC = 1 (the persistent double-buffered passes, hm_ntt_dma.inl / k_ntt_*_dma): the tile already sits in `lds` in the image of
-// hm_lds_idx (an LDS-DMA put it there while the previous tile was being transformed), the first round reads it from there; the shared
-// twiddles were staged by the caller at `lds_tw` (a pass over several tiles stages them once per modulus).
 // pre() (phase 0 only): called between the first round's twiddle requests and everything that touches LDS or the pass's input — the
 // one-launch transform waits there for the other workgroups' hand-off, with the second pass's first twiddles already on their way
-template <int TL, int LOGR, bool STRIDED, bool INV, int MODE, int PHASE, int LDAUX = 0, int STAUX = 0, int EPICH = HM_EPI_CHUNK, int SRC = 0, class PRE = HmNoPre>
+template <int TL, int LOGR, bool STRIDED, bool INV, int MODE, int PHASE, int LDAUX = 0, int STAUX = 0, int EPICH = HM_EPI_CHUNK, class PRE = HmNoPre>
 HM_HD void hm_ntt_phase(HmNttState &st, int tid, uint64_t *lds, const uint64_t *src, uint64_t *dst, uint32_t tile,
-                        const HmW *twl, const HmW *twist_tile, uint32_t s0, uint32_t prefix0, uint64_t q, HmTw sc, HmEpi ep,
-                        const uint64_t *lds_tw = nullptr, PRE pre = PRE()) {
+                        const HmW *twl, const HmW *twist_tile, uint32_t s0, uint32_t prefix0, uint64_t q, HmTw sc, HmEpi ep, PRE pre = PRE()) {
   using PS = HmPass<LOGR, STRIDED, INV>;
   constexpr int n = PS::n;
   static_assert(PHASE >= 0 && PHASE <= n, "a pass of n rounds has phases 0 .. n");
   constexpr int TWR = PS::twistRound;
   constexpr int iTW = TWR < 0 ? -1 : (INV ? n - 1 - TWR : TWR);   // execution index of the twisted round
-  const HmW *ltw = SRC ? lds_tw : lds + (1 << TL);
+  const HmW *ltw = reinterpret_cast<const HmW *>(lds + (1 << TL));   // the staged shared twiddles
   // register pressure: the inverse ROW pass has 120 registers of loads in flight in its first phase (data, the first
   // round's shared twiddles, the twist constants and the NEXT round's private twiddles); inside the one-launch transform
   // that no longer fits 128.  The next round's twiddles are then requested after the first round's butterflies instead
@@ -394,15 +398,10 @@ HM_HD void hm_ntt_phase(HmNttState &st, int tid, uint64_t *lds, const uint64_t *
   constexpr bool LATE_TW1 = ((INV && HM_LATE_TW1) || MODE == 5) && !STRIDED;   // MODE 5: 64 accumulator registers are live beside the pass
   if constexpr (PHASE == 0) {
     constexpr int r0 = PS::exec(0), r1 = PS::exec(1);
-    // SRC = 1: every shared round reads the staged copy, the first one included (it was staged for an earlier tile)
-    if (SRC && HM_TW_IN_LDS(STRIDED) && PS::shared(r0)) { /* from the staged copy: hm_ntt_phase_lds0 */ }
-    else hm_ph_load_tw<TL, LOGR, STRIDED, r0, PS::shared(r0)>(st, tid, twl, s0, prefix0);
+    hm_ph_load_tw<TL, LOGR, STRIDED, r0, PS::shared(r0)>(st, tid, twl, s0, prefix0);
     pre();
-    if (PS::anyLds() && !SRC) hm_ph_stage_tw<TL, LOGR, STRIDED>(tid, lds, twl);
-    if (SRC) {   // the tile is read from its LDS image by hm_ntt_phase_lds0 (after the caller has issued the next tile's DMA);
-      // here only what comes from global memory is requested: the MODE 4 operand lands in st.v for the time being
-      if (MODE == 4) hm_ph_load_global<TL, LOGR, STRIDED, r0, LDAUX>(st, tid, ep.b, tile);
-    } else if (MODE == 4) hm_ph_load_global_mix<TL, LOGR, STRIDED, r0, LDAUX>(st, tid, src, tile, q, ep);
+    if (PS::anyLds()) hm_ph_stage_tw<TL, LOGR, STRIDED>(tid, lds, twl);
+    if (MODE == 4) hm_ph_load_global_mix<TL, LOGR, STRIDED, r0, LDAUX>(st, tid, src, tile, q, ep);
     else hm_ph_load_global<TL, LOGR, STRIDED, r0, LDAUX>(st, tid, src, tile);
     // the twist constants are requested one phase ahead of the twisted round (phase iTW + 1)
     if (iTW >= 0 && iTW <= 1) hm_ph_load_twist<TL, LOGR, STRIDED, (TWR >= 0 ? TWR : 0)>(st, tid, twist_tile);
@@ -448,67 +447,23 @@ HM_HD void hm_ntt_phase(HmNttState &st, int tid, uint64_t *lds, const uint64_t *
     hm_ph_store_global<TL, LOGR, STRIDED, rl, MODE, STAUX, EPICH>(st, tid, dst, tile, q, sc, ep);
   }
 }
-// SRC = 1: the LDS half of phase 0 — the first round's elements from the tile image (MODE 4: plus k * the operand requested in phase 0),
-// its shared twiddles from the staged copy
-template <int TL, int LOGR, bool STRIDED, bool INV, int MODE>
-HM_HD void hm_ntt_phase_lds0(HmNttState &st, int tid, const uint64_t *lds, const uint64_t *lds_tw, uint32_t s0, uint32_t prefix0, uint64_t q, HmEpi ep) {
-  using PS = HmPass<LOGR, STRIDED, INV>;
-  constexpr int r0 = PS::exec(0);
-  using G = HmRound<TL, LOGR, STRIDED, r0>;
-  if (HM_TW_IN_LDS(STRIDED) && PS::shared(r0)) hm_ph_load_tw<TL, LOGR, STRIDED, r0, true>(st, tid, lds_tw, s0, prefix0);
-#pragma unroll
-  for (int a = 0; a < HM_UNITS; ++a) {
-    int i0, i1, x, c;
-    G::unit(tid, a, i0, i1, x, c);
-    uint64_t p0, p1;
-    hm_ld2(lds + hm_lds_idx<TL, LOGR, STRIDED>(x, c), p0, p1);
-    if (MODE == 4) {
-      st.v[i0] = hm_addmod(p0, hm_mont_const_mul(st.v[i0], ep.bk.w, q), q);
-      st.v[i1] = hm_addmod(p1, hm_mont_const_mul(st.v[i1], ep.bk.w, q), q);
-    } else { st.v[i0] = p0; st.v[i1] = p1; }
-  }
-}
-struct HmNoMid { HM_HD void operator()() const {} };
 // all phases of a pass with `sync()` between them (the GPU passes __syncthreads, the emulator runs the phases itself)
-// SRC = 1: mid() runs between the global requests of phase 0 and the LDS reads of the tile image (the caller issues the next tile's DMA
-// there: requests behind the DMA would wait for it, vmcnt retires in order)
-template <int TL, int LOGR, bool STRIDED, bool INV, int MODE, int LDAUX = 0, int STAUX = 0, int EPICH = HM_EPI_CHUNK, int SRC = 0, class SYNC, class MID = HmNoMid, class PRE = HmNoPre>
+template <int TL, int LOGR, bool STRIDED, bool INV, int MODE, int LDAUX = 0, int STAUX = 0, int EPICH = HM_EPI_CHUNK, class SYNC, class PRE = HmNoPre>
 HM_HD void hm_ntt_pass_phases(HmNttState &st, int tid, uint64_t *lds, const uint64_t *src, uint64_t *dst, uint32_t tile,
-                              const HmW *twl, const HmW *twist_tile, uint32_t s0, uint32_t prefix0, uint64_t q, HmTw sc, HmEpi ep, SYNC sync,
-                              const uint64_t *lds_tw = nullptr, MID mid = MID(), PRE pre = PRE()) {
+                              const HmW *twl, const HmW *twist_tile, uint32_t s0, uint32_t prefix0, uint64_t q, HmTw sc, HmEpi ep, SYNC sync, PRE pre = PRE()) {
   constexpr int n = HmRounds<LOGR>::n;
-  hm_ntt_phase<TL, LOGR, STRIDED, INV, MODE, 0, LDAUX, STAUX, EPICH, SRC>(st, tid, lds, src, dst, tile, twl, twist_tile, s0, prefix0, q, sc, ep, lds_tw, pre);
-  if constexpr (SRC != 0) {
-    mid();
-    hm_ntt_phase_lds0<TL, LOGR, STRIDED, INV, MODE>(st, tid, lds, lds_tw, s0, prefix0, q, ep);
-  }
-  hm_ntt_phase<TL, LOGR, STRIDED, INV, MODE, 1, LDAUX, STAUX, EPICH, SRC>(st, tid, lds, src, dst, tile, twl, twist_tile, s0, prefix0, q, sc, ep, lds_tw);
+  hm_ntt_phase<TL, LOGR, STRIDED, INV, MODE, 0, LDAUX, STAUX, EPICH>(st, tid, lds, src, dst, tile, twl, twist_tile, s0, prefix0, q, sc, ep, pre);
+  hm_ntt_phase<TL, LOGR, STRIDED, INV, MODE, 1, LDAUX, STAUX, EPICH>(st, tid, lds, src, dst, tile, twl, twist_tile, s0, prefix0, q, sc, ep);
   sync();
-  hm_ntt_phase<TL, LOGR, STRIDED, INV, MODE, 2, LDAUX, STAUX, EPICH, SRC>(st, tid, lds, src, dst, tile, twl, twist_tile, s0, prefix0, q, sc, ep, lds_tw);
+  hm_ntt_phase<TL, LOGR, STRIDED, INV, MODE, 2, LDAUX, STAUX, EPICH>(st, tid, lds, src, dst, tile, twl, twist_tile, s0, prefix0, q, sc, ep);
   if constexpr (n >= 3) {
     sync();
-    hm_ntt_phase<TL, LOGR, STRIDED, INV, MODE, 3, LDAUX, STAUX, EPICH, SRC>(st, tid, lds, src, dst, tile, twl, twist_tile, s0, prefix0, q, sc, ep, lds_tw);
+    hm_ntt_phase<TL, LOGR, STRIDED, INV, MODE, 3, LDAUX, STAUX, EPICH>(st, tid, lds, src, dst, tile, twl, twist_tile, s0, prefix0, q, sc, ep);
   }
   if constexpr (n >= 4) {
     sync();
-    hm_ntt_phase<TL, LOGR, STRIDED, INV, MODE, 4, LDAUX, STAUX, EPICH, SRC>(st, tid, lds, src, dst, tile, twl, twist_tile, s0, prefix0, q, sc, ep, lds_tw);
+    hm_ntt_phase<TL, LOGR, STRIDED, INV, MODE, 4, LDAUX, STAUX, EPICH>(st, tid, lds, src, dst, tile, twl, twist_tile, s0, prefix0, q, sc, ep);
   }
-}
-// inverse of hm_lds_idx for the 16-byte unit at even word w of the tile image: coordinates (x, c) of its first word
-template <int TL, int LOGR, bool STRIDED>
-HM_HD void hm_lds_unidx(int w, int &x, int &c) {
-  if (STRIDED) {
-    constexpr int LOGC = TL - LOGR;
-    int xf = w >> LOGC;
-    c = w & ((1 << LOGC) - 1);
-    if (LOGC <= 4) xf ^= (xf >> 2) & ((1 << (LOGC <= 4 ? 5 - LOGC : 0)) - 1);   // the swizzle moves bits [0, 5 - LOGC) of x by bits [2, ..): an involution
-    x = xf;
-    return;
-  }
-  c = w >> LOGR;
-  int xw = w & ((1 << LOGR) - 1);
-  if (LOGR == 8) xw ^= (((xw >> 5) & 7) << 2) ^ (((xw >> 5) & 1) << 1);
-  x = xw;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -528,6 +483,40 @@ HM_HD void hm_lds_unidx(int w, int &x, int &c) {
 // products took twelve and 19.  x < 4q (the transform's lazy output; any x below 2^63 is allowed), y < q: a term adds less than
 // 1.5q + 2^28, so up to five terms stay below 8q <= 2^63 with no folding.  hm_mac_final multiplies the sum by 2^128 mod q the same way
 // (sum 2^-64 2^128 2^-64 = sum) and subtracts q once: 16 instructions per output.
+#if HM_GENERIC
+// generic: Barrett's quotient from two APPROXIMATE high products and no 128-bit shift (round 3).  With X = 2x (x < 8q < 2^63) and
+// Y = y 2^(64-k) (y < q < 2^k) the high word of X Y IS floor(x y / 2^(k-1)); hm_shoup_quot gives it and then floor(zh mu / 2^64) from
+// three v_mad_u64_u32 each, at most 2 below the true value.  The estimate never exceeds floor(x y / q) and is at most
+// 2 (Barrett) + 2 (zh) + 2 (second product) = 6 below it, so x y - qe q lies in [0, 7q): about 19 instructions per product.  Two
+// products fit a word (14q < 16q <= 2^64); from the third term on the accumulator is first brought below 8q (one conditional
+// subtraction per accumulator and digit), so any number of terms stays below 15q; hm_mac_final reduces from below 16q.
+struct HmMacMod {
+  uint64_t mu, nq, nq8, z;
+  uint32_t ysh;
+};
+HM_HD HmMacMod hm_mac_mod(const HmMod &m) {
+  HmMacMod r;
+  r.z = hm_opaque_zero();
+  r.mu = m.mu;
+  r.nq = r.z - m.q;
+  r.nq8 = r.z - 8 * m.q;
+  r.ysh = 63 - m.sh;
+  return r;
+}
+HM_HD void hm_mac_add(uint64_t &acc, uint64_t x, uint64_t y, const HmMod &, const HmMacMod &mm, bool fold) {
+  if (fold) acc = hm_csub_neg(acc, mm.nq8);                        // [0, 15q) -> [0, 8q)
+  const uint64_t zh = hm_shoup_quot(x << 1, y << mm.ysh, mm.z);    // floor(x y / 2^(k-1)) - {0, 1, 2}
+  const uint64_t qe = hm_shoup_quot(zh, mm.mu, mm.z);              // floor(x y / q) - {0 .. 6}
+  acc = acc + x * y + qe * mm.nq;                                  // + (x y mod q) + {0 .. 6} q, exact in the low word
+}
+HM_HD uint64_t hm_mac_final(uint64_t acc, const HmMod &m) { return hm_reduce16(acc, m.q); }
+// [0, 8q) -> [0, 2q): the wide accumulators take transform outputs below 2q, so that the sum stays inside hm_barrett's range
+HM_HD void hm_ph_below_2q(HmNttState &st, uint64_t q) {
+  const HmBflyMod m = hm_bfly_mod(q);
+#pragma unroll
+  for (int i = 0; i < HM_EPT; ++i) st.v[i] = hm_csub_neg(hm_csub_neg(st.v[i], m.nq4), m.nq2);
+}
+#else
 struct HmMacMod {
   HmBflyMod b;
   uint64_t r128;
@@ -539,18 +528,19 @@ HM_HD HmMacMod hm_mac_mod(const HmMod &m) {
   return r;
 }
 HM_HD void hm_mac_add(uint64_t &acc, uint64_t x, uint64_t y, const HmMod &, const HmMacMod &mm, bool) { acc = hm_mont_acc(acc, x, y, mm.b); }
-HM_HD void hm_mac_add(hm_u128 &acc, uint64_t x, uint64_t y, const HmMod &, const HmMacMod &, bool) { acc += (hm_u128)x * y; }
 HM_HD uint64_t hm_mac_final(uint64_t acc, const HmMod &m) {   // acc < 8q
   const HmBflyMod b = hm_bfly_mod(m.q);
   return hm_csub_neg(hm_mont_acc(0, acc, m.r128, b), b.nq);   // [0, 1.5q + 2^28) -> [0, q)
 }
-HM_HD uint64_t hm_mac_final(hm_u128 acc, const HmMod &m) { return hm_barrett(acc, m); }   // 4 terms x (x < 2q) x (y < q) < 2^123
 // [0, 4q) -> [0, 2q): the wide accumulators take transform outputs below 2q, so that the sum stays inside hm_barrett's range
 HM_HD void hm_ph_below_2q(HmNttState &st, uint64_t q) {
   const HmBflyMod m = hm_bfly_mod(q);
 #pragma unroll
   for (int i = 0; i < HM_EPT; ++i) st.v[i] = hm_csub_neg(st.v[i], m.nq2);
 }
+#endif
+HM_HD void hm_mac_add(hm_u128 &acc, uint64_t x, uint64_t y, const HmMod &, const HmMacMod &, bool) { acc += (hm_u128)x * y; }
+HM_HD uint64_t hm_mac_final(hm_u128 acc, const HmMod &m) { return hm_barrett(acc, m); }   // 4 terms x (x < 2q) x (y < q) < 2^123
 template <int TL, int LOGR, int R, int OUTS, int CH = 2, class ACC = uint64_t>
 HM_HD void hm_ph_mac(const HmNttState &st, ACC (&acc)[OUTS][HM_EPT], int tid, const uint64_t *const (&y)[OUTS], uint32_t tile, const HmMod &m, uint32_t term) {
   using G = HmRound<TL, LOGR, false, R>;

@@ -63,7 +63,20 @@ static uint64_t smallest_primitive_root(uint64_t q, uint32_t N) {
   return best;
 }
 
-void Params::init(uint32_t logN_, uint32_t L_, uint32_t K_, const uint64_t *q, const uint64_t *p, const uint64_t *psi_in) {
+std::vector<uint64_t> Params::chain_below(uint32_t logN, uint32_t bits, uint32_t count) {
+  if (bits < 21 || bits > 60 || logN + 1 >= bits) throw std::invalid_argument("chain_below: bits must be in [21, 60] and above log2(2N)");
+  std::vector<uint64_t> out;
+  const uint64_t step = 2ull << logN;
+  uint64_t cand = (1ull << bits) + 1;
+  while (out.size() < count) {
+    if (cand <= step) throw std::invalid_argument("chain_below: not enough primes = 1 mod 2N below 2^" + std::to_string(bits));
+    cand -= step;
+    if (is_prime(cand)) out.push_back(cand);
+  }
+  return out;
+}
+
+void Params::init(uint32_t logN_, uint32_t L_, uint32_t K_, const uint64_t *q, const uint64_t *p, const uint64_t *psi_in, bool forGeneric) {
   if (logN_ < 13 || logN_ > 17) throw std::invalid_argument("logN must be in [13,17] for the HIP backend");
   if (L_ == 0 || L_ + K_ > 4096) throw std::invalid_argument("bad limb counts");
   logN = logN_; N = 1u << logN; L = L_; K = K_;
@@ -79,11 +92,13 @@ void Params::init(uint32_t logN_, uint32_t L_, uint32_t K_, const uint64_t *q, c
       if (is_prime(cand)) mod[m++] = cand;
     }
   }
+  mont32 = true;
+  generic = forGeneric;
   for (uint32_t m = 0; m < M; ++m) {
     const uint64_t qm = mod[m];
-    if (qm >> 60 || (qm & 0xffffffffull) != 1 || (qm >> 32) == 0 || !is_prime(qm))
-      throw std::invalid_argument("modulus " + std::to_string(qm) + " is not a prime = 1 mod 2^32 below 2^60 (the transform's word-wise "
-                                  "Montgomery reduction needs q = h 2^32 + 1)");
+    if (qm >> 60 || qm < (1ull << 20) || (qm - 1) % (2ull * N) != 0 || !is_prime(qm))
+      throw std::invalid_argument("modulus " + std::to_string(qm) + " is not a prime = 1 mod 2N between 2^20 and 2^60");
+    if ((qm & 0xffffffffull) != 1 || (qm >> 32) == 0) mont32 = false;
     for (uint32_t j = 0; j < m; ++j)
       if (mod[j] == qm) throw std::invalid_argument("duplicate modulus");
     psi[m] = psi_in ? psi_in[m] : smallest_primitive_root(qm, N);
@@ -101,33 +116,43 @@ void Params::init(uint32_t logN_, uint32_t L_, uint32_t K_, const uint64_t *q, c
       c.nqinv = 0 - x;
     }
     c.ninv = invmod(N, qm);
-    c.r128 = mulmod(c.r64, c.r64, qm);
+    if (forGeneric) c.ninvs = shoup(c.ninv, qm);
+    else c.r128 = mulmod(c.r64, c.r64, qm);
   }
+  if (!forGeneric && !mont32)
+    throw std::invalid_argument("the chain holds a modulus that is not h 2^32 + 1: it needs the generic arithmetic back-end");
 }
 
-void Params::make_table(uint32_t m, bool inverse, HmW *out) const {
-  const uint64_t q = mod[m];
-  const uint64_t base = inverse ? invmod(psi[m], q) : psi[m];
+template <class ENTRY, class MAKE>
+static void table_of(const Params &P, uint32_t m, bool inverse, ENTRY *out, MAKE make) {
+  const uint64_t q = P.mod[m];
+  const uint64_t base = inverse ? invmod(P.psi[m], q) : P.psi[m];
   uint64_t p = 1;
-  for (uint32_t i = 0; i < N; ++i) {
-    out[bitrev(i, logN)] = hm_to_mont(p, q);   // Montgomery form: the butterflies' product is x wt 2^-64 (hm_mont_acc)
+  for (uint32_t i = 0; i < P.N; ++i) {
+    out[bitrev(i, P.logN)] = make(p, q);
     p = mulmod(p, base, q);
   }
 }
-
-void Params::make_twist(uint32_t m, bool inverse, HmW *out) const {
-  const uint64_t q = mod[m];
-  const uint64_t base = inverse ? invmod(psi[m], q) : psi[m];
-  const uint32_t rows = N >> 8, bits = logN - 8;
+template <class ENTRY, class MAKE>
+static void twist_of(const Params &P, uint32_t m, bool inverse, ENTRY *out, MAKE make) {
+  const uint64_t q = P.mod[m];
+  const uint64_t base = inverse ? invmod(P.psi[m], q) : P.psi[m];
+  const uint32_t rows = P.N >> 8, bits = P.logN - 8;
   for (uint32_t r = 0; r < rows; ++r) {
     const uint64_t a = powmod(base, 1 + 2ull * bitrev(r, bits), q);
     uint64_t p = 1;
     for (uint32_t k = 0; k < 3; ++k) {
       p = mulmod(p, a, q);
-      out[3 * r + k] = hm_to_mont(p, q);
+      out[3 * r + k] = make(p, q);
     }
   }
 }
+static uint64_t mont_entry(uint64_t w, uint64_t q) { return hm_to_mont(w, q); }   // Montgomery form: the butterflies' product is x wt 2^-64 (hm_mont_acc)
+static HmTw shoup_entry(uint64_t w, uint64_t q) { return HmTw{w, shoup(w, q)}; }
+void Params::make_table(uint32_t m, bool inverse, uint64_t *out) const { table_of(*this, m, inverse, out, mont_entry); }
+void Params::make_table(uint32_t m, bool inverse, HmTw *out) const { table_of(*this, m, inverse, out, shoup_entry); }
+void Params::make_twist(uint32_t m, bool inverse, uint64_t *out) const { twist_of(*this, m, inverse, out, mont_entry); }
+void Params::make_twist(uint32_t m, bool inverse, HmTw *out) const { twist_of(*this, m, inverse, out, shoup_entry); }
 
 void Params::bconv_consts(const uint32_t *in_ids, uint32_t n_in, const uint32_t *out_ids, uint32_t n_out,
                           uint64_t *qhat_inv, uint64_t *table) const {

@@ -7,6 +7,9 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HOMULATOR_HIP_LIB") or os.path.join(_HERE, "lib", "libhomulator_hip.so")  # override: A/B builds
+# the two arithmetic back-ends libhomulator_hip.so maps from its own directory (hm_dispatch.cpp): word-wise Montgomery for chains of
+# primes h 2^32 + 1 (the default), Shoup / Barrett for any other NTT-friendly chain below 2^60
+BACKEND_LIBS = ("libhm_m32.so", "libhm_gen.so")
 
 OP_MUL, OP_MAC2, OP_MAC_ADD, OP_ADD, OP_SUB, OP_MUL_CONST, OP_SUB_SCALE, OP_COPY, OP_SUB_SCALE_ADD = range(9)
 
@@ -147,7 +150,8 @@ class Context:
     """One GPU, one parameter set.  Thin, 1:1 with the C ABI."""
 
     def __init__(self, logN, L, K, device=0, q=None, p=None):
-        """q / p: the L chain moduli and the K special moduli (primes = 1 mod 2^32 below 2^60); default: the library's own chain"""
+        """q / p: the L chain moduli and the K special moduli (distinct primes = 1 mod 2N below 2^60; hm_create runs them on the
+        word-wise Montgomery back-end if they all are h 2^32 + 1, on the generic one otherwise); default: the library's own chain"""
         self.L = load()
         self.h = C.c_void_p()
         qa = None if q is None else np.ascontiguousarray(np.asarray(q, dtype=np.uint64))
@@ -159,6 +163,7 @@ class Context:
         if st != 0:
             raise HmError(f"hm_create failed ({st}): {self.L.hm_last_error(None).decode()}")
         self.logN, self.N, self.nQ, self.K = logN, 1 << logN, L, K
+        self.chain = None if qa is None else [int(x) for x in qa] + ([] if pa is None else [int(x) for x in pa])
         q = C.c_uint64()
         self.moduli = []
         for m in range(L + K):

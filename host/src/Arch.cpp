@@ -145,10 +145,18 @@ void Arch::bindParams(uint32_t maxLevel, uint32_t curLevel, uint32_t alpha) {
   curLevel_ = curLevel;
   if (hostParams) return;
   hm::Params *hp = new hm::Params;
-  hp->init(logN, maxLevel, alpha, nullptr, nullptr, nullptr);
+  // config key `chain_bits` (build-specific; the reference pins no modulus): 0 = the default chain (primes h 2^32 + 1 below 2^60: the
+  // word-wise Montgomery back-end); b in [21, 60] = the maxLevel + alpha largest primes = 1 mod 2N below 2^b — 60 is SURVEY.md 8(d)'s
+  // chain as written, 36 a chain of 36-bit words as upstream's `elementBitWidth` models (config/config_4.cfg:9).  hm_create picks the
+  // arithmetic back-end from the chain it is handed.
+  const uint32_t chainBits = config->getValueOr("chain_bits", 0);
+  std::vector<uint64_t> chain;
+  if (chainBits) chain = hm::Params::chain_below(logN, chainBits, maxLevel + alpha);
+  const uint64_t *cq = chainBits ? chain.data() : nullptr, *cp = chainBits ? chain.data() + maxLevel : nullptr;
+  hp->init(logN, maxLevel, alpha, cq, cp, nullptr, /*forGeneric: the host side only needs moduli and conversion constants*/ chainBits != 0);
   hostParams = hp;
   if (backendKind == BACKEND_HIP) {
-    hm_params p = {logN, maxLevel, alpha, (int32_t)config->getValueOr("device", 0), nullptr, nullptr, nullptr};
+    hm_params p = {logN, maxLevel, alpha, (int32_t)config->getValueOr("device", 0), cq, cp, nullptr};
     if (const char *e = getenv("HOMULATOR_DEVICE")) p.device = atoi(e);
     if (hm_create(&ctx, &p) != HM_OK)
       throw std::runtime_error(std::string("HIP backend unavailable: ") + hm_last_error(nullptr));

@@ -112,7 +112,25 @@ static uint64_t min_primitive_root_2n(uint64_t q, uint32_t N) {
   return best;
 }
 
-ho_ctx *ho_create(uint32_t logN, uint32_t L, uint32_t K) {
+void ho_destroy(ho_ctx *c);
+/* the `count` largest primes below 2^bits that are 1 mod 2N, descending: SURVEY.md 8(d)'s chain is bits = 60; bits = 36 gives a chain of
+ * 36-bit words as the reference's configuration models (config/config_4.cfg:9 elementBitWidth, script/README.md:17-22).  Returns 0 when
+ * the range does not hold that many. */
+int ho_chain_below(uint32_t logN, uint32_t bits, uint32_t count, uint64_t *out) {
+  if (bits < 21 || bits > 60 || logN + 1 >= bits) return 0;
+  const uint64_t step = 2ull << logN;
+  uint64_t cand = (1ull << bits) + 1;
+  for (uint32_t m = 0; m < count;) {
+    if (cand <= step) return 0;
+    cand -= step;
+    if (is_prime_u64(cand)) out[m++] = cand;
+  }
+  return 1;
+}
+
+/* moduli == NULL: the default chain, the L+K largest primes below 2^60 that are 1 mod 2^32 (hence 1 mod 2N): DESIGN.md section 2.
+ * Otherwise L+K distinct primes = 1 mod 2N below 2^60, first L = Q, next K = P (checked). */
+ho_ctx *ho_create_chain(uint32_t logN, uint32_t L, uint32_t K, const uint64_t *moduli) {
   if (logN < 2 || logN > 17 || L == 0) return NULL;
   ho_ctx *c = (ho_ctx *)calloc(1, sizeof(*c));
   c->logN = logN; c->N = 1u << logN; c->L = L; c->K = K;
@@ -120,10 +138,20 @@ ho_ctx *ho_create(uint32_t logN, uint32_t L, uint32_t K) {
   c->mod = calloc(M, 8); c->psi = calloc(M, 8); c->ninv = calloc(M, 8);
   c->w = calloc(M, sizeof(void *)); c->ws = calloc(M, sizeof(void *));
   c->wi = calloc(M, sizeof(void *)); c->wis = calloc(M, sizeof(void *));
-  uint64_t step = 1ull << 32, cand = (1ull << 60) + 1;   /* q = 1 mod 2^32 (hence 1 mod 2N): DESIGN.md section 2 */
-  for (uint32_t m = 0; m < M;) {
-    cand -= step;
-    if (is_prime_u64(cand)) c->mod[m++] = cand;
+  if (moduli) {
+    for (uint32_t m = 0; m < M; ++m) {
+      const uint64_t q = moduli[m];
+      int ok = !(q >> 60) && q > 2ull * N && (q - 1) % (2ull * N) == 0 && is_prime_u64(q);
+      for (uint32_t j = 0; ok && j < m; ++j) ok = moduli[j] != q;
+      if (!ok) { ho_destroy(c); return NULL; }
+      c->mod[m] = q;
+    }
+  } else {
+    uint64_t step = 1ull << 32, cand = (1ull << 60) + 1;
+    for (uint32_t m = 0; m < M;) {
+      cand -= step;
+      if (is_prime_u64(cand)) c->mod[m++] = cand;
+    }
   }
   for (uint32_t m = 0; m < M; ++m) {
     uint64_t q = c->mod[m];
@@ -141,6 +169,8 @@ ho_ctx *ho_create(uint32_t logN, uint32_t L, uint32_t K) {
   }
   return c;
 }
+
+ho_ctx *ho_create(uint32_t logN, uint32_t L, uint32_t K) { return ho_create_chain(logN, L, K, NULL); }
 
 void ho_destroy(ho_ctx *c) {
   if (!c) return;

@@ -31,6 +31,12 @@ typedef struct ho_ctx ho_ctx;
  * are Q, the next K are P.  psi = smallest primitive 2N-th root of unity of each prime.
  * "mod id" m: m < L -> q_m ; m >= L -> p_{m-L}. */
 ho_ctx *ho_create(uint32_t logN, uint32_t L, uint32_t K);
+/* the same over a caller-given chain: L+K distinct primes = 1 mod 2N below 2^60 (first L = Q, next K = P); NULL = the default chain.
+ * Returns NULL if a modulus does not qualify. */
+ho_ctx *ho_create_chain(uint32_t logN, uint32_t L, uint32_t K, const uint64_t *moduli);
+/* the `count` largest primes below 2^bits that are 1 mod 2N, descending (bits = 60: the chain of SURVEY.md 8(d) as written; bits = 36:
+ * 36-bit words as the reference's configuration models).  Returns 0 if the range does not hold that many. */
+int ho_chain_below(uint32_t logN, uint32_t bits, uint32_t count, uint64_t *out);
 void ho_destroy(ho_ctx *);
 uint32_t ho_N(const ho_ctx *);
 uint32_t ho_L(const ho_ctx *);

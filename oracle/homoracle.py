@@ -32,6 +32,10 @@ def lib():
         u32, u64, p = C.c_uint32, C.c_uint64, C.c_void_p
         L.ho_create.restype = p
         L.ho_create.argtypes = [u32, u32, u32]
+        L.ho_create_chain.restype = p
+        L.ho_create_chain.argtypes = [u32, u32, u32, p]
+        L.ho_chain_below.restype = C.c_int
+        L.ho_chain_below.argtypes = [u32, u32, u32, p]
         L.ho_destroy.argtypes = [p]
         for f in ("ho_N", "ho_L", "ho_K"):
             getattr(L, f).restype = u32
@@ -83,14 +87,32 @@ class KsDump(C.Structure):
                 ("modup_intt", "modup_decomp", "ext", "ip", "moddown_intt", "moddown_bconv", "moddown_ntt")]
 
 
-class Oracle:
-    """One parameter set (N = 2^logN, L Q-primes, K = alpha special primes)."""
+def chain_below(logN, bits, count):
+    """the `count` largest primes below 2^bits that are 1 mod 2N, descending (bits = 60: SURVEY.md 8(d)'s chain as written)"""
+    out = np.zeros(count, dtype=np.uint64)
+    if not lib().ho_chain_below(logN, bits, count, _ptr(out)):
+        raise ValueError(f"no {count} primes = 1 mod 2^{logN + 1} below 2^{bits}")
+    return [int(x) for x in out]
 
-    def __init__(self, logN, L, K):
+
+class Oracle:
+    """One parameter set (N = 2^logN, L Q-primes, K = alpha special primes).
+    chain: "mont32" (default: the L+K largest primes h 2^32 + 1 below 2^60), "survey" (SURVEY.md 8(d) as written: the
+    largest primes = 1 mod 2N below 2^60), an int b (the largest such primes below 2^b, e.g. 36 for the reference's 36-bit words), or an
+    explicit list of L + K moduli (first L = Q, next K = P)."""
+
+    def __init__(self, logN, L, K, chain="mont32"):
         self.l = lib()
-        self.h = self.l.ho_create(logN, L, K)
+        if chain == "mont32" or chain is None:
+            self.h = self.l.ho_create(logN, L, K)
+        else:
+            mods = chain_below(logN, 60, L + K) if chain == "survey" else chain_below(logN, int(chain), L + K) if isinstance(chain, int) else [int(x) for x in chain]
+            if len(mods) != L + K:
+                raise ValueError("the chain needs L + K moduli")
+            arr = np.ascontiguousarray(np.asarray(mods, dtype=np.uint64))
+            self.h = self.l.ho_create_chain(logN, L, K, _ptr(arr))
         if not self.h:
-            raise ValueError("ho_create failed")
+            raise ValueError("ho_create failed (moduli must be distinct primes = 1 mod 2N below 2^60)")
         self.logN, self.N, self.L, self.K = logN, 1 << logN, L, K
         self.moduli = [int(self.l.ho_modulus(self.h, i)) for i in range(L + K)]
         self.psis = [int(self.l.ho_psi(self.h, i)) for i in range(L + K)]

@@ -3,8 +3,11 @@
 // thread, so that index maths, twiddle indexing, lazy-reduction ranges and the host-side parameter
 // tables (hm_params.cpp) are checked against the oracle on the CPU before a GPU is involved.
 // It is not a CPU backend: the product library never links or calls this.
+// Built twice, like the kernels: libhm_emu.so (HM_GENERIC = 0: word-wise Montgomery on primes h 2^32 + 1) and libhm_emu_gen.so
+// (-DHM_GENERIC=1: Shoup / Barrett arithmetic on any NTT-friendly chain).
 #include <cstdint>
 #include <cstring>
+#include <stdexcept>
 #include <vector>
 #include "../../homulator_amd/csrc/hm_elem_core.h"
 #include "../../homulator_amd/csrc/hm_modarith.h"
@@ -23,8 +26,6 @@ struct G16 {
   template <int LOGR> static constexpr int rounds() { return hm16::HmRounds<LOGR>::n; }
   template <int TL, int LOGR, bool STRIDED> static constexpr int ldsWords() { return hm16::HmLds<TL, LOGR, STRIDED>::WORDS; }
   template <int TL, int LOGR, bool STRIDED, bool INV, int MODE, int P, class... A> static void phase(A &&...a) { hm16::hm_ntt_phase<TL, LOGR, STRIDED, INV, MODE, P>(a...); }
-  template <int TL, int LOGR, bool STRIDED, bool INV, int MODE, int P, class... A> static void phase_src1(A &&...a) { hm16::hm_ntt_phase<TL, LOGR, STRIDED, INV, MODE, P, 0, 0, HM_EPI_CHUNK, 1>(a...); }
-  template <int TL, int LOGR, bool STRIDED, bool INV, int MODE, class... A> static void lds0(A &&...a) { hm16::hm_ntt_phase_lds0<TL, LOGR, STRIDED, INV, MODE>(a...); }
 };
 struct G8 {
   typedef hm8::HmNttState State;
@@ -32,8 +33,6 @@ struct G8 {
   template <int LOGR> static constexpr int rounds() { return hm8::HmRounds<LOGR>::n; }
   template <int TL, int LOGR, bool STRIDED> static constexpr int ldsWords() { return hm8::HmLds<TL, LOGR, STRIDED>::WORDS; }
   template <int TL, int LOGR, bool STRIDED, bool INV, int MODE, int P, class... A> static void phase(A &&...a) { hm8::hm_ntt_phase<TL, LOGR, STRIDED, INV, MODE, P>(a...); }
-  template <int TL, int LOGR, bool STRIDED, bool INV, int MODE, int P, class... A> static void phase_src1(A &&...a) { hm8::hm_ntt_phase<TL, LOGR, STRIDED, INV, MODE, P, 0, 0, HM_EPI_CHUNK, 1>(a...); }
-  template <int TL, int LOGR, bool STRIDED, bool INV, int MODE, class... A> static void lds0(A &&...a) { hm8::hm_ntt_phase_lds0<TL, LOGR, STRIDED, INV, MODE>(a...); }
 };
 
 // phase P of every thread of the workgroup, then phase P + 1, ... (a barrier on the GPU = the end of a phase loop here)
@@ -73,52 +72,6 @@ static void run_ntt(const Emu &e, uint32_t mod, const uint64_t *in, uint64_t *ou
   }
 }
 
-// ---- the persistent double-buffered passes (k_ntt_*_dma): the tile is put into its LDS image the way the LDS-DMA does it — 16-byte unit
-// at (even) word w of the image <- the coefficients hm_lds_unidx names, the staged twiddles linearly behind it — and the pass runs its
-// first round from the image (phase SRC = 1: global requests, [the kernel issues the next tile's DMA here], LDS reads, rounds)
-template <class G, int TL, int LOGR, bool STRIDED, bool INV, int MODE, int P>
-static void run_phases_src1(std::vector<typename G::State> &st, uint64_t *lds, uint64_t *dst, uint32_t tile, const HmW *twl, const HmW *twt, uint32_t s0,
-                            uint32_t prefix0, uint64_t q, HmTw sc, HmEpi ep) {
-  for (int t = 0; t < (int)st.size(); ++t) G::template phase_src1<TL, LOGR, STRIDED, INV, MODE, P>(st[t], t, lds, nullptr, dst, tile, twl, twt, s0, prefix0, q, sc, ep, lds + (1 << TL));
-  if constexpr (P == 0)
-    for (int t = 0; t < (int)st.size(); ++t) G::template lds0<TL, LOGR, STRIDED, INV, MODE>(st[t], t, lds, lds + (1 << TL), s0, prefix0, q, ep);
-  if constexpr (P < G::template rounds<LOGR>()) run_phases_src1<G, TL, LOGR, STRIDED, INV, MODE, P + 1>(st, lds, dst, tile, twl, twt, s0, prefix0, q, sc, ep);
-}
-template <class G, int LOGR, bool STRIDED, bool INV, int MODE>
-static void run_pass_dma(const Emu &e, uint32_t mod, const uint64_t *src, uint64_t *dst, HmTw sc, HmEpi ep = hm_epi_none()) {
-  constexpr int TL = HM_TL(STRIDED), TILE = 1 << TL, THREADS = TILE / G::EPT, LOGC = TL - LOGR;
-  constexpr int NTW = STRIDED ? (1 << LOGR) : 128;
-  const uint32_t tiles = e.P.N >> TL;
-  const uint64_t q = e.P.mod[mod];
-  const HmW *twl = (INV ? e.inv : e.fwd)[mod].data();
-  const uint32_t s0 = STRIDED ? 0u : (e.P.logN - HM_ROW_LOG);
-  std::vector<uint64_t> lds(TILE + NTW);
-  std::vector<typename G::State> st(THREADS);
-  const HmW *twist = (INV ? e.twi : e.twf)[mod].data();
-  std::vector<uint64_t> in(src, src + e.P.N);   // (a pass may run in place: the kernel's DMA reads a tile before anybody stores to it)
-  for (uint32_t tile = 0; tile < tiles; ++tile) {
-    for (int w = 0; w < TILE; w += 2) {
-      int x, c;
-      if (G::EPT == 16) hm16::hm_lds_unidx<TL, LOGR, STRIDED>(w, x, c); else hm8::hm_lds_unidx<TL, LOGR, STRIDED>(w, x, c);
-      const uint32_t g = STRIDED ? ((uint32_t)x << HM_ROW_LOG) + (tile << LOGC) + (uint32_t)c : (tile << TL) + ((uint32_t)c << LOGR) + (uint32_t)x;
-      lds[w] = in[g]; lds[w + 1] = in[g + 1];
-    }
-    for (int k = 0; k < NTW; ++k) lds[TILE + k] = twl[k];
-    const uint32_t prefix0 = STRIDED ? 0u : (tile << (TL - LOGR));
-    run_phases_src1<G, TL, LOGR, STRIDED, INV, MODE, 0>(st, lds.data(), dst, tile, twl, twist + (size_t)prefix0 * 3, s0, prefix0, q, sc, ep);
-  }
-}
-template <class G, int LOG1>
-static void run_ntt_dma(const Emu &e, uint32_t mod, const uint64_t *in, uint64_t *out, int inverse, HmTw sc) {
-  if (!inverse) {
-    run_pass_dma<G, LOG1, true, false, 0>(e, mod, in, out, sc);
-    run_pass_dma<G, HM_ROW_LOG, false, false, 1>(e, mod, out, out, sc);
-  } else {
-    run_pass_dma<G, HM_ROW_LOG, false, true, 0>(e, mod, in, out, sc);
-    run_pass_dma<G, LOG1, true, true, 2>(e, mod, out, out, sc);
-  }
-}
-
 template <int N_IN>
 static void emu_bconv_n(Emu &e, HmBconvProb &p, const std::vector<uint64_t> &tb, const uint32_t *out_ids) {
   const uint32_t row = HM_BCONV_ROW(p.n_in);
@@ -136,9 +89,17 @@ static void emu_bconv_n(Emu &e, HmBconvProb &p, const std::vector<uint64_t> &tb,
 }
 
 extern "C" {
-void *emu_create(uint32_t logN, uint32_t L, uint32_t K) {
+// q == nullptr: the default chain; otherwise a caller-chosen one (q: L moduli, p: K special moduli; primes = 1 mod 2N below 2^60).
+// Returns nullptr if the chain does not fit this build's arithmetic.
+static void *emu_make(uint32_t logN, uint32_t L, uint32_t K, const uint64_t *q, const uint64_t *p, bool tables) {
   Emu *e = new Emu;
-  e->P.init(logN, L, K, nullptr, nullptr, nullptr);
+  try {
+    e->P.init(logN, L, K, q, p, nullptr, HM_GENERIC != 0);
+  } catch (const std::exception &) {
+    delete e;
+    return nullptr;
+  }
+  if (!tables) return e;
   e->fwd.resize(L + K); e->inv.resize(L + K); e->twf.resize(L + K); e->twi.resize(L + K);
   for (uint32_t m = 0; m < L + K; ++m) {
     e->fwd[m].resize(e->P.N); e->inv[m].resize(e->P.N);
@@ -150,13 +111,11 @@ void *emu_create(uint32_t logN, uint32_t L, uint32_t K) {
   }
   return e;
 }
-// the same with a caller-chosen chain (q: L moduli, p: K special moduli; primes = 1 mod 2N below 2^60): only the modulus constants are
-// built, for the element-wise checks that need no twiddle tables
-void *emu_create_mods(uint32_t logN, uint32_t L, uint32_t K, const uint64_t *q, const uint64_t *p) {
-  Emu *e = new Emu;
-  e->P.init(logN, L, K, q, p, nullptr);
-  return e;
-}
+void *emu_create(uint32_t logN, uint32_t L, uint32_t K) { return emu_make(logN, L, K, nullptr, nullptr, true); }
+void *emu_create_chain(uint32_t logN, uint32_t L, uint32_t K, const uint64_t *q, const uint64_t *p) { return emu_make(logN, L, K, q, p, true); }
+// only the modulus constants (the element-wise checks that need no twiddle tables)
+void *emu_create_mods(uint32_t logN, uint32_t L, uint32_t K, const uint64_t *q, const uint64_t *p) { return emu_make(logN, L, K, q, p, false); }
+int emu_generic(void) { return HM_GENERIC; }
 void emu_destroy(void *h) { delete (Emu *)h; }
 uint64_t emu_modulus(void *h, uint32_t m) { return ((Emu *)h)->P.mod[m]; }
 uint64_t emu_psi(void *h, uint32_t m) { return ((Emu *)h)->P.psi[m]; }
@@ -165,7 +124,7 @@ int emu_ntt(void *h, uint32_t mod, const uint64_t *in, uint64_t *out, int invers
   Emu &e = *(Emu *)h;
   uint64_t q = e.P.mod[mod], k = e.P.modc[mod].ninv;
   if (has_scale) k = hm::mulmod(k, scale, q);
-  HmTw sc = {hm_to_mont(k, q), 0};
+  HmTw sc = hm_kconst(k, q);
   switch (e.P.logN - HM_ROW_LOG) {
   case 5: run_ntt<G16, 5>(e, mod, in, out, inverse, sc); break;
   case 6: run_ntt<G16, 6>(e, mod, in, out, inverse, sc); break;
@@ -177,37 +136,16 @@ int emu_ntt(void *h, uint32_t mod, const uint64_t *in, uint64_t *out, int invers
   return 0;
 }
 
-// the same transform through the persistent double-buffered passes' code path (tile image by DMA address map, first round from LDS)
-int emu_ntt_dma(void *h, uint32_t mod, const uint64_t *in, uint64_t *out, int inverse, int geo8) {
-  Emu &e = *(Emu *)h;
-  const uint64_t q = e.P.mod[mod], k = e.P.modc[mod].ninv;
-  HmTw sc = {hm_to_mont(k, q), 0};
-  if (geo8) {
-    if (e.P.logN != 16) return 1;
-    run_ntt_dma<G8, 8>(e, mod, in, out, inverse, sc);
-    return 0;
-  }
-  switch (e.P.logN - HM_ROW_LOG) {
-  case 5: run_ntt_dma<G16, 5>(e, mod, in, out, inverse, sc); break;
-  case 6: run_ntt_dma<G16, 6>(e, mod, in, out, inverse, sc); break;
-  case 7: run_ntt_dma<G16, 7>(e, mod, in, out, inverse, sc); break;
-  case 8: run_ntt_dma<G16, 8>(e, mod, in, out, inverse, sc); break;
-  case 9: run_ntt_dma<G16, 9>(e, mod, in, out, inverse, sc); break;
-  default: return 1;
-  }
-  return 0;
-}
-
 // fused forward transform: out = (minuend - NTT(in [+ mix_k * mix])) * k [+ addend [* addend_k]]   (mix_k / addend_k = 0: none)
 int emu_ntt_sub_scale(void *h, uint32_t mod, const uint64_t *in, const uint64_t *minuend, const uint64_t *addend, uint64_t *out,
                       uint64_t k, const uint64_t *mix, uint64_t mix_k, uint64_t addend_k) {
   Emu &e = *(Emu *)h;
   const uint64_t q = e.P.mod[mod];
-  HmTw sc = {hm_to_mont(k, q), 0};
+  HmTw sc = hm_kconst(k, q);
   HmEpi ep = hm_epi_none();
   ep.a = minuend; ep.d = addend;
-  if (addend_k) ep.dk = HmTw{hm_to_mont(addend_k, q), 0};
-  if (mix) { ep.b = mix; ep.bk = HmTw{hm_to_mont(mix_k, q), 0}; }
+  if (addend_k) ep.dk = hm_kconst(addend_k, q);
+  if (mix) { ep.b = mix; ep.bk = hm_kconst(mix_k, q); }
   switch (e.P.logN - HM_ROW_LOG) {
 #define HM_CASE(n) case n: if (mix) run_pass<G16, n, true, false, 4>(e, mod, in, out, sc, ep); else run_pass<G16, n, true, false, 0>(e, mod, in, out, sc); break;
     HM_CASE(5) HM_CASE(6) HM_CASE(7) HM_CASE(8) HM_CASE(9)
@@ -223,7 +161,7 @@ int emu_ntt8(void *h, uint32_t mod, const uint64_t *in, uint64_t *out, int inver
   if (e.P.logN != 16) return 1;
   uint64_t q = e.P.mod[mod], k = e.P.modc[mod].ninv;
   if (has_scale) k = hm::mulmod(k, scale, q);
-  run_ntt<G8, 8>(e, mod, in, out, inverse, HmTw{hm_to_mont(k, q), 0});
+  run_ntt<G8, 8>(e, mod, in, out, inverse, hm_kconst(k, q));
   return 0;
 }
 int emu_ntt_sub_scale8(void *h, uint32_t mod, const uint64_t *in, const uint64_t *minuend, const uint64_t *addend, uint64_t *out,
@@ -231,11 +169,11 @@ int emu_ntt_sub_scale8(void *h, uint32_t mod, const uint64_t *in, const uint64_t
   Emu &e = *(Emu *)h;
   if (e.P.logN != 16) return 1;
   const uint64_t q = e.P.mod[mod];
-  HmTw sc = {hm_to_mont(k, q), 0};
+  HmTw sc = hm_kconst(k, q);
   HmEpi ep = hm_epi_none();
   ep.a = minuend; ep.d = addend;
-  if (addend_k) ep.dk = HmTw{hm_to_mont(addend_k, q), 0};
-  if (mix) { ep.b = mix; ep.bk = HmTw{hm_to_mont(mix_k, q), 0}; }
+  if (addend_k) ep.dk = hm_kconst(addend_k, q);
+  if (mix) { ep.b = mix; ep.bk = hm_kconst(mix_k, q); }
   if (mix) run_pass<G8, 8, true, false, 4>(e, mod, in, out, sc, ep); else run_pass<G8, 8, true, false, 0>(e, mod, in, out, sc);
   run_pass<G8, HM_ROW_LOG, false, false, 3>(e, mod, out, out, sc, ep);
   return 0;
@@ -311,6 +249,7 @@ int emu_mac(void *h, uint32_t mod, uint64_t *acc, const uint64_t *x, const uint6
 uint64_t emu_mac_final(void *h, uint32_t mod, uint64_t acc) { return hm16::hm_mac_final(acc, ((Emu *)h)->P.modc[mod]); }
 // the word-wise Montgomery product itself (hm_mont_acc): out[i] = c[i] + x[i] * wt[i] * 2^-64 mod q + {0, q}; and the per-launch constant
 // product (hm_mont_const_mul), the wide reduction (hm_redc_wide) and one forward / inverse butterfly of each kind
+#if !HM_GENERIC
 void emu_mont_acc(void *h, uint32_t mod, const uint64_t *c, const uint64_t *x, const uint64_t *wt, uint64_t *out, uint32_t n) {
   const HmBflyMod m = hm_bfly_mod(((Emu *)h)->P.mod[mod]);
   for (uint32_t i = 0; i < n; ++i) out[i] = hm_mont_acc(c[i], x[i], wt[i], m);
@@ -319,6 +258,7 @@ uint64_t emu_mont_const_mul(void *h, uint32_t mod, uint64_t x, uint64_t k) {
   const uint64_t q = ((Emu *)h)->P.mod[mod];
   return hm_mont_const_mul(x, hm_to_mont(k, q), q);
 }
+#endif
 uint64_t emu_redc_wide(void *h, uint32_t mod, uint64_t lo, uint64_t hi, int terms) {
   const HmMod &m = ((Emu *)h)->P.modc[mod];
   const hm_u128 z = ((hm_u128)hi << 64) | lo;
@@ -327,7 +267,7 @@ uint64_t emu_redc_wide(void *h, uint32_t mod, uint64_t lo, uint64_t hi, int term
 void emu_bfly(void *h, uint32_t mod, int kind, uint64_t *X, uint64_t *Y, uint64_t w) {   // kind 0..2: forward; 3: inverse
   const uint64_t q = ((Emu *)h)->P.mod[mod];
   const HmBflyMod m = hm_bfly_mod(q);
-  const HmW wt = hm_to_mont(w, q);
+  const HmW wt = hm_tw_entry(w, q);
   if (kind == 0) hm_bfly_fwd_k<0>(*X, *Y, wt, m);
   else if (kind == 1) hm_bfly_fwd_k<1>(*X, *Y, wt, m);
   else if (kind == 2) hm_bfly_fwd_k<2>(*X, *Y, wt, m);

@@ -33,36 +33,60 @@ def test_create_fails_loudly_without_gpu():
     assert "no HIP device" in str(e.value) or "hip" in str(e.value).lower()
 
 
-def test_create_refuses_moduli_that_are_not_1_mod_2_32():
-    """hm_create validates the chain before it touches the device: a prime that is 1 mod 2N but not 1 mod 2^32 (the chain rule of rounds
-    1-3) is refused with HM_ERR_ARG and named in the message; a chain of the required form passes the check (and then fails on the
-    missing device here, or builds a context on a GPU box)"""
+def test_create_picks_the_arithmetic_backend_from_the_chain(monkeypatch):
+    """hm_create validates the chain before it touches the device and picks the back-end from it: a prime that is 1 mod 2N but not
+    h 2^32 + 1 (SURVEY.md 8d's rule, rounds 1-3) goes to the generic back-end and passes the check (then fails on the missing device here,
+    or builds a context on a GPU box); a composite or a prime that is not 1 mod 2N is refused by either back-end with HM_ERR_ARG and
+    named in the message; HOMULATOR_ARITH=mont32 refuses a chain the word-wise Montgomery arithmetic cannot run"""
     import pytest
     from homulator_amd import hip
-    old_rule = 1152921504606584833          # 2^60 - 2^18 + 1: prime, 1 mod 2^17, not 1 mod 2^32
-    with pytest.raises(hip.HmError) as e:
-        hip.Context(13, 1, 1, q=[old_rule], p=[0xfffffa000000001])
-    assert "2^32" in str(e.value) and str(old_rule) in str(e.value)
-    with pytest.raises(hip.HmError) as e:   # composite of the right form
-        hip.Context(13, 1, 1, q=[(1 << 32) + 1], p=[0xfffffa000000001])
-    assert "2^32" in str(e.value)
-    try:
-        ctx = hip.Context(13, 1, 1, q=[0xfffff8800000001], p=[0xfffffa000000001])
-    except hip.HmError as ex:
-        assert "no HIP device" in str(ex) or "hip" in str(ex).lower()
-    else:
-        assert ctx.moduli == [0xfffff8800000001, 0xfffffa000000001]
+    survey = 1152921504606584833            # 2^60 - 2^18 + 1: prime, 1 mod 2^17, not 1 mod 2^32
+    m32a, m32b = 0xfffff8800000001, 0xfffffa000000001
+
+    def create(q, p, logN=13):
+        try:
+            ctx = hip.Context(logN, len(q), len(p), q=q, p=p)
+        except hip.HmError as ex:
+            return str(ex)
+        arith = ctx.counter("arith")
         ctx.close()
+        return arith
+
+    for chain, arith in ((([survey], [m32b]), 1), (([m32a], [m32b]), 0), (([(1 << 35) - 2 ** 14 * 3 + 1 - 0], [m32b]), None)):
+        r = create(*chain)
+        if isinstance(r, str) and arith is not None:
+            assert "no HIP device" in r or "hip" in r.lower(), r          # the chain passed the check; there is no GPU here
+        elif arith is not None:
+            assert r == arith
+    r = create([(1 << 32) + 1], [m32b])     # composite of the Montgomery form
+    assert isinstance(r, str) and "prime" in r and str((1 << 32) + 1) in r
+    r = create([0xffffffffffffffc5 >> 4], [m32b])   # odd, not 1 mod 2N
+    assert isinstance(r, str) and "prime" in r
+    r = create([survey, survey], [m32b])
+    assert isinstance(r, str) and "duplicate" in r
+    monkeypatch.setenv("HOMULATOR_ARITH", "mont32")
+    r = create([survey], [m32b])
+    assert isinstance(r, str) and "2^32" in r
+    monkeypatch.setenv("HOMULATOR_ARITH", "generic")   # a Montgomery-form chain may run on the generic arithmetic (A/B runs)
+    r = create([m32a], [m32b])
+    assert r == 1 or (isinstance(r, str) and ("no HIP device" in r or "hip" in r.lower()))
 
 
 def test_fat_binary_targets_gfx950():
-    """The hipcc wrapper silently falls back to gfx906 under some flag combinations: check the embedded code object."""
+    """The hipcc wrapper silently falls back to gfx906 under some flag combinations: check the embedded code object of both arithmetic
+    back-ends (libhm_m32.so, libhm_gen.so)."""
+    import pytest
     from homulator_amd import hip
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "homulator_amd", "csrc")], stdout=subprocess.DEVNULL)
+    for backend in hip.BACKEND_LIBS:
+        _check_code_object(os.path.join(os.path.dirname(hip.LIB_PATH), backend))
+
+
+def _check_code_object(lib_path):
     import tempfile
     with tempfile.TemporaryDirectory() as td:
         fat = os.path.join(td, "fat.bin")
-        subprocess.check_call(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", hip.LIB_PATH, fat])
+        subprocess.check_call(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", lib_path, fat])
         out = subprocess.check_output(["/opt/rocm/lib/llvm/bin/clang-offload-bundler", "--list", "--type=o", "--input=" + fat], text=True)
         assert "gfx950" in out and "gfx906" not in out, out
         # no kernel may spill to scratch (a switch over 32 base-conversion sizes once did: 2.7 KB per lane, 4x slower op)

@@ -14,12 +14,15 @@ from oracle.homoracle import Oracle
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-@pytest.fixture(scope="module")
-def emu():
+def _load(name):
     subprocess.check_call(["make", "-C", os.path.join(HERE, "emu")], stdout=subprocess.DEVNULL)
-    L = C.CDLL(os.path.join(HERE, "emu", "libhm_emu.so"))
+    L = C.CDLL(os.path.join(HERE, "emu", name))
     L.emu_create.restype = C.c_void_p
     L.emu_create.argtypes = [C.c_uint32] * 3
+    L.emu_create_chain.restype = C.c_void_p
+    L.emu_create_chain.argtypes = [C.c_uint32] * 3 + [C.c_void_p] * 2
+    L.emu_create_mods.restype = C.c_void_p
+    L.emu_create_mods.argtypes = [C.c_uint32] * 3 + [C.c_void_p] * 2
     L.emu_destroy.argtypes = [C.c_void_p]
     L.emu_modulus.restype = C.c_uint64
     L.emu_modulus.argtypes = [C.c_void_p, C.c_uint32]
@@ -33,7 +36,52 @@ def emu():
     L.emu_bconv_consts.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
     L.emu_automorph.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
     L.emu_fill.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p]
+    L.emu_mac.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]
+    L.emu_mac_final.restype = C.c_uint64
+    L.emu_mac_final.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64]
+    L.emu_redc_wide.restype = C.c_uint64
+    L.emu_redc_wide.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_int]
+    L.emu_bfly.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64]
     return L
+
+
+class Emu:
+    """one build of the emulator (the kernels' headers compiled for one arithmetic back-end) + the chain the tests give it:
+    "mont32" = libhm_emu.so on the default chain; "survey" / an int b = libhm_emu_gen.so (HM_GENERIC) on the largest primes = 1 mod 2N
+    below 2^60 / 2^b; "generic-on-mont32" = the generic arithmetic on the default chain"""
+
+    def __init__(self, chain):
+        self.chain = chain
+        self.lib = _load("libhm_emu.so" if chain == "mont32" else "libhm_emu_gen.so")
+        assert self.lib.emu_generic() == (0 if chain == "mont32" else 1)
+
+    def oracle(self, logN, L, K):
+        return Oracle(logN, L, K, chain="mont32" if self.chain in ("mont32", "generic-on-mont32") else self.chain)
+
+    def create(self, o):
+        """an emulator context on the oracle's chain"""
+        mods = np.array(o.moduli, dtype=np.uint64)
+        h = self.lib.emu_create_chain(o.logN, o.L, o.K, p(mods[:o.L]), p(mods[o.L:]))
+        assert h, "the emulator refused the chain"
+        return h
+
+    def __getattr__(self, name):
+        return getattr(self.lib, name)
+
+
+@pytest.fixture(scope="module", params=["mont32", "survey", 36, "generic-on-mont32"], ids=str)
+def emu(request):
+    return Emu(request.param)
+
+
+@pytest.fixture(scope="module")
+def emu_m32():
+    return Emu("mont32")
+
+
+@pytest.fixture(scope="module")
+def emu_gen():
+    return Emu("survey")
 
 
 def p(a):
@@ -43,8 +91,8 @@ def p(a):
 @pytest.mark.parametrize("logN", [13, 14, 15, 16, 17])
 def test_emu_params_and_ntt(emu, logN):
     L, K = 3, 2
-    o = Oracle(logN, L, K)
-    h = emu.emu_create(logN, L, K)
+    o = emu.oracle(logN, L, K)
+    h = emu.create(o)
     try:
         assert [emu.emu_modulus(h, m) for m in range(L + K)] == o.moduli
         assert [emu.emu_psi(h, m) for m in range(L + K)] == o.psis
@@ -71,8 +119,8 @@ def test_emu_params_and_ntt(emu, logN):
 @pytest.mark.parametrize("logN", [13, 15, 16])
 def test_emu_fused_ntt_sub_scale_and_tensor(emu, logN):
     L, K = 3, 1
-    o = Oracle(logN, L, K)
-    h = emu.emu_create(logN, L, K)
+    o = emu.oracle(logN, L, K)
+    h = emu.create(o)
     try:
         for m in (0, L):
             q = o.moduli[m]
@@ -106,8 +154,8 @@ def test_emu_fused_ntt_sub_scale_and_tensor(emu, logN):
 
 def test_emu_ewe_bconv_auto_fill(emu):
     logN, L, K = 13, 5, 2
-    o = Oracle(logN, L, K)
-    h = emu.emu_create(logN, L, K)
+    o = emu.oracle(logN, L, K)
+    h = emu.create(o)
     try:
         N = o.N
         for m in (0, 6):
@@ -157,8 +205,8 @@ def test_emu_ewe_bconv_auto_fill(emu):
 def test_emu_bconv_28_inputs_parameter_set_A(emu):
     """alpha = 28 (parameter set A): two carry-free column groups per output, all inputs at q_i - 1"""
     logN, L, K = 13, 30, 28
-    o = Oracle(logN, L, K)
-    h = emu.emu_create(logN, L, K)
+    o = emu.oracle(logN, L, K)
+    h = emu.create(o)
     try:
         in_ids, out_ids = [L + i for i in range(28)], [0, 1, 2, 29]
         x = o.fill_uniform(in_ids, 5)
@@ -175,8 +223,8 @@ def test_emu_bconv_28_inputs_parameter_set_A(emu):
 def test_emu_bconv_widest_accumulator(emu):
     """16 input limbs all at q_i - 1: the 128-bit accumulator reaches ~2^124 (fold path of hm_barrett_wide)."""
     logN, L, K = 13, 20, 2
-    o = Oracle(logN, L, K)
-    h = emu.emu_create(logN, L, K)
+    o = emu.oracle(logN, L, K)
+    h = emu.create(o)
     try:
         in_ids, out_ids = list(range(16)), [16, 17, 18, 19, 20, 21]
         x = o.fill_uniform(in_ids, 5)
@@ -197,8 +245,8 @@ def test_emu_ntt_eight_coefficients_per_thread(emu):
     emu.emu_ntt8.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_int]
     emu.emu_ntt_sub_scale8.argtypes = [C.c_void_p, C.c_uint32] + [C.c_void_p] * 4 + [C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64]
     logN, L, K = 16, 3, 2
-    o = Oracle(logN, L, K)
-    h = emu.emu_create(logN, L, K)
+    o = emu.oracle(logN, L, K)
+    h = emu.create(o)
     try:
         for m in (0, L + K - 1):
             x = o.fill_uniform([m], 42 + m)[0]
@@ -235,44 +283,14 @@ def test_emu_ntt_eight_coefficients_per_thread(emu):
         emu.emu_destroy(h)
 
 
-@pytest.mark.parametrize("logN,geo8", [(13, 0), (14, 0), (15, 0), (16, 0), (16, 1), (17, 0)])
-def test_emu_ntt_through_the_dma_tile_image(emu, logN, geo8):
-    """the persistent double-buffered passes (round 4) on the CPU emulator: the tile image is filled through the LDS-DMA's source-address
-    map (hm_lds_unidx: the inverse of the image's XOR swizzle), the staged twiddles sit behind it, and the first round reads the image
-    (phase SRC = 1 + hm_ntt_phase_lds0); forward, inverse in place, worst-case operands, every ring size, both geometries"""
-    emu.emu_ntt_dma.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
-    L, K = 2, 1
-    o = Oracle(logN, L, K)
-    h = emu.emu_create(logN, L, K)
-    try:
-        for m in (0, L + K - 1):
-            x = o.fill_uniform([m], 7 + m)[0]
-            x[0], x[1], x[-1] = 0, o.moduli[m] - 1, o.moduli[m] - 1
-            out = np.empty_like(x)
-            assert emu.emu_ntt_dma(h, m, p(x), p(out), 0, geo8) == 0
-            assert np.array_equal(out, o.ntt([m], x[None])[0]), f"forward mod={m}"
-            assert emu.emu_ntt_dma(h, m, p(out), p(out), 1, geo8) == 0
-            assert np.array_equal(out, x), f"inverse in place mod={m}"
-        worst = np.full(1 << logN, o.moduli[1] - 1, dtype=np.uint64)
-        out = np.empty_like(worst)
-        emu.emu_ntt_dma(h, 1, p(worst), p(out), 0, geo8)
-        assert np.array_equal(out, o.ntt([1], worst[None])[0])
-    finally:
-        emu.emu_destroy(h)
-
-
-def test_emu_key_mac_lazy_ranges(emu):
+def test_emu_key_mac_lazy_ranges(emu_m32):
+    emu = emu_m32
     """the fused transform x key kernel's multiply-accumulate (hm_mac_add): the word-wise Montgomery product with the key word as the
     constant.  For x anywhere below 8q (twice the transform's lazy output range), y below q: every product adds x*y*2^-64 mod q plus at
     most q, less than 1.5q + 2^28, so five terms stay below 8q <= 2^63 (the kernel takes at most four); the final product with 2^128 mod q
     and one subtraction give x.y mod q — with the extreme operands (0, 1, q-1, 8q-1, values next to powers of two) and random ones, for
     the default chain (60-bit moduli) and for 59-, 45- and 40-bit moduli"""
-    emu.emu_mac.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]
-    emu.emu_mac_final.restype = C.c_uint64
-    emu.emu_mac_final.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64]
     from sympy import isprime
-    emu.emu_create_mods.restype = C.c_void_p
-    emu.emu_create_mods.argtypes = [C.c_uint32] * 3 + [C.c_void_p] * 2
     small = []
     for bits in (59, 45, 40, 59, 45, 40):   # (every modulus of a context is 1 mod 2^32)
         c = (1 << bits) + 1 - (1 << 32)
@@ -307,21 +325,17 @@ def test_emu_key_mac_lazy_ranges(emu):
         emu.emu_destroy(h)
 
 
-def test_emu_montgomery_products_and_butterfly_ranges(emu):
+def test_emu_montgomery_products_and_butterfly_ranges(emu_m32):
+    emu = emu_m32
     """the word-wise Montgomery arithmetic on moduli q = h 2^32 + 1 (hm_modarith.h) against Python integers, at the edges of every stated range:
     hm_mont_acc (c + x wt 2^-64 mod q + {0, q}, at most floor(x wt / 2^64) + q + h + 1 < 1.5q + 2^28 for x up to 2^63 - 1, wt up to q - 1, no 64-bit overflow with c up
     to 8q), the per-launch constant product, the two-step reduction of the 128-bit conversion accumulator (16 and 32 terms at their bounds),
     and the butterflies of each kind at the bounds hm_fwd_bound assumes (inputs below 6q / 8q, outputs below 8q / 6q / 4q; inverse 4q -> 4q);
     60-, 59-, 45- and 40-bit moduli"""
     from sympy import isprime
-    emu.emu_create_mods.restype = C.c_void_p
-    emu.emu_create_mods.argtypes = [C.c_uint32] * 3 + [C.c_void_p] * 2
     emu.emu_mont_acc.argtypes = [C.c_void_p, C.c_uint32] + [C.c_void_p] * 4 + [C.c_uint32]
     emu.emu_mont_const_mul.restype = C.c_uint64
     emu.emu_mont_const_mul.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64]
-    emu.emu_redc_wide.restype = C.c_uint64
-    emu.emu_redc_wide.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_int]
-    emu.emu_bfly.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64]
     small = []
     for bits in (59, 45, 40, 59, 45, 40):
         c = (1 << bits) + 1 - (1 << 32)
@@ -364,6 +378,90 @@ def test_emu_montgomery_products_and_butterfly_ranges(emu):
             vals = lambda m: [0, 1, q - 1, m * q - 1, m * q - 2, (m * q) >> 1] + [int(v) % (m * q) for v in rng.integers(0, 1 << 62, 200)]
             for x in vals(xmax):
                 for y in vals(ymax)[::7] + [ymax * q - 1]:
+                    for w in (1, q - 1, 3 + (q >> 3)):
+                        Xb[0], Yb[0] = x, y
+                        emu.emu_bfly(h, mod, kind, Xb, Yb, w)
+                        a, b = int(Xb[0]), int(Yb[0])
+                        assert a < omax * q and b < omax * q, (mod, kind, x, y, w, a // q, b // q)
+                        if kind < 3:
+                            assert a % q == (x + w * y) % q and b % q == (x - w * y) % q, (mod, kind, x, y, w)
+                        else:
+                            assert a % q == (x + y) % q and b % q == (x - y) * w % q, (mod, kind, x, y, w)
+        emu.emu_destroy(h)
+
+
+def _mixed_chain(step_log):
+    """59-, 45- and 31-bit primes = 1 mod 2^step_log (twice): a chain an FHE library might hand over"""
+    from sympy import isprime
+    small = []
+    for bits in (59, 45, 31, 59, 45, 31):
+        c = (1 << bits) - (1 << step_log) + 1 - (len(small) << 20)
+        while not isprime(c) or c in small:
+            c -= 1 << step_log
+        small.append(c)
+    return small
+
+
+def test_emu_generic_key_mac_lazy_ranges(emu_gen):
+    """the generic back-end's key multiply-accumulate (hm_mac_add under HM_GENERIC): Barrett's quotient from two approximate high
+    products.  For x anywhere below 8q (the generic transform's lazy output), y below q: every product adds x*y mod q plus at most 6q,
+    two terms stay below 14q, with the fold from the third term on any number of terms stays below 15q, and the final reduction is
+    x.y mod q — extreme operands (0, 1, q-1, 8q-1, values next to powers of two) and random ones, for SURVEY.md 8d's 60-bit chain and
+    for 59-, 45- and 31-bit moduli (the operand shift 64 - k and the quotient constant depend on the width k)"""
+    emu = emu_gen
+    o = emu.oracle(13, 4, 2)
+    chain = np.array(_mixed_chain(14), dtype=np.uint64)
+    rng = np.random.default_rng(5)
+    for h, mod in [(emu.create(o), m) for m in range(6)] + [(emu.emu_create_mods(13, 4, 2, p(chain[:4]), p(chain[4:])), m) for m in range(6)]:
+        assert h
+        q = emu.emu_modulus(h, mod)
+        xs = [0, 1, q - 1, q, 2 * q, 4 * q - 1, 8 * q - 1, 8 * q - 2, (1 << 32) - 1, 1 << 32, (1 << 62) + 1, (1 << 32) + 1]
+        ys = [0, 1, q - 1, q - 2, (1 << 32) - 1, 1 << 32, (1 << 59) + 12345, q >> 1]
+        ex = [(x, y) for x in xs if x < 8 * q for y in ys if y < q]
+        n = 4096
+        X = np.concatenate([np.array([e[0] for e in ex], dtype=np.uint64), (rng.integers(0, 1 << 63, n, dtype=np.uint64) % np.uint64(8 * q))])
+        Y = np.concatenate([np.array([e[1] for e in ex], dtype=np.uint64), (rng.integers(0, 1 << 63, n, dtype=np.uint64) % np.uint64(q))])
+        n = len(X)
+        acc = np.zeros(n, dtype=np.uint64)
+        want = [0] * n
+        for term in range(6):   # more terms than the kernel takes: the fold keeps the sum in range for any number
+            Xt, Yt = np.roll(X, term * 7), np.roll(Y, term * 3)
+            before = acc.copy()
+            emu.emu_mac(h, mod, p(acc), p(Xt), p(Yt), n, 1 if term >= 2 else 0)
+            for i in range(n):
+                want[i] = (want[i] + int(Xt[i]) * int(Yt[i])) % q
+                a = int(acc[i])
+                assert a % q == want[i], (mod, term, i)
+                assert a < (14 * q if term < 2 else 15 * q), (mod, term, i, a // q)
+                if term < 2:
+                    assert a - int(before[i]) < 7 * q
+        for i in range(0, n, 97):
+            assert emu.emu_mac_final(h, mod, int(acc[i])) == want[i]
+        emu.emu_destroy(h)
+
+
+def test_emu_generic_butterfly_and_reduction_ranges(emu_gen):
+    """the generic back-end's butterflies (Shoup product with the approximate quotient: [0, 4q) for ANY 64-bit operand) at the bounds its
+    stage schedule assumes — twice the word-wise Montgomery ones: inputs below 12q / 16q, outputs below 16q / 12q / 8q; inverse 4q -> 4q —
+    and the Montgomery reduction of the 128-bit conversion accumulator for any odd q (16 and 32 terms at their bounds), for SURVEY.md
+    8d's 60-bit chain and 59-, 45- and 31-bit moduli"""
+    emu = emu_gen
+    o = emu.oracle(13, 4, 2)
+    chain = np.array(_mixed_chain(14), dtype=np.uint64)
+    rng = np.random.default_rng(23)
+    for h, mod in [(emu.create(o), m) for m in (0, 5)] + [(emu.emu_create_mods(13, 4, 2, p(chain[:4]), p(chain[4:])), m) for m in range(3)]:
+        assert h
+        q = emu.emu_modulus(h, mod)
+        r64inv = pow(1 << 64, -1, q)
+        for terms in (16, 32):
+            zmax = terms * ((1 << 60) - 1) * (q - 1)
+            for z in [0, 1, q, zmax, zmax - 1, (1 << 64) - 1, 1 << 64, (zmax >> 1) + 977] + [int(rng.integers(0, 1 << 62)) * int(rng.integers(0, 1 << 62)) % (zmax + 1) for _ in range(2000)]:
+                assert emu.emu_redc_wide(h, mod, z & ((1 << 64) - 1), z >> 64, terms) == z * r64inv % q, (mod, terms, z)
+        Xb, Yb = (C.c_uint64 * 1)(), (C.c_uint64 * 1)()
+        for kind, xmax, ymax, omax in ((0, 12, 16, 16), (1, 16, 16, 12), (2, 16, 16, 8), (3, 4, 4, 4)):
+            vals = lambda m: [0, 1, q - 1, m * q - 1, m * q - 2, (m * q) >> 1] + [int(v) % (m * q) for v in rng.integers(0, 1 << 62, 200)]
+            for x in vals(xmax):
+                for y in vals(ymax)[::7] + [ymax * q - 1, (1 << 64) - 1 if kind < 3 else 4 * q - 1]:
                     for w in (1, q - 1, 3 + (q >> 3)):
                         Xb[0], Yb[0] = x, y
                         emu.emu_bfly(h, mod, kind, Xb, Yb, w)

@@ -8,12 +8,24 @@ from oracle.homoracle import Oracle
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=[16, 15])
-def env(request):
+# Every kernel family runs on BOTH arithmetic back-ends (hm_create picks one from the chain it is given): "mont32" = the default chain
+# (primes h 2^32 + 1: word-wise Montgomery), "survey" = SURVEY.md 8(d)'s chain as written (the largest primes = 1 mod 2N below 2^60) and
+# 36 = the largest such primes below 2^36 (36-bit words as the reference's configuration models): the generic back-end.
+CHAINS = [(16, "mont32"), (15, "mont32"), (16, "survey"), (15, 36)]
+
+
+def make_env(logN, L, K, chain):
     from homulator_amd import hip
-    logN, L, K = request.param, 6, 3
-    ctx = hip.Context(logN, L, K)
-    o = Oracle(logN, L, K)
+    o = Oracle(logN, L, K, chain=chain)
+    ctx = hip.Context(logN, L, K) if chain == "mont32" else hip.Context(logN, L, K, q=o.moduli[:L], p=o.moduli[L:])
+    assert ctx.counter("arith") == (0 if chain == "mont32" else 1)
+    return ctx, o, hip
+
+
+@pytest.fixture(scope="module", params=CHAINS, ids=lambda p: f"N{p[0]}-{p[1]}")
+def env(request):
+    logN, chain = request.param
+    ctx, o, hip = make_env(logN, 6, 3, chain)
     yield ctx, o, hip
     ctx.close()
 
@@ -48,13 +60,13 @@ def test_ntt_forward_inverse_bit_exact(env):
     d.free(); out.free()
 
 
+@pytest.mark.parametrize("chain", ["mont32", "survey", 45])
 @pytest.mark.parametrize("logN", [13, 14, 17])
-def test_ntt_other_ring_sizes(logN):
+def test_ntt_other_ring_sizes(logN, chain):
     """every COL-pass instantiation (N / 256 = 32, 64, 512 rows: two rounds, three rounds, 8-column tiles) on the GPU: forward,
     inverse, fused epilogue with mix prologue, with the all-(q-1) worst case of the lazy ranges; 2^15 and 2^16 run above"""
-    from homulator_amd import hip
     L, K = 3, 2
-    ctx, o = hip.Context(logN, L, K), Oracle(logN, L, K)
+    ctx, o, _ = make_env(logN, L, K, chain)
     try:
         ids = [0, 1, 2, 3, 4, 0, 4]
         x, mn, ad, mx = (o.fill_uniform(ids, s) for s in (123, 124, 125, 126))
@@ -332,14 +344,14 @@ def test_ntt_inner_product_fused(env, terms, outs):
         b_.free()
 
 
+@pytest.mark.parametrize("chain", ["mont32", "survey"])
 @pytest.mark.parametrize("n_in", [1, 2, 5, 9, 15])
-def test_ntt_inner_product_with_conversion_inside(n_in):
+def test_ntt_inner_product_with_conversion_inside(n_in, chain):
     """ModUp_BCONV + ModUp_NTT + inner product in one call (hm_ntt_ip_desc.conv): the conversion runs inside the first pass of the
     transform that consumes it (k_bconv_col), the converted limb-polys never exist.  Against the oracle's conversion, transform and
     MAC chain; two digits of n_in limbs each, two "ops" sharing the key, output limbs = everything outside the digit."""
-    from homulator_amd import hip
     L, K = 2 * n_in, 3
-    ctx, o = hip.Context(16, L, K), Oracle(16, L, K)
+    ctx, o, _ = make_env(16, L, K, chain)
     try:
         ell, beta, nops = 2 * n_in, 2, 2
         ext = o.ext_ids(ell); E = len(ext)
@@ -381,17 +393,16 @@ def test_ntt_inner_product_with_conversion_inside(n_in):
         ctx.close()
 
 
-@pytest.mark.parametrize("logN", [16, 15])
+@pytest.mark.parametrize("logN,chain", [(16, "mont32"), (15, "mont32"), (16, 50), (15, "survey")])
 @pytest.mark.parametrize("n_in,outs_per_wg", [(1, 0), (2, 2), (5, 1), (9, 2), (15, 2), (15, 1)])
-def test_mix_sub_scale_with_conversion_inside(logN, n_in, outs_per_wg):
+def test_mix_sub_scale_with_conversion_inside(logN, chain, n_in, outs_per_wg):
     """ModDown_BCONV + ModDowNTT + ModDownSub + rescale in one call (hm_ntt_fused_desc.conv, round 4): the P -> Q conversion runs inside the
     first pass of the merged transform (k_bconv_col with the mix prologue), ModdownBConvOut never exists.  Two "keys" of n_in special limbs
     each converted to an ODD number of Q limbs (the last output group of a workgroup pair is half empty), with and without the mix operand,
     plus limb-polys that are NOT fed by a conversion in the same call; one or two outputs per workgroup; N = 2^16 and 2^15.  Against the
     oracle's conversion, transform and element-wise chain."""
-    from homulator_amd import hip
     ell, K, N = 7, n_in, 1 << logN
-    ctx, o = hip.Context(logN, ell, K), Oracle(logN, ell, K)
+    ctx, o, _ = make_env(logN, ell, K, chain)
     try:
         ctx.set_option("bconv_col_outs", outs_per_wg)
         qs, ps = list(range(ell)), list(range(ell, ell + K))
@@ -434,23 +445,26 @@ def test_mix_sub_scale_with_conversion_inside(logN, n_in, outs_per_wg):
         ctx.close()
 
 
-def test_inner_product_with_narrow_moduli():
-    """the key multiply-accumulate of hm_ntt_inner_product over a caller-chosen chain of 59-, 45- and 40-bit moduli (the lazy product's
-    operand shift and quotient constant depend on the modulus width): evaluation-form operands only (no transform, so no oracle is
-    needed), 4 terms, both keys, extreme operands; expected values from Python integers"""
+@pytest.mark.parametrize("form", ["generic", "mont32"])
+def test_inner_product_with_narrow_moduli(form):
+    """the key multiply-accumulate of hm_ntt_inner_product over a caller-chosen chain of mixed widths (the lazy product's operand shift
+    and quotient constant depend on the modulus width): 59-, 45- and 31-bit primes = 1 mod 2N on the generic back-end (a chain an FHE
+    library would hand over), 59-, 45- and 40-bit primes h 2^32 + 1 on the word-wise Montgomery one.  Evaluation-form operands only (no
+    transform, so no oracle is needed), 4 terms, both keys, extreme operands; expected values from Python integers"""
     from sympy import isprime
     from homulator_amd import hip
     logN, N = 13, 1 << 13
     chain = []
-    for bits in (59, 45, 40, 59, 45, 40):   # (every modulus of a context is 1 mod 2^32)
-        c = (1 << bits) + 1 - (1 << 32)
+    step = 1 << 32 if form == "mont32" else 2 * N
+    for bits in ((59, 45, 40, 59, 45, 40) if form == "mont32" else (59, 45, 31, 59, 45, 31)):
+        c = (1 << bits) + 1 - step
         while not isprime(c) or c in chain:
-            c -= 1 << 32
+            c -= step
             assert c > 1 << (bits - 1)
         chain.append(c)
     ctx = hip.Context(logN, 4, 2, q=chain[:4], p=chain[4:])
     try:
-        assert ctx.moduli == chain
+        assert ctx.moduli == chain and ctx.counter("arith") == (0 if form == "mont32" else 1)
         ids = [0, 1, 2, 3, 4, 5, 2, 2]
         n, terms, outs = len(ids), 4, 2
         rng = np.random.default_rng(11)

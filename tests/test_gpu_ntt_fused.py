@@ -1,8 +1,10 @@
-"""GPU parity of the one-launch transform (k_ntt_fused: both passes in one kernel, the hand-off between them through the XCD's
-L2 behind a per-limb rendezvous) against the two-kernel transform and the CPU oracle, bit for bit.  Covers what the
-rendezvous can get wrong: more limb-polys than the chip holds at once (workgroups of later limbs start while earlier ones
-wait), repeated launches (the rendezvous words reset themselves), in-place transforms, two contexts sharing the chip
-(uneven load), every ring size (2 .. 32 workgroups per limb-poly) and the fused prologue / epilogue variants."""
+"""GPU parity of the one-launch transform (k_ntt_fused8: both passes in one kernel of the small-launch geometry, the hand-off between
+them through the XCD's L2 behind a per-limb rendezvous on XCD-local atomics; the default for launches of up to 96 limb-polys at
+N = 2^16) against the two-kernel transform and the CPU oracle, bit for bit.  Covers what the rendezvous can get wrong: more limb-polys than
+the chip holds at once (workgroups of later limbs start while earlier ones wait), repeated launches (the rendezvous words reset
+themselves), in-place transforms, two contexts sharing the chip (uneven load), the fused prologue / epilogue variants, the agent-scope
+path, a timed-out rendezvous, and both arithmetic back-ends.  (The wide-geometry form of rounds 3 / 4, any ring size, lost every A/B
+and left the tree in round 5.)"""
 import numpy as np
 import pytest
 
@@ -11,73 +13,35 @@ from oracle.homoracle import Oracle
 pytestmark = pytest.mark.gpu
 
 
-def _ctx(logN, L, K):
+def _ctx(logN, L, K, chain="mont32"):
     from homulator_amd import hip
-    return hip.Context(logN, L, K), Oracle(logN, L, K)
-
-
-@pytest.mark.parametrize("logN", [13, 14, 15, 16, 17])
-def test_fused_equals_two_kernel_and_oracle(logN):
-    ctx, o = _ctx(logN, 4, 2)
-    try:
-        ids = [0, 1, 2, 3, 4, 5, 0, 5, 3]
-        x = o.fill_uniform(ids, 77)
-        x[0, :] = o.moduli[ids[0]] - 1          # worst case of the lazy ranges
-        x[1, :3] = [0, 1, o.moduli[ids[1]] - 1]
-        d, a, b = ctx.from_host(x), ctx.alloc(len(ids)), ctx.alloc(len(ids))
-        exp = o.ntt(ids, x)
-        for inverse in (False, True):
-            src = x if not inverse else exp
-            dsrc = ctx.from_host(src)
-            ctx.set_option("ntt_fused", 1)
-            ctx.ntt(dsrc, a, ids, inverse=inverse)
-            ctx.set_option("ntt_fused", 0)
-            ctx.ntt(dsrc, b, ids, inverse=inverse)
-            A, B = a.download(), b.download()
-            assert np.array_equal(A, B)
-            assert np.array_equal(A, o.ntt(ids, src, inverse=inverse))
-            dsrc.free()
-        # merged ModDown + rescale form: mix prologue + sub-scale-add epilogue
-        mn, ad, mx = (o.fill_uniform(ids, s) for s in (124, 125, 126))
-        k = [o.moduli[m] - 2 - r for r, m in enumerate(ids)]
-        mk = [(kk * 3 + 1) % o.moduli[m] for kk, m in zip(k, ids)]
-        ak = [(kk * 5 + 1) % o.moduli[m] for kk, m in zip(k, ids)]
-        dmn, dad, dmx = ctx.from_host(mn), ctx.from_host(ad), ctx.from_host(mx)
-        xin = o.ewe(3, ids, x, None, o.ewe(5, ids, mx, k=mk))
-        exp3 = o.ewe(3, ids, o.ewe(6, ids, mn, None, o.ntt(ids, xin), k=k), None, o.ewe(5, ids, ad, k=ak))
-        for fused in (1, 0):
-            ctx.set_option("ntt_fused", fused)
-            ctx.ntt_mix_sub_scale(d, dmn, a, ids, k, addend=dad, addend_k=ak, mix=dmx, mix_k=mk)
-            assert np.array_equal(a.download(), exp3)
-            ctx.ntt_sub_scale(d, dmn, a, ids, k)
-            assert np.array_equal(a.download(), o.ewe(6, ids, mn, None, o.ntt(ids, x), k=k))
-        assert ctx.counter("ntt_cross_xcd") == 0, "a limb-poly's workgroups were spread over several XCDs (slow path taken: correct, but unexpected)"
-    finally:
-        ctx.close()
+    o = Oracle(logN, L, K, chain=chain)
+    return (hip.Context(logN, L, K) if chain == "mont32" else hip.Context(logN, L, K, q=o.moduli[:L], p=o.moduli[L:])), o
 
 
 def test_more_limbs_than_the_chip_holds_repeated_and_in_place():
-    """700 limb-polys of N = 2^16 = 11 200 workgroups on 1 024 slots: later limbs start while earlier ones sit in their rendezvous;
-    three launches back to back reuse the same rendezvous words; then the inverse in place brings the input back."""
+    """448 limb-polys of N = 2^16 = 7 168 workgroups in ONE one-launch transform (threshold raised to the launch-table size): later
+    limbs start while earlier ones sit in their rendezvous; three launches back to back reuse the same rendezvous words; then the inverse
+    in place brings the input back."""
     ctx, o = _ctx(16, 6, 3)
     try:
-        n = 700
+        n = 448
         ids = [(i * 7) % 9 for i in range(n)]
         src = ctx.alloc(n)
         ctx.fill_uniform(src, ids, 4242)
         x = src.download()
         out, ref = ctx.alloc(n), ctx.alloc(n)
-        ctx.set_option("ntt_fused", 0)
+        ctx.set_option("ntt_fused_small", 0)
         ctx.ntt(src, ref, ids)
         R = ref.download()
-        ctx.set_option("ntt_fused", 1)
+        ctx.set_option("ntt_fused_small", 448)
         for _ in range(3):
             ctx.ntt(src, out, ids)
         assert np.array_equal(out.download(), R)
         ctx.ntt(out, out, ids, inverse=True)
         assert np.array_equal(out.download(), x)
         # a sample of limbs against the oracle (the two-kernel path is compared with it in test_gpu_kernels.py)
-        pick = [0, 1, 350, 699]
+        pick = [0, 1, 224, 447]
         assert np.array_equal(R[pick], o.ntt([ids[i] for i in pick], x[pick]))
         assert ctx.counter("ntt_cross_xcd") == 0
     finally:
@@ -85,8 +49,8 @@ def test_more_limbs_than_the_chip_holds_repeated_and_in_place():
 
 
 def test_two_contexts_share_the_chip():
-    """uneven load: two contexts (own stream each) enqueue one-launch transforms of different sizes alternately; every output is
-    checked against the two-kernel result"""
+    """uneven load: two contexts (own stream each) enqueue one-launch transforms of different sizes alternately (threshold raised so that
+    every size takes the form); every output is checked against the two-kernel result, and no limb-poly may have been spread over XCDs"""
     from homulator_amd import hip
     c1, c2 = hip.Context(16, 6, 3), hip.Context(16, 6, 3)
     try:
@@ -98,19 +62,20 @@ def test_two_contexts_share_the_chip():
             jobs.append((c, ids, s, f, r))
         for c in (c1, c2):
             c.sync()
-        for c in (c1, c2):
-            c.set_option("ntt_fused", 1)
+            c.set_option("ntt_fused_small", 448)
         for rep in range(4):
             for c, ids, s, f, r in jobs:
                 c.ntt(s, f, ids)
         for c in (c1, c2):
             c.sync()
-            c.set_option("ntt_fused", 0)
+            c.set_option("ntt_fused_small", 0)
         for c, ids, s, f, r in jobs:
             c.ntt(s, r, ids)
         for c, ids, s, f, r in jobs:
             assert np.array_equal(f.download(), r.download())
-        # the default one-launch form (k_ntt_fused8) under the same concurrency: two contexts, alternating launches of <= 96 limb-polys
+        # the shipped threshold under the same concurrency: alternating launches of <= 96 limb-polys
+        for c in (c1, c2):
+            c.set_option("ntt_fused_small", 96)
         small = [j for j in jobs if len(j[1]) <= 96]
         for rep in range(6):
             for c, ids, s, f, r in small:
@@ -165,14 +130,15 @@ def test_small_launch_geometry_equals_wide_and_oracle():
         ctx.close()
 
 
-def test_one_launch_small_geometry_equals_two_kernels_and_oracle():
+@pytest.mark.parametrize("chain", ["mont32", "survey"])
+def test_one_launch_small_geometry_equals_two_kernels_and_oracle(chain):
     """launches of up to `ntt_fused_small` limb-polys at N = 2^16 run both passes in ONE launch of the 8-coefficient geometry
     (k_ntt_fused8: the hand-off through the XCD's L2 behind a rendezvous on XCD-local atomics).  The same calls as two kernels
     (option 0) and the oracle must agree bit for bit: forward, inverse in place with a scale, fused epilogue with and without the
     mix prologue, worst-case operands, 1 .. 96 limb-polys (96 = the shipped threshold: 1 536 workgroups, past one round of the chip),
     launches repeated back to back (the rendezvous words return to zero), out of place and in place; no limb-poly may have taken
-    the agent-scope path"""
-    ctx, o = _ctx(16, 6, 3)
+    the agent-scope path; on both arithmetic back-ends"""
+    ctx, o = _ctx(16, 6, 3, chain)
     try:
         assert ctx.counter("ntt_fused_small") == 96, "the shipped default"
         for n in (1, 9, 35, 50, 64, 72, 96):
@@ -215,7 +181,7 @@ def test_agent_scope_path_of_the_rendezvous():
     """the dispatcher has never spread a limb-poly's workgroups over XCDs, so the agent-scope path of the rendezvous (found through the
     XCC-id mask: L2 write-back, second rendezvous on an agent-scope counter, acquire) would never run: the test hook makes the workgroups
     of odd tiles publish another XCC id and nobody accept the XCD-local count.  Results must not change, every limb-poly must be counted
-    as spread, and the words must be back at rest for the next (ordinary) launch — in both geometries"""
+    as spread, and the words must be back at rest for the next (ordinary) launch"""
     ctx, o = _ctx(16, 6, 3)
     try:
         n = 21
@@ -223,8 +189,7 @@ def test_agent_scope_path_of_the_rendezvous():
         x = o.fill_uniform(ids, 991)
         d, a = ctx.from_host(x), ctx.alloc(n)
         exp = o.ntt(ids, x)
-        for wide in (0, 1):
-            ctx.set_option("ntt_fused", wide)
+        for rep in (0, 1):
             before = ctx.counter("ntt_cross_xcd")
             ctx.set_option("ntt_fused_test_spread", 1)
             for _ in range(2):

@@ -2,8 +2,8 @@
 on; the hand-off between the passes stays in that XCD's L2) against the two-kernel transform and the CPU oracle, bit for bit.  Covers
 what the queues can get wrong: every grid size from fewer workgroups than XCDs' worth of items to more workgroups than items, every
 look-ahead and group size (incl. groups that straddle the end of the list), more limb-polys than one launch table holds, repeated
-launches (the last workgroup out resets the queue words), in-place transforms, two contexts sharing the chip, every ring size and the
-fused prologue / epilogue forms, both geometries."""
+launches (the host zeroes the queue words in front of every launch), in-place transforms, two contexts sharing the chip and the
+fused prologue / epilogue forms (N = 2^16, the 8-coefficient geometry: the only form left in round 5, on XCD-local atomics)."""
 import numpy as np
 import pytest
 
@@ -17,8 +17,8 @@ def _ctx(logN, L, K):
     return hip.Context(logN, L, K), Oracle(logN, L, K)
 
 
-@pytest.mark.parametrize("logN", [13, 14, 15, 16, 17])
-@pytest.mark.parametrize("geo", [1, 2])
+@pytest.mark.parametrize("logN", [16])
+@pytest.mark.parametrize("geo", [1])
 def test_queue_equals_two_kernel_and_oracle(logN, geo):
     ctx, o = _ctx(logN, 4, 2)
     try:
@@ -56,7 +56,7 @@ def test_queue_equals_two_kernel_and_oracle(logN, geo):
         ctx.close()
 
 
-@pytest.mark.parametrize("geo", [1, 2])
+@pytest.mark.parametrize("geo", [1])
 def test_grid_sizes_lookahead_and_groups(geo):
     """50 limb-polys (the sweep of the extended basis: does not divide by the 8 queues) and 13, through grids of 8 .. 2048 workgroups,
     look-aheads 1 .. 4 and groups of 1, 2, 3 limb-polys (3 does not divide 50: the last group is padded)"""
@@ -83,7 +83,7 @@ def test_grid_sizes_lookahead_and_groups(geo):
         ctx.close()
 
 
-@pytest.mark.parametrize("geo", [1, 2])
+@pytest.mark.parametrize("geo", [1])
 def test_more_limbs_than_a_launch_table_repeated_and_in_place(geo):
     """700 limb-polys of N = 2^16 (two launches of the 448-entry table); three runs back to back reuse the queue words; then the inverse
     in place (the hand-off lands on the input's own lines) brings the input back"""
@@ -126,7 +126,7 @@ def test_two_contexts_share_the_chip():
         for c in (c1, c2):
             c.sync()
         c1.set_option("ntt_queue", 1)
-        c2.set_option("ntt_queue", 2)
+        c2.set_option("ntt_queue", 1)
         for rep in range(4):
             for c, ids, s, f, r in jobs:
                 c.ntt(s, f, ids)

@@ -14,12 +14,22 @@ SEED = 0x484F4D55
 _oracles = {}
 
 
-def oracle(logN, L, K):
-    key = (logN, L, K)
+def oracle(logN, L, K, chain="mont32"):
+    key = (logN, L, K, chain)
     if key not in _oracles:
-        _oracles[key] = Oracle(logN, L, K)
+        _oracles[key] = Oracle(logN, L, K, chain=chain)
         _oracles[key].set_threads(8)
     return _oracles[key]
+
+
+# The ops run on both arithmetic back-ends: config key `chain_bits` hands the host layer (and hm_create) the largest primes = 1 mod 2N
+# below 2^bits instead of the default chain of primes h 2^32 + 1; 60 = SURVEY.md 8(d)'s chain as written, 36 = 36-bit words as upstream's
+# elementBitWidth models (config/config_4.cfg:9)
+def chain_overrides(chain, base=None):
+    ov = dict(base or {})
+    if chain != "mont32":
+        ov["chain_bits"] = 60 if chain == "survey" else int(chain)
+    return ov or None
 
 
 def inputs(o, ell):
@@ -59,22 +69,26 @@ CASES = [("config_4_N15.cfg", 15, 16, 10, 4), ("config_4_N15.cfg", 15, 8, 8, 8),
          ("config_4.cfg", 16, 45, 35, 15)]
 
 
+@pytest.mark.parametrize("chain", ["mont32", "survey", 36])
 @pytest.mark.parametrize("cfg,logN,L,ell,alpha", CASES)
 @pytest.mark.parametrize("fuse", [False, True, "no_hpip", "no_bconv", "moddown"])
-def test_hmult_bit_exact(cfg, logN, L, ell, alpha, fuse):
+def test_hmult_bit_exact(cfg, logN, L, ell, alpha, fuse, chain):
     """fuse = True is the bench path (ModUp conversion + transforms + key MAC in one C-ABI call: k_bconv_col, k_ntt_row_ip);
     "no_bconv" = the same with the conversion as its own launch (fuse_bconv = 0); "no_hpip" = fused plan with separate ModUp
     transforms and inner product (fuse_hpip = 0)"""
     from homulator_amd import host
-    o = oracle(logN, L, alpha)
+    if chain == 36 and (logN != 15 or fuse not in (False, True)):
+        pytest.skip("the 36-bit chain runs the N = 2^15 configurations unfused and fully fused")
+    o = oracle(logN, L, alpha, chain)
     ct1, ct2, evk = inputs(o, ell)
     ids = list(range(ell))
     hpip = fuse in (True, "no_bconv", "moddown")   # "no_bconv": fused transform x key kernel fed by a separate conversion launch; "moddown": pass 9 on
     mode = fuse
     op = host.Op(cfg, "hmult", L, ell, alpha, fuse=bool(fuse),
-                 overrides={"fuse_hpip": 0} if fuse == "no_hpip" else {"fuse_bconv": 0} if fuse == "no_bconv" else {"fuse_moddown": 1} if fuse == "moddown" else None)
+                 overrides=chain_overrides(chain, {"fuse_hpip": 0} if fuse == "no_hpip" else {"fuse_bconv": 0} if fuse == "no_bconv" else {"fuse_moddown": 1} if fuse == "moddown" else None))
     fuse = bool(fuse)
     op.execute(1)
+    assert op.backend_counter("arith") == (0 if chain == "mont32" else 1)
     assert np.array_equal(op.read("ct1.c0"), ct1[0]) and np.array_equal(op.read("ct2.c1"), ct2[1])
     d0 = o.ewe(0, ids, ct1[0], ct2[0])
     d1 = o.ewe(1, ids, ct1[0], ct2[1], ct1[1], ct2[0])
@@ -123,11 +137,12 @@ def test_hmult_mixed_conversion_launch(fuse):
 
 @pytest.mark.parametrize("cfg,logN,L,ell,alpha", CASES)
 @pytest.mark.parametrize("fuse", [False, True])
-def test_hrotate_bit_exact(cfg, logN, L, ell, alpha, fuse):
+@pytest.mark.parametrize("chain", ["mont32", "survey"])
+def test_hrotate_bit_exact(cfg, logN, L, ell, alpha, fuse, chain):
     from homulator_amd import host
-    o = oracle(logN, L, alpha)
+    o = oracle(logN, L, alpha, chain)
     ct1, _, evk = inputs(o, ell)
-    op = host.Op(cfg, "hrotate", L, ell, alpha, fuse=fuse)
+    op = host.Op(cfg, "hrotate", L, ell, alpha, fuse=fuse, overrides=chain_overrides(chain))
     op.execute(1)
     r0, r1 = o.automorph_eval(ct1[0], 5), o.automorph_eval(ct1[1], 5)
     assert np.array_equal(op.read("AUTOOutput(0)"), r0) and np.array_equal(op.read("AUTOOutput(1)"), r1)
@@ -151,14 +166,15 @@ def test_hrotate_other_galois_element():
     op.close()
 
 
+@pytest.mark.parametrize("chain", ["mont32", "survey"])
 @pytest.mark.parametrize("cfg,logN,L,ell,alpha", [("config_4_N15.cfg", 15, 16, 10, 4), ("config_4.cfg", 16, 45, 35, 15)])
-def test_hadd_pmult_padd_bit_exact(cfg, logN, L, ell, alpha):
+def test_hadd_pmult_padd_bit_exact(cfg, logN, L, ell, alpha, chain):
     from homulator_amd import host
-    o = oracle(logN, L, alpha)
+    o = oracle(logN, L, alpha, chain)
     ct1, ct2, _ = inputs(o, ell)
     pt = o.fill_uniform(list(range(ell)), SEED + 4000)
     for name, exp in (("hadd", o.hadd(ell, ct1, ct2)), ("pmult", o.pmult(ell, ct1, pt)), ("padd", o.padd(ell, ct1, pt))):
-        op = host.Op(cfg, name, L, ell, alpha)
+        op = host.Op(cfg, name, L, ell, alpha, overrides=chain_overrides(chain))
         op.execute(1)
         assert np.array_equal(op.read("out.c0"), exp[0]), name
         assert np.array_equal(op.read("out.c1"), exp[1]), name
