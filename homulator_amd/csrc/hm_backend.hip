@@ -9,6 +9,7 @@
 #include <cstring>
 #include <map>
 #include <tuple>
+#include <type_traits>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -345,182 +346,10 @@ __global__ void __launch_bounds__((1 << HM_TL_ROW) / 8) k_ntt_fused8(HmNttArgs a
   hm_ntt_fused_body<8, INV, MODE_A, MODE_B, Geo8, NTIN ? 2 : 0>(a, f);
 }
 
-// ---- both passes of a transform in ONE persistent launch, fed from per-XCD work queues (round 4) ----------------------------------
-// What round 4's counters say about the hand-off between the passes (profiles/r04_l2_handoff.txt): the XCD's L2 is WRITE-BACK for plain
-// stores — with at most ~3 MiB live per L2 the first pass's stores never reach the fabric when the second pass's final stores land on the
-// same lines (WRITE_SIZE halves) — and the second pass's loads of the hand-off HIT (TCC_MISS falls by exactly the hand-off's line count);
-// a line that was allocated by a store is still filled from the fabric once when it is first read (TCC_EA0_RDREQ keeps the hand-off's
-// lines), unless it was resident before the store: a transform IN PLACE (in == out) moves each limb-poly across the fabric twice, not four
-// times.  Round 3's one-launch kernel could not show it: a workgroup per tile with a rendezvous in the middle keeps 8 limb-polys in flight
-// per XCD (12 MiB through a 4 MiB L2) and idles every slot at the rendezvous.
-//
-// Here the grid is PERSISTENT (a few workgroups per CU, the launch decides how many) and every workgroup pulls work items from the queue of
-// the XCD it really runs on (HW_REG_XCC_ID):
-//   * an item = one pass over one 4096-coefficient tile of one limb-poly; a queue's items come in blocks of (group of Gc same-modulus
-//     limb-polys) x (tiles), in the order  A(0) .. A(LA-1), B(0), A(LA), B(1), A(LA+1), ...  (A = first pass, B = second pass, LA = look-ahead
-//     in groups): the second pass of a group is handed out when its first pass finished LA blocks ago, so nobody waits in steady state, and
-//     at most LA + (workgroups in flight / tiles) groups are between their passes: the hand-off stays in the L2;
-//   * a queue's slot s gets its group from a global counter when its first item is pulled: limb-polys are dealt to the XCDs on demand (the
-//     50 limb-polys of a sweep do not divide by 8), and ALL items of a limb-poly run on ONE XCD by construction — whatever the dispatcher does
-//     with the grid, the hand-off never crosses XCDs (no agent-scope path, no placement assumption); an XCD without workgroups takes nothing;
-//   * a waiting workgroup only ever waits for items that running workgroups have already pulled: no residency assumption either.
-// Hand-off protocol (same as k_ntt_fused's same-XCD path): plain stores, every storing wave s_waitcnt vmcnt(0), workgroup barrier, one lane
-// adds to the limb-poly's counter; the consumer polls that counter (agent-scope relaxed load), barrier, then reads the hand-off with loads
-// that bypass its CU's vector L1 (sc1 / nt), which another CU's stores never refresh.
-// Round 5: the queue's control words live in the owning XCD's L2 too.  Round 4's form pulled, claimed and polled at agent scope — two
-// dependent round trips to memory in front of every item's first load (the L2s of the eight XCDs are not coherent with each other) — and
-// measured 0.59-0.65 us per limb-NTT against 0.47-0.51 for two kernels.  All items of a queue run on ONE XCD by construction, so every word
-// of a queue (the item counter, the slot -> group words, the per-limb-poly "first pass stored" counters) is touched by that XCD only and
-// can be served by its L2: returning atomics without the agent-scope bit.  Only the counter that deals groups to XCDs is shared
-// (agent scope, once per group and XCD).  Words of different XCDs never share a 128-byte line.  The NEXT item is pulled while the
-// current one is being transformed (the pull's latency hides behind the pass).  Nobody resets the words in the kernel (the XCD that owns
-// a line would have to): the host zeroes the structure with a memset node in front of every launch.
-#define HM_Q_MAX_SLOTS (HM_NTT_MAX_ENTRIES + 32)
-#define HM_Q_NONE 0xFFFFFFFFu
-#define HM_Q_SPIN_LIMIT (1u << 20)   // a queue wait that long is a bug, reported through the context
-struct HmNttQueue {                  // device; zeroed by the host before every launch
-  unsigned next_group, pad0[31];           // agent scope: deals groups to the XCDs on demand (own line)
-  struct Xcd {
-    unsigned next_item, pad[31];           // XCD-local (own line)
-    unsigned slot_group[HM_Q_MAX_SLOTS];   // XCD-local: 0 = unclaimed, 1 = being claimed, else group + 2 (HM_Q_NONE: no group left)
-    unsigned pad2[32 - HM_Q_MAX_SLOTS % 32];
-  } xcd[8];
-  struct Done { unsigned n, pad[31]; } first_done[HM_NTT_MAX_ENTRIES];   // XCD-local, a line per limb-poly: tiles whose first pass has been stored
-};
-static_assert(sizeof(HmNttQueue::Xcd) % 128 == 0, "queue words of different XCDs never share a line");
-struct HmNttQueueArgs {
-  HmNttQueue *q;
-  unsigned *err;          // host-visible: 3 = a queue wait timed out
-  uint32_t n_groups;      // groups of `gc` consecutive entries of HmNttArgs::limb (dense: entry = group * gc + member)
-  uint32_t gc;            // limb-polys per group (same modulus: their tiles are handed out side by side and share the row twiddles in L2)
-  uint32_t lookahead;     // LA >= 1
-};
-#ifndef HM_Q_IN_AUX
-#define HM_Q_IN_AUX 0     // cache policy of the first pass's input loads (2 = nt: streamed once)
-#endif
-#ifndef HM_Q_OUT_AUX
-#define HM_Q_OUT_AUX 0    // ... of the second pass's output stores
-#endif
-#ifndef HM_Q_MID_AUX
-#define HM_Q_MID_AUX 16   // the hand-off loads: sc1 (L1 bypass, served by the XCD's L2)
-#endif
-// 32-bit atomics executed in the L2 of the XCD the wave runs on (no sc1: not agent scope); the loads are atomic ORs of zero (a plain
-// load with workgroup scope may be served by the CU's vector L1, which another CU's atomics never refresh)
-__device__ __forceinline__ unsigned hm_l2_add32(unsigned *p, unsigned v) {
-  unsigned old;
-  asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(old) : "v"(p), "v"(v) : "memory");
-  return old;
-}
-__device__ __forceinline__ void hm_l2_add32_noret(unsigned *p, unsigned v) { asm volatile("global_atomic_add %0, %1, off" ::"v"(p), "v"(v) : "memory"); }
-__device__ __forceinline__ unsigned hm_l2_load32(unsigned *p) { return hm_l2_add32(p, 0u); }
-__device__ __forceinline__ unsigned hm_l2_swap32(unsigned *p, unsigned v) {
-  unsigned old;
-  asm volatile("global_atomic_swap %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(old) : "v"(p), "v"(v) : "memory");
-  return old;
-}
-__device__ __forceinline__ unsigned hm_l2_cas32(unsigned *p, unsigned expect, unsigned desired) {   // returns the old value
-  unsigned old;
-  unsigned long long pair = ((unsigned long long)expect << 32) | desired;   // data = {new, compare}
-  asm volatile("global_atomic_cmpswap %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(old) : "v"(p), "v"(pair) : "memory");
-  return old;
-}
-// group of slot s on this XCD's queue (claimed from the global counter by whoever needs it first; claims are made in slot order, so the
-// groups of a queue increase with s and "no group left" is final)
-__device__ __forceinline__ unsigned hm_q_slot_group(HmNttQueue *Q, HmNttQueue::Xcd *x, unsigned s, unsigned n_groups, unsigned *err) {
-  if (s >= HM_Q_MAX_SLOTS) return HM_Q_NONE;
-  unsigned v = hm_l2_load32(&x->slot_group[s]);
-  unsigned spins = 0;
-  while (v < 2) {
-    if (v == 0) {
-      if (s > 0) {   // in slot order
-        while (hm_l2_load32(&x->slot_group[s - 1]) < 2) { __builtin_amdgcn_s_sleep(1); if (++spins > HM_Q_SPIN_LIMIT) { __hip_atomic_store(err, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return HM_Q_NONE; } }
-      }
-      if (hm_l2_cas32(&x->slot_group[s], 0u, 1u) == 0u) {
-        const unsigned g = __hip_atomic_fetch_add(&Q->next_group, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        v = g < n_groups ? g + 2 : HM_Q_NONE;
-        (void)hm_l2_swap32(&x->slot_group[s], v);
-        return v;
-      }
-    }
-    __builtin_amdgcn_s_sleep(1);
-    if (++spins > HM_Q_SPIN_LIMIT) { __hip_atomic_store(err, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return HM_Q_NONE; }
-    v = hm_l2_load32(&x->slot_group[s]);
-  }
-  return v;
-}
-// MODE_A: first pass (0, or 4 = mix prologue); MODE_B: last pass (1 forward, 3 fused epilogue, 2 inverse)
-template <int LOG1, bool INV, int MODE_A, int MODE_B, class GEO>
-__device__ __forceinline__ void hm_ntt_queue_body(const HmNttArgs &a, const HmNttQueueArgs &f) {
-  static_assert(HM_TL_COL == HM_TL_ROW, "one tile size for both passes");
-  constexpr int TL = HM_TL_ROW;
-  constexpr int W1 = GEO::template ldsWords<TL, LOG1, true>(), W2 = GEO::template ldsWords<TL, HM_ROW_LOG, false>();
-  __shared__ __attribute__((aligned(16))) uint64_t lds[W1 > W2 ? W1 : W2];
-  __shared__ uint32_t ctl[4];   // [0] entry (HM_Q_NONE: leave, NONE - 1: skip), [1] tile, [2] pass
-  const uint32_t tiles = 1u << (a.logN - TL);
-  const uint32_t per_block = tiles * f.gc;
-  HmNttQueue *Q = f.q;
-  HmNttQueue::Xcd *x = &Q->xcd[hm_xcc_id()];
-  // item index -> (slot, pass, member, tile); published through LDS by lane 0
-  auto decode = [&](unsigned i) {
-    const unsigned j = i / per_block, w = i % per_block;
-    unsigned second, s;
-    if (j < f.lookahead) { second = 0; s = j; }
-    else { const unsigned m = j - f.lookahead; second = (m & 1u) ^ 1u; s = second ? m / 2 : f.lookahead + m / 2; }
-    const unsigned v = hm_q_slot_group(Q, x, s, f.n_groups, f.err);
-    unsigned entry = HM_Q_NONE;
-    if (v != HM_Q_NONE) {
-      entry = (v - 2) * f.gc + w % f.gc;
-      if (entry >= a.n_limbs || a.limb[entry].mod == HM_NTT_NONE) entry = HM_Q_NONE - 1;   // padding of the last group
-    } else if (!second) entry = HM_Q_NONE - 1;   // a first-pass block beyond the last group: later blocks may still hold second passes
-    ctl[0] = entry; ctl[1] = w / f.gc; ctl[2] = second;
-  };
-  unsigned pulled = 0;   // lane 0: the item pulled ahead
-  if (threadIdx.x == 0) decode(hm_l2_add32(&x->next_item, 1u));
-#pragma unroll 1
-  for (;;) {
-    __syncthreads();
-    // wave-uniform by construction: scalar registers (as VGPR values they made every descriptor and branch below look divergent)
-    const uint32_t entry = __builtin_amdgcn_readfirstlane(ctl[0]), tile = __builtin_amdgcn_readfirstlane(ctl[1]), second = __builtin_amdgcn_readfirstlane(ctl[2]);
-    __syncthreads();   // ctl is rewritten below; the passes start with their own LDS traffic
-    if (entry == HM_Q_NONE) break;
-    // the next item is pulled now: the round trip hides behind this item's pass (workgroup-scope atomic = no agent-scope bit: served by
-    // the XCD's L2; the compiler places the wait where the value is first used, at the bottom of the loop)
-    if (threadIdx.x == 0) pulled = __hip_atomic_fetch_add(&x->next_item, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    if (entry != HM_Q_NONE - 1) {
-      // a thread id the compiler cannot connect across the items (see hm_ntt_fused_body)
-      int tid = threadIdx.x;
-      asm volatile("" : "+v"(tid));
-      __builtin_assume(tid >= 0 && tid < (1 << TL) / GEO::EPT);
-      if (!second) {
-        if (!INV) hm_ntt_pass_run<LOG1, true, false, MODE_A, HM_Q_IN_AUX, 0, HM_EPI_CHUNK, GEO>(a, lds, entry, tile, tid);
-        else hm_ntt_pass_run<HM_ROW_LOG, false, true, MODE_A, HM_Q_IN_AUX, 0, HM_EPI_CHUNK, GEO>(a, lds, entry, tile, tid);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave: its stores have reached the L2
-        __syncthreads();
-        if (threadIdx.x == 0) hm_l2_add32_noret(&Q->first_done[entry].n, 1u);
-      } else {
-        // all first passes of the limb-poly are stored: waited for inside the pass, behind its first twiddle requests
-        auto wait = [&] {
-          if (threadIdx.x == 0) {
-            unsigned spins = 0;
-            while (hm_l2_load32(&Q->first_done[entry].n) < tiles) {
-              __builtin_amdgcn_s_sleep(1);
-              if (++spins > HM_Q_SPIN_LIMIT) { __hip_atomic_store(f.err, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
-            }
-          }
-          __syncthreads();
-        };
-        if (!INV) hm_ntt_pass_run<HM_ROW_LOG, false, false, MODE_B, HM_Q_MID_AUX, HM_Q_OUT_AUX, 1, GEO>(a, lds, entry, tile, tid, wait);
-        else hm_ntt_pass_run<LOG1, true, true, MODE_B, HM_Q_MID_AUX, HM_Q_OUT_AUX, HM_EPI_CHUNK, GEO>(a, lds, entry, tile, tid, wait);
-      }
-    }
-    if (threadIdx.x == 0) decode(pulled);
-  }   // (the barriers at the top of the loop keep the next item's LDS writes behind this item's last reads)
-}
-// (8-coefficient geometry, N = 2^16; the 16-coefficient form of round 4 was slower in every measurement and is gone)
-template <bool INV, int MODE_A, int MODE_B>
-__global__ void __launch_bounds__((1 << HM_TL_ROW) / 8) k_ntt_queue8(HmNttArgs a, HmNttQueueArgs f) {
-  hm_ntt_queue_body<8, INV, MODE_A, MODE_B, Geo8>(a, f);
-}
+// (Rounds 4 / 5 also built both passes as ONE persistent launch fed from per-XCD work queues — k_ntt_queue8: items of a limb-poly on one XCD
+// by construction, the hand-off in that XCD's L2, round 5 with every control word on XCD-local atomics and pulls ahead.  It keeps the
+// hand-off resident only at a look-ahead where second passes wait for first passes (-24 % fabric traffic, +27 % time) and loses 14 % at
+// the look-ahead where nobody waits, because the L2 then no longer holds the hand-off: profiles/r05_ntt_queue.txt.  Removed in round 5.)
 
 // ---- K1 x K5: last transform pass x evaluation key, both keys, all digits of one extended limb in one workgroup ---------
 #define HM_NIP_MAX_TERMS 4
@@ -532,14 +361,16 @@ struct HmNipLimb {                       // 32 bytes
   uint16_t y[HM_NIP_MAX_OUT][HM_NIP_MAX_TERMS];
   uint16_t out[HM_NIP_MAX_OUT];
   uint16_t mod;                          // HM_NTT_NONE: empty slot
-  uint16_t coeff_mask;                   // bit j: digit j goes through the transform (its x limb is relative to `hand`)
-};
+  uint16_t coeff_mask;                   // bit j: digit j goes through the transform (its x limb is relative to `hand`); bit 15 (HM_NIP_INV_OUT):
+};                                       // the outputs leave as the first pass of their INVERSE transform (round 5)
+#define HM_NIP_INV_OUT 0x8000u
 struct HmNipArgs {
   const uint64_t *hand;   // first-pass hand-off (written by k_ntt_col just before)
   const uint64_t *x;      // evaluation-form operands (a digit's own limbs)
   const uint64_t *y;      // evaluation key
   uint64_t *out;
   const HmW *tw, *twist;
+  const HmW *tw_inv, *twist_inv;   // inverse tables (HM_NIP_INV_OUT limbs)
   const HmMod *mods;
   uint32_t logN, n_limbs, logG, n_terms;
   const HmNipLimb *limb;  // device, [n_limbs]
@@ -565,7 +396,10 @@ typedef const HmNipLimb __attribute__((address_space(4))) *HmConstNipLimb;
 #ifndef HM_NIP_ST_AUX
 #define HM_NIP_ST_AUX 0
 #endif
-template <int OUTS>
+// INVOUT (round 5): 0 = no limb of the launch hands its outputs over as the first pass of their inverse transform (HM_NIP_INV_OUT), 1 = all of
+// them do, 2 = per limb (the record says).  mont32 runs a mixed launch as ONE kernel (2: 155 VGPRs); in the generic build that form spills
+// (the Shoup twiddles take twice the registers), so there the two kinds of limbs are two launches (0 and 1).
+template <int OUTS, int INVOUT>
 __global__ void __launch_bounds__((1 << HM_TL_ROW) / HM_EPT) __attribute__((amdgpu_waves_per_eu(HM_NIP_WAVES))) k_ntt_row_ip(HmNipArgs a) {
   constexpr int TL = HM_TL_ROW, LOGR = HM_ROW_LOG, R2 = HmRounds<LOGR>::n - 1;
   __shared__ __attribute__((aligned(16))) uint64_t lds[HmLds<TL, LOGR, false>::WORDS];
@@ -639,6 +473,33 @@ __global__ void __launch_bounds__((1 << HM_TL_ROW) / HM_EPT) __attribute__((amdg
   uint64_t *out[OUTS];
 #pragma unroll
   for (int k = 0; k < OUTS; ++k) out[k] = a.out + (size_t)rec->out[k] * N;
+  if (INVOUT == 1 || (INVOUT == 2 && (mask & HM_NIP_INV_OUT))) {   // wave-uniform
+    // Round 5 (InnerProOut -> ModDownINTTOut, src/Operation.cpp:294-445): the special limbs of the key-switch sum are only ever read by
+    // the ModDown's inverse transform, whose first pass is a ROW pass over exactly this workgroup's 16 rows.  The reduced accumulators
+    // sit in the registers of the forward ROW pass's last round, which is the inverse ROW pass's first: the inverse pass runs from
+    // them (key 0, then key 1, on the tile this workgroup owns) and stores its hand-off where the ModDown INTT launch runs the
+    // remaining COL pass (hm_ntt_second_pass); InnerProduceOut_Key{k}'s special limbs are never written or read back.
+    const HmW *twl_i = a.tw_inv + (size_t)mod * N;
+    const HmW *twt_i = a.twist_inv + ((size_t)mod * (N >> LOGR) + prefix0) * 3;
+    // (straight-line code for the two keys: a loop with barriers inside is not unrolled and the accumulators end up in scratch)
+    auto inverse_first_pass = [&](auto KK) {
+      constexpr int k = decltype(KK)::value;
+      HmNttState st;
+#pragma unroll
+      for (int i = 0; i < HM_EPT; ++i) st.v[i] = hm_mac_final(acc[k][i], m);
+      int tid = threadIdx.x;
+      asm volatile("" : "+v"(tid));   // (lane offsets recomputed per pass, as in the digit loop)
+      __builtin_assume(tid >= 0 && tid < (1 << HM_TL_ROW) / HM_EPT);
+      __syncthreads();   // the previous pass's last round has read the tile
+      const HmTw sc = {0, 0};
+      const HmEpi ep = hm_epi_none();
+      int nsync = 0;
+      hm_ntt_pass_phases<TL, LOGR, false, true, 0, 0, 0, HM_EPI_CHUNK, true>(st, tid, lds, nullptr, out[k], tile, twl_i, twt_i, s0, prefix0, m.q, sc, ep, [&] { hm_pass_sync<false>(nsync++); });
+    };
+    inverse_first_pass(std::integral_constant<int, 0>());
+    if constexpr (OUTS == 2) inverse_first_pass(std::integral_constant<int, 1>());
+    return;
+  }
   hm_ph_mac_store<TL, LOGR, R2, OUTS, Acc, HM_NIP_ST_AUX>(acc, threadIdx.x, out, tile, m);
 }
 
@@ -842,10 +703,7 @@ struct hm_ctx {
   bool fused_broken = false;        // a rendezvous timed out: no one-launch transforms any more, graphs that hold one refuse to replay
   bool capture_has_fused = false;   // the capture in progress recorded a one-launch transform
   uint32_t fused_small = 96;  // launches of up to this many entries (N = 2^16) run as ONE launch in the small-launch geometry (k_ntt_fused8): 2-5 us faster than two kernels up to ~100 limb-polys, slower from 128 (tools/ntt_fused_small_ab.py); 0 = off
-  // persistent two-pass transform fed from per-XCD queues (k_ntt_queue): 0 off, 1 = 8-coefficient geometry (N = 2^16), 2 = 16-coefficient
-  uint32_t queue_ntt = 0, queue_wgs = 0 /* workgroups of the grid; 0 = 2 (geometry 8) or 4 (16) per CU */, queue_la = 2, queue_gc = 0 /* 0 = auto */;
   uint32_t bcol_outs = 0;   // output limbs per workgroup of the fused conversion + first pass (1 | 2; 0 = by launch size)
-  HmNttQueue *ntt_q = nullptr;
   int n_cu = 256;
   // multi-GPU
   int rank = 0, world = 1;
@@ -971,8 +829,6 @@ extern "C" hm_status hm_create(hm_ctx **out, const hm_params *p) {
   HM_HIP(nullptr, hipMemcpy(cc->d_mods, cc->P.modc.data(), sizeof(HmMod) * M, hipMemcpyHostToDevice));
   HM_HIP(nullptr, hipMalloc(&cc->ntt_ws, sizeof(HmNttSync)));
   HM_HIP(nullptr, hipMemset(cc->ntt_ws, 0, sizeof(HmNttSync)));
-  HM_HIP(nullptr, hipMalloc(&cc->ntt_q, sizeof(HmNttQueue)));
-  HM_HIP(nullptr, hipMemset(cc->ntt_q, 0, sizeof(HmNttQueue)));
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, cc->device) == hipSuccess && prop.multiProcessorCount > 0) cc->n_cu = prop.multiProcessorCount;
@@ -996,10 +852,6 @@ extern "C" hm_status hm_create(hm_ctx **out, const hm_params *p) {
     if (slots < (cc->P.N >> HM_TL_ROW)) cc->fused_small = 0;
   }
   if (const char *e = getenv("HOMULATOR_BCOL_OUTS")) cc->bcol_outs = (uint32_t)std::min(2, std::max(0, atoi(e)));
-  if (const char *e = getenv("HOMULATOR_NTT_QUEUE")) cc->queue_ntt = (uint32_t)std::min(1, std::max(0, atoi(e)));
-  if (const char *e = getenv("HOMULATOR_NTT_QUEUE_WGS")) cc->queue_wgs = (uint32_t)std::min(8192, std::max(0, atoi(e)));
-  if (const char *e = getenv("HOMULATOR_NTT_QUEUE_LA")) cc->queue_la = (uint32_t)std::min(16, std::max(1, atoi(e)));
-  if (const char *e = getenv("HOMULATOR_NTT_QUEUE_GROUP")) cc->queue_gc = (uint32_t)std::min(8, std::max(0, atoi(e)));
   HM_HIP(nullptr, hipHostMalloc(reinterpret_cast<void **>(&cc->err_host), 64, hipHostMallocMapped));
   memset(cc->err_host, 0, 64);
   HM_HIP(nullptr, hipHostGetDevicePointer(reinterpret_cast<void **>(&cc->err_dev), cc->err_host, 0));
@@ -1027,7 +879,6 @@ extern "C" void hm_destroy(hm_ctx *c) {
   (void)hipFree(c->d_twist_inv);
   (void)hipFree(c->d_mods);
   (void)hipFree(c->ntt_ws);
-  (void)hipFree(c->ntt_q);
   (void)hipHostFree(c->err_host);
   if (c->xstream) { (void)hipStreamSynchronize(c->xstream); (void)hipStreamDestroy(c->xstream); }
   if (c->xdep) (void)hipEventDestroy(c->xdep);
@@ -1090,12 +941,10 @@ static hm_status check_device_error(hm_ctx *c) {
     c->fused_broken = true;   // graphs captured with one-launch transforms inside refuse to replay (hm_graph_launch)
     (void)hipStreamSynchronize(c->stream);
     (void)hipMemsetAsync(c->ntt_ws, 0, sizeof(HmNttSync), c->stream);
-    (void)hipMemsetAsync(c->ntt_q, 0, sizeof(HmNttQueue), c->stream);
-    c->queue_ntt = 0;
     (void)hipStreamSynchronize(c->stream);
     const char *why = code == 1 ? "XCD-local rendezvous: the workgroups of a limb-poly were not co-resident"
                     : code == 2 ? "agent-scope rendezvous of a limb-poly spread over XCDs"
-                                : "work-queue wait";
+                                : "unknown";
     return fail(c, HM_ERR_HIP, "one-launch transform: wait %u timed out (%s); results of the last launches are invalid, the context now uses two-kernel transforms and refuses to replay graphs that hold one-launch transforms", code, why);
   }
   return HM_OK;
@@ -1161,10 +1010,6 @@ extern "C" hm_status hm_set_option(hm_ctx *c, const char *name, uint64_t value) 
     return HM_OK;
   }
   if (!strcmp(name, "bconv_col_outs")) { if (value > 2) return fail(c, HM_ERR_ARG, "hm_set_option: bconv_col_outs is 0 (by launch size), 1 or 2"); c->bcol_outs = (uint32_t)value; return HM_OK; }
-  if (!strcmp(name, "ntt_queue")) { if (value > 1) return fail(c, HM_ERR_ARG, "hm_set_option: ntt_queue is 0 or 1"); c->queue_ntt = (uint32_t)value; return HM_OK; }
-  if (!strcmp(name, "ntt_queue_wgs")) { if (value > 8192) return fail(c, HM_ERR_ARG, "hm_set_option: ntt_queue_wgs above 8192"); c->queue_wgs = (uint32_t)value; return HM_OK; }
-  if (!strcmp(name, "ntt_queue_lookahead")) { if (value < 1 || value > 16) return fail(c, HM_ERR_ARG, "hm_set_option: ntt_queue_lookahead in [1,16]"); c->queue_la = (uint32_t)value; return HM_OK; }
-  if (!strcmp(name, "ntt_queue_group")) { if (value > 8) return fail(c, HM_ERR_ARG, "hm_set_option: ntt_queue_group in [0,8]"); c->queue_gc = (uint32_t)value; return HM_OK; }
   if (!strcmp(name, "ntt_small_mode")) { c->small_mode = (uint32_t)value & 3u; return HM_OK; }
   if (!strcmp(name, "ntt_small_limbs")) { c->small_ept8 = value != 0; c->small_limbs = (uint32_t)value; return HM_OK; }
   return fail(c, HM_ERR_ARG, "hm_set_option: unknown option %s", name);
@@ -1402,73 +1247,6 @@ static hm_status ntt_common(hm_ctx *c, const char *what, const uint64_t *in, con
     if (f.addend_k && f.addend_k[g] == 0) return fail(c, HM_ERR_ARG, "%s: addend_k[%u] is zero (pass addend = NULL instead)", what, g);
   }
   HM_HIP(c, hipSetDevice(c->device));
-  // persistent two-pass transform from per-XCD queues (k_ntt_queue); the 8-coefficient geometry exists for N = 2^16
-  if (c->queue_ntt && c->P.logN == 16 && !f.firstPassOnly && !f.secondPassOnly) {
-    // dense entry list, same-modulus limb-polys adjacent (their tiles are handed out side by side: one fetch of the row twiddles per group)
-    std::vector<uint32_t> order(n);
-    for (uint32_t i = 0; i < n; ++i) order[i] = i;
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return mod_ids[x] < mod_ids[y]; });
-    uint32_t gc = c->queue_gc;
-    if (!gc) {   // auto: pairs when (nearly) every modulus of a large launch comes at least twice
-      std::map<uint32_t, uint32_t> cnt;
-      for (uint32_t i = 0; i < n; ++i) cnt[mod_ids[i]]++;
-      size_t paired = 0;
-      for (auto &kv : cnt) paired += kv.second / 2 * 2;
-      gc = (n >= 64 && paired * 8 >= (size_t)n * 7) ? 2 : 1;
-    }
-    const uint32_t maxE = HM_NTT_MAX_ENTRIES / gc * gc;
-    for (uint32_t base = 0; base < n; base += maxE) {
-      const uint32_t cnt = std::min(maxE, n - base);
-      std::vector<HmNttEntry> tab(cnt);
-      memset(tab.data(), 0, sizeof(HmNttEntry) * cnt);
-      HmNttArgs a;
-      for (uint32_t e = 0; e < cnt; ++e) {
-        const uint32_t g = order[base + e], m = mod_ids[g];
-        const uint64_t q = c->P.mod[m];
-        HmNttEntry &t = tab[e];
-        a.limb[e] = HmLimb{(uint16_t)limb_at(in_limbs, g), (uint16_t)limb_at(out_limbs, g), (uint16_t)m, 0};
-        if (inverse) {
-          uint64_t v = c->P.modc[m].ninv;
-          if (k) v = hm::mulmod(v, k[g], q);
-          t.sc = hm_kconst(v, q);
-        } else if (fused) {
-          t.sc = hm_kconst(k[g], q);
-          a.limb[e].aux = (uint16_t)limb_at(f.minuend_limbs, g);
-          t.alimb = f.addend_limbs && f.addend_limbs[g] == HM_NO_LIMB ? (uint16_t)HM_NTT_NONE : (uint16_t)limb_at(f.addend_limbs, g);
-          if (f.addend_k) t.ak = hm_kconst(f.addend_k[g], q);
-          if (f.mix) {
-            t.mixlimb = (uint16_t)limb_at(f.mix_limbs, g);
-            t.mixk = hm_kconst(f.mix_k[g], q);
-          }
-        }
-      }
-      const HmNttEntry *dtab = nullptr;
-      if (inverse || fused) {
-        if ((st = ntt_table(c, tab, &dtab))) return st;
-      }
-      a.in = in; a.out = out;
-      a.tw = inverse ? c->d_tw_inv : c->d_tw_fwd;
-      a.twist = inverse ? c->d_twist_inv : c->d_twist_fwd;
-      a.mods = c->d_mods;
-      a.entry = dtab;
-      a.minuend = f.minuend; a.addend = f.addend; a.mix = f.mix;
-      a.logN = c->P.logN; a.n_limbs = cnt; a.logG = 0;
-      HmNttQueueArgs qa;
-      qa.q = c->ntt_q; qa.err = c->err_dev; qa.gc = gc; qa.n_groups = (cnt + gc - 1) / gc; qa.lookahead = c->queue_la;
-      const uint32_t items = 2 * qa.n_groups * gc * (c->P.N >> HM_TL_ROW);
-      uint32_t wgs = c->queue_wgs ? c->queue_wgs : (uint32_t)c->n_cu * 2u;
-      wgs = std::max(8u, std::min(wgs, items));
-      const bool mixPro = fused && f.mix;
-      const dim3 grid(wgs), block((1 << HM_TL_ROW) / 8);
-      HM_HIP(c, hipMemsetAsync(c->ntt_q, 0, sizeof(HmNttQueue), c->stream));   // every word is owned by one XCD's L2 during the launch: only the host resets them
-      if (inverse) hipLaunchKernelGGL((k_ntt_queue8<true, 0, 2>), grid, block, 0, c->stream, a, qa);
-      else if (mixPro) hipLaunchKernelGGL((k_ntt_queue8<false, 4, 3>), grid, block, 0, c->stream, a, qa);
-      else if (fused) hipLaunchKernelGGL((k_ntt_queue8<false, 0, 3>), grid, block, 0, c->stream, a, qa);
-      else hipLaunchKernelGGL((k_ntt_queue8<false, 0, 1>), grid, block, 0, c->stream, a, qa);
-      HM_HIP(c, hipGetLastError());
-    }
-    return HM_OK;
-  }
   // group limb-polys that share a modulus (see hm_block_map): G = the largest of 8, 4, 2 for which at least 7 of 8 limb-polys
   // of the call fall into full same-modulus groups (a batch of 10 ops x 2 keys has 20 limb-polys per modulus, a 50-limb sweep
   // of the extended basis one: G = 2 then costs nothing); leftovers of a modulus share groups with other leftovers
@@ -1477,7 +1255,7 @@ static hm_status ntt_common(hm_ctx *c, const char *what, const uint64_t *in, con
   uint32_t logG = 1;
   // a call that will run as ONE launch (k_ntt_fused8) takes single limb-polys as groups: a kernel then has at most 15 workgroups per XCD
   // waiting for siblings that have no slot yet (launch_ntt), and the 50-limb sweep 56 entries instead of 64
-  if (c->P.logN == 16 && c->fused_small && !c->queue_ntt && !f.firstPassOnly && !f.secondPassOnly &&
+  if (c->P.logN == 16 && c->fused_small && !f.firstPassOnly && !f.secondPassOnly &&
       (n + 7) / 8 * 8 <= c->fused_small) logG = 0;
 #ifndef HM_NTT_MAX_LOGG
 #define HM_NTT_MAX_LOGG 3
@@ -1574,6 +1352,16 @@ extern "C" hm_status hm_ntt(hm_ctx *c, const uint64_t *in, const uint32_t *in_li
   if (!in || !out) return fail(c, HM_ERR_ARG, "hm_ntt: null buffer");
   if (scale && !inverse) return fail(c, HM_ERR_ARG, "hm_ntt: scale is only defined for the inverse transform");
   return ntt_common(c, "hm_ntt", in, in_limbs, out, out_limbs, mod_ids, n, inverse, scale, NttFused{});
+}
+
+extern "C" hm_status hm_ntt_second_pass(hm_ctx *c, uint64_t *buf, const uint32_t *limbs, const uint32_t *mod_ids, uint32_t n, int inverse,
+                                        const uint64_t *scale) {
+  if (!c) return HM_ERR_ARG;
+  if (!buf) return fail(c, HM_ERR_ARG, "hm_ntt_second_pass: null buffer");
+  if (scale && !inverse) return fail(c, HM_ERR_ARG, "hm_ntt_second_pass: scale is only defined for the inverse transform");
+  NttFused f;
+  f.secondPassOnly = true;
+  return ntt_common(c, "hm_ntt_second_pass", buf, limbs, buf, limbs, mod_ids, n, inverse, scale, f);
 }
 
 extern "C" hm_status hm_ntt_sub_scale(hm_ctx *c, const uint64_t *in, const uint32_t *in_limbs, const uint64_t *minuend,
@@ -1810,6 +1598,10 @@ extern "C" hm_status hm_ntt_inner_product(hm_ctx *c, const hm_ntt_ip_desc *d) {
   const uint32_t n = d->n, T = d->n_terms, K = d->n_out;
   if (T == 0 || T > HM_NIP_MAX_TERMS || K == 0 || K > HM_NIP_MAX_OUT)
     return fail(c, HM_ERR_ARG, "hm_ntt_inner_product: n_terms in [1,%d], n_out in [1,%d]", HM_NIP_MAX_TERMS, HM_NIP_MAX_OUT);
+  if (d->out_inverse && c->P.logN != HM_ROW_LOG + 8) {   // the epilogue is the inverse ROW pass over the workgroup's own rows: tiles of whole rows at any N, but built and tested for 2^16
+    for (uint32_t i = 0; i < n; ++i)
+      if (d->out_inverse[i]) return fail(c, HM_ERR_UNSUPPORTED, "hm_ntt_inner_product: out_inverse needs N = 2^16");
+  }
   hm_status st;
   if ((st = check_limbs(c, "hm_ntt_inner_product", d->x_limbs, n * T)) || (st = check_limbs(c, "hm_ntt_inner_product", d->y_limbs, n * T * K)) ||
       (st = check_limbs(c, "hm_ntt_inner_product", d->out_limbs, n * K)) || (st = check_mods(c, "hm_ntt_inner_product", d->mod_ids, n)))
@@ -1851,14 +1643,24 @@ extern "C" hm_status hm_ntt_inner_product(hm_ctx *c, const hm_ntt_ip_desc *d) {
     if ((st = ntt_common(c, "hm_ntt_inner_product", d->x, cin.data(), d->hand, chand.data(), cmod.data(), (uint32_t)cin.size(), 0, nullptr, f))) return st;
   }
   HM_HIP(c, hipSetDevice(c->device));
-  // 2. same-modulus groups (the ops of a batch bring one limb-poly per modulus each: they share the row twiddles AND the key)
+  // 2. same-modulus groups (the ops of a batch bring one limb-poly per modulus each: they share the row twiddles AND the key).  Limbs whose
+  // outputs leave as the first pass of their inverse transform (out_inverse): in the same launch (mont32) or in one of their own (generic)
+  bool anyInv = false;
+  for (uint32_t i = 0; d->out_inverse && i < n; ++i) anyInv |= d->out_inverse[i] != 0;
+  const bool split = anyInv && HM_GENERIC != 0;
+  for (int set = 0; set < (split ? 2 : 1); ++set) {
+  auto inSet = [&](uint32_t i) { return !split || (d->out_inverse[i] ? 1 : 0) == set; };
+  const int invForm = !anyInv ? 0 : split ? set : 2;
   std::map<uint32_t, std::vector<uint32_t>> byMod;
-  for (uint32_t i = 0; i < n; ++i) byMod[d->mod_ids[i]].push_back(i);
+  uint32_t nSet = 0;
+  for (uint32_t i = 0; i < n; ++i)
+    if (inSet(i)) { byMod[d->mod_ids[i]].push_back(i); ++nSet; }
+  if (!nSet) continue;
   uint32_t logG = 0;
   for (uint32_t lg = 3; lg >= 1; --lg) {
     size_t full = 0;
     for (auto &kv : byMod) full += kv.second.size() >> lg << lg;
-    if (full * 8 >= (size_t)n * 7 && n >= (8u << lg)) { logG = lg; break; }
+    if (full * 8 >= (size_t)nSet * 7 && nSet >= (8u << lg)) { logG = lg; break; }
   }
   const uint32_t G = 1u << logG;
   std::vector<std::vector<int>> groups;
@@ -1884,7 +1686,10 @@ extern "C" hm_status hm_ntt_inner_product(hm_ctx *c, const hm_ntt_ip_desc *d) {
       uint32_t w = 0;
       for (int gi : g)
         if (gi >= 0)
-          for (uint32_t j = 0; j < T; ++j) w += d->x_is_coeff[(uint32_t)gi * T + j] ? 3 : 1;
+          {
+            for (uint32_t j = 0; j < T; ++j) w += d->x_is_coeff[(uint32_t)gi * T + j] ? 3 : 1;
+            if (d->out_inverse && d->out_inverse[gi]) w += 2 * K;   // ... and an inverse first pass per output on top
+          }
       return w;
     };
     std::stable_sort(groups.begin(), groups.end(), [&](const std::vector<int> &a, const std::vector<int> &b) { return weight(a) > weight(b); });
@@ -1910,6 +1715,7 @@ extern "C" hm_status hm_ntt_inner_product(hm_ctx *c, const hm_ntt_ip_desc *d) {
           const bool tr = d->x_is_coeff[i * T + j] != 0;
           l.x[j] = (uint16_t)(tr ? d->hand_limbs[i * T + j] : d->x_limbs[i * T + j]);
           if (tr) l.coeff_mask |= (uint16_t)(1u << j);
+          if (d->out_inverse && d->out_inverse[i]) l.coeff_mask |= (uint16_t)HM_NIP_INV_OUT;
           for (uint32_t k = 0; k < K; ++k) l.y[k][j] = (uint16_t)d->y_limbs[(i * K + k) * T + j];
         }
         for (uint32_t k = 0; k < K; ++k) l.out[k] = (uint16_t)d->out_limbs[i * K + k];
@@ -1918,13 +1724,19 @@ extern "C" hm_status hm_ntt_inner_product(hm_ctx *c, const hm_ntt_ip_desc *d) {
     if ((st = device_table(c, recs.data(), sizeof(HmNipLimb) * cnt, &dtab))) return st;
     a.limb = static_cast<const HmNipLimb *>(dtab);
     a.hand = d->hand; a.x = d->x; a.y = d->y; a.out = d->out;
-    a.tw = c->d_tw_fwd; a.twist = c->d_twist_fwd; a.mods = c->d_mods;
+    a.tw = c->d_tw_fwd; a.twist = c->d_twist_fwd; a.tw_inv = c->d_tw_inv; a.twist_inv = c->d_twist_inv; a.mods = c->d_mods;
     a.logN = c->P.logN; a.n_limbs = cnt; a.logG = logG; a.n_terms = T;
     const dim3 grid(cnt * (c->P.N >> HM_TL_ROW)), block((1 << HM_TL_ROW) / HM_EPT);
-    if (K == 1) hipLaunchKernelGGL((k_ntt_row_ip<1>), grid, block, 0, c->stream, a);
-    else hipLaunchKernelGGL((k_ntt_row_ip<2>), grid, block, 0, c->stream, a);
+    typedef void (*nip_kernel)(HmNipArgs);
+#if HM_GENERIC
+    static const nip_kernel kern[2][3] = {{k_ntt_row_ip<1, 0>, k_ntt_row_ip<1, 1>, nullptr}, {k_ntt_row_ip<2, 0>, k_ntt_row_ip<2, 1>, nullptr}};
+#else
+    static const nip_kernel kern[2][3] = {{k_ntt_row_ip<1, 0>, nullptr, k_ntt_row_ip<1, 2>}, {k_ntt_row_ip<2, 0>, nullptr, k_ntt_row_ip<2, 2>}};
+#endif
+    hipLaunchKernelGGL(kern[K - 1][invForm], grid, block, 0, c->stream, a);
     HM_HIP(c, hipGetLastError());
   }
+  }   // sets
   return HM_OK;
 }
 

@@ -382,7 +382,10 @@ HM_HD void hm_ph_twist(HmNttState &st, uint64_t q) {
 // LDAUX / STAUX: cache-policy bits of the pass's data loads / stores (hm_gld2)
 // pre() (phase 0 only): called between the first round's twiddle requests and everything that touches LDS or the pass's input — the
 // one-launch transform waits there for the other workgroups' hand-off, with the second pass's first twiddles already on their way
-template <int TL, int LOGR, bool STRIDED, bool INV, int MODE, int PHASE, int LDAUX = 0, int STAUX = 0, int EPICH = HM_EPI_CHUNK, class PRE = HmNoPre>
+// FROMREG (round 5): the pass's input is already in st.v, in the layout of its first executed round (the inner-product kernel hands its
+// reduced accumulators to the inverse ROW pass this way: the forward ROW pass's last round and the inverse ROW pass's first are the same
+// round); phase 0 then requests twiddles only
+template <int TL, int LOGR, bool STRIDED, bool INV, int MODE, int PHASE, int LDAUX = 0, int STAUX = 0, int EPICH = HM_EPI_CHUNK, class PRE = HmNoPre, bool FROMREG = false>
 HM_HD void hm_ntt_phase(HmNttState &st, int tid, uint64_t *lds, const uint64_t *src, uint64_t *dst, uint32_t tile,
                         const HmW *twl, const HmW *twist_tile, uint32_t s0, uint32_t prefix0, uint64_t q, HmTw sc, HmEpi ep, PRE pre = PRE()) {
   using PS = HmPass<LOGR, STRIDED, INV>;
@@ -401,7 +404,8 @@ HM_HD void hm_ntt_phase(HmNttState &st, int tid, uint64_t *lds, const uint64_t *
     hm_ph_load_tw<TL, LOGR, STRIDED, r0, PS::shared(r0)>(st, tid, twl, s0, prefix0);
     pre();
     if (PS::anyLds()) hm_ph_stage_tw<TL, LOGR, STRIDED>(tid, lds, twl);
-    if (MODE == 4) hm_ph_load_global_mix<TL, LOGR, STRIDED, r0, LDAUX>(st, tid, src, tile, q, ep);
+    if (FROMREG) { static_assert(!FROMREG || MODE != 4, "the mix prologue reads its operands from memory"); }
+    else if (MODE == 4) hm_ph_load_global_mix<TL, LOGR, STRIDED, r0, LDAUX>(st, tid, src, tile, q, ep);
     else hm_ph_load_global<TL, LOGR, STRIDED, r0, LDAUX>(st, tid, src, tile);
     // the twist constants are requested one phase ahead of the twisted round (phase iTW + 1)
     if (iTW >= 0 && iTW <= 1) hm_ph_load_twist<TL, LOGR, STRIDED, (TWR >= 0 ? TWR : 0)>(st, tid, twist_tile);
@@ -448,11 +452,11 @@ HM_HD void hm_ntt_phase(HmNttState &st, int tid, uint64_t *lds, const uint64_t *
   }
 }
 // all phases of a pass with `sync()` between them (the GPU passes __syncthreads, the emulator runs the phases itself)
-template <int TL, int LOGR, bool STRIDED, bool INV, int MODE, int LDAUX = 0, int STAUX = 0, int EPICH = HM_EPI_CHUNK, class SYNC, class PRE = HmNoPre>
+template <int TL, int LOGR, bool STRIDED, bool INV, int MODE, int LDAUX = 0, int STAUX = 0, int EPICH = HM_EPI_CHUNK, bool FROMREG = false, class SYNC, class PRE = HmNoPre>
 HM_HD void hm_ntt_pass_phases(HmNttState &st, int tid, uint64_t *lds, const uint64_t *src, uint64_t *dst, uint32_t tile,
                               const HmW *twl, const HmW *twist_tile, uint32_t s0, uint32_t prefix0, uint64_t q, HmTw sc, HmEpi ep, SYNC sync, PRE pre = PRE()) {
   constexpr int n = HmRounds<LOGR>::n;
-  hm_ntt_phase<TL, LOGR, STRIDED, INV, MODE, 0, LDAUX, STAUX, EPICH>(st, tid, lds, src, dst, tile, twl, twist_tile, s0, prefix0, q, sc, ep, pre);
+  hm_ntt_phase<TL, LOGR, STRIDED, INV, MODE, 0, LDAUX, STAUX, EPICH, PRE, FROMREG>(st, tid, lds, src, dst, tile, twl, twist_tile, s0, prefix0, q, sc, ep, pre);
   hm_ntt_phase<TL, LOGR, STRIDED, INV, MODE, 1, LDAUX, STAUX, EPICH>(st, tid, lds, src, dst, tile, twl, twist_tile, s0, prefix0, q, sc, ep);
   sync();
   hm_ntt_phase<TL, LOGR, STRIDED, INV, MODE, 2, LDAUX, STAUX, EPICH>(st, tid, lds, src, dst, tile, twl, twist_tile, s0, prefix0, q, sc, ep);

@@ -20,7 +20,7 @@ SYMBOLS = [
     "hm_bconv", "hm_bconv_batch", "hm_bconv_consts", "hm_fill_uniform", "hm_timer_start", "hm_timer_stop", "hm_comm_unique_id", "hm_comm_init_rccl", "hm_comm_init_external",
     "hm_capture_begin", "hm_capture_end", "hm_graph_launch", "hm_graph_destroy", "hm_comm_info", "hm_slice_rows", "hm_limbs_to_slices", "hm_slices_to_limbs", "hm_replicate_limbs",
     "hm_set_option", "hm_get_counter", "hm_ntt_inner_product", "hm_exchange_stream", "hm_exchange_mark", "hm_exchange_wait",
-    "hm_bconv_col", "hm_limbs_to_colslices", "hm_colslices_to_limbs",
+    "hm_bconv_col", "hm_limbs_to_colslices", "hm_colslices_to_limbs", "hm_ntt_second_pass",
 ]
 
 
@@ -34,7 +34,8 @@ class hm_ntt_fused_desc(C.Structure):
 class hm_ntt_ip_desc(C.Structure):
     _fields_ = [("x", C.c_void_p), ("x_limbs", C.c_void_p), ("x_is_coeff", C.c_void_p), ("hand", C.c_void_p), ("hand_limbs", C.c_void_p),
                 ("y", C.c_void_p), ("y_limbs", C.c_void_p), ("out", C.c_void_p), ("out_limbs", C.c_void_p), ("mod_ids", C.c_void_p),
-                ("n", C.c_uint32), ("n_terms", C.c_uint32), ("n_out", C.c_uint32), ("conv", C.c_void_p), ("n_conv", C.c_uint32)]
+                ("n", C.c_uint32), ("n_terms", C.c_uint32), ("n_out", C.c_uint32), ("conv", C.c_void_p), ("n_conv", C.c_uint32),
+                ("out_inverse", C.c_void_p)]
 
 
 class hm_bconv_desc(C.Structure):
@@ -79,6 +80,7 @@ def load():
     L.hm_stream.argtypes = [vp]
     L.hm_wait_for.argtypes = [vp, vp]
     L.hm_ntt.argtypes = [vp, vp, vp, vp, vp, vp, u32, i32, vp]
+    L.hm_ntt_second_pass.argtypes = [vp, vp, vp, vp, u32, i32, vp]
     L.hm_ntt_sub_scale.argtypes = [vp] + [vp] * 9 + [u32, vp]
     L.hm_ntt_mix_sub_scale.argtypes = [vp, C.POINTER(hm_ntt_fused_desc)]
     L.hm_tensor.argtypes = [vp] + [vp] * 15 + [u32]
@@ -245,7 +247,14 @@ class Context:
         self._ck(self.L.hm_inner_product(self.h, x.ptr, keep[0][1], y.ptr, keep[1][1], out.ptr, keep[2][1], keep[3][1], len(mod_ids),
                                          n_terms, n_out))
 
-    def ntt_inner_product(self, x, x_limbs, x_is_coeff, hand, hand_limbs, y, y_limbs, out, out_limbs, mod_ids, n_terms, n_out, conv=None):
+    def ntt_second_pass(self, buf, mod_ids, inverse=False, limbs=None, scale=None):
+        """the last pass of transforms whose first pass another call has already run into `buf` (in place)"""
+        k1, pl = _u32(limbs)
+        k2, pm = _u32(mod_ids)
+        k3, ps = _u64(scale)
+        self._ck(self.L.hm_ntt_second_pass(self.h, buf.ptr, pl, pm, len(mod_ids), 1 if inverse else 0, ps))
+
+    def ntt_inner_product(self, x, x_limbs, x_is_coeff, hand, hand_limbs, y, y_limbs, out, out_limbs, mod_ids, n_terms, n_out, conv=None, out_inverse=None):
         """out[i][k] = sum_j (NTT(x[i][j]) if x_is_coeff[i][j] else x[i][j]) * y[i][k][j]: the HPIP unit as a fused NTT-epilogue x key MAC.
         conv = [(src, in_limbs, in_ids, hand_out_limbs, out_ids), ...]: the transformed digits are these base conversions, computed inside
         the transforms' first pass (their outputs are hand-off limbs of `hand`)"""
@@ -259,9 +268,11 @@ class Context:
                 keep2.append(arrs)
                 dd.in_, dd.in_limbs, dd.in_ids, dd.n_in = src.ptr, arrs[0][1], arrs[1][1], len(in_ids)
                 dd.out, dd.out_limbs, dd.out_ids, dd.n_out, dd.log_len = hand.ptr, arrs[2][1], arrs[3][1], len(out_ids), 0
+        inv = None if out_inverse is None else np.ascontiguousarray(np.asarray(out_inverse, dtype=np.uint8))
         d = hm_ntt_ip_desc(x.ptr, keep[0][1], flags.ctypes.data_as(C.c_void_p), None if hand is None else hand.ptr, keep[1][1], y.ptr, keep[2][1],
                            out.ptr, keep[3][1], keep[4][1], len(mod_ids), n_terms, n_out,
-                           C.cast(descs, C.c_void_p) if conv else None, len(conv) if conv else 0)
+                           C.cast(descs, C.c_void_p) if conv else None, len(conv) if conv else 0,
+                           None if inv is None else inv.ctypes.data_as(C.c_void_p))
         self._ck(self.L.hm_ntt_inner_product(self.h, C.byref(d)))
 
     def automorph(self, src, dst, n, galois, in_limbs=None, out_limbs=None):

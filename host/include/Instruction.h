@@ -42,6 +42,8 @@ public:
   std::vector<AddrType> fConvIn;
   std::vector<uint32_t> fConvMods;     // ... its input moduli
   // (10) a BCONV_STEP2 record with the element-wise epilogue out = (fSubFrom - conv) * constant [+ fAdd] (the rescale residue of 4c)
+  bool ipInvOut = false;     // IP record (7b, round 5): its outputs leave the kernel as the first pass of their inverse transform
+  bool secondOnly = false;   // INTT record (7b): the first pass has been run into its output limb by the producing IP record
   bool fusedEpi = false;
   AddrType fSubFrom = 0, fAdd = 0;
   bool fusedTensor = false;            // MAC2 record that also produces d0 -> extraOutputs[0] and d2 -> extraOutputs[1]

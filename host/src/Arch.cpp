@@ -19,6 +19,8 @@ struct Arch::Launch {
   int recordSlot = -1;            // exchange launches of a pipelined sharded plan: the mark set behind them (hm_exchange_mark)
   std::vector<int> waitSlots;     // marks the compute stream waits for before this launch (hm_exchange_wait)
   std::vector<uint8_t> ipCoeff;   // L_NTT_IP: per (limb, digit) 1 = transformed inside the kernel (a = source, c = first-pass scratch)
+  std::vector<uint8_t> ipInv;     // L_NTT_IP (7b): per limb, 1 = the outputs leave as the first pass of their inverse transform
+  bool secondOnly = false;        // L_INTT (7b): hm_ntt_second_pass — the first pass was run by the inner-product kernel
   uint32_t ipTerms = 0, ipOuts = 0;
   std::string name;
   std::string statKey;
@@ -89,6 +91,11 @@ Arch::Arch(Config *cfg) : config(cfg) {
   // fused; one at a time 24.9 + 70.5 against 9.5 + 89.2): the separate conversion kernel converts to all 35 outputs of a key from inputs it
   // loads and splits ONCE, the fused form loads the 15 input tiles again for every pair of outputs, and the 73 MB of ModdownBConvOut traffic it
   // saves is worth less than that.  Opt-in (config key fuse_moddown = 1).
+  // (7b, round 5) InnerProOut -> ModDownINTTOut (src/Operation.cpp:294-445): the special limbs of the key-switch sum are read by nothing but
+  // the ModDown's inverse transform, whose first pass is a ROW pass over the 16 rows the inner-product workgroup already owns: the kernel
+  // runs it on its accumulators and the INTT launch keeps the COL pass.  N = 2^16, one GPU.  Config key fuse_ip_inv (default 1).
+  fuseIpInv = cfg->getValueOr("fuse_ip_inv", 1) != 0;
+  if (const char *e = getenv("HOMULATOR_FUSE_IP_INV")) fuseIpInv = std::string(e) != "0";
   fuseModDown = cfg->getValueOr("fuse_moddown", 0) != 0;
   if (const char *e = getenv("HOMULATOR_FUSE_MODDOWN")) fuseModDown = std::string(e) != "0";
   // sharded runs: the exchanges of digit j+1 run on the context's exchange stream while digit j converts and transforms (SURVEY.md 7:
@@ -521,6 +528,47 @@ void Arch::fusePasses(std::vector<Stage> &st) {
         }
       }
   }
+  // (7b, round 5) an inner-product record (HPIP form) whose outputs are read by inverse transforms and nothing else — the special limbs of
+  //      the key-switch sum (ModDownINTTOut_Key(k)) and, with (4c), the last Q limb (the rescale residue's INTT) — hands them over as the
+  //      FIRST pass of that inverse transform: a ROW pass over the 16 rows of the limb-poly the workgroup has just accumulated (the forward
+  //      ROW pass's last round and the inverse ROW pass's first are the same round, so the pass runs from the registers).  The kernel stores
+  //      the pass's hand-off into the INTT's output limb, the INTT record keeps its COL pass (hm_ntt_second_pass, with its scale), and the
+  //      evaluation-form sums of those limbs (InnerProduceOut_Key{k}[0 .. alpha)) are never written or read back.
+  if (fuseHpip && fuseIpInv && world_ == 1 && logN == 16) {
+    std::map<AddrType, std::vector<Instruction *>> readers;
+    for (auto &s : st)
+      for (Instruction *i : s.ins) {
+        if (dead.count(i)) continue;
+        if (i->ops == IP && !i->ipX.empty()) {
+          for (AddrType x : (i->ipSrc.empty() ? i->ipX : i->ipSrc)) readers[x].push_back(i);
+          for (auto &cin : i->ipConvIn) for (AddrType x : cin) readers[x].push_back(i);
+          for (auto &y : i->ipY) for (AddrType yy : y) readers[yy].push_back(i);
+        } else {
+          for (AddrType a : operands(i)) readers[a].push_back(i);
+          if (i->fusedSubScale) { readers[i->fMinuend].push_back(i); if (i->fAddend) readers[i->fAddend].push_back(i); if (i->fMix) readers[i->fMix].push_back(i); }
+        }
+      }
+    for (auto &s : st)
+      for (Instruction *ip : s.ins) {
+        if (ip->ops != IP || ip->ipX.empty() || dead.count(ip) || ip->ipInvOut) continue;
+        if (std::find(ip->ipCoeff.begin(), ip->ipCoeff.end(), 1) == ip->ipCoeff.end()) continue;   // the fused transform x key kernel only
+        std::vector<AddrType *> outs = {&ip->OutputOperand};
+        for (AddrType &o : ip->extraOutputs) outs.push_back(&o);
+        std::vector<Instruction *> inv;
+        for (AddrType *o : outs) {
+          auto &rd = readers[*o];
+          if (rd.size() != 1 || rd[0]->ops != INTT || dead.count(rd[0]) || rd[0]->mod_id != ip->mod_id || rd[0]->secondOnly || rd[0]->operandList[0] != *o) break;
+          inv.push_back(rd[0]);
+        }
+        if (inv.size() != outs.size()) continue;
+        for (size_t k = 0; k < outs.size(); ++k) {
+          *outs[k] = inv[k]->OutputOperand;                      // the hand-off lands where the inverse transform finishes in place
+          inv[k]->operandList[0] = inv[k]->OutputOperand;
+          inv[k]->secondOnly = true;
+        }
+        ip->ipInvOut = true;
+      }
+  }
   // (9, round 4) the ModDown side of (8): a fused forward transform (ModDowNTT + ModDownSub [+ rescale]) whose input is a P -> Q conversion
   //     output that nobody else reads takes the conversion into its first pass (src/Operation.cpp:489-590): ModdownBConvOut_Key(k) is
   //     never written or read back.  The last limb of a key keeps its conversion: the rescale residue is formed from it element-wise (4c).
@@ -627,7 +675,7 @@ void Arch::buildLaunches() {
     size_t first = parts.size();
     for (Instruction *i : s.ins) {
       const bool nip = i->ops == IP && std::find(i->ipCoeff.begin(), i->ipCoeff.end(), 1) != i->ipCoeff.end();
-      int key = nip ? 400 + (int)i->ipX.size() * 10 + (int)i->ipY.size() : i->ops == IP && !i->ipX.empty() ? 300 + (int)i->ipX.size() * 10 + (int)i->ipY.size() : i->fusedTensor ? 200 : i->fusedSubScale ? (i->fMix ? 203 : 201) + (i->fConvIn.empty() ? 0 : 4) : i->ops == MULT ? 100 + i->opcode : (i->ops == NTT && i->passthrough) ? 100 + EWE_COPY : i->ops == AUTO ? 1000 + (int)i->galois : (int)i->ops;
+      int key = nip ? 400 + (int)i->ipX.size() * 10 + (int)i->ipY.size() : i->ops == IP && !i->ipX.empty() ? 300 + (int)i->ipX.size() * 10 + (int)i->ipY.size() : i->fusedTensor ? 200 : i->fusedSubScale ? (i->fMix ? 203 : 201) + (i->fConvIn.empty() ? 0 : 4) : i->ops == MULT ? 100 + i->opcode : (i->ops == NTT && i->passthrough) ? 100 + EWE_COPY : i->ops == AUTO ? 1000 + (int)i->galois : (int)i->ops + (i->secondOnly ? 5000 : 0);
       size_t p = first;
       for (; p < parts.size(); ++p)
         if (parts[p].key == key) break;
@@ -902,6 +950,7 @@ void Arch::buildLaunches() {
             L->out.push_back(limbOf(i->OutputOperand));
             for (AddrType o : i->extraOutputs) L->out.push_back(limbOf(o));
             L->mods.push_back(i->mod_id);
+            L->ipInv.push_back(i->ipInvOut ? 1 : 0);
             lp += (unsigned long long)L->ipTerms * L->ipOuts + L->ipOuts;
           }
         for (auto &q : L->probs) lp += q.in.size();
@@ -964,6 +1013,7 @@ void Arch::buildLaunches() {
         L->bytes = 2 * LP * count;
       } else if (f->ops == NTT || f->ops == INTT) {
         L->kind = f->ops == NTT ? Launch::L_NTT : Launch::L_INTT; L->statKey = "NTT";
+        L->secondOnly = f->secondOnly;
         for (const Part *g : group)
           for (Instruction *i : g->ins) {
             L->a.push_back(limbOf(i->operandList[0])); L->out.push_back(limbOf(i->OutputOperand)); L->mods.push_back(i->mod_id);
@@ -1131,6 +1181,9 @@ void Arch::replicateForBatch() {
         std::vector<uint32_t> f(l->ipCoeff.begin(), l->ipCoeff.end());
         inter(f, l->ipTerms, false);
         l->ipCoeff.assign(f.begin(), f.end());
+        std::vector<uint32_t> fi(l->ipInv.begin(), l->ipInv.end());
+        inter(fi, 1, false);
+        l->ipInv.assign(fi.begin(), fi.end());
       }
     } else {
       rep(l->a, true); rep(l->b, true); rep(l->c, true); rep(l->d, true);
@@ -1273,7 +1326,8 @@ void Arch::enqueue(Launch &l) {
     st = hm_ntt(ctx, pool, l.a.data(), pool, l.out.data(), l.mods.data(), cnt, 0, nullptr);
     break;
   case Launch::L_INTT:
-    st = hm_ntt(ctx, pool, l.a.data(), pool, l.out.data(), l.mods.data(), cnt, 1, l.hasK ? l.k.data() : nullptr);
+    if (l.secondOnly) st = hm_ntt_second_pass(ctx, pool, l.out.data(), l.mods.data(), cnt, 1, l.hasK ? l.k.data() : nullptr);
+    else st = hm_ntt(ctx, pool, l.a.data(), pool, l.out.data(), l.mods.data(), cnt, 1, l.hasK ? l.k.data() : nullptr);
     break;
   case Launch::L_NTT_SUBSCALE:
     if (!l.mixK.empty() || !l.probs.empty()) {
@@ -1295,7 +1349,8 @@ void Arch::enqueue(Launch &l) {
     for (auto &q : l.probs)
       descs.push_back(hm_bconv_desc{pool, q.in.data(), q.inMods.data(), (uint32_t)q.in.size(), pool, q.out.data(), q.outMods.data(), (uint32_t)q.out.size(), 0});
     hm_ntt_ip_desc d = {pool, l.a.data(), l.ipCoeff.data(), pool, l.c.data(), pool, l.b.data(), pool, l.out.data(), l.mods.data(),
-                        (uint32_t)l.mods.size(), l.ipTerms, l.ipOuts, descs.empty() ? nullptr : descs.data(), (uint32_t)descs.size()};
+                        (uint32_t)l.mods.size(), l.ipTerms, l.ipOuts, descs.empty() ? nullptr : descs.data(), (uint32_t)descs.size(),
+                        std::find(l.ipInv.begin(), l.ipInv.end(), 1) != l.ipInv.end() ? l.ipInv.data() : nullptr};
     st = hm_ntt_inner_product(ctx, &d);
     break;
   }

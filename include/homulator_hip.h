@@ -182,8 +182,22 @@ typedef struct hm_ntt_ip_desc {
    * N = 2^15 or 2^16 and n_in <= 15 (HM_ERR_UNSUPPORTED otherwise: convert with hm_bconv_batch first).  Bit-identical to
    * hm_bconv_batch + hm_ntt_inner_product. */
   const struct hm_bconv_desc *conv; uint32_t n_conv;
+  /* optional (NULL: none; round 5): out_inverse[i] != 0 — the outputs of limb i are only ever read by an inverse transform (the special
+   * limbs of the key-switch sum: InnerProOut -> ModDownINTTOut_Key(k), src/Operation.cpp:294-445).  The kernel then runs the FIRST pass
+   * of that inverse transform on its accumulators (the ROW pass over the 16 rows the workgroup already owns) and stores the pass's
+   * hand-off at out + out_limbs[i][k] * N instead of the evaluation-form sum; hm_ntt_second_pass(.., inverse = 1, ..) on those limbs
+   * finishes the transform.  The sums themselves never reach HBM.  N = 2^16 (HM_ERR_UNSUPPORTED otherwise).  Bit-identical to the call
+   * without it followed by hm_ntt(.., inverse = 1, ..). */
+  const uint8_t *out_inverse;
 } hm_ntt_ip_desc;
 hm_status hm_ntt_inner_product(hm_ctx *ctx, const hm_ntt_ip_desc *desc);
+/* K1, second half: the last pass of a transform whose first pass has already been run into `buf` by another call — the inverse ROW pass of
+ * hm_ntt_inner_product's out_inverse limbs (inverse != 0: the COL pass, x N^-1 [x scale[i]]) or the first pass of hm_bconv_col
+ * (inverse == 0: the ROW pass).  In place on buf + limbs[i] * N.  Same reference interface as hm_ntt: Arch::issueIns(cluster, "NTT" / "INTT",
+ * group) include/Arch.h:276 for the second half of InsGen::GenNTT's instructions (src/InsGen.cpp:17-44; NTTU stages 9-16,
+ * src/Components.cpp:380-436). */
+hm_status hm_ntt_second_pass(hm_ctx *ctx, uint64_t *buf, const uint32_t *limbs, const uint32_t *mod_ids, uint32_t n, int inverse,
+                             const uint64_t *scale);
 
 /* K4 — fast base conversion, matrix step: out_t = sum_i in_i * [Q_D / q_i]_t mod t for the input
  * basis in_ids (n_in <= 32) and output basis out_ids (n_out <= 64).  `in` must already hold

@@ -445,6 +445,51 @@ def test_mix_sub_scale_with_conversion_inside(logN, chain, n_in, outs_per_wg):
         ctx.close()
 
 
+@pytest.mark.parametrize("chain", ["mont32", "survey"])
+def test_inner_product_hands_over_the_first_pass_of_the_inverse_transform(chain):
+    """hm_ntt_ip_desc.out_inverse + hm_ntt_second_pass (round 5; InnerProOut -> ModDownINTTOut, src/Operation.cpp:294-445): the flagged limbs'
+    outputs leave the kernel as the first pass (the ROW pass over the workgroup's own rows) of their inverse transform and the second
+    call finishes it in place, with a scale; together bit-identical to the plain call followed by hm_ntt(inverse).  Mixed launch
+    (flagged and unflagged limbs), transformed and evaluation-form digits, worst-case operands, both keys and one key, repeated"""
+    L, K, N = 4, 3, 1 << 16
+    ctx, o, _ = make_env(16, L, K, chain)
+    try:
+        ids = [0, 1, 2, 3, 4, 5, 6, 4, 5]
+        n, T = len(ids), 2
+        flags = [0, 0, 1, 0, 1, 1, 1, 0, 1]
+        xe = [o.fill_uniform(ids, 7 + j) for j in range(T)]            # digit 0: coefficient form (transformed inside), digit 1: evaluation form
+        xe[0][2, :] = o.moduli[ids[2]] - 1
+        xe[1][4, :] = o.moduli[ids[4]] - 1
+        for outs in (2, 1):
+            y = [[o.fill_uniform(ids, 30 + 10 * k + j) for j in range(T)] for k in range(outs)]
+            y[0][0][4, :] = o.moduli[ids[4]] - 1
+            xb = ctx.from_host(np.concatenate(xe))
+            yb = ctx.from_host(np.concatenate([y[k][j] for k in range(outs) for j in range(T)]))
+            hand, out = ctx.alloc(n), ctx.alloc(n * outs)
+            xl = [j * n + i for i in range(n) for j in range(T)]
+            coeff = [1 if j == 0 else 0 for i in range(n) for j in range(T)]
+            hl = [i for i in range(n) for j in range(T)]
+            yl = [(k * T + j) * n + i for i in range(n) for k in range(outs) for j in range(T)]
+            ol = [k * n + i for i in range(n) for k in range(outs)]
+            scale = [o.moduli[m] - 3 - i for i, m in enumerate(ids)]
+            X0 = o.ntt(ids, xe[0])
+            for rep in range(2):
+                ctx.fill_uniform(out, ids * outs, 99)
+                ctx.ntt_inner_product(xb, xl, coeff, hand, hl, yb, yl, out, ol, ids, T, outs, out_inverse=flags)
+                fl = [k * n + i for k in range(outs) for i in range(n) if flags[i]]
+                ctx.ntt_second_pass(out, [ids[l % n] for l in fl], inverse=True, limbs=fl, scale=[scale[l % n] for l in fl])
+                got = out.download().reshape(outs, n, N)
+                for k in range(outs):
+                    acc = o.ewe(1, ids, X0, y[k][0], xe[1], y[k][1])
+                    inv = o.ewe(5, ids, o.ntt(ids, acc, inverse=True), k=scale)
+                    for i in range(n):
+                        assert np.array_equal(got[k, i], inv[i] if flags[i] else acc[i]), (chain, outs, rep, k, i)
+            for b_ in (xb, yb, hand, out):
+                b_.free()
+    finally:
+        ctx.close()
+
+
 @pytest.mark.parametrize("form", ["generic", "mont32"])
 def test_inner_product_with_narrow_moduli(form):
     """the key multiply-accumulate of hm_ntt_inner_product over a caller-chosen chain of mixed widths (the lazy product's operand shift

@@ -36,11 +36,13 @@ def inputs(o, ell):
     return o.synth_ct(ell, SEED), o.synth_ct(ell, SEED + 2000), o.synth_evk(ell, SEED + 10000)
 
 
-def check_keyswitch_buffers(op, dd, ell, K, beta, fused, hpip=True, bconv=True):   # bconv: True | "residue" | "moddown"
+def check_keyswitch_buffers(op, dd, ell, K, beta, fused, hpip=True, bconv=True, ip_rows=None):   # bconv: True | "residue" | "moddown"
     """hpip (fused only): the ModUp transforms' last pass runs inside the inner-product kernel: NTTOut_beta(j) is
     then only first-pass scratch and InnerProduceOut_Key{k} is compared with the oracle's `ip` dump instead.  bconv (fused only,
     round 4): the ModDown conversion runs inside the first pass of the transform that consumes it: ModdownBConvOut_Key{k} no longer
-    exists (the results are compared through the outputs)"""
+    exists (the results are compared through the outputs).  ip_rows (fused, round 5, N = 2^16): the rows of InnerProduceOut_Key{k} that still
+    hold the evaluation-form sum — the special limbs (and an hmult's last Q limb) leave the kernel as the first pass of their inverse
+    transform (pass 7b) and are compared through the outputs"""
     E = ell + K
     if not fused:
         assert np.array_equal(op.read("ModUpINTTOut"), dd["modup_intt"])
@@ -55,7 +57,8 @@ def check_keyswitch_buffers(op, dd, ell, K, beta, fused, hpip=True, bconv=True):
         sel = [t for t in range(E) if fused is False or not (lo <= t < hi)]   # fused: the digit's own limbs are aliased away
         assert np.array_equal(got[sel], dd["ext"][j][sel]), f"NTTOut_beta({j})"
     for k in range(2):
-        assert np.array_equal(op.read(f"InnerProduceOut_Key{k}"), dd["ip"][k]), f"InnerProduceOut_Key{k}"
+        rows_ip = slice(0, E) if ip_rows is None else slice(0, ip_rows)
+        assert np.array_equal(op.read(f"InnerProduceOut_Key{k}")[rows_ip], dd["ip"][k][rows_ip]), f"InnerProduceOut_Key{k}"
         if bconv == "moddown":      # pass 9: the conversion runs inside its consumer, the buffer is never written
             continue
         got_c = op.read(f"ModdownBConvOut_Key{k}")
@@ -71,7 +74,7 @@ CASES = [("config_4_N15.cfg", 15, 16, 10, 4), ("config_4_N15.cfg", 15, 8, 8, 8),
 
 @pytest.mark.parametrize("chain", ["mont32", "survey", 36])
 @pytest.mark.parametrize("cfg,logN,L,ell,alpha", CASES)
-@pytest.mark.parametrize("fuse", [False, True, "no_hpip", "no_bconv", "moddown"])
+@pytest.mark.parametrize("fuse", [False, True, "no_hpip", "no_bconv", "moddown", "no_ip_inv"])
 def test_hmult_bit_exact(cfg, logN, L, ell, alpha, fuse, chain):
     """fuse = True is the bench path (ModUp conversion + transforms + key MAC in one C-ABI call: k_bconv_col, k_ntt_row_ip);
     "no_bconv" = the same with the conversion as its own launch (fuse_bconv = 0); "no_hpip" = fused plan with separate ModUp
@@ -82,10 +85,13 @@ def test_hmult_bit_exact(cfg, logN, L, ell, alpha, fuse, chain):
     o = oracle(logN, L, alpha, chain)
     ct1, ct2, evk = inputs(o, ell)
     ids = list(range(ell))
-    hpip = fuse in (True, "no_bconv", "moddown")   # "no_bconv": fused transform x key kernel fed by a separate conversion launch; "moddown": pass 9 on
+    hpip = fuse in (True, "no_bconv", "moddown", "no_ip_inv")   # "no_bconv": fused transform x key kernel fed by a separate conversion launch; "moddown": pass 9 on
     mode = fuse
+    # pass 7b (N = 2^16, fused transform x key kernel): the special limbs and the last Q limb of the key-switch sum leave as the first pass of
+    # their inverse transform; "no_ip_inv" keeps them in evaluation form (every row compared)
+    ip_rows = ell - 1 if (hpip and logN == 16 and fuse != "no_ip_inv") else None
     op = host.Op(cfg, "hmult", L, ell, alpha, fuse=bool(fuse),
-                 overrides=chain_overrides(chain, {"fuse_hpip": 0} if fuse == "no_hpip" else {"fuse_bconv": 0} if fuse == "no_bconv" else {"fuse_moddown": 1} if fuse == "moddown" else None))
+                 overrides=chain_overrides(chain, {"fuse_hpip": 0} if fuse == "no_hpip" else {"fuse_bconv": 0} if fuse == "no_bconv" else {"fuse_moddown": 1} if fuse == "moddown" else {"fuse_ip_inv": 0} if fuse == "no_ip_inv" else None))
     fuse = bool(fuse)
     op.execute(1)
     assert op.backend_counter("arith") == (0 if chain == "mont32" else 1)
@@ -97,7 +103,7 @@ def test_hmult_bit_exact(cfg, logN, L, ell, alpha, fuse, chain):
     assert np.array_equal(op.read("TensorD1Out"), d1)
     assert np.array_equal(op.read("TensorD2Out"), d2)
     k0, k1, dd = o.keyswitch(ell, d2, evk, dump=True)
-    check_keyswitch_buffers(op, dd, ell, alpha, o.beta(ell), fuse, hpip, bconv="moddown" if mode == "moddown" else "residue" if mode in (True, "no_hpip") else True)
+    check_keyswitch_buffers(op, dd, ell, alpha, o.beta(ell), fuse, hpip, bconv="moddown" if mode == "moddown" else "residue" if mode in (True, "no_hpip", "no_ip_inv") else True, ip_rows=ip_rows)
     if not fuse:
         assert np.array_equal(op.read("KeySwitchFinalOutput_Key(0)"), k0)
         assert np.array_equal(op.read("KeySwitchFinalOutput_Key(1)"), k1)
@@ -128,8 +134,8 @@ def test_hmult_mixed_conversion_launch(fuse):
     ids = list(range(ell))
     d2 = o.ewe(0, ids, ct1[1], ct2[1])
     k0, k1, dd = o.keyswitch(ell, d2, evk, dump=True)
-    for k in range(2):
-        assert np.array_equal(op.read(f"InnerProduceOut_Key{k}"), dd["ip"][k]), f"InnerProduceOut_Key{k}"
+    for k in range(2):   # (rows [0, l - 1): the last Q limb and the special limbs leave as the first pass of their inverse transform, pass 7b)
+        assert np.array_equal(op.read(f"InnerProduceOut_Key{k}")[:ell - 1], dd["ip"][k][:ell - 1]), f"InnerProduceOut_Key{k}"
     exp = o.hmult(ell, ct1, ct2, evk, rescale=True)
     assert np.array_equal(op.read("out.c0"), exp[0]) and np.array_equal(op.read("out.c1"), exp[1])
     op.close()
@@ -147,7 +153,7 @@ def test_hrotate_bit_exact(cfg, logN, L, ell, alpha, fuse, chain):
     r0, r1 = o.automorph_eval(ct1[0], 5), o.automorph_eval(ct1[1], 5)
     assert np.array_equal(op.read("AUTOOutput(0)"), r0) and np.array_equal(op.read("AUTOOutput(1)"), r1)
     k0, k1, dd = o.keyswitch(ell, r1, evk, dump=True)
-    check_keyswitch_buffers(op, dd, ell, alpha, o.beta(ell), fuse)
+    check_keyswitch_buffers(op, dd, ell, alpha, o.beta(ell), fuse, ip_rows=ell if (fuse and logN == 16) else None)   # 7b: the special limbs
     exp = o.hrotate(ell, ct1, 5, evk)
     assert np.array_equal(op.read("out.c0"), exp[0])
     assert np.array_equal(op.read("out.c1"), exp[1])

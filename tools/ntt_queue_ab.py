@@ -10,7 +10,7 @@ def t(fn, iters):
     for _ in range(iters): fn()
     return ctx.timer_stop() / iters * 1e-3
 sizes = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [8, 50, 128, 512, 1150]
-arms = [(0, 0, 2, 0)] + [tuple(int(v) for v in a.split(":")) for a in os.environ.get("QUEUE_ARMS", "1:512:2:0,1:512:1:0,1:512:3:0,1:768:2:0,1:1024:2:0,2:1024:2:0").split(",")]
+arms = [(0, 0, 2, 0)] + [tuple(int(v) for v in a.split(":")) for a in os.environ.get("QUEUE_ARMS", "1:512:2:0,1:512:3:0,1:512:4:0,1:768:4:0,1:1024:4:0").split(",")]
 print(os.path.basename(os.environ.get("HOMULATOR_HIP_LIB", "default")))
 for n in sizes:
     sets = 6 if n <= 128 else 2
@@ -31,6 +31,6 @@ for n in sizes:
     print(f"n={n:5d}:")
     for (arm, inplace), v in res.items():
         v = sorted(v)
-        name = "two-kernel" if arm[0] == 0 else f"queue geo{8 if arm[0] == 1 else 16} wgs={arm[1]} la={arm[2]} gc={arm[3]}"
+        name = "two-kernel" if arm[0] == 0 else f"queue wgs={arm[1]} la={arm[2]} gc={arm[3]}"
         print(f"   {name:36s} {'in place ' if inplace else 'out-of-pl'} {v[1]:8.1f} us ({v[1]/n:.3f}/limb, min {v[0]/n:.3f})", flush=True)
     for a, b in bufs: a.free(); b.free()
