@@ -3,7 +3,7 @@
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/${1:-r03u}; shift; mkdir -p $OUT
 export TMPDIR=/tmp; cd /tmp
 for v in default "$@"; do
-  if [ $v = default ]; then unset HOMULATOR_HIP_LIB; else export HOMULATOR_HIP_LIB=$ROOT/ab_builds/libhm_$v.so; fi
+  if [ $v = default ]; then unset HOMULATOR_HIP_LIB; else export HOMULATOR_HIP_LIB=$ROOT/ab_builds/$v/libhomulator_hip.so; fi
   timeout -k 10 200 rocprofv3 --kernel-trace -d $OUT/kt_$v -o kt --output-format csv -- python3 $ROOT/tools/bcol_ab.py 10 3 > $OUT/kt_$v.log 2>&1 || echo "$v failed"
   python3 - <<P >> $OUT/kernels.txt
 import csv, glob, collections
