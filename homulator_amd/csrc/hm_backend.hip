@@ -396,111 +396,27 @@ typedef const HmNipLimb __attribute__((address_space(4))) *HmConstNipLimb;
 #ifndef HM_NIP_ST_AUX
 #define HM_NIP_ST_AUX 0
 #endif
-// INVOUT (round 5): 0 = no limb of the launch hands its outputs over as the first pass of their inverse transform (HM_NIP_INV_OUT), 1 = all of
-// them do, 2 = per limb (the record says).  mont32 runs a mixed launch as ONE kernel (2: 155 VGPRs); in the generic build that form spills
-// (the Shoup twiddles take twice the registers), so there the two kinds of limbs are two launches (0 and 1).
+template <int K> struct HmNipKey { static constexpr int value = K; };
+namespace hm16 {
+#include "hm_nip_body.inl"
+}
+#undef HM_EPT
+#define HM_EPT 8
+namespace hm8 {
+#include "hm_nip_body.inl"
+}
+#undef HM_EPT
+#define HM_EPT 16
 template <int OUTS, int INVOUT>
 __global__ void __launch_bounds__((1 << HM_TL_ROW) / HM_EPT) __attribute__((amdgpu_waves_per_eu(HM_NIP_WAVES))) k_ntt_row_ip(HmNipArgs a) {
-  constexpr int TL = HM_TL_ROW, LOGR = HM_ROW_LOG, R2 = HmRounds<LOGR>::n - 1;
-  __shared__ __attribute__((aligned(16))) uint64_t lds[HmLds<TL, LOGR, false>::WORDS];
-  uint32_t entry, tile;
-  if (!hm_block_map(1u << (a.logN - TL), a.n_limbs, a.logG, entry, tile)) return;
-  const HmConstNipLimb rec = (HmConstNipLimb)(uintptr_t)a.limb + entry;
-  const uint32_t mod = rec->mod;
-  if (mod == HM_NTT_NONE) return;
-  const size_t N = (size_t)1 << a.logN;
-  const HmMod m = HM_CONST_MODS(a.mods)[mod];
-  const HmW *twl = a.tw + (size_t)mod * N;
-  const uint32_t s0 = a.logN - LOGR, prefix0 = tile << (TL - LOGR);
-  const HmW *twt = a.twist + ((size_t)mod * (N >> LOGR) + prefix0) * 3;
-  const uint32_t mask = rec->coeff_mask;
-#if HM_NIP_WIDE
-  typedef hm_u128 Acc;
-#else
-  typedef uint64_t Acc;
-#endif
-  Acc acc[OUTS][HM_EPT];
-#pragma unroll
-  for (int k = 0; k < OUTS; ++k)
-#pragma unroll
-    for (int i = 0; i < HM_EPT; ++i) acc[k][i] = 0;
-#pragma unroll 1
-  for (uint32_t j = 0; j < a.n_terms; ++j) {
-    HmNttState st;
-    // a thread id the compiler cannot see through: otherwise the ~60 lane offsets of the pass are hoisted out of the digit
-    // loop as loop invariants and live (spilled) beside the accumulators
-    int tid = threadIdx.x;
-    asm volatile("" : "+v"(tid));
-    __builtin_assume(tid >= 0 && tid < (1 << HM_TL_ROW) / HM_EPT);
-    const uint32_t xl = rec->x[j];
-    const uint64_t *y[OUTS];
-#pragma unroll
-    for (int k = 0; k < OUTS; ++k) y[k] = a.y + (size_t)rec->y[k][j] * N;
-#if HM_NIP_PREFETCH
-    uint64_t e[OUTS][HM_EPT];
-    hm_ph_key_load<TL, LOGR, R2, OUTS>(e, tid, y, tile);
-#endif
-#if defined(HM_ABL_NIP_NOTRANSFORM)   // timing-only ablation: every digit taken as if already in evaluation form (loads + key MAC only)
-    if (false) {
-#else
-    if (mask & (1u << j)) {   // wave-uniform
-#endif
-      const uint64_t *src = a.hand + (size_t)xl * N;
-      const HmTw sc = {0, 0};
-      const HmEpi ep = hm_epi_none();
-      if (j) __syncthreads();   // the previous digit's last round has read the tile
-      int nsync = 0;
-      hm_ntt_pass_phases<TL, LOGR, false, false, 5, HM_NIP_LD_AUX>(st, tid, lds, src, nullptr, tile, twl, twt, s0, prefix0, m.q, sc, ep, [&] { hm_pass_sync<false>(nsync++); });
-#if HM_NIP_WIDE
-      hm_ph_below_2q(st, m.q);
-#endif
-    } else {
-      hm_ph_load_global<TL, LOGR, false, R2, HM_NIP_LD_AUX>(st, tid, a.x + (size_t)xl * N, tile);
-    }
-#if HM_NIP_PREFETCH
-    hm_ph_mac_regs<OUTS, Acc>(st, acc, e, m, j);
-#else
-#if defined(HM_ABL_NIP_NOMAC)          // timing-only ablation: transforms only (no key loads, no products)
-#pragma unroll
-    for (int k = 0; k < OUTS; ++k)
-#pragma unroll
-      for (int i = 0; i < HM_EPT; ++i) acc[k][i] += st.v[i] + k;
-#else
-    hm_ph_mac<TL, LOGR, R2, OUTS, HM_NIP_MAC_CH, Acc>(st, acc, tid, y, tile, m, j);
-#endif
-#endif
-  }
-  uint64_t *out[OUTS];
-#pragma unroll
-  for (int k = 0; k < OUTS; ++k) out[k] = a.out + (size_t)rec->out[k] * N;
-  if (INVOUT == 1 || (INVOUT == 2 && (mask & HM_NIP_INV_OUT))) {   // wave-uniform
-    // Round 5 (InnerProOut -> ModDownINTTOut, src/Operation.cpp:294-445): the special limbs of the key-switch sum are only ever read by
-    // the ModDown's inverse transform, whose first pass is a ROW pass over exactly this workgroup's 16 rows.  The reduced accumulators
-    // sit in the registers of the forward ROW pass's last round, which is the inverse ROW pass's first: the inverse pass runs from
-    // them (key 0, then key 1, on the tile this workgroup owns) and stores its hand-off where the ModDown INTT launch runs the
-    // remaining COL pass (hm_ntt_second_pass); InnerProduceOut_Key{k}'s special limbs are never written or read back.
-    const HmW *twl_i = a.tw_inv + (size_t)mod * N;
-    const HmW *twt_i = a.twist_inv + ((size_t)mod * (N >> LOGR) + prefix0) * 3;
-    // (straight-line code for the two keys: a loop with barriers inside is not unrolled and the accumulators end up in scratch)
-    auto inverse_first_pass = [&](auto KK) {
-      constexpr int k = decltype(KK)::value;
-      HmNttState st;
-#pragma unroll
-      for (int i = 0; i < HM_EPT; ++i) st.v[i] = hm_mac_final(acc[k][i], m);
-      int tid = threadIdx.x;
-      asm volatile("" : "+v"(tid));   // (lane offsets recomputed per pass, as in the digit loop)
-      __builtin_assume(tid >= 0 && tid < (1 << HM_TL_ROW) / HM_EPT);
-      __syncthreads();   // the previous pass's last round has read the tile
-      const HmTw sc = {0, 0};
-      const HmEpi ep = hm_epi_none();
-      int nsync = 0;
-      hm_ntt_pass_phases<TL, LOGR, false, true, 0, 0, 0, HM_EPI_CHUNK, true>(st, tid, lds, nullptr, out[k], tile, twl_i, twt_i, s0, prefix0, m.q, sc, ep, [&] { hm_pass_sync<false>(nsync++); });
-    };
-    inverse_first_pass(std::integral_constant<int, 0>());
-    if constexpr (OUTS == 2) inverse_first_pass(std::integral_constant<int, 1>());
-    return;
-  }
-  hm_ph_mac_store<TL, LOGR, R2, OUTS, Acc, HM_NIP_ST_AUX>(acc, threadIdx.x, out, tile, m);
+  hm16::hm_nip_body<OUTS, INVOUT>(a);
+}
+// The same in the small-launch geometry (round 5): one op at a time the launch is 800 workgroups on 768 slots (155 VGPRs: three 256-thread
+// workgroups per CU) and pays a second, nearly empty round.  512-thread workgroups with 8 coefficients per thread halve the serial work of
+// a workgroup and the accumulator registers per thread: the last round's idle time halves with them.  N = 2^16.
+template <int OUTS, int INVOUT>
+__global__ void __launch_bounds__((1 << HM_TL_ROW) / 8) k_ntt_row_ip8(HmNipArgs a) {
+  hm8::hm_nip_body<OUTS, INVOUT>(a);
 }
 
 #include "hm_bcol.h"
@@ -704,6 +620,7 @@ struct hm_ctx {
   bool capture_has_fused = false;   // the capture in progress recorded a one-launch transform
   uint32_t fused_small = 96;  // launches of up to this many entries (N = 2^16) run as ONE launch in the small-launch geometry (k_ntt_fused8): 2-5 us faster than two kernels up to ~100 limb-polys, slower from 128 (tools/ntt_fused_small_ab.py); 0 = off
   uint32_t bcol_outs = 0;   // output limbs per workgroup of the fused conversion + first pass (1 | 2; 0 = by launch size)
+  uint32_t nip_small = 64;  // transform x key launches of at most this many limb records (N = 2^16) run in the small-launch geometry (k_ntt_row_ip8); 0 = off
   int n_cu = 256;
   // multi-GPU
   int rank = 0, world = 1;
@@ -851,6 +768,7 @@ extern "C" hm_status hm_create(hm_ctx **out, const hm_params *p) {
     cc->fused_slots_per_xcd = slots;
     if (slots < (cc->P.N >> HM_TL_ROW)) cc->fused_small = 0;
   }
+  if (const char *e = getenv("HOMULATOR_NIP_SMALL")) cc->nip_small = (uint32_t)std::max(0, atoi(e));
   if (const char *e = getenv("HOMULATOR_BCOL_OUTS")) cc->bcol_outs = (uint32_t)std::min(2, std::max(0, atoi(e)));
   HM_HIP(nullptr, hipHostMalloc(reinterpret_cast<void **>(&cc->err_host), 64, hipHostMallocMapped));
   memset(cc->err_host, 0, 64);
@@ -1010,6 +928,7 @@ extern "C" hm_status hm_set_option(hm_ctx *c, const char *name, uint64_t value) 
     return HM_OK;
   }
   if (!strcmp(name, "bconv_col_outs")) { if (value > 2) return fail(c, HM_ERR_ARG, "hm_set_option: bconv_col_outs is 0 (by launch size), 1 or 2"); c->bcol_outs = (uint32_t)value; return HM_OK; }
+  if (!strcmp(name, "nip_small_limbs")) { c->nip_small = (uint32_t)value; return HM_OK; }
   if (!strcmp(name, "ntt_small_mode")) { c->small_mode = (uint32_t)value & 3u; return HM_OK; }
   if (!strcmp(name, "ntt_small_limbs")) { c->small_ept8 = value != 0; c->small_limbs = (uint32_t)value; return HM_OK; }
   return fail(c, HM_ERR_ARG, "hm_set_option: unknown option %s", name);
@@ -1730,10 +1649,14 @@ extern "C" hm_status hm_ntt_inner_product(hm_ctx *c, const hm_ntt_ip_desc *d) {
     typedef void (*nip_kernel)(HmNipArgs);
 #if HM_GENERIC
     static const nip_kernel kern[2][3] = {{k_ntt_row_ip<1, 0>, k_ntt_row_ip<1, 1>, nullptr}, {k_ntt_row_ip<2, 0>, k_ntt_row_ip<2, 1>, nullptr}};
+    static const nip_kernel kern8[2][3] = {{k_ntt_row_ip8<1, 0>, k_ntt_row_ip8<1, 1>, nullptr}, {k_ntt_row_ip8<2, 0>, k_ntt_row_ip8<2, 1>, nullptr}};
 #else
     static const nip_kernel kern[2][3] = {{k_ntt_row_ip<1, 0>, nullptr, k_ntt_row_ip<1, 2>}, {k_ntt_row_ip<2, 0>, nullptr, k_ntt_row_ip<2, 2>}};
+    static const nip_kernel kern8[2][3] = {{k_ntt_row_ip8<1, 0>, nullptr, k_ntt_row_ip8<1, 2>}, {k_ntt_row_ip8<2, 0>, nullptr, k_ntt_row_ip8<2, 2>}};
 #endif
-    hipLaunchKernelGGL(kern[K - 1][invForm], grid, block, 0, c->stream, a);
+    // small launches (one op at a time: 50 limb records = 800 workgroups on 768 slots of the wide form) take the small-launch geometry
+    if (c->P.logN == 16 && cnt <= c->nip_small) hipLaunchKernelGGL(kern8[K - 1][invForm], grid, dim3((1 << HM_TL_ROW) / 8), 0, c->stream, a);
+    else hipLaunchKernelGGL(kern[K - 1][invForm], grid, block, 0, c->stream, a);
     HM_HIP(c, hipGetLastError());
   }
   }   // sets

@@ -375,7 +375,16 @@ def test_ntt_inner_product_with_conversion_inside(n_in, chain):
                     yl += [(k * beta + j) * E + t for j in range(beta)]
                     ol.append((b * 2 + k) * E + t)
                 mods.append(ext[t])
+        # both geometries of the transform x key kernel: the small-launch one (512-thread workgroups, 8 coefficients per thread: launches of
+        # up to 64 limb records, round 5) and the wide one must agree bit for bit
+        ctx.set_option("nip_small_limbs", 0)
         ctx.ntt_inner_product(ownb, xl, flags, hand, hl, evkb, yl, out, ol, mods, beta, 2, conv=conv)
+        wide = out.download()
+        ctx.set_option("nip_small_limbs", 4096)
+        ctx.fill_uniform(out, [0] * (nops * 2 * E), 3)
+        ctx.ntt_inner_product(ownb, xl, flags, hand, hl, evkb, yl, out, ol, mods, beta, 2, conv=conv)
+        assert np.array_equal(out.download(), wide), "k_ntt_row_ip8 differs from k_ntt_row_ip"
+        ctx.set_option("nip_small_limbs", 64)
         got = out.download().reshape(nops, 2, E, -1)
         for b in range(nops):
             X = []
@@ -474,6 +483,7 @@ def test_inner_product_hands_over_the_first_pass_of_the_inverse_transform(chain)
             scale = [o.moduli[m] - 3 - i for i, m in enumerate(ids)]
             X0 = o.ntt(ids, xe[0])
             for rep in range(2):
+                ctx.set_option("nip_small_limbs", 64 if rep == 0 else 0)   # the small-launch geometry, then the wide one
                 ctx.fill_uniform(out, ids * outs, 99)
                 ctx.ntt_inner_product(xb, xl, coeff, hand, hl, yb, yl, out, ol, ids, T, outs, out_inverse=flags)
                 fl = [k * n + i for k in range(outs) for i in range(n) if flags[i]]
