@@ -92,7 +92,7 @@ __device__ __forceinline__ void hm_ntt_pass_run(const HmNttArgs &a, uint64_t *ld
   // loaded them with vector loads and kept 12-16 VGPRs of uniform values alive through the whole pass)
   typedef const HmNttEntry __attribute__((address_space(4))) *ConstEntry;
   const ConstEntry entries = (ConstEntry)(uintptr_t)a.entry;
-  if constexpr (MODE == 2) { sc.w = entries[entry].sc.w; sc.ws = entries[entry].sc.ws; }
+  if constexpr (MODE == 2) { sc.w = entries[entry].sc.w; sc.ws = entries[entry].sc.ws; ep.pack = entries[entry].pack; }
   if constexpr (MODE == 3) {
     const auto &en = entries[entry];
     sc.w = en.sc.w; sc.ws = en.sc.ws;
@@ -1142,6 +1142,7 @@ struct NttFused {
   const uint64_t *mix = nullptr;
   const uint32_t *mix_limbs = nullptr;
   const uint64_t *mix_k = nullptr;
+  const uint8_t *outPacked = nullptr;   // inverse: per limb-poly, store the split-30 packed form (hm_pack30)
   bool firstPassOnly = false;   // forward transform: run the COL pass only (the hand-off stays in `out`)
   bool secondPassOnly = false;  // forward transform: the hand-off is already in `out` (a fused conversion wrote it): run the ROW pass only
 };
@@ -1227,6 +1228,7 @@ static hm_status ntt_common(hm_ctx *c, const char *what, const uint64_t *in, con
           uint64_t v = c->P.modc[m].ninv;
           if (k) v = hm::mulmod(v, k[g], q);
           t.sc = hm_kconst(v, q);
+          t.pack = f.outPacked && f.outPacked[g] ? 1 : 0;
         } else if (fused) {
           t.sc = hm_kconst(k[g], q);
           a.limb[e].aux = (uint16_t)limb_at(f.minuend_limbs, g);
@@ -1281,6 +1283,18 @@ extern "C" hm_status hm_ntt_second_pass(hm_ctx *c, uint64_t *buf, const uint32_t
   NttFused f;
   f.secondPassOnly = true;
   return ntt_common(c, "hm_ntt_second_pass", buf, limbs, buf, limbs, mod_ids, n, inverse, scale, f);
+}
+
+extern "C" hm_status hm_ntt_ex(hm_ctx *c, const hm_ntt_desc *d) {
+  if (!c) return HM_ERR_ARG;
+  if (!d || !d->out || (!d->in && !d->second_pass_only)) return fail(c, HM_ERR_ARG, "hm_ntt_ex: null buffer");
+  if (d->scale && !d->inverse) return fail(c, HM_ERR_ARG, "hm_ntt_ex: scale is only defined for the inverse transform");
+  if (d->out_packed && !d->inverse) return fail(c, HM_ERR_ARG, "hm_ntt_ex: out_packed is only defined for the inverse transform");
+  NttFused f;
+  f.secondPassOnly = d->second_pass_only != 0;
+  f.outPacked = d->out_packed;
+  if (f.secondPassOnly) return ntt_common(c, "hm_ntt_ex", d->out, d->out_limbs, d->out, d->out_limbs, d->mod_ids, d->n, d->inverse, d->scale, f);
+  return ntt_common(c, "hm_ntt_ex", d->in, d->in_limbs, d->out, d->out_limbs, d->mod_ids, d->n, d->inverse, d->scale, f);
 }
 
 extern "C" hm_status hm_ntt_sub_scale(hm_ctx *c, const uint64_t *in, const uint32_t *in_limbs, const uint64_t *minuend,
@@ -1735,6 +1749,7 @@ extern "C" hm_status hm_bconv_batch(hm_ctx *c, const hm_bconv_desc *descs, uint3
     HmBconvProb &p = probs[pi];
     memset(&p, 0, sizeof p);
     p.in = d.in; p.out = d.out; p.table = it->second; p.n_in = d.n_in; p.n_out = d.n_out;
+    p.in_packed = d.in_packed ? 1u : 0u;
     p.qn = it->second + (size_t)HM_BCONV_ROW(d.n_in) * d.n_out;
     for (uint32_t i = 0; i < d.n_in; ++i) p.in_limb[i] = limb_at(d.in_limbs, i);
     for (uint32_t t = 0; t < d.n_out; ++t) {
@@ -1853,6 +1868,7 @@ static hm_status bconv_col_launch(hm_ctx *c, const hm_bconv_desc *descs, uint32_
     HmBcolProb p;
     memset(&p, 0, sizeof p);
     p.in = d.in; p.table = it->second; p.qn = it->second + (size_t)HM_BCONV_ROW(d.n_in) * d.n_out; p.n_in = d.n_in; p.n_out = d.n_out;
+    p.in_packed = d.in_packed ? 1u : 0u;
     for (uint32_t i = 0; i < d.n_in; ++i) p.in_limb[i] = limb_at(d.in_limbs, i);
     for (uint32_t t = 0; t < d.n_out; ++t) { p.out_limb[t] = limb_at(d.out_limbs, t); p.out_mod[t] = d.out_ids[t]; }
     if (mix) {   // x = conv + k * mix before the first butterfly: constants in Shoup form, a device table cached by content

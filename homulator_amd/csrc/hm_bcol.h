@@ -22,6 +22,7 @@ struct HmBcolProb {
   uint32_t out_mod[HM_BCONV_MAX_OUT];    // its modulus id (shared twiddles)
   uint32_t mix_limb[HM_BCONV_MAX_OUT];   // MIX: the operand added to output o before the transform (limb of HmBcolArgs::mix), constant in mixk
   const HmTw *mixk;                      // MIX: device, [n_out]
+  uint32_t in_packed;                    // the inputs are stored in the split-30 packed form (hm_pack30): no shift / mask per input and workgroup
 };
 struct HmBcolArgs {
   const HmBcolProb *prob;   // device
@@ -78,6 +79,45 @@ __device__ __forceinline__ void hm_bcol_rounds(HmNttState &st, int tid, uint64_t
     hm_ntt_phase<TL, LOG1, true, false, 0, 3>(st, tid, lds, nullptr, dst, tile, twl, nullptr, 0, 0, q, sc, ep);
   }
 }
+// conversion of a thread's HM_UNITS access units for the NOUT outputs of the workgroup (a function template, not a lambda: a lambda that
+// captures the constant-address-space problem record by reference loses the address space)
+template <int N_IN, int NOUT, bool MIX, bool PACKED, class G0, class PROB>
+__device__ __forceinline__ void hm_bcol_units(const PROB &p, HmNttState &st0, HmNttState &st1, const uint64_t *mix0, const uint64_t *mix1, uint32_t o0, uint32_t o1,
+                                              uint32_t tile, int tid, size_t N) {
+#pragma unroll
+  for (int u = 0; u < HM_UNITS; ++u) {   // (hm_bcol_part.hip is compiled with a raised pragma-unroll threshold: this loop must be unrolled)
+    int i0, i1, x, c;
+    G0::unit(tid, u, i0, i1, x, c);
+    uint32_t yl[2][N_IN], yh[2][N_IN];
+#pragma unroll
+    for (int i = 0; i < N_IN; ++i) {
+      uint64_t v0, v1;
+      hm_gld2<G0>(p.in + (size_t)p.in_limb[i] * N, tile, tid, u, v0, v1);
+#if defined(HM_ABL_BCOL_PACKED)   // timing-only ablation: inputs taken as if already stored split (no shift / mask per input and output)
+      yl[0][i] = (uint32_t)v0; yh[0][i] = (uint32_t)(v0 >> 32);
+      yl[1][i] = (uint32_t)v1; yh[1][i] = (uint32_t)(v1 >> 32);
+#else
+      if (PACKED) {
+        yl[0][i] = (uint32_t)v0; yh[0][i] = (uint32_t)(v0 >> 32);
+        yl[1][i] = (uint32_t)v1; yh[1][i] = (uint32_t)(v1 >> 32);
+      } else {
+        yl[0][i] = (uint32_t)v0 & 0x3FFFFFFFu; yh[0][i] = (uint32_t)(v0 >> 30);
+        yl[1][i] = (uint32_t)v1 & 0x3FFFFFFFu; yh[1][i] = (uint32_t)(v1 >> 30);
+      }
+#endif
+    }
+    hm_bcol_convert<N_IN, MIX, G0>(yl, yh, p.table, p.qn, p.mixk, mix0, o0, tile, tid, u, st0.v[i0], st0.v[i1]);
+    // an odd basis' last group converts its one output twice (wave-uniform; the copy is never transformed or stored)
+    if (NOUT == 2) hm_bcol_convert<N_IN, MIX, G0>(yl, yh, p.table, p.qn, p.mixk, mix1, o1, tile, tid, u, st1.v[i0], st1.v[i1]);
+#if defined(__HIP_DEVICE_COMPILE__)
+    // the results are "used" here: otherwise the products are sunk below the barrier to their first real use and ALL units' inputs are
+    // loaded (and spilled) up front
+    asm volatile("" : "+v"(st0.v[i0]), "+v"(st0.v[i1]));
+    if (NOUT == 2) asm volatile("" : "+v"(st1.v[i0]), "+v"(st1.v[i1]));
+#endif
+    __builtin_amdgcn_sched_barrier(0);   // one unit's loads in flight at a time (N_IN x 16 bytes per lane)
+  }
+}
 template <int N_IN, int LOG1, int NOUT, bool MIX>
 __device__ __forceinline__ void hm_bconv_col_body(const HmBcolArgs &a) {
   constexpr int TL = HM_TL_COL;
@@ -104,34 +144,9 @@ __device__ __forceinline__ void hm_bconv_col_body(const HmBcolArgs &a) {
   const bool two = NOUT == 2 && o0 + 1 < p.n_out;   // wave-uniform: the last group of an odd basis has one output
   const uint32_t o1 = two ? o0 + 1 : o0;
   const uint64_t *mix0 = MIX ? a.mix + (size_t)p.mix_limb[o0] * N : nullptr, *mix1 = MIX ? a.mix + (size_t)p.mix_limb[o1] * N : nullptr;
-#pragma unroll
-  for (int u = 0; u < HM_UNITS; ++u) {   // (hm_bcol_part.hip is compiled with a raised pragma-unroll threshold: this loop must be unrolled)
-    int i0, i1, x, c;
-    G0::unit(tid, u, i0, i1, x, c);
-    uint32_t yl[2][N_IN], yh[2][N_IN];
-#pragma unroll
-    for (int i = 0; i < N_IN; ++i) {
-      uint64_t v0, v1;
-      hm_gld2<G0>(p.in + (size_t)p.in_limb[i] * N, tile, tid, u, v0, v1);
-#if defined(HM_ABL_BCOL_PACKED)   // timing-only ablation: inputs taken as if already stored split (no shift / mask per input and output)
-      yl[0][i] = (uint32_t)v0; yh[0][i] = (uint32_t)(v0 >> 32);
-      yl[1][i] = (uint32_t)v1; yh[1][i] = (uint32_t)(v1 >> 32);
-#else
-      yl[0][i] = (uint32_t)v0 & 0x3FFFFFFFu; yh[0][i] = (uint32_t)(v0 >> 30);
-      yl[1][i] = (uint32_t)v1 & 0x3FFFFFFFu; yh[1][i] = (uint32_t)(v1 >> 30);
-#endif
-    }
-    hm_bcol_convert<N_IN, MIX, G0>(yl, yh, p.table, p.qn, p.mixk, mix0, o0, tile, tid, u, st0.v[i0], st0.v[i1]);
-    // an odd basis' last group converts its one output twice (wave-uniform; the copy is never transformed or stored)
-    if (NOUT == 2) hm_bcol_convert<N_IN, MIX, G0>(yl, yh, p.table, p.qn, p.mixk, mix1, o1, tile, tid, u, st1.v[i0], st1.v[i1]);
-#if defined(__HIP_DEVICE_COMPILE__)
-    // the results are "used" here: otherwise the products are sunk below the barrier to their first real use and ALL units' inputs are
-    // loaded (and spilled) up front
-    asm volatile("" : "+v"(st0.v[i0]), "+v"(st0.v[i1]));
-    if (NOUT == 2) asm volatile("" : "+v"(st1.v[i0]), "+v"(st1.v[i1]));
-#endif
-    __builtin_amdgcn_sched_barrier(0);   // one unit's loads in flight at a time (N_IN x 16 bytes per lane)
-  }
+  // the inputs' form is wave-uniform: two copies of the unit loop (a per-value select would cost what the packed form saves)
+  if (p.in_packed) hm_bcol_units<N_IN, NOUT, MIX, true, G0>(p, st0, st1, mix0, mix1, o0, o1, tile, tid, N);
+  else hm_bcol_units<N_IN, NOUT, MIX, false, G0>(p, st0, st1, mix0, mix1, o0, o1, tile, tid, N);
   __syncthreads();
   hm_bcol_rounds<TL, LOG1>(st0, tid, lds, HM_CONST_QN(p.qn)[o0].q, a.tw + (size_t)p.out_mod[o0] * N, a.out + (size_t)p.out_limb[o0] * N, tile);
   if (NOUT == 2 && two) {

@@ -139,6 +139,7 @@ struct HmBconvProb {
   const uint64_t *ep_a, *ep_b;
   const HmTw *ep_k;                      // device, [n_out]
   uint32_t ep_a_limb[HM_BCONV_MAX_OUT], ep_b_limb[HM_BCONV_MAX_OUT];
+  uint32_t in_packed;                    // the inputs are stored in the split-30 packed form (hm_pack30)
 };
 struct HmBconvArgs {
   const HmBconvProb *prob;  // device, [n_prob]: read with scalar loads (wave-uniform index)
@@ -252,8 +253,8 @@ HM_HD void hm_bconv_thread(const PROB &p, uint32_t logN, uint32_t x, uint32_t t0
     else v[0] = p.in[(size_t)p.in_limb[i] * N + x];
 #pragma unroll
     for (int c = 0; c < CPT; ++c) {
-      yl[c][i] = (uint32_t)v[c] & 0x3FFFFFFFu;
-      yh[c][i] = (uint32_t)(v[c] >> 30);
+      if (p.in_packed) { yl[c][i] = (uint32_t)v[c]; yh[c][i] = (uint32_t)(v[c] >> 32); }   // (wave-uniform)
+      else { yl[c][i] = (uint32_t)v[c] & 0x3FFFFFFFu; yh[c][i] = (uint32_t)(v[c] >> 30); }
     }
   }
   for (uint32_t t = t0; t < t1; ++t) {

@@ -83,7 +83,8 @@ struct HmLimb {  // one limb-poly of an automorphism / fill launch: limb indices
 //   last pass,  MODE 3:  out = (minuend - NTT(x)) * sc [+ addend * ak]
 struct HmNttEntry {                  // the part of a record that is not needed to start loading (device table)
   uint16_t alimb, mixlimb;           // MODE 3 addend limb (HM_NTT_NONE: no addend), MODE 4 operand limb
-  uint16_t pad[2];
+  uint16_t pack;                     // MODE 2 (round 5): the output is stored in the split-30 packed form of the base conversions' inputs
+  uint16_t pad;
   uint64_t pad1;
   HmTw sc;                           // inverse: N^-1 * extra scale; fused forward: the epilogue constant k
   HmTw ak;                           // fused forward: addend constant (w == 0: none)
@@ -113,8 +114,15 @@ struct HmEpi {  // the prologue / epilogue operands of one limb-poly, resolved b
   HmTw dk;                   // addend constant; dk.w == 0: none
   const uint64_t *b;         // mix operand (MODE 4)
   HmTw bk;
+  uint32_t pack;             // MODE 2: store hm_pack30(value) (wave-uniform)
 };
-HM_HD HmEpi hm_epi_none() { return HmEpi{nullptr, nullptr, HmTw{0, 0}, nullptr, HmTw{0, 0}}; }
+HM_HD HmEpi hm_epi_none() { return HmEpi{nullptr, nullptr, HmTw{0, 0}, nullptr, HmTw{0, 0}, 0}; }
+// Split-30 packed form (round 5): x < 2^60 stored as (x mod 2^30) | ((x >> 30) << 32) — the two 30-bit halves a base conversion multiplies
+// with, one per dword.  The inverse transforms that feed ONLY base conversions (ModUp_DecompOut, ModDownBConvStep1: src/Operation.cpp:
+// 104-135, 447-487) store this form (two instructions per value, once), and every conversion workgroup that reads the value (one per pair
+// of output limbs: 18 readers per value in a 35-output ModUp digit) takes the halves as they are instead of shifting and masking again.
+HM_HD uint64_t hm_pack30(uint64_t x) { return (x & 0x3FFFFFFFull) | ((x >> 30) << 32); }
+HM_HD uint64_t hm_unpack30(uint64_t p) { return (p & 0x3FFFFFFFull) | ((p >> 32) << 30); }
 
 // 16-byte accesses (two adjacent words; p is 16-byte aligned)
 HM_HD void hm_ld2(const uint64_t *p, uint64_t &a, uint64_t &b) {

@@ -244,7 +244,7 @@ HM_HD void hm_ph_load_global_mix(HmNttState &st, int tid, const uint64_t *g, uin
 template <int MODE>
 HM_HD uint64_t hm_epilogue(uint64_t a, uint64_t va, uint64_t vd, uint64_t q, HmTw sc, const HmEpi &ep) {
   if (MODE == 1) return hm_reduce_fwd(a, q);
-  if (MODE == 2) return hm_kmul(a, sc, q);
+  if (MODE == 2) { a = hm_kmul(a, sc, q); return ep.pack ? hm_pack30(a) : a; }
   if (MODE == 3) {  // a in [0, 2 HM_LAZY_Q q): minuend - a + 2 HM_LAZY_Q q stays positive and below 9q < 2^64 (mont32: 5q < 2^63); the product reduces it
     a = hm_kmul(va + 2 * HM_LAZY_Q * q - a, sc, q);
     if (ep.d) a = hm_addmod(a, ep.dk.w ? hm_kmul(vd, ep.dk, q) : vd, q);

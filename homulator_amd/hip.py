@@ -20,7 +20,7 @@ SYMBOLS = [
     "hm_bconv", "hm_bconv_batch", "hm_bconv_consts", "hm_fill_uniform", "hm_timer_start", "hm_timer_stop", "hm_comm_unique_id", "hm_comm_init_rccl", "hm_comm_init_external",
     "hm_capture_begin", "hm_capture_end", "hm_graph_launch", "hm_graph_destroy", "hm_comm_info", "hm_slice_rows", "hm_limbs_to_slices", "hm_slices_to_limbs", "hm_replicate_limbs",
     "hm_set_option", "hm_get_counter", "hm_ntt_inner_product", "hm_exchange_stream", "hm_exchange_mark", "hm_exchange_wait",
-    "hm_bconv_col", "hm_limbs_to_colslices", "hm_colslices_to_limbs", "hm_ntt_second_pass",
+    "hm_bconv_col", "hm_limbs_to_colslices", "hm_colslices_to_limbs", "hm_ntt_second_pass", "hm_ntt_ex",
 ]
 
 
@@ -42,7 +42,12 @@ class hm_bconv_desc(C.Structure):
     _fields_ = [("in_", C.c_void_p), ("in_limbs", C.c_void_p), ("in_ids", C.c_void_p), ("n_in", C.c_uint32),
                 ("out", C.c_void_p), ("out_limbs", C.c_void_p), ("out_ids", C.c_void_p), ("n_out", C.c_uint32),
                 ("log_len", C.c_uint32), ("sub_from", C.c_void_p), ("sub_from_limbs", C.c_void_p), ("add", C.c_void_p), ("add_limbs", C.c_void_p),
-                ("sub_k", C.c_void_p)]
+                ("sub_k", C.c_void_p), ("in_packed", C.c_uint32)]
+
+
+class hm_ntt_desc(C.Structure):
+    _fields_ = [("in_", C.c_void_p), ("in_limbs", C.c_void_p), ("out", C.c_void_p), ("out_limbs", C.c_void_p), ("mod_ids", C.c_void_p), ("n", C.c_uint32),
+                ("inverse", C.c_int), ("scale", C.c_void_p), ("second_pass_only", C.c_int), ("out_packed", C.c_void_p)]
 
 
 class hm_params(C.Structure):
@@ -81,6 +86,7 @@ def load():
     L.hm_wait_for.argtypes = [vp, vp]
     L.hm_ntt.argtypes = [vp, vp, vp, vp, vp, vp, u32, i32, vp]
     L.hm_ntt_second_pass.argtypes = [vp, vp, vp, vp, u32, i32, vp]
+    L.hm_ntt_ex.argtypes = [vp, C.POINTER(hm_ntt_desc)]
     L.hm_ntt_sub_scale.argtypes = [vp] + [vp] * 9 + [u32, vp]
     L.hm_ntt_mix_sub_scale.argtypes = [vp, C.POINTER(hm_ntt_fused_desc)]
     L.hm_tensor.argtypes = [vp] + [vp] * 15 + [u32]
@@ -201,13 +207,19 @@ class Context:
         return list(range(ell)) + [self.nQ + i for i in range(self.K)]
 
     # ---- compute calls (device pointers + limb lists)
-    def ntt(self, src, dst, mod_ids, inverse=False, in_limbs=None, out_limbs=None, scale=None):
+    def ntt(self, src, dst, mod_ids, inverse=False, in_limbs=None, out_limbs=None, scale=None, out_packed=None):
+        """out_packed (inverse only): per limb, store the split-30 packed form the base conversions take with in_packed (hm_ntt_ex)"""
         n = len(mod_ids)
         k1, pi = _u32(in_limbs)
         k2, po = _u32(out_limbs)
         k3, pm = _u32(mod_ids)
         k4, ps = _u64(scale)
-        self._ck(self.L.hm_ntt(self.h, src.ptr, pi, dst.ptr, po, pm, n, 1 if inverse else 0, ps))
+        if out_packed is None:
+            self._ck(self.L.hm_ntt(self.h, src.ptr, pi, dst.ptr, po, pm, n, 1 if inverse else 0, ps))
+            return
+        pk = np.ascontiguousarray(np.asarray(out_packed, dtype=np.uint8))
+        d = hm_ntt_desc(src.ptr, pi, dst.ptr, po, pm, n, 1 if inverse else 0, ps, 0, pk.ctypes.data_as(C.c_void_p))
+        self._ck(self.L.hm_ntt_ex(self.h, C.byref(d)))
 
     def ntt_sub_scale(self, src, minuend, out, mod_ids, k, addend=None, in_limbs=None, minuend_limbs=None, addend_limbs=None,
                       out_limbs=None):
@@ -227,9 +239,10 @@ class Context:
         descs, keep2 = None, []
         if conv:
             descs = (hm_bconv_desc * len(conv))()
-            for dd, (csrc, c_in_limbs, in_ids, c_out_limbs, out_ids) in zip(descs, conv):
+            for dd, (csrc, c_in_limbs, in_ids, c_out_limbs, out_ids, *pk) in zip(descs, conv):
                 arrs = [_u32(c_in_limbs), _u32(in_ids), _u32(c_out_limbs), _u32(out_ids)]
                 keep2.append(arrs)
+                dd.in_packed = 1 if pk and pk[0] else 0
                 dd.in_, dd.in_limbs, dd.in_ids, dd.n_in = csrc.ptr, arrs[0][1], arrs[1][1], len(in_ids)
                 dd.out, dd.out_limbs, dd.out_ids, dd.n_out, dd.log_len = out.ptr, arrs[2][1], arrs[3][1], len(out_ids), 0
         d = hm_ntt_fused_desc(ptr(src) if src is not None else out.ptr, keep[0][1], ptr(mix), keep[1][1], ks[0][1], minuend.ptr, keep[2][1], ptr(addend), keep[3][1], ks[1][1],
@@ -263,9 +276,10 @@ class Context:
         descs, keep2 = None, []
         if conv:
             descs = (hm_bconv_desc * len(conv))()
-            for dd, (src, in_limbs, in_ids, out_limbs_, out_ids) in zip(descs, conv):
+            for dd, (src, in_limbs, in_ids, out_limbs_, out_ids, *pk) in zip(descs, conv):
                 arrs = [_u32(in_limbs), _u32(in_ids), _u32(out_limbs_), _u32(out_ids)]
                 keep2.append(arrs)
+                dd.in_packed = 1 if pk and pk[0] else 0
                 dd.in_, dd.in_limbs, dd.in_ids, dd.n_in = src.ptr, arrs[0][1], arrs[1][1], len(in_ids)
                 dd.out, dd.out_limbs, dd.out_ids, dd.n_out, dd.log_len = hand.ptr, arrs[2][1], arrs[3][1], len(out_ids), 0
         inv = None if out_inverse is None else np.ascontiguousarray(np.asarray(out_inverse, dtype=np.uint8))
@@ -295,11 +309,12 @@ class Context:
         self._ck(self.L.hm_bconv(self.h, src.ptr, pil, pii, len(in_ids), dst.ptr, pol, poi, len(out_ids)))
 
     def bconv_batch(self, probs, log_len=0):
-        """several conversions in one launch: probs = [(src, in_limbs, in_ids, dst, out_limbs, out_ids), ...]"""
+        """several conversions in one launch: probs = [(src, in_limbs, in_ids, dst, out_limbs, out_ids[, in_packed]), ...]"""
         keep, descs = [], (hm_bconv_desc * len(probs))()
-        for d, (src, in_limbs, in_ids, dst, out_limbs, out_ids) in zip(descs, probs):
+        for d, (src, in_limbs, in_ids, dst, out_limbs, out_ids, *pk) in zip(descs, probs):
             arrs = [_u32(in_limbs), _u32(in_ids), _u32(out_limbs), _u32(out_ids)]
             keep.append(arrs)
+            d.in_packed = 1 if pk and pk[0] else 0
             d.in_, d.in_limbs, d.in_ids, d.n_in = src.ptr, arrs[0][1], arrs[1][1], len(in_ids)
             d.out, d.out_limbs, d.out_ids, d.n_out, d.log_len = dst.ptr, arrs[2][1], arrs[3][1], len(out_ids), log_len
         self._ck(self.L.hm_bconv_batch(self.h, descs, len(probs)))

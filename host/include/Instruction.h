@@ -44,6 +44,9 @@ public:
   // (10) a BCONV_STEP2 record with the element-wise epilogue out = (fSubFrom - conv) * constant [+ fAdd] (the rescale residue of 4c)
   bool ipInvOut = false;     // IP record (7b, round 5): its outputs leave the kernel as the first pass of their inverse transform
   bool secondOnly = false;   // INTT record (7b): the first pass has been run into its output limb by the producing IP record
+  bool packedOut = false;    // INTT record (11, round 5): the output is stored in the split-30 packed form (only base conversions read it)
+  bool inPacked = false;     // BCONV record / fused transform with fConvIn (11): the conversion's inputs are stored packed
+  std::vector<uint8_t> ipConvPacked;   // IP record (11): per digit, the inputs of the digit's fused conversion are stored packed
   bool fusedEpi = false;
   AddrType fSubFrom = 0, fAdd = 0;
   bool fusedTensor = false;            // MAC2 record that also produces d0 -> extraOutputs[0] and d2 -> extraOutputs[1]

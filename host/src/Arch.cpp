@@ -21,13 +21,14 @@ struct Arch::Launch {
   std::vector<uint8_t> ipCoeff;   // L_NTT_IP: per (limb, digit) 1 = transformed inside the kernel (a = source, c = first-pass scratch)
   std::vector<uint8_t> ipInv;     // L_NTT_IP (7b): per limb, 1 = the outputs leave as the first pass of their inverse transform
   bool secondOnly = false;        // L_INTT (7b): hm_ntt_second_pass — the first pass was run by the inner-product kernel
+  std::vector<uint8_t> outPacked; // L_INTT (11): per limb-poly, 1 = stored in the split-30 packed form of the conversions' inputs
   uint32_t ipTerms = 0, ipOuts = 0;
   std::string name;
   std::string statKey;
   int opcode = 0;
   uint32_t galois = 0;
   std::vector<uint32_t> a, b, c, d, out, out1, out2, mods, inMods;
-  struct Prob { std::vector<uint32_t> in, inMods, out, outMods, epA, epB; std::vector<uint64_t> epK; bool epi = false, epAdd = false; };
+  struct Prob { std::vector<uint32_t> in, inMods, out, outMods, epA, epB; std::vector<uint64_t> epK; bool epi = false, epAdd = false, inPacked = false; };
   std::vector<Prob> probs;  // BCONV: independent conversions batched into one launch
   // multi-GPU: exchange steps (limb list + owner of each limb) and the coefficient-slice buffers of a sharded BCONV
   std::vector<uint32_t> exLimbs, exOwners;
@@ -96,6 +97,11 @@ Arch::Arch(Config *cfg) : config(cfg) {
   // runs it on its accumulators and the INTT launch keeps the COL pass.  N = 2^16, one GPU.  Config key fuse_ip_inv (default 1).
   fuseIpInv = cfg->getValueOr("fuse_ip_inv", 1) != 0;
   if (const char *e = getenv("HOMULATOR_FUSE_IP_INV")) fuseIpInv = std::string(e) != "0";
+  // (11, round 5) the inverse transforms whose outputs are read by base conversions only (ModUp_DecompOut, ModDownBConvStep1) store them in
+  // the split-30 packed form the conversions multiply with: two instructions per value in the producer instead of two per value and reading
+  // workgroup (18 per value in a 35-output ModUp digit).  Config key pack_bconv_in (default 1).
+  packBconvIn = cfg->getValueOr("pack_bconv_in", 1) != 0;
+  if (const char *e = getenv("HOMULATOR_PACK_BCONV_IN")) packBconvIn = std::string(e) != "0";
   fuseModDown = cfg->getValueOr("fuse_moddown", 0) != 0;
   if (const char *e = getenv("HOMULATOR_FUSE_MODDOWN")) fuseModDown = std::string(e) != "0";
   // sharded runs: the exchanges of digit j+1 run on the context's exchange stream while digit j converts and transforms (SURVEY.md 7:
@@ -640,6 +646,56 @@ void Arch::fusePasses(std::vector<Stage> &st) {
         dead.insert(e);
       }
   }
+  // (11, round 5) split-30 packed conversion inputs.  A limb-poly that an inverse transform writes and that nothing but base conversions read
+  //      (as a conversion INPUT: a separate conversion, a conversion inside a transform x key record or inside a fused transform) is
+  //      stored packed; a conversion takes packed inputs only if all of them are.
+  if (packBconvIn && world_ == 1) {
+    struct Conv { std::vector<AddrType> in; Instruction *ins; int digit; };   // digit: index into ipConvIn, -1 = the record's own conversion
+    std::vector<Conv> convs;
+    std::map<AddrType, int> otherReads;   // reads of an address that are not a conversion input
+    for (auto &s : st)
+      for (Instruction *i : s.ins) {
+        if (dead.count(i)) continue;
+        if (i->ops == IP && !i->ipX.empty()) {
+          const auto &src = i->ipSrc.empty() ? i->ipX : i->ipSrc;
+          for (size_t j = 0; j < src.size(); ++j) {
+            const bool conv = j < i->ipConvIn.size() && !i->ipConvIn[j].empty();
+            if (conv) convs.push_back(Conv{i->ipConvIn[j], i, (int)j});
+            else otherReads[src[j]]++;
+          }
+          for (auto &y : i->ipY) for (AddrType yy : y) otherReads[yy]++;
+          continue;
+        }
+        if (i->ops == BCONV_STEP2) convs.push_back(Conv{std::vector<AddrType>(i->operandList.begin(), i->operandList.end() - 1), i, -1});
+        else if (!i->fConvIn.empty()) convs.push_back(Conv{i->fConvIn, i, -1});
+        else for (AddrType a : operands(i)) otherReads[a]++;
+        if (i->fusedSubScale) { otherReads[i->fMinuend]++; if (i->fAddend) otherReads[i->fAddend]++; if (i->fMix) otherReads[i->fMix]++; }
+        if (i->fusedEpi) { otherReads[i->fSubFrom]++; if (i->fAdd) otherReads[i->fAdd]++; }
+      }
+    std::set<AddrType> cand;
+    for (auto &s : st)
+      for (Instruction *x : s.ins)
+        if (x->ops == INTT && !dead.count(x) && !otherReads.count(x->OutputOperand)) cand.insert(x->OutputOperand);
+    for (bool changed = true; changed;) {   // a conversion with one plain input keeps all of its inputs plain
+      changed = false;
+      for (const Conv &cv : convs) {
+        bool all = true;
+        for (AddrType a : cv.in) all &= cand.count(a) != 0;
+        if (all) continue;
+        for (AddrType a : cv.in) changed |= cand.erase(a) != 0;
+      }
+    }
+    std::set<AddrType> read;
+    for (const Conv &cv : convs) {
+      if (cv.in.empty() || !cand.count(cv.in[0])) continue;
+      if (cv.digit >= 0) { cv.ins->ipConvPacked.resize(cv.ins->ipConvIn.size(), 0); cv.ins->ipConvPacked[(size_t)cv.digit] = 1; }
+      else cv.ins->inPacked = true;
+      read.insert(cv.in.begin(), cv.in.end());
+    }
+    for (auto &s : st)
+      for (Instruction *x : s.ins)
+        if (x->ops == INTT && !dead.count(x) && read.count(x->OutputOperand)) x->packedOut = true;
+  }
   // drop dead instructions and empty stages; upstream instructions of eliminated pass-through records are
   // accounted on the first surviving instruction so that the retired total still matches getTotalIns()
   unsigned long long orphan = 0;
@@ -940,8 +996,9 @@ void Arch::buildLaunches() {
               std::vector<uint32_t> in;
               for (AddrType x : i->ipConvIn[j]) in.push_back(limbOf(x));
               Launch::Prob *pr = nullptr;
-              for (auto &q : L->probs) if (q.in == in && q.inMods == i->ipConvMods[j]) pr = &q;
-              if (!pr) { L->probs.push_back(Launch::Prob{in, i->ipConvMods[j], {}, {}}); pr = &L->probs.back(); }
+              const bool pk = j < i->ipConvPacked.size() && i->ipConvPacked[j];
+              for (auto &q : L->probs) if (q.in == in && q.inMods == i->ipConvMods[j] && q.inPacked == pk) pr = &q;
+              if (!pr) { L->probs.push_back(Launch::Prob{in, i->ipConvMods[j], {}, {}}); pr = &L->probs.back(); pr->inPacked = pk; }
               pr->out.push_back(limbOf(i->ipX[j]));      // the hand-off limb of (limb, digit)
               pr->outMods.push_back(i->mod_id);
               lp -= 1;                                      // the converted limb is neither written nor read: source = the conversion's inputs
@@ -1000,8 +1057,8 @@ void Arch::buildLaunches() {
             std::vector<uint32_t> in;
             for (AddrType x : i->fConvIn) in.push_back(limbOf(x));
             Launch::Prob *pr = nullptr;
-            for (auto &q : L->probs) if (q.in == in && q.inMods == i->fConvMods) pr = &q;
-            if (!pr) { L->probs.push_back(Launch::Prob{in, i->fConvMods, {}, {}}); pr = &L->probs.back(); L->bytes += LP * in.size(); }
+            for (auto &q : L->probs) if (q.in == in && q.inMods == i->fConvMods && q.inPacked == i->inPacked) pr = &q;
+            if (!pr) { L->probs.push_back(Launch::Prob{in, i->fConvMods, {}, {}}); pr = &L->probs.back(); pr->inPacked = i->inPacked; L->bytes += LP * in.size(); }
             pr->out.push_back(limbOf(i->OutputOperand));   // the hand-off lands in the output limb
             pr->outMods.push_back(i->mod_id);
             L->bytes -= LP;                                  // the converted limb-poly is neither written nor read
@@ -1019,6 +1076,7 @@ void Arch::buildLaunches() {
             L->a.push_back(limbOf(i->operandList[0])); L->out.push_back(limbOf(i->OutputOperand)); L->mods.push_back(i->mod_id);
             L->k.push_back(i->hasConstant ? i->constant : 1);
             L->hasK |= i->hasConstant;
+            if (f->ops == INTT) L->outPacked.push_back(i->packedOut ? 1 : 0);
           }
         L->bytes = 2 * LP * count;
       } else if (f->ops == AUTO) {
@@ -1048,8 +1106,8 @@ void Arch::buildLaunches() {
             std::vector<uint32_t> in;
             for (size_t x = 0; x + 1 < i->operandList.size(); ++x) in.push_back(limbOf(i->operandList[x]));
             Launch::Prob *pr = nullptr;
-            for (auto &q : L->probs) if (q.in == in && q.inMods == i->inMods && q.epi == i->fusedEpi && q.epAdd == (i->fAdd != 0)) pr = &q;
-            if (!pr) { L->probs.push_back(Launch::Prob{in, i->inMods, {}, {}}); pr = &L->probs.back(); pr->epi = i->fusedEpi; pr->epAdd = i->fAdd != 0; }
+            for (auto &q : L->probs) if (q.in == in && q.inMods == i->inMods && q.epi == i->fusedEpi && q.epAdd == (i->fAdd != 0) && q.inPacked == i->inPacked) pr = &q;
+            if (!pr) { L->probs.push_back(Launch::Prob{in, i->inMods, {}, {}}); pr = &L->probs.back(); pr->epi = i->fusedEpi; pr->epAdd = i->fAdd != 0; pr->inPacked = i->inPacked; }
             pr->out.push_back(limbOf(i->OutputOperand));
             pr->outMods.push_back(i->mod_id);
             if (i->fusedEpi) {   // (10): out = (fSubFrom - conv) * k [+ fAdd]
@@ -1186,6 +1244,11 @@ void Arch::replicateForBatch() {
         l->ipInv.assign(fi.begin(), fi.end());
       }
     } else {
+      {
+        const size_t n0 = l->outPacked.size();
+        for (uint32_t c = 1; c < batch_; ++c)
+          for (size_t i = 0; i < n0; ++i) l->outPacked.push_back(l->outPacked[i]);
+      }
       rep(l->a, true); rep(l->b, true); rep(l->c, true); rep(l->d, true);
       rep(l->out, true); rep(l->out1, true); rep(l->out2, true); rep(l->mods, false);
       for (std::vector<uint64_t> *kv : {&l->k, &l->mixK, &l->addK}) {
@@ -1325,14 +1388,18 @@ void Arch::enqueue(Launch &l) {
   case Launch::L_NTT:
     st = hm_ntt(ctx, pool, l.a.data(), pool, l.out.data(), l.mods.data(), cnt, 0, nullptr);
     break;
-  case Launch::L_INTT:
-    if (l.secondOnly) st = hm_ntt_second_pass(ctx, pool, l.out.data(), l.mods.data(), cnt, 1, l.hasK ? l.k.data() : nullptr);
-    else st = hm_ntt(ctx, pool, l.a.data(), pool, l.out.data(), l.mods.data(), cnt, 1, l.hasK ? l.k.data() : nullptr);
+  case Launch::L_INTT: {
+    const bool anyPacked = std::find(l.outPacked.begin(), l.outPacked.end(), 1) != l.outPacked.end();
+    hm_ntt_desc d = {pool, l.a.data(), pool, l.out.data(), l.mods.data(), cnt, 1, l.hasK ? l.k.data() : nullptr, l.secondOnly ? 1 : 0,
+                     anyPacked ? l.outPacked.data() : nullptr};
+    st = hm_ntt_ex(ctx, &d);
     break;
+  }
   case Launch::L_NTT_SUBSCALE:
     if (!l.mixK.empty() || !l.probs.empty()) {
       for (auto &q : l.probs)
-        descs.push_back(hm_bconv_desc{pool, q.in.data(), q.inMods.data(), (uint32_t)q.in.size(), pool, q.out.data(), q.outMods.data(), (uint32_t)q.out.size(), 0});
+        descs.push_back(hm_bconv_desc{pool, q.in.data(), q.inMods.data(), (uint32_t)q.in.size(), pool, q.out.data(), q.outMods.data(), (uint32_t)q.out.size(), 0,
+                                    nullptr, nullptr, nullptr, nullptr, nullptr, q.inPacked ? 1u : 0u});
       hm_ntt_fused_desc d = {pool, l.a.data(), l.mixK.empty() ? nullptr : pool, l.mixK.empty() ? nullptr : l.d.data(), l.mixK.empty() ? nullptr : l.mixK.data(), pool, l.b.data(),
                              l.c.empty() ? nullptr : pool, l.c.empty() ? nullptr : l.c.data(), l.addK.empty() ? nullptr : l.addK.data(), pool, l.out.data(), l.mods.data(), cnt,
                              l.k.data(), descs.empty() ? nullptr : descs.data(), (uint32_t)descs.size()};
@@ -1347,7 +1414,8 @@ void Arch::enqueue(Launch &l) {
     break;
   case Launch::L_NTT_IP: {
     for (auto &q : l.probs)
-      descs.push_back(hm_bconv_desc{pool, q.in.data(), q.inMods.data(), (uint32_t)q.in.size(), pool, q.out.data(), q.outMods.data(), (uint32_t)q.out.size(), 0});
+      descs.push_back(hm_bconv_desc{pool, q.in.data(), q.inMods.data(), (uint32_t)q.in.size(), pool, q.out.data(), q.outMods.data(), (uint32_t)q.out.size(), 0,
+                                    nullptr, nullptr, nullptr, nullptr, nullptr, q.inPacked ? 1u : 0u});
     hm_ntt_ip_desc d = {pool, l.a.data(), l.ipCoeff.data(), pool, l.c.data(), pool, l.b.data(), pool, l.out.data(), l.mods.data(),
                         (uint32_t)l.mods.size(), l.ipTerms, l.ipOuts, descs.empty() ? nullptr : descs.data(), (uint32_t)descs.size(),
                         std::find(l.ipInv.begin(), l.ipInv.end(), 1) != l.ipInv.end() ? l.ipInv.data() : nullptr};
@@ -1390,7 +1458,7 @@ void Arch::enqueue(Launch &l) {
       descs.push_back(hm_bconv_desc{l.slicesIn ? l.slicesIn : pool, q.in.data(), q.inMods.data(), (uint32_t)q.in.size(),
                                     l.slicesOut ? l.slicesOut : pool, q.out.data(), q.outMods.data(), (uint32_t)q.out.size(), l.logLen,
                                     q.epi ? pool : nullptr, q.epi ? q.epA.data() : nullptr, q.epAdd ? pool : nullptr, q.epAdd ? q.epB.data() : nullptr,
-                                    q.epi ? q.epK.data() : nullptr});
+                                    q.epi ? q.epK.data() : nullptr, q.inPacked ? 1u : 0u});
     st = hm_bconv_batch(ctx, descs.data(), (uint32_t)descs.size());
     break;
   }

@@ -198,6 +198,19 @@ hm_status hm_ntt_inner_product(hm_ctx *ctx, const hm_ntt_ip_desc *desc);
  * src/Components.cpp:380-436). */
 hm_status hm_ntt_second_pass(hm_ctx *ctx, uint64_t *buf, const uint32_t *limbs, const uint32_t *mod_ids, uint32_t n, int inverse,
                              const uint64_t *scale);
+/* K1 with its options in one record (round 5): hm_ntt (second_pass_only == 0) or hm_ntt_second_pass (!= 0; `in` is ignored), plus
+ * out_packed (inverse only; NULL: none): out_packed[i] != 0 stores limb i in the split-30 packed form that the base conversions take with
+ * hm_bconv_desc.in_packed — for the inverse transforms whose outputs feed nothing but base conversions (ModUp_INTT + ModUp_DecompOut,
+ * ModDownINTTOut + ModDownBConvStep1: src/Operation.cpp:72-135, 417-487).  Same reference interface as hm_ntt. */
+typedef struct hm_ntt_desc {
+  const uint64_t *in;  const uint32_t *in_limbs;
+  uint64_t *out;       const uint32_t *out_limbs;
+  const uint32_t *mod_ids; uint32_t n;
+  int inverse;         const uint64_t *scale;
+  int second_pass_only;
+  const uint8_t *out_packed;
+} hm_ntt_desc;
+hm_status hm_ntt_ex(hm_ctx *ctx, const hm_ntt_desc *desc);
 
 /* K4 — fast base conversion, matrix step: out_t = sum_i in_i * [Q_D / q_i]_t mod t for the input
  * basis in_ids (n_in <= 32) and output basis out_ids (n_out <= 64).  `in` must already hold
@@ -219,6 +232,11 @@ struct hm_bconv_desc {
    * 806-822) formed by the conversion kernel itself: one launch less than conversion + HM_OP_SUB_SCALE_ADD.  sub_k: host array of n_out
    * residues; add may be NULL.  hm_bconv_batch only (not the conversions of hm_ntt_ip_desc / hm_ntt_fused_desc). */
   const uint64_t *sub_from; const uint32_t *sub_from_limbs; const uint64_t *add; const uint32_t *add_limbs; const uint64_t *sub_k;
+  /* round 5: != 0 — the inputs are stored in the split-30 packed form (x mod 2^30) | ((x >> 30) << 32), as hm_ntt_ex writes them for limbs
+   * with out_packed set: the conversion multiplies the two 30-bit halves of every input anyway, and a value that is stored split is not
+   * shifted and masked again by each of the workgroups that read it (one per pair of output limbs).  All three conversion entry points
+   * (hm_bconv_batch, hm_bconv_col, the conv lists of hm_ntt_ip_desc / hm_ntt_fused_desc). */
+  uint32_t in_packed;
 };
 hm_status hm_bconv_batch(hm_ctx *ctx, const hm_bconv_desc *descs, uint32_t n_desc);
 /* K4 + first pass of K1 in one kernel, as a call of its own (round 4): every output of every conversion is converted AND taken through the

@@ -206,12 +206,24 @@ void emu_ewe(void *h, int op, uint32_t mod, const uint64_t *a, const uint64_t *b
   }
 }
 
+// packed != 0: the inputs are first brought into the split-30 packed form (hm_pack30) and the conversion is told so (in_packed)
+void emu_bconv_form(void *h, const uint32_t *in_ids, uint32_t n_in, const uint32_t *out_ids, uint32_t n_out,
+                    const uint64_t *in, uint64_t *out, int packed);
 void emu_bconv(void *h, const uint32_t *in_ids, uint32_t n_in, const uint32_t *out_ids, uint32_t n_out,
-               const uint64_t *in, uint64_t *out) {
+               const uint64_t *in, uint64_t *out) { emu_bconv_form(h, in_ids, n_in, out_ids, n_out, in, out, 0); }
+void emu_bconv_form(void *h, const uint32_t *in_ids, uint32_t n_in, const uint32_t *out_ids, uint32_t n_out,
+                    const uint64_t *in, uint64_t *out, int packed) {
   Emu &e = *(Emu *)h;
   std::vector<uint64_t> qh(n_in), tb((size_t)n_in * n_out);
   e.P.bconv_consts(in_ids, n_in, out_ids, n_out, qh.data(), tb.data());
-  HmBconvProb p;
+  std::vector<uint64_t> pk;
+  if (packed) {
+    pk.assign(in, in + (size_t)n_in * e.P.N);
+    for (uint64_t &v : pk) v = hm_pack30(v);
+    in = pk.data();
+  }
+  HmBconvProb p{};
+  p.in_packed = packed ? 1u : 0u;
   p.in = in; p.out = out; p.table = tb.data(); p.n_in = n_in; p.n_out = n_out;
   for (uint32_t i = 0; i < n_in; ++i) p.in_limb[i] = i;
   for (uint32_t t = 0; t < n_out; ++t) p.out_limb[t] = t;

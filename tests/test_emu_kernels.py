@@ -33,6 +33,7 @@ def _load(name):
     L.emu_tensor.argtypes = [C.c_void_p, C.c_uint32] + [C.c_void_p] * 7
     L.emu_ewe.argtypes = [C.c_void_p, C.c_int, C.c_uint32] + [C.c_void_p] * 4 + [C.c_uint64, C.c_void_p]
     L.emu_bconv.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    L.emu_bconv_form.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int]
     L.emu_bconv_consts.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
     L.emu_automorph.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
     L.emu_fill.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p]
@@ -183,6 +184,9 @@ def test_emu_ewe_bconv_auto_fill(emu):
                 x[r, :2] = [o.moduli[m] - 1, 0]
             out = np.empty((len(out_ids), N), dtype=np.uint64)
             emu.emu_bconv(h, p(ii), len(ii), p(oi), len(oi), p(x), p(out))
+            assert np.array_equal(out, o.bconv_matmul(in_ids, out_ids, x))
+            out[:] = 0   # the same from inputs in the split-30 packed form (round 5)
+            emu.emu_bconv_form(h, p(ii), len(ii), p(oi), len(oi), p(x), p(out), 1)
             assert np.array_equal(out, o.bconv_matmul(in_ids, out_ids, x))
             qh = np.empty(len(ii), dtype=np.uint64)
             tb = np.empty((len(ii), len(oi)), dtype=np.uint64)

@@ -547,3 +547,60 @@ def test_inner_product_with_narrow_moduli(form):
                 assert np.array_equal(got[k * n + i].astype(object), acc), (k, i, m)
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("chain", ["mont32", "survey"])
+def test_packed_conversion_inputs(chain):
+    """round 5: hm_ntt_ex(out_packed) stores the inverse transform's output in the split-30 packed form (x mod 2^30) | ((x >> 30) << 32), and
+    the three conversion entry points take it with hm_bconv_desc.in_packed: k_bconv (hm_bconv_batch), k_bconv_col inside the merged
+    transform (hm_ntt_fused_desc.conv) and inside the transform x key call (hm_ntt_ip_desc.conv).  Same results as the plain form, bit for
+    bit, with a launch that mixes packed and plain limbs; worst-case operands"""
+    L, K, N = 7, 5, 1 << 16
+    ctx, o, _ = make_env(16, L, K, chain)
+    try:
+        qs, ps = list(range(L)), list(range(L, L + K))
+        y = o.fill_uniform(ps, 21)
+        y[0, :] = o.moduli[ps[0]] - 1
+        y[1, :4] = [0, 1, o.moduli[ps[1]] - 1, 12345]
+        Y = o.ntt(ps, y)                                     # evaluation form: the inverse transform brings y back, packed
+        src, plain, packed = ctx.from_host(Y), ctx.alloc(K), ctx.alloc(K)
+        scale = [o.moduli[m] - 3 - i for i, m in enumerate(ps)]
+        ctx.ntt(src, plain, ps, inverse=True, scale=scale)
+        flags = [1, 1, 0, 1, 1]
+        ctx.ntt(src, packed, ps, inverse=True, scale=scale, out_packed=flags)
+        P, Q = plain.download(), packed.download()
+        assert np.array_equal(P, o.ewe(5, ps, y, k=scale))
+        pk = lambda a: (a & np.uint64(0x3FFFFFFF)) | ((a >> np.uint64(30)) << np.uint64(32))
+        for i in range(K):
+            assert np.array_equal(Q[i], pk(P[i]) if flags[i] else P[i]), i
+        ctx.ntt(src, packed, ps, inverse=True, scale=scale, out_packed=[1] * K)
+        # 1. k_bconv
+        a, b = ctx.alloc(L), ctx.alloc(L)
+        ctx.bconv_batch([(plain, None, ps, a, None, qs)])
+        ctx.bconv_batch([(packed, None, ps, b, None, qs, 1)])
+        exp = o.bconv_matmul(ps, qs, P)
+        assert np.array_equal(a.download(), exp) and np.array_equal(b.download(), exp)
+        # 2. inside the merged transform's first pass
+        ids = qs
+        mn, ad, mx = (o.fill_uniform(ids, s) for s in (23, 24, 25))
+        k = [o.moduli[m] - 2 - r for r, m in enumerate(ids)]
+        mk = [(kk * 3 + 1) % o.moduli[m] for kk, m in zip(k, ids)]
+        ak = [(kk * 5 + 1) % o.moduli[m] for kk, m in zip(k, ids)]
+        dmn, dad, dmx = ctx.from_host(mn), ctx.from_host(ad), ctx.from_host(mx)
+        x = o.ewe(3, ids, exp, None, o.ewe(5, ids, mx, k=mk))
+        want = o.ewe(3, ids, o.ewe(6, ids, mn, None, o.ntt(ids, x), k=k), None, o.ewe(5, ids, ad, k=ak))
+        for srcbuf, flag in ((plain, 0), (packed, 1)):
+            ctx.fill_uniform(a, ids, 99)
+            ctx.ntt_mix_sub_scale(None, dmn, a, ids, k, addend=dad, addend_k=ak, mix=dmx, mix_k=mk, conv=[(srcbuf, None, ps, list(range(L)), qs, flag)])
+            assert np.array_equal(a.download(), want), flag
+        # 3. inside the transform x key call: one digit (the special limbs) converted to the Q limbs, one key
+        evk = o.fill_uniform(qs, 77)
+        evkb, hand, out = ctx.from_host(evk), ctx.alloc(L), ctx.alloc(L)
+        want3 = o.ewe(0, qs, o.ntt(qs, exp), evk)
+        for srcbuf, flag in ((plain, 0), (packed, 1)):
+            ctx.fill_uniform(out, qs, 98)
+            ctx.ntt_inner_product(srcbuf, [0] * L, [1] * L, hand, list(range(L)), evkb, list(range(L)), out, list(range(L)), qs, 1, 1,
+                                  conv=[(srcbuf, None, ps, list(range(L)), qs, flag)])
+            assert np.array_equal(out.download(), want3), flag
+    finally:
+        ctx.close()

@@ -36,7 +36,7 @@ def inputs(o, ell):
     return o.synth_ct(ell, SEED), o.synth_ct(ell, SEED + 2000), o.synth_evk(ell, SEED + 10000)
 
 
-def check_keyswitch_buffers(op, dd, ell, K, beta, fused, hpip=True, bconv=True, ip_rows=None):   # bconv: True | "residue" | "moddown"
+def check_keyswitch_buffers(op, dd, ell, K, beta, fused, hpip=True, bconv=True, ip_rows=None, packed=True):   # bconv: True | "residue" | "moddown"
     """hpip (fused only): the ModUp transforms' last pass runs inside the inner-product kernel: NTTOut_beta(j) is
     then only first-pass scratch and InnerProduceOut_Key{k} is compared with the oracle's `ip` dump instead.  bconv (fused only,
     round 4): the ModDown conversion runs inside the first pass of the transform that consumes it: ModdownBConvOut_Key{k} no longer
@@ -48,7 +48,10 @@ def check_keyswitch_buffers(op, dd, ell, K, beta, fused, hpip=True, bconv=True, 
         assert np.array_equal(op.read("ModUpINTTOut"), dd["modup_intt"])
         for k in range(2):
             assert np.array_equal(op.read(f"INTTOut_ModDown_Key({k})"), dd["moddown_intt"][k])
-    assert np.array_equal(op.read("ModUpDecompOut"), dd["modup_decomp"])
+    got_d = op.read("ModUpDecompOut")
+    if fused and packed:   # pass (11): limb-polys that only base conversions read are stored split-30 packed: (x mod 2^30) | ((x >> 30) << 32)
+        got_d = (got_d & np.uint64(0x3FFFFFFF)) | ((got_d >> np.uint64(32)) << np.uint64(30))
+    assert np.array_equal(got_d, dd["modup_decomp"])
     for j in range(beta):
         if fused and hpip:
             continue
@@ -74,7 +77,7 @@ CASES = [("config_4_N15.cfg", 15, 16, 10, 4), ("config_4_N15.cfg", 15, 8, 8, 8),
 
 @pytest.mark.parametrize("chain", ["mont32", "survey", 36])
 @pytest.mark.parametrize("cfg,logN,L,ell,alpha", CASES)
-@pytest.mark.parametrize("fuse", [False, True, "no_hpip", "no_bconv", "moddown", "no_ip_inv"])
+@pytest.mark.parametrize("fuse", [False, True, "no_hpip", "no_bconv", "moddown", "no_ip_inv", "no_pack"])
 def test_hmult_bit_exact(cfg, logN, L, ell, alpha, fuse, chain):
     """fuse = True is the bench path (ModUp conversion + transforms + key MAC in one C-ABI call: k_bconv_col, k_ntt_row_ip);
     "no_bconv" = the same with the conversion as its own launch (fuse_bconv = 0); "no_hpip" = fused plan with separate ModUp
@@ -85,13 +88,13 @@ def test_hmult_bit_exact(cfg, logN, L, ell, alpha, fuse, chain):
     o = oracle(logN, L, alpha, chain)
     ct1, ct2, evk = inputs(o, ell)
     ids = list(range(ell))
-    hpip = fuse in (True, "no_bconv", "moddown", "no_ip_inv")   # "no_bconv": fused transform x key kernel fed by a separate conversion launch; "moddown": pass 9 on
+    hpip = fuse in (True, "no_bconv", "moddown", "no_ip_inv", "no_pack")   # "no_bconv": fused transform x key kernel fed by a separate conversion launch; "moddown": pass 9 on
     mode = fuse
     # pass 7b (N = 2^16, fused transform x key kernel): the special limbs and the last Q limb of the key-switch sum leave as the first pass of
     # their inverse transform; "no_ip_inv" keeps them in evaluation form (every row compared)
     ip_rows = ell - 1 if (hpip and logN == 16 and fuse != "no_ip_inv") else None
     op = host.Op(cfg, "hmult", L, ell, alpha, fuse=bool(fuse),
-                 overrides=chain_overrides(chain, {"fuse_hpip": 0} if fuse == "no_hpip" else {"fuse_bconv": 0} if fuse == "no_bconv" else {"fuse_moddown": 1} if fuse == "moddown" else {"fuse_ip_inv": 0} if fuse == "no_ip_inv" else None))
+                 overrides=chain_overrides(chain, {"fuse_hpip": 0} if fuse == "no_hpip" else {"fuse_bconv": 0} if fuse == "no_bconv" else {"fuse_moddown": 1} if fuse == "moddown" else {"fuse_ip_inv": 0} if fuse == "no_ip_inv" else {"pack_bconv_in": 0} if fuse == "no_pack" else None))
     fuse = bool(fuse)
     op.execute(1)
     assert op.backend_counter("arith") == (0 if chain == "mont32" else 1)
@@ -103,7 +106,7 @@ def test_hmult_bit_exact(cfg, logN, L, ell, alpha, fuse, chain):
     assert np.array_equal(op.read("TensorD1Out"), d1)
     assert np.array_equal(op.read("TensorD2Out"), d2)
     k0, k1, dd = o.keyswitch(ell, d2, evk, dump=True)
-    check_keyswitch_buffers(op, dd, ell, alpha, o.beta(ell), fuse, hpip, bconv="moddown" if mode == "moddown" else "residue" if mode in (True, "no_hpip", "no_ip_inv") else True, ip_rows=ip_rows)
+    check_keyswitch_buffers(op, dd, ell, alpha, o.beta(ell), fuse, hpip, bconv="moddown" if mode == "moddown" else "residue" if mode in (True, "no_hpip", "no_ip_inv", "no_pack") else True, ip_rows=ip_rows, packed=mode != "no_pack")
     if not fuse:
         assert np.array_equal(op.read("KeySwitchFinalOutput_Key(0)"), k0)
         assert np.array_equal(op.read("KeySwitchFinalOutput_Key(1)"), k1)
