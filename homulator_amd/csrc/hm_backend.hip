@@ -502,7 +502,8 @@ __global__ void __launch_bounds__(HM_BCONV_THREADS) k_bconv(HmBconvArgs a) {
   const uint32_t t1 = min(t0 + a.chunk, p.n_out);
   const uint32_t x = (blockIdx.x * HM_BCONV_THREADS + threadIdx.x) * HM_BCONV_CPT;
   if (x >= (1u << a.logN)) return;
-  hm_bconv_thread<N_IN, HM_BCONV_CPT>(p, a.logN, x, t0, t1);
+  if (p.in_packed) hm_bconv_thread<N_IN, HM_BCONV_CPT, true>(p, a.logN, x, t0, t1);   // (wave-uniform: two copies of the body)
+  else hm_bconv_thread<N_IN, HM_BCONV_CPT, false>(p, a.logN, x, t0, t1);
 }
 typedef void (*hm_bconv_kernel)(HmBconvArgs);
 static const hm_bconv_kernel k_bconv_by_n_in[HM_BCONV_MAX_IN + 1] = {
@@ -1832,7 +1833,7 @@ static hm_status bconv_col_launch(hm_ctx *c, const hm_bconv_desc *descs, uint32_
     for (uint32_t pi = 0; pi < n_desc; ++pi) wgs += (size_t)descs[pi].n_out * n_tiles;
     NOUT = wgs > 4096 ? 2 : 1;
   }
-  std::map<uint32_t, std::vector<HmBcolProb>> byIn;
+  std::map<uint32_t, std::vector<HmBcolProb>> byIn;   // key: n_in, + 256 for conversions whose inputs are stored packed (kernels of their own)
   for (uint32_t pi = 0; pi < n_desc; ++pi) {
     const hm_bconv_desc &d = descs[pi];
     if (!d.in || !d.out || !d.in_ids || !d.out_ids) return fail(c, HM_ERR_ARG, "fused conversion: null argument");
@@ -1885,7 +1886,8 @@ static hm_status bconv_col_launch(hm_ctx *c, const hm_bconv_desc *descs, uint32_
       if (st) return st;
       p.mixk = static_cast<const HmTw *>(dk);
     }
-    byIn[d.n_in].push_back(p);
+    if (mix && d.in_packed) return fail(c, HM_ERR_UNSUPPORTED, "fused conversion: packed inputs and the mix prologue do not combine (convert from plain inputs)");
+    byIn[d.n_in + (d.in_packed ? 256u : 0u)].push_back(p);
   }
   struct Lnch { uint32_t n_in; dim3 grid; HmBcolArgs a; };
   std::vector<Lnch> ls;
@@ -1908,7 +1910,7 @@ static hm_status bconv_col_launch(hm_ctx *c, const hm_bconv_desc *descs, uint32_
   // stream between a fork and a join event was measured slower: +21 us per op, profiles/README.md "side launches"; removed in round 5.)
   const dim3 block((1 << HM_TL_COL) / HM_EPT);
   for (size_t i = 0; i < ls.size(); ++i) {
-    const hm_bcol_kernel kern = hm_bcol_kernel_for(ls[i].n_in, c->P.logN, NOUT, mix != nullptr);
+    const hm_bcol_kernel kern = hm_bcol_kernel_for(ls[i].n_in & 255u, c->P.logN, NOUT, mix != nullptr, ls[i].n_in >= 256u);
     if (!kern) return fail(c, HM_ERR_UNSUPPORTED, "fused conversion: no kernel for n_in %u at N = 2^%u", ls[i].n_in, c->P.logN);
     hipLaunchKernelGGL(kern, ls[i].grid, block, 0, c->stream, ls[i].a);
     HM_HIP(c, hipGetLastError());

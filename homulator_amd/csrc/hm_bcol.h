@@ -118,7 +118,7 @@ __device__ __forceinline__ void hm_bcol_units(const PROB &p, HmNttState &st0, Hm
     __builtin_amdgcn_sched_barrier(0);   // one unit's loads in flight at a time (N_IN x 16 bytes per lane)
   }
 }
-template <int N_IN, int LOG1, int NOUT, bool MIX>
+template <int N_IN, int LOG1, int NOUT, bool MIX, bool PACKED>
 __device__ __forceinline__ void hm_bconv_col_body(const HmBcolArgs &a) {
   constexpr int TL = HM_TL_COL;
   using PS = HmPass<LOG1, true, false>;
@@ -144,9 +144,9 @@ __device__ __forceinline__ void hm_bconv_col_body(const HmBcolArgs &a) {
   const bool two = NOUT == 2 && o0 + 1 < p.n_out;   // wave-uniform: the last group of an odd basis has one output
   const uint32_t o1 = two ? o0 + 1 : o0;
   const uint64_t *mix0 = MIX ? a.mix + (size_t)p.mix_limb[o0] * N : nullptr, *mix1 = MIX ? a.mix + (size_t)p.mix_limb[o1] * N : nullptr;
-  // the inputs' form is wave-uniform: two copies of the unit loop (a per-value select would cost what the packed form saves)
-  if (p.in_packed) hm_bcol_units<N_IN, NOUT, MIX, true, G0>(p, st0, st1, mix0, mix1, o0, o1, tile, tid, N);
-  else hm_bcol_units<N_IN, NOUT, MIX, false, G0>(p, st0, st1, mix0, mix1, o0, o1, tile, tid, N);
+  // (the inputs' form is a template parameter of the KERNEL: two copies of the unit loop in one kernel shared one scalar-register budget,
+  // and the packed copy reloaded spilled table words 1 262 times per workgroup — measured +0 % instead of the -16 % of the form on its own)
+  hm_bcol_units<N_IN, NOUT, MIX, PACKED, G0>(p, st0, st1, mix0, mix1, o0, o1, tile, tid, N);
   __syncthreads();
   hm_bcol_rounds<TL, LOG1>(st0, tid, lds, HM_CONST_QN(p.qn)[o0].q, a.tw + (size_t)p.out_mod[o0] * N, a.out + (size_t)p.out_limb[o0] * N, tile);
   if (NOUT == 2 && two) {
@@ -156,20 +156,23 @@ __device__ __forceinline__ void hm_bconv_col_body(const HmBcolArgs &a) {
     hm_bcol_rounds<TL, LOG1>(st1, tid, lds, HM_CONST_QN(p.qn)[o1].q, a.tw + (size_t)p.out_mod[o1] * N, a.out + (size_t)p.out_limb[o1] * N, tile);
   }
 }
-template <int N_IN, int LOG1, bool MIX>
+// PACKED: the inputs of every conversion of the launch are stored in the split-30 packed form (HmBcolProb::in_packed; the host launches
+// packed and plain conversions separately)
+template <int N_IN, int LOG1, bool MIX, bool PACKED>
 __global__ void __launch_bounds__((1 << HM_TL_COL) / HM_EPT) __attribute__((amdgpu_waves_per_eu(HM_NTT_MIN_WAVES))) k_bconv_col(HmBcolArgs a) {
-  hm_bconv_col_body<N_IN, LOG1, 1, MIX>(a);
+  hm_bconv_col_body<N_IN, LOG1, 1, MIX, PACKED>(a);
 }
 #ifndef HM_BCOL2_WAVES
 #define HM_BCOL2_WAVES 3   // two outputs wait in registers beside the split inputs: 168 VGPRs, three workgroups per CU
 #endif
-template <int N_IN, int LOG1, bool MIX>
+template <int N_IN, int LOG1, bool MIX, bool PACKED>
 __global__ void __launch_bounds__((1 << HM_TL_COL) / HM_EPT) __attribute__((amdgpu_waves_per_eu(HM_BCOL2_WAVES))) k_bconv_col2(HmBcolArgs a) {
-  hm_bconv_col_body<N_IN, LOG1, 2, MIX>(a);
+  hm_bconv_col_body<N_IN, LOG1, 2, MIX, PACKED>(a);
 }
 
 
 #define HM_BCOL_MAX_IN 15   // 16 inputs: hipcc leaves the input arrays in scratch (1 KB per lane)
 typedef void (*hm_bcol_kernel)(HmBcolArgs);
-// nullptr: no such kernel (ring sizes other than 2^15 and 2^16 convert with hm_bconv_batch first)
-hm_bcol_kernel hm_bcol_kernel_for(uint32_t n_in, uint32_t logN, uint32_t n_out_per_wg, bool mix);
+// nullptr: no such kernel (ring sizes other than 2^15 and 2^16 convert with hm_bconv_batch first; packed inputs with the mix prologue:
+// the opt-in fused ModDown conversion takes plain inputs)
+hm_bcol_kernel hm_bcol_kernel_for(uint32_t n_in, uint32_t logN, uint32_t n_out_per_wg, bool mix, bool packed);

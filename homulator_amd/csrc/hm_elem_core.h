@@ -237,7 +237,9 @@ typedef const HmQn *HmConstQn;
 // (Requesting the NEXT output's row ahead of the products changed nothing: hipcc sinks the loads to the end of the
 // iteration, and the kernel is bound by VALU issue — per output and coefficient 4 * N_IN multiply-adds plus ~50
 // instructions of column recombination and Montgomery reduction — not by the scalar-cache latency.)
-template <int N_IN, int CPT, class PROB>
+// PACKED: the inputs are stored in the split-30 packed form (hm_pack30): the halves are taken as they are (a template parameter: chosen per
+// value at run time the select costs what the packed form saves)
+template <int N_IN, int CPT, bool PACKED = false, class PROB>
 HM_HD void hm_bconv_thread(const PROB &p, uint32_t logN, uint32_t x, uint32_t t0, uint32_t t1) {
   const size_t N = (size_t)1 << logN;
   constexpr int NG = (N_IN + 7) / 8;  // 8-entry groups per row
@@ -253,7 +255,7 @@ HM_HD void hm_bconv_thread(const PROB &p, uint32_t logN, uint32_t x, uint32_t t0
     else v[0] = p.in[(size_t)p.in_limb[i] * N + x];
 #pragma unroll
     for (int c = 0; c < CPT; ++c) {
-      if (p.in_packed) { yl[c][i] = (uint32_t)v[c]; yh[c][i] = (uint32_t)(v[c] >> 32); }   // (wave-uniform)
+      if (PACKED) { yl[c][i] = (uint32_t)v[c]; yh[c][i] = (uint32_t)(v[c] >> 32); }
       else { yl[c][i] = (uint32_t)v[c] & 0x3FFFFFFFu; yh[c][i] = (uint32_t)(v[c] >> 30); }
     }
   }

@@ -667,8 +667,10 @@ void Arch::fusePasses(std::vector<Stage> &st) {
           continue;
         }
         if (i->ops == BCONV_STEP2) convs.push_back(Conv{std::vector<AddrType>(i->operandList.begin(), i->operandList.end() - 1), i, -1});
-        else if (!i->fConvIn.empty()) convs.push_back(Conv{i->fConvIn, i, -1});
-        else for (AddrType a : operands(i)) otherReads[a]++;
+        else if (!i->fConvIn.empty()) {
+          if (i->fMix) { for (AddrType a : i->fConvIn) otherReads[a]++; }   // (the fused conversion with the mix prologue takes plain inputs)
+          else convs.push_back(Conv{i->fConvIn, i, -1});
+        } else for (AddrType a : operands(i)) otherReads[a]++;
         if (i->fusedSubScale) { otherReads[i->fMinuend]++; if (i->fAddend) otherReads[i->fAddend]++; if (i->fMix) otherReads[i->fMix]++; }
         if (i->fusedEpi) { otherReads[i->fSubFrom]++; if (i->fAdd) otherReads[i->fAdd]++; }
       }

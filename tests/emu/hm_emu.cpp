@@ -84,7 +84,10 @@ static void emu_bconv_n(Emu &e, HmBconvProb &p, const std::vector<uint64_t> &tb,
   p.qn = qn.data();
   for (uint32_t t0 = 0; t0 < p.n_out; t0 += HM_BCONV_CHUNK) {
     uint32_t t1 = t0 + HM_BCONV_CHUNK < p.n_out ? t0 + HM_BCONV_CHUNK : p.n_out;
-    for (uint32_t x = 0; x < e.P.N; x += HM_BCONV_CPT) hm_bconv_thread<N_IN, HM_BCONV_CPT>(p, e.P.logN, x, t0, t1);
+    for (uint32_t x = 0; x < e.P.N; x += HM_BCONV_CPT) {
+      if (p.in_packed) hm_bconv_thread<N_IN, HM_BCONV_CPT, true>(p, e.P.logN, x, t0, t1);
+      else hm_bconv_thread<N_IN, HM_BCONV_CPT, false>(p, e.P.logN, x, t0, t1);
+    }
   }
 }
 
