@@ -199,9 +199,11 @@ def exchange_overlap(stage_rows, ops_per_launch, us_per_step, instances, pipelin
 
 
 def roofline_op(batched_rows, batch, rin):
-    """NTT_IP = k_bconv_col<n_in> (conversion + first pass) + k_ntt_row_ip (second pass + key MAC, both keys, all digits).  Algorithmic limb-polys
-    per op at 45/35/15 (SURVEY.md 8d conventions: every operand read once, every result written once; beta = 3, E = 50, l = 35): conversion
-    inputs 35 + hand-off written and read 2 x 115 + own-digit limbs 35 + outputs 2 x 50 = 400 per op, + the key 2 x 3 x 50 = 300 ONCE per launch."""
+    """NTT_IP = k_bconv_col<n_in> (conversion + first pass) + k_ntt_row_ip (second pass + key MAC, both keys, all digits; round 5: + the first
+    inverse pass of the ModDown on the 15 special limbs and the last Q limb).  Algorithmic limb-polys per op at 45/35/15 (SURVEY.md 8d
+    conventions: every operand read once, every result written once; beta = 3, E = 50, l = 35): conversion inputs 35 + hand-off written and
+    read 2 x 115 + own-digit limbs 35 + outputs 2 x 50 = 400 per op, + the key 2 x 3 x 50 = 300 ONCE per launch (the figure of rounds 3 / 4,
+    kept so that the fractions stay comparable)."""
     if not batched_rows:
         return None
     us = [ns * 1e-3 / batch for kind, _, ns in batched_rows if kind == "NTT_IP"]
@@ -209,12 +211,12 @@ def roofline_op(batched_rows, batch, rin):
         return None
     alg = (400 + 300 / batch) * LP
     pmc = rin.get("ntt_ip_bytes_per_op") if rin.get("whole_op_batch") == batch else None
-    return {"kernel": "NTT_IP launch = k_bconv_col2<15> + k_bconv_col2<5> + k_ntt_row_ip<2> (ModUp conversion + transforms + key MAC in one C-ABI call)", "bound": "valu",
+    return {"kernel": "NTT_IP launch = k_bconv_col2<15, 8, false, true> + k_bconv_col2<5, 8, false, true> + k_ntt_row_ip<2, 2> (ModUp conversion from split-30 packed inputs + transforms + key MAC + the ModDown's first inverse pass on the special limbs, in one C-ABI call)", "bound": "valu",
             "us_per_op": us[0], "algorithmic_bytes_per_op_evk_once": alg, "achieved": alg / (us[0] * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": alg / (us[0] * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": pmc,
             "traffic_frac_of_peak": None if not pmc else pmc / (us[0] * 1e-6) / 1e9 / HBM_PEAK_GBS,
             "valu_wave_instructions_per_op": rin.get("ntt_ip_valu_per_op"), "source": rin.get("whole_op_source"),
-            "note": "timed alone on the chip (stage_us_per_op_batched); `bound`: 83-93 % VALU issue (profiles/r03_pmc_kernels_batch10.txt)"}
+            "note": "timed alone on the chip (stage_us_per_op_batched); `bound`: VALU issue — per-kernel SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES, wait and LDS counters of the batched op at this round's HEAD: profiles/r05_pmc_kernels_batch10.txt"}
 
 
 DEFAULT_BATCH = 10

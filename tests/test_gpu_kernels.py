@@ -580,19 +580,25 @@ def test_packed_conversion_inputs(chain):
         ctx.bconv_batch([(packed, None, ps, b, None, qs, 1)])
         exp = o.bconv_matmul(ps, qs, P)
         assert np.array_equal(a.download(), exp) and np.array_equal(b.download(), exp)
-        # 2. inside the merged transform's first pass
+        # 2. inside a fused transform's first pass (ModDown finish without the rescale's mix operand: hrotate's form); with the mix prologue
+        #    the fused conversion takes plain inputs only (the opt-in fused ModDown conversion of an hmult): refused, not silently wrong
         ids = qs
         mn, ad, mx = (o.fill_uniform(ids, s) for s in (23, 24, 25))
         k = [o.moduli[m] - 2 - r for r, m in enumerate(ids)]
         mk = [(kk * 3 + 1) % o.moduli[m] for kk, m in zip(k, ids)]
         ak = [(kk * 5 + 1) % o.moduli[m] for kk, m in zip(k, ids)]
         dmn, dad, dmx = ctx.from_host(mn), ctx.from_host(ad), ctx.from_host(mx)
-        x = o.ewe(3, ids, exp, None, o.ewe(5, ids, mx, k=mk))
-        want = o.ewe(3, ids, o.ewe(6, ids, mn, None, o.ntt(ids, x), k=k), None, o.ewe(5, ids, ad, k=ak))
+        want = o.ewe(3, ids, o.ewe(6, ids, mn, None, o.ntt(ids, exp), k=k), None, o.ewe(5, ids, ad, k=ak))
         for srcbuf, flag in ((plain, 0), (packed, 1)):
             ctx.fill_uniform(a, ids, 99)
-            ctx.ntt_mix_sub_scale(None, dmn, a, ids, k, addend=dad, addend_k=ak, mix=dmx, mix_k=mk, conv=[(srcbuf, None, ps, list(range(L)), qs, flag)])
+            ctx.ntt_mix_sub_scale(None, dmn, a, ids, k, addend=dad, addend_k=ak, conv=[(srcbuf, None, ps, list(range(L)), qs, flag)])
             assert np.array_equal(a.download(), want), flag
+        x = o.ewe(3, ids, exp, None, o.ewe(5, ids, mx, k=mk))
+        want_mix = o.ewe(3, ids, o.ewe(6, ids, mn, None, o.ntt(ids, x), k=k), None, o.ewe(5, ids, ad, k=ak))
+        ctx.ntt_mix_sub_scale(None, dmn, a, ids, k, addend=dad, addend_k=ak, mix=dmx, mix_k=mk, conv=[(plain, None, ps, list(range(L)), qs, 0)])
+        assert np.array_equal(a.download(), want_mix)
+        with pytest.raises(_.HmError, match="packed"):
+            ctx.ntt_mix_sub_scale(None, dmn, a, ids, k, addend=dad, addend_k=ak, mix=dmx, mix_k=mk, conv=[(packed, None, ps, list(range(L)), qs, 1)])
         # 3. inside the transform x key call: one digit (the special limbs) converted to the Q limbs, one key
         evk = o.fill_uniform(qs, 77)
         evkb, hand, out = ctx.from_host(evk), ctx.alloc(L), ctx.alloc(L)
