@@ -348,7 +348,7 @@ def main():
     t_pre = time.perf_counter()
     run(streams * batch)
     sync_all()
-    n_pre = max(1, min(1000, int(float(os.environ.get("HOMULATOR_PREWARM_S", "0.3")) / max(time.perf_counter() - t_pre, 1e-4))))
+    n_pre = max(1, min(1000, int(float(os.environ.get("HOMULATOR_PREWARM_S", "0.6")) / max(time.perf_counter() - t_pre, 1e-4))))
     if dist is not None:
         cnt = torch.tensor([n_pre], device=red_dev)
         dist.broadcast(cnt, src=0)
