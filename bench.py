@@ -180,15 +180,31 @@ def cpu_baseline(opn="hmult", runs=5):
                       f"{cores} threads (OpenMP over limbs) = `value`, 1 thread = `single_thread_value`"}
 
 
+EXCHANGE_KINDS = ("EXCH_IN", "EXCH_OUT", "REPLICATE", "EXCH_IN_COL", "EXCH_OUT_COL")   # the launch kinds that are collectives (host/src/Arch.cpp kLaunchKindNames)
+
+
+def sharded_plan_note(op, world, batch):
+    """which of the two sharded plans the host layer chose for this rank count (config key shard_plan), read off the op's own plan"""
+    kinds = [ln.split()[0] for ln in op.plan()]
+    n_coll = sum(1 for k in kinds if k in EXCHANGE_KINDS)
+    if "BCONV_COL" not in kinds and not any(k.startswith("EXCH") for k in kinds):
+        return (f"limbs sharded over {world} GPUs (limb e -> e % {world}), gather plan: the inputs of both base conversions and the rescale residue are "
+                f"all-gathered over RCCL ({n_coll} collectives per key switch), every rank then runs the one-GPU fused kernels on the limbs it owns; "
+                f"{batch} hmults per launch share the collectives")
+    return (f"limbs sharded over {world} GPUs (limb e -> e % {world}), all-to-all plan: RCCL all-to-all around every digit's ModUp conversion and around the "
+            f"ModDown conversion on column slices (2 beta + 2 per key switch, digit j+1's exchange on the exchange stream beside digit j's conversion and "
+            f"transform) + replicate of the rescale residue ({n_coll} collectives per key switch); {batch} hmults per launch share the exchanges")
+
+
 def exchange_overlap(stage_rows, ops_per_launch, us_per_step, instances, pipelined):
     """hidden / exposed exchange time per op.  The stage rows time every launch ALONE (an exchange launch together with the wait for
     its own mark).  What the compute launches alone do not explain of the step time is the exposed exchange time; the rest of the
     exchange time ran beside compute: with per-digit pipelined exchanges (the default when sharded: digit j+1's all-to-all on the
     context's exchange stream while digit j converts and transforms) already inside ONE instance, with --sharded-streams 2 also across
     instances.  One instance without pipelining hides nothing by construction."""
-    ex = sum(ns for kind, _, ns in stage_rows if kind in ("EXCH_IN", "EXCH_OUT", "REPLICATE")) * 1e-3 / ops_per_launch
-    comp = sum(ns for kind, _, ns in stage_rows if kind not in ("EXCH_IN", "EXCH_OUT", "REPLICATE")) * 1e-3 / ops_per_launch
-    n_coll = sum(1 for kind, _, _ in stage_rows if kind in ("EXCH_IN", "EXCH_OUT", "REPLICATE"))
+    ex = sum(ns for kind, _, ns in stage_rows if kind in EXCHANGE_KINDS) * 1e-3 / ops_per_launch
+    comp = sum(ns for kind, _, ns in stage_rows if kind not in EXCHANGE_KINDS) * 1e-3 / ops_per_launch
+    n_coll = sum(1 for kind, _, _ in stage_rows if kind in EXCHANGE_KINDS)
     if instances <= 1 and not pipelined:
         return {"hidden_us_per_op": 0.0, "exposed_us_per_op": round(ex, 2), "instances_in_flight": 1, "pipelined_per_digit": False, "collectives_per_launch": n_coll,
                 "note": "one sharded instance, bulk-synchronous exchanges on the op's own stream: nothing is hidden (DESIGN.md section 7)"}
@@ -421,7 +437,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": f"{CFG} {opn} L={L} l={ELL} alpha={ALPHA} (N=2^16, beta=3, " + ("full hybrid key switch + rescale)" if opn == "hmult" else "automorphism + full hybrid key switch)"),
-                       "parallelism": "single GPU" if world == 1 else f"limbs sharded over {world} GPUs (limb e -> e % {world}); RCCL all-to-all around every digit's ModUp conversion and around the ModDown conversion (2 beta + 2 per key switch, digit j+1's exchange on the exchange stream beside digit j's conversion and transform) + replicate of the rescale residue; {batch} hmults per launch share the exchanges",
+                       "parallelism": "single GPU" if world == 1 else sharded_plan_note(op, world, batch),
                        "launches_per_op": op.launch_count(), "streams": streams, "batch": batch, "transport": transport,
                        "hip_graph": bool(world == 1 and args.graph),
                        "moduli": MODULI_NOTE[arith],
@@ -436,7 +452,7 @@ def main():
             "launches_in_timed_region_per_instance": args.steps // (batch * streams),
             "stage_us": [[kind, name, round(ns * 1e-3, 2)] for kind, name, ns in stage_rows],
             "stage_us_per_op_batched": None if not batched_rows else [[kind, name, round(ns * 1e-3 / batch, 2)] for kind, name, ns in batched_rows],
-            "exchange_us_per_op": round(sum(ns for kind, _, ns in stage_rows if kind in ("EXCH_IN", "EXCH_OUT", "REPLICATE")) * 1e-3 / (batch if world > 1 else 1), 2),
+            "exchange_us_per_op": round(sum(ns for kind, _, ns in stage_rows if kind in EXCHANGE_KINDS) * 1e-3 / (batch if world > 1 else 1), 2),
             "exchange_overlap": exchange_overlap(stage_rows, batch if world > 1 else 1, ms * 1e3, streams if world > 1 else 1,
                                                  world > 1 and any(" mark=" in ln for ln in op.plan())),   # the op's own plan says whether its exchanges are pipelined
             "hmult_hbm_gbs_algorithmic": alg_bytes / (ms * 1e-3) / 1e9,

@@ -111,6 +111,7 @@ private:
   bool fuse;
   bool shardFused = false;      // sharded: conversion + first pass on column slices, transform x key kernel on the owner (config key shard_fused)
   bool pipelineDigits = false;  // sharded: per-digit exchanges on the exchange stream (config key pipeline_digits, default 1 when world > 1)
+  bool shardGather = false;     // sharded (round 5): the conversions' inputs are replicated (all-gather) and every rank converts for its own output limbs with the one-GPU kernels: config key shard_plan
   bool fuseHpip = true;
   bool fuseBconv = true;  // config key fuse_bconv: the ModUp conversion runs inside the first pass of the fused transform x key kernel   // config key fuse_hpip: the ModUp transforms' last pass runs inside the inner-product kernel
   bool fuseIpInv = true;     // pass (7b): the inner product's special limbs leave as the first pass of the ModDown's inverse transform

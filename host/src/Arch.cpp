@@ -114,6 +114,19 @@ Arch::Arch(Config *cfg) : config(cfg) {
   // shard_fused, default 1; needs world <= N / 4096 and N = 2^15 | 2^16).  Otherwise the per-digit transforms stay launches of their own.
   shardFused = world_ > 1 && cfg->getValueOr("shard_fused", 1) != 0 && fuseHpip && fuseBconv && (logN == 16 || logN == 15) && world_ <= (n >> 12);
   if (const char *e = getenv("HOMULATOR_SHARD_FUSED")) shardFused = shardFused && std::string(e) != "0";
+  // Round 5: a second sharded plan, chosen by the bytes it moves.  `gather`: the conversions' INPUT limbs (the l scaled
+  // limbs of the ModUp, the 2 alpha of the ModDown) are replicated to every rank (hm_replicate_limbs: one collective each) and every rank
+  // runs the ONE-GPU kernels — conversion inside the first pass, transform x key — for the output limbs it owns: per-rank ingress
+  // (l + 2 alpha)(G - 1) / G limb-polys against (2 beta E + 2 alpha)(G - 1) / G^2 for the all-to-all pair around every conversion: half the
+  // bytes at G = 2, the same at G = 4, twice at G = 8 — and 3 collectives per key switch instead of 2 beta + 3.  The links are point to
+  // point (one 77 GB/s link per pair and direction), so at G <= 4 the bytes decide.  Config key shard_plan: 0 = by rank count (gather up to 4
+  // ranks, all-to-all above), 1 = all-to-all (the transposed-domain plan of round 4), 2 = gather.
+  {
+    uint32_t plan = cfg->getValueOr("shard_plan", 0);
+    if (const char *e = getenv("HOMULATOR_SHARD_PLAN")) plan = (uint32_t)atoi(e);
+    shardGather = world_ > 1 && (plan == 2 || (plan == 0 && world_ <= 4));
+    if (shardGather) { shardFused = false; pipelineDigits = false; }
+  }
   if (pipelineDigits && !shardFused) fuseHpip = false;
   stat = new Statistic();
 }
@@ -501,7 +514,7 @@ void Arch::fusePasses(std::vector<Stage> &st) {
         ip->ipSrc = ip->ipX;
         ip->ipCoeff.assign(ip->ipX.size(), 0);
         std::vector<Instruction *> conv(ip->ipX.size(), nullptr);
-        bool allConv = fuseBconv && (world_ == 1 || shardFused) && (logN == 16 || logN == 15);
+        bool allConv = fuseBconv && (world_ == 1 || shardFused || shardGather) && (logN == 16 || logN == 15);
         for (size_t j = 0; j < ip->ipX.size(); ++j) {
           auto p = producer.find(ip->ipX[j]);
           if (p == producer.end()) continue;
@@ -540,7 +553,7 @@ void Arch::fusePasses(std::vector<Stage> &st) {
   //      ROW pass's last round and the inverse ROW pass's first are the same round, so the pass runs from the registers).  The kernel stores
   //      the pass's hand-off into the INTT's output limb, the INTT record keeps its COL pass (hm_ntt_second_pass, with its scale), and the
   //      evaluation-form sums of those limbs (InnerProduceOut_Key{k}[0 .. alpha)) are never written or read back.
-  if (fuseHpip && fuseIpInv && world_ == 1 && logN == 16) {
+  if (fuseHpip && fuseIpInv && (world_ == 1 || shardGather) && logN == 16) {
     std::map<AddrType, std::vector<Instruction *>> readers;
     for (auto &s : st)
       for (Instruction *i : s.ins) {
@@ -578,7 +591,7 @@ void Arch::fusePasses(std::vector<Stage> &st) {
   // (9, round 4) the ModDown side of (8): a fused forward transform (ModDowNTT + ModDownSub [+ rescale]) whose input is a P -> Q conversion
   //     output that nobody else reads takes the conversion into its first pass (src/Operation.cpp:489-590): ModdownBConvOut_Key(k) is
   //     never written or read back.  The last limb of a key keeps its conversion: the rescale residue is formed from it element-wise (4c).
-  if (fuseBconv && fuseModDown && world_ == 1 && (logN == 16 || logN == 15)) {
+  if (fuseBconv && fuseModDown && (world_ == 1 || shardGather) && (logN == 16 || logN == 15)) {
     std::map<AddrType, std::vector<Instruction *>> readers;
     for (auto &s : st)
       for (Instruction *i : s.ins) {
@@ -607,7 +620,7 @@ void Arch::fusePasses(std::vector<Stage> &st) {
   }
   // (10, round 4) r = (wa - conv_last) * kT [+ wb] (4c) directly behind the conversion that produces conv_last: the one-limb element-wise
   //      launch becomes the conversion kernel's epilogue (hm_bconv_desc::sub_from)
-  if (fuseBconv && world_ == 1) {
+  if (fuseBconv && (world_ == 1 || shardGather)) {
     std::map<AddrType, int> nread;
     for (auto &s : st)
       for (Instruction *i : s.ins) {
@@ -649,7 +662,7 @@ void Arch::fusePasses(std::vector<Stage> &st) {
   // (11, round 5) split-30 packed conversion inputs.  A limb-poly that an inverse transform writes and that nothing but base conversions read
   //      (as a conversion INPUT: a separate conversion, a conversion inside a transform x key record or inside a fused transform) is
   //      stored packed; a conversion takes packed inputs only if all of them are.
-  if (packBconvIn && world_ == 1) {
+  if (packBconvIn && (world_ == 1 || shardGather)) {
     struct Conv { std::vector<AddrType> in; Instruction *ins; int digit; };   // digit: index into ipConvIn, -1 = the record's own conversion
     std::vector<Conv> convs;
     std::map<AddrType, int> otherReads;   // reads of an address that are not a conversion input
@@ -816,7 +829,7 @@ void Arch::buildLaunches() {
       Instruction *f = group[0]->ins[0];
       std::vector<Part> mineParts;
       bool nipSharded = false;
-      if (world_ > 1 && f->ops == IP)
+      if (world_ > 1 && f->ops == IP && !shardGather)
         for (const Part *g : group)
           for (Instruction *i : g->ins)
             for (auto &cin : i->ipConvIn) nipSharded |= !cin.empty();
@@ -916,8 +929,8 @@ void Arch::buildLaunches() {
         }
         continue;
       }
-      if (world_ > 1 && f->ops != BCONV_STEP2) {
-        // (a) operands written on another rank (the rescale's r = INTT(x_last)): replicate them first — every
+      if (world_ > 1 && (f->ops != BCONV_STEP2 || shardGather)) {
+        // (a) operands written on another rank (the rescale's r = INTT(x_last); with the gather plan also the conversions' inputs): replicate them first — every
         //     rank derives the same list from the global graph, so the collective is entered by all
         std::vector<AddrType> need;
         for (const Part *g : group)
@@ -1119,7 +1132,7 @@ void Arch::buildLaunches() {
             }
           }
         }
-        if (world_ > 1 && batch_ > 1) {  // sharded batch: the ops of the batch share the exchanges around the conversion
+        if (world_ > 1 && batch_ > 1 && !shardGather) {  // sharded batch: the ops of the batch share the exchanges around the conversion
           const uint32_t per = (uint32_t)limbIndex.size();
           const size_t p0 = L->probs.size();
           for (uint32_t c = 1; c < batch_; ++c)
@@ -1132,7 +1145,7 @@ void Arch::buildLaunches() {
           L->refInstructions *= batch_;
         }
         for (auto &q : L->probs) L->bytes += LP * (q.in.size() + q.out.size());
-        if (world_ > 1) {
+        if (world_ > 1 && !shardGather) {
           // limb-sharded -> coefficient slices -> convert every output on this rank's slice -> limb-sharded
           Launch *XI = new Launch, *XO = new Launch;
           XI->kind = Launch::L_EXCH_IN; XO->kind = Launch::L_EXCH_OUT; XI->statKey = XO->statKey = "XCHG";
@@ -1202,7 +1215,7 @@ void Arch::replicateForBatch() {
       for (size_t i = 0; i < n0; ++i) v.push_back(isLimb && v[i] != HM_NO_LIMB && !sharedLimbs.count(v[i]) ? v[i] + c * per : v[i]);
   };
   for (Launch *l : launches) {
-    if (world_ > 1 && (l->kind == Launch::L_BCONV || l->kind == Launch::L_EXCH_IN || l->kind == Launch::L_EXCH_OUT)) continue;  // built batched
+    if (world_ > 1 && !shardGather && (l->kind == Launch::L_BCONV || l->kind == Launch::L_EXCH_IN || l->kind == Launch::L_EXCH_OUT)) continue;  // built batched
     if (l->kind == Launch::L_BCONV_COL || l->kind == Launch::L_EXCH_IN_COL || l->kind == Launch::L_EXCH_OUT_COL) continue;           // built batched
     if (l->kind == Launch::L_REPLICATE) {
       const size_t n0 = l->exLimbs.size();

@@ -51,7 +51,7 @@ def test_sharded_plans_are_collectively_consistent(opname, world, batch, pipelin
     from homulator_amd import host
     L, ell, alpha = 45, 35, 15
     beta = -(-ell // alpha)
-    ov = {"pipeline_digits": pipeline, **({"batch": batch} if batch > 1 else {})}
+    ov = {"shard_plan": 1, "pipeline_digits": pipeline, **({"batch": batch} if batch > 1 else {})}   # (auto picks the gather plan up to 4 ranks)
     if not fused:
         ov.update({"shard_fused": 0, "fuse_hpip": 0 if pipeline else 1})
     single = host.Op("config_4.cfg", opname, L, ell, alpha, backend=host.BACKEND_COUNT, overrides=ov)
@@ -122,6 +122,52 @@ def test_sharded_plans_are_collectively_consistent(opname, world, batch, pipelin
     # the instruction accounting of the sharded plans adds up to the one-GPU total
     assert sum(int(re.search(r"ref=(\d+)", ln).group(1)) for pl in plans for ln in pl if kind(ln) not in ("BCONV",)) + \
         sum(int(re.search(r"ref=(\d+)", ln).group(1)) for ln in plans[0] if kind(ln) == "BCONV") == total_ref
+
+
+@pytest.mark.parametrize("opname", ["hmult", "hrotate"])
+@pytest.mark.parametrize("world,batch,plan", [(2, 1, 0), (4, 1, 0), (8, 1, 2), (2, 4, 2), (4, 16, 0)])
+def test_gather_plan_is_collectively_consistent(opname, world, batch, plan):
+    """shard_plan = 2 (and the automatic choice up to 4 ranks): the conversions' INPUTS are replicated (all-gather of the ModUp INTT's
+    limbs, of the inner product's P-limbs after their inverse transform, and of the rescale residue), every rank then runs the
+    one-GPU kernels on the limbs it owns: one NTT_IP launch (conversion + transform + key product of its extended limbs), one ModDown
+    conversion of its output limbs.  3 collectives per hmult (2 per hrotate) instead of 2 beta + 3, no column slices."""
+    from homulator_amd import host
+    L, ell, alpha = 45, 35, 15
+    ov = {**({"shard_plan": plan} if plan else {}), **({"batch": batch} if batch > 1 else {})}
+    single = host.Op("config_4.cfg", opname, L, ell, alpha, backend=host.BACKEND_COUNT, overrides=ov)
+    plans = [host.Op("config_4.cfg", opname, L, ell, alpha, backend=host.BACKEND_COUNT, rank=r, world=world, overrides=ov).plan() for r in range(world)]
+    kind = lambda ln: ln.split()[0]
+    num = lambda ln, key: int(re.search(rf" {key}=(\d+)", ln).group(1))
+    coll = [[ln for ln in pl if kind(ln) in ("EXCH_IN", "EXCH_OUT", "REPLICATE", "EXCH_IN_COL", "EXCH_OUT_COL")] for pl in plans]
+    assert all(c == coll[0] for c in coll)
+    assert [kind(ln) for ln in coll[0]] == ["REPLICATE"] * (3 if opname == "hmult" else 2)
+    # what is gathered: every limb of the ModUp input (ell per op), every P-limb of both keys (2 alpha per op), the two residues
+    sizes = [len(re.search(r"limbs=(\S+)", ln).group(1).strip(",").split(",")) for ln in coll[0]]
+    assert sizes == [ell * batch, 2 * alpha * batch] + ([2 * batch] if opname == "hmult" else [])
+    for i, ln in enumerate(coll[0]):   # the first two lists span every rank (limb e -> e % world); the residue is limb ell-1's: one owner
+        owners = {int(x.split(":")[1]) for x in re.search(r"limbs=(\S+)", ln).group(1).strip(",").split(",")}
+        assert owners == (set(range(world)) if i < 2 else {(ell - 1) % world}), (i, owners)
+    for pl in plans:
+        ks = [kind(ln) for ln in pl]
+        assert ks.count("NTT_IP") == 1 and ks.count("BCONV") == 1 and "BCONV_COL" not in ks and "NTT" not in ks and "IP" not in ks
+        # the order on every rank: gather -> transform x key -> inverse -> gather -> conversion (-> gather) -> merged ModDown + rescale transform
+        assert ks.index("REPLICATE") < ks.index("NTT_IP") < ks.index("BCONV") < ks.index("NTT_SUBSCALE")
+    # the work of every launch kind is partitioned exactly (conversions included: each rank converts the output limbs it owns) ...
+    for k in ("TENSOR", "AUTO", "INTT", "NTT_IP", "BCONV", "NTT_SUBSCALE"):
+        assert sum(num(ln, "n") for pl in plans for ln in pl if kind(ln) == k) == sum(num(ln, "n") for ln in single.plan() if kind(ln) == k), k
+    per_rank = [sum(num(ln, "n") for ln in pl if kind(ln) != "REPLICATE") for pl in plans]
+    assert max(per_rank) - min(per_rank) <= 12 * batch
+    # ... and so is the instruction accounting
+    assert sum(num(ln, "ref") for pl in plans for ln in pl) == sum(num(ln, "ref") for ln in single.plan())
+
+
+def test_plan_choice_by_world_size():
+    """shard_plan = 0: gather up to 4 ranks (its 3 collectives move fewer bytes per rank there), all-to-all on column slices above"""
+    from homulator_amd import host
+    for world, gather in ((2, True), (4, True), (8, False), (16, False)):
+        pl = host.Op("config_4.cfg", "hmult", 45, 35, 15, backend=host.BACKEND_COUNT, rank=0, world=world).plan()
+        ks = [ln.split()[0] for ln in pl]
+        assert ("BCONV_COL" not in ks and ks.count("REPLICATE") == 3) if gather else ("BCONV_COL" in ks and ks.count("REPLICATE") == 1), (world, ks)
 
 
 def test_slice_rows_layout():

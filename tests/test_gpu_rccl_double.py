@@ -20,9 +20,9 @@ sys.path.insert(0, %(root)r)
 import numpy as np
 from homulator_amd import host
 from oracle.homoracle import Oracle
-world, cfg, opname, L, ell, alpha, logN, batch = %(case)r
+world, cfg, opname, L, ell, alpha, logN, batch, plan = %(case)r
 uid = host.rccl_unique_id()                      # ncclGetUniqueId of the double (also loads it once, before the threads)
-ops = [host.Op(cfg, opname, L, ell, alpha, rank=r, world=world, overrides={"batch": batch} if batch > 1 else None) for r in range(world)]
+ops = [host.Op(cfg, opname, L, ell, alpha, rank=r, world=world, overrides={"batch": batch, "shard_plan": plan}) for r in range(world)]
 err = [None] * world
 def work(r):
     try:
@@ -60,11 +60,14 @@ assert e.value == 0 and g.value > 0 and b.value > 0
 
 
 @pytest.mark.parametrize("case", [
-    (8, "config_4.cfg", "hmult", 45, 35, 15, 16, 1),      # BASELINE configs[4]
-    (8, "config_4.cfg", "hrotate", 45, 35, 15, 16, 1),
-    (4, "config_4_N15.cfg", "hmult", 16, 10, 4, 15, 3),   # batched
-    (2, "config_4_N15.cfg", "hmult", 6, 5, 2, 15, 1),
-], ids=lambda c: f"{c[0]}ranks-{c[2]}-{c[3]}-{c[4]}-{c[5]}-b{c[7]}")
+    (8, "config_4.cfg", "hmult", 45, 35, 15, 16, 1, 0),      # BASELINE configs[4]: all-to-all plan (the choice above 4 ranks)
+    (8, "config_4.cfg", "hrotate", 45, 35, 15, 16, 1, 0),
+    (4, "config_4_N15.cfg", "hmult", 16, 10, 4, 15, 3, 1),   # batched
+    (2, "config_4_N15.cfg", "hmult", 6, 5, 2, 15, 1, 1),
+    (8, "config_4.cfg", "hmult", 45, 35, 15, 16, 1, 2),      # gather plan: 3 send/receive groups per hmult (every owner to every peer)
+    (4, "config_4_N15.cfg", "hmult", 16, 10, 4, 15, 3, 0),   # ... where it is the automatic choice, batched
+    (2, "config_4.cfg", "hrotate", 45, 35, 15, 16, 1, 0),
+], ids=lambda c: f"{c[0]}ranks-{c[2]}-{c[3]}-{c[4]}-{c[5]}-b{c[7]}-plan{c[8]}")
 def test_rccl_code_path_with_many_ranks(case):
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "mock_rccl")], stdout=subprocess.DEVNULL)
     lib = os.path.join(ROOT, "tests", "mock_rccl", "libmockrccl.so")
@@ -73,7 +76,9 @@ def test_rccl_code_path_with_many_ranks(case):
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     assert "errors 0" in r.stdout, r.stdout
     world = case[0]
-    if world == 8 and case[2] == "hmult":
+    if world == 8 and case[2] == "hmult" and case[8] == 2:
+        assert "groups 48 " in r.stdout, r.stdout     # 2 runs x 3 gathers x 8 ranks
+    if world == 8 and case[2] == "hmult" and case[8] == 0:
         # per-digit pipelined exchanges (default when sharded): 2 runs x (2 beta + 2 = 8 all-to-alls + 1 replicate) x 8 ranks = 144
         # groups; every rank enters every one, also the ranks that own nothing of a list
         assert "groups 144 " in r.stdout, r.stdout

@@ -27,20 +27,24 @@ def assemble(ops, name, n_limbs, N, copy=0):
     return full
 
 
-@pytest.mark.parametrize("world,cfg,opname,L,ell,alpha,logN,batch,fused", [
-    (8, "config_4.cfg", "hmult", 45, 35, 15, 16, 1, 1),       # BASELINE configs[4], round-4 plan: the fused kernels on column slices
-    (8, "config_4.cfg", "hmult", 45, 35, 15, 16, 1, 0),       # ... and the round-3 plan (shard_fused = 0)
-    (8, "config_4.cfg", "hrotate", 45, 35, 15, 16, 1, 1),
-    (8, "config_4_N15.cfg", "hmult", 16, 10, 4, 15, 3, 1),    # batched: the ops of a batch share every exchange; N = 2^15: one 32-column tile per rank
-    (4, "config_4_N15.cfg", "hmult", 6, 5, 2, 15, 1, 1),      # fewer limbs than ranks in some lists
-    (16, "config_4.cfg", "hmult", 45, 35, 15, 16, 1, 1),      # 16 ranks: one 16-column first-pass tile per rank
+@pytest.mark.parametrize("world,cfg,opname,L,ell,alpha,logN,batch,fused,plan", [
+    (8, "config_4.cfg", "hmult", 45, 35, 15, 16, 1, 1, 0),       # BASELINE configs[4], round-4 plan (the choice above 4 ranks): the fused kernels on column slices
+    (8, "config_4.cfg", "hmult", 45, 35, 15, 16, 1, 0, 0),       # ... and the round-3 plan (shard_fused = 0)
+    (8, "config_4.cfg", "hrotate", 45, 35, 15, 16, 1, 1, 0),
+    (8, "config_4_N15.cfg", "hmult", 16, 10, 4, 15, 3, 1, 0),    # batched: the ops of a batch share every exchange; N = 2^15: one 32-column tile per rank
+    (4, "config_4_N15.cfg", "hmult", 6, 5, 2, 15, 1, 1, 1),      # fewer limbs than ranks in some lists
+    (16, "config_4.cfg", "hmult", 45, 35, 15, 16, 1, 1, 0),      # 16 ranks: one 16-column first-pass tile per rank
+    (8, "config_4.cfg", "hmult", 45, 35, 15, 16, 1, 1, 2),       # round-5 gather plan forced at 8 ranks: 3 collectives, one-GPU kernels per rank
+    (8, "config_4.cfg", "hrotate", 45, 35, 15, 16, 1, 1, 2),
+    (4, "config_4.cfg", "hmult", 45, 35, 15, 16, 2, 1, 0),       # ... and where it is the automatic choice, batched
+    (4, "config_4_N15.cfg", "hmult", 6, 5, 2, 15, 1, 1, 2),      # ranks that own no limb of a gathered list
 ])
-def test_sharded_in_process(world, cfg, opname, L, ell, alpha, logN, batch, fused):
+def test_sharded_in_process(world, cfg, opname, L, ell, alpha, logN, batch, fused, plan):
     from homulator_amd import host
     from homulator_amd.dist import run_in_process
 
     def make(r):
-        ov = {**({"batch": batch} if batch > 1 else {}), **({} if fused else {"shard_fused": 0})}
+        ov = {**({"batch": batch} if batch > 1 else {}), **({} if fused else {"shard_fused": 0}), **({"shard_plan": plan} if plan else {})}
         return host.Op(cfg, opname, L, ell, alpha, rank=r, world=world, overrides=ov or None)
 
     def body(r, op):
@@ -51,7 +55,12 @@ def test_sharded_in_process(world, cfg, opname, L, ell, alpha, logN, batch, fuse
     ops, res, grp = run_in_process(world, make, body)
     assert all(res) and not grp.failed
     kinds = [ln.split()[0] for ln in ops[0].plan()]
-    assert ("BCONV_COL" in kinds and "NTT_IP" in kinds and "NTT" not in kinds) if fused else ("BCONV_COL" not in kinds and "NTT" in kinds)
+    gather = plan == 2 or (plan == 0 and world <= 4)
+    if gather:
+        assert "BCONV_COL" not in kinds and "NTT_IP" in kinds and not any(k.startswith("EXCH") for k in kinds)
+        assert grp.calls[0] // 2 == (3 if opname == "hmult" else 2), grp.calls
+    else:
+        assert ("BCONV_COL" in kinds and "NTT_IP" in kinds and "NTT" not in kinds) if fused else ("BCONV_COL" not in kinds and "NTT" in kinds)
     assert len(set(grp.calls)) == 1 and grp.calls[0] > 0, grp.calls          # every rank entered every exchange
     N = 1 << logN
     n_out = ell - 1 if opname == "hmult" else ell
@@ -64,7 +73,7 @@ def test_sharded_in_process(world, cfg, opname, L, ell, alpha, logN, batch, fuse
         exp = o.hmult(ell, ct1, ct2, evk) if opname == "hmult" else o.hrotate(ell, ct1, 5, evk)
         assert np.array_equal(assemble(ops, "out.c0", n_out, N, c), exp[0])
         assert np.array_equal(assemble(ops, "out.c1", n_out, N, c), exp[1])
-    if world == 8 and opname == "hmult" and batch == 1:   # (both plans: the same exchanges, in the transposed domain or not)
+    if world == 8 and opname == "hmult" and batch == 1 and not gather:   # (both plans: the same exchanges, in the transposed domain or not)
         # every pair of one exchange carries slices of N/8 coefficients; rank 0's ingress per hmult is
         # 7/8 of (its share of) the exchanged limb-polys: nonzero, identical on the two runs, below the 13.7 MiB bound + replicate
         runs = 2       # execute(1) twice
@@ -94,7 +103,8 @@ def test_bench_flow_rehearsal_four_ranks():
     assert d["n_gpus"] == 4 and d["steps"] == 8 and d["value"] > 0
     assert d["config"]["transport"] == "gloo-rehearsal" and d["exchange_us_per_op"] > 0
     ov = d["exchange_overlap"]   # over gloo the exchanges are host-synchronous: whatever the estimate calls hidden is noise, the sum is the exchange time
-    assert ov["instances_in_flight"] == 1 and ov["pipelined_per_digit"] and ov["hidden_us_per_op"] >= 0.0
+    assert "gather plan" in d["config"]["parallelism"] and ov["collectives_per_launch"] == 3     # 4 ranks: the automatic choice
+    assert ov["instances_in_flight"] == 1 and not ov["pipelined_per_digit"] and ov["hidden_us_per_op"] >= 0.0
     assert abs(ov["hidden_us_per_op"] + ov["exposed_us_per_op"] - d["exchange_us_per_op"]) < 0.05
 
 

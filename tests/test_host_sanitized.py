@@ -33,10 +33,11 @@ for cfg, L, ell, alpha in (("config_4_N15.cfg", 16, 10, 4), ("config_4_N15.cfg",
             op.close(); n += 1
 for world in (2, 4, 8):
     for batch in (1, 3):
-        for r in range(world):
-            op = host.Op("config_4.cfg", "hmult", 45, 35, 15, backend=host.BACKEND_COUNT, rank=r, world=world, overrides={"batch": batch} if batch > 1 else None)
-            assert any(l.startswith("EXCH_IN") for l in op.plan())
-            op.close(); n += 1
+        for plan in (1, 2):      # all-to-all on column slices | gather of the conversions' inputs
+            for r in range(world):
+                op = host.Op("config_4.cfg", "hmult", 45, 35, 15, backend=host.BACKEND_COUNT, rank=r, world=world, overrides={"batch": batch, "shard_plan": plan})
+                assert any(l.startswith("EXCH_IN" if plan == 1 else "REPLICATE") for l in op.plan())
+                op.close(); n += 1
 ch = host.Chain("config_4_N15.cfg", "hmult,hrotate,hadd,hmult,padd", 6, 5, 2, overrides={"backend": host.BACKEND_COUNT})
 assert len(ch) == 5
 ch.close()
