@@ -621,6 +621,9 @@ struct hm_ctx {
   bool capture_has_fused = false;   // the capture in progress recorded a one-launch transform
   uint32_t fused_small = 96;  // launches of up to this many entries (N = 2^16) run as ONE launch in the small-launch geometry (k_ntt_fused8): 2-5 us faster than two kernels up to ~100 limb-polys, slower from 128 (tools/ntt_fused_small_ab.py); 0 = off
   uint32_t bcol_outs = 0;   // output limbs per workgroup of the fused conversion + first pass (1 | 2; 0 = by launch size)
+  // hm_replicate_limbs of a list with ONE owner (the rescale residues of a batch) and at least this many bytes, on >= 4 ranks: the owner scatters
+  // one chunk to every peer and the peers exchange their chunks (each link carries 2 / (W - 1) of the list instead of all of it); 0 = never
+  uint64_t replicate_split_bytes = 2u << 20;
   uint32_t nip_small = 64;  // transform x key launches of at most this many limb records (N = 2^16) run in the small-launch geometry (k_ntt_row_ip8); 0 = off
   int n_cu = 256;
   // multi-GPU
@@ -769,6 +772,7 @@ extern "C" hm_status hm_create(hm_ctx **out, const hm_params *p) {
     cc->fused_slots_per_xcd = slots;
     if (slots < (cc->P.N >> HM_TL_ROW)) cc->fused_small = 0;
   }
+  if (const char *e = getenv("HOMULATOR_REPLICATE_SPLIT")) cc->replicate_split_bytes = strtoull(e, nullptr, 10);
   if (const char *e = getenv("HOMULATOR_NIP_SMALL")) cc->nip_small = (uint32_t)std::max(0, atoi(e));
   if (const char *e = getenv("HOMULATOR_BCOL_OUTS")) cc->bcol_outs = (uint32_t)std::min(2, std::max(0, atoi(e)));
   HM_HIP(nullptr, hipHostMalloc(reinterpret_cast<void **>(&cc->err_host), 64, hipHostMallocMapped));
@@ -929,6 +933,7 @@ extern "C" hm_status hm_set_option(hm_ctx *c, const char *name, uint64_t value) 
     return HM_OK;
   }
   if (!strcmp(name, "bconv_col_outs")) { if (value > 2) return fail(c, HM_ERR_ARG, "hm_set_option: bconv_col_outs is 0 (by launch size), 1 or 2"); c->bcol_outs = (uint32_t)value; return HM_OK; }
+  if (!strcmp(name, "replicate_split_bytes")) { c->replicate_split_bytes = value; return HM_OK; }
   if (!strcmp(name, "nip_small_limbs")) { c->nip_small = (uint32_t)value; return HM_OK; }
   if (!strcmp(name, "ntt_small_mode")) { c->small_mode = (uint32_t)value & 3u; return HM_OK; }
   if (!strcmp(name, "ntt_small_limbs")) { c->small_ept8 = value != 0; c->small_limbs = (uint32_t)value; return HM_OK; }
@@ -2257,6 +2262,29 @@ extern "C" hm_status hm_replicate_limbs(hm_ctx *c, uint64_t *buf, const uint32_t
   hipStream_t S;
   if ((st = exchange_stream_begin(c, &S))) return st;
   if ((st = chunk_copy(c, S, buf, c->stage_send, N, so, dof))) return st;
+  // one owner, many ranks, a list worth splitting: scatter + exchange of chunks.  The packed list [n][N] is cut into W - 1 runs of whole
+  // 512-word blocks; peer k (the ranks other than the owner, in rank order) gets run k from the owner, then sends it to the other peers.
+  // Every rank takes the same decision from the same lists.
+  const uint32_t owner = n ? owners[0] : 0;
+  const size_t total = (size_t)n * N * 8;
+  if (W >= 4 && n && cnt[owner] == n && c->replicate_split_bytes && total >= c->replicate_split_bytes) {
+    const size_t run = ((total / 4096 + (W - 2)) / (W - 1)) * 4096;
+    auto run_of = [&](uint32_t p) { return (size_t)(p < owner ? p : p - 1) * run; };               // byte offset of peer p's run
+    auto len_of = [&](uint32_t p) { const size_t o = run_of(p); return o >= total ? (size_t)0 : std::min(run, total - o); };
+    std::vector<size_t> so1(W, 0), sb1(W, 0), ro1(W, 0), rb1(W, 0), so2(W, 0), sb2(W, 0), ro2(W, 0), rb2(W, 0);
+    for (uint32_t p = 0; p < W; ++p) {
+      if (p == me || p == owner) continue;
+      if (me == owner) { so1[p] = run_of(p); sb1[p] = len_of(p); }             // phase 1: the owner's runs go out
+      else { so2[p] = run_of(me); sb2[p] = len_of(me); ro2[p] = run_of(p); rb2[p] = len_of(p); }   // phase 2: my run to the other peers, theirs to me
+    }
+    if (me != owner) { ro1[owner] = run_of(me); rb1[owner] = len_of(me); }
+    if ((st = all_to_all(c, S, c->stage_send, so1, sb1, c->stage_recv, ro1, rb1))) return st;
+    if ((st = all_to_all(c, S, c->stage_recv, so2, sb2, c->stage_recv, ro2, rb2))) return st;
+    if (me == owner) return HM_OK;
+    so.clear(); dof.clear();
+    for (uint32_t i = 0; i < n; ++i) { so.push_back(i); dof.push_back(limbs[i]); }
+    return chunk_copy(c, S, c->stage_recv, buf, N, so, dof);
+  }
   if ((st = all_to_all(c, S, c->stage_send, send_off, send_bytes, c->stage_recv, recv_off, recv_bytes))) return st;
   so.clear(); dof.clear();
   for (uint32_t p = 0; p < W; ++p) {

@@ -67,6 +67,7 @@ assert e.value == 0 and g.value > 0 and b.value > 0
     (8, "config_4.cfg", "hmult", 45, 35, 15, 16, 1, 2),      # gather plan: 3 send/receive groups per hmult (every owner to every peer)
     (4, "config_4_N15.cfg", "hmult", 16, 10, 4, 15, 3, 0),   # ... where it is the automatic choice, batched
     (2, "config_4.cfg", "hrotate", 45, 35, 15, 16, 1, 0),
+    (8, "config_4.cfg", "hmult", 45, 35, 15, 16, 2, 0),      # two ops' residues from one owner: scatter + exchange of chunks (one group more)
 ], ids=lambda c: f"{c[0]}ranks-{c[2]}-{c[3]}-{c[4]}-{c[5]}-b{c[7]}-plan{c[8]}")
 def test_rccl_code_path_with_many_ranks(case):
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "mock_rccl")], stdout=subprocess.DEVNULL)
@@ -78,7 +79,9 @@ def test_rccl_code_path_with_many_ranks(case):
     world = case[0]
     if world == 8 and case[2] == "hmult" and case[8] == 2:
         assert "groups 48 " in r.stdout, r.stdout     # 2 runs x 3 gathers x 8 ranks
-    if world == 8 and case[2] == "hmult" and case[8] == 0:
+    if world == 8 and case[2] == "hmult" and case[8] == 0 and case[7] == 2:
+        assert "groups 160 " in r.stdout, r.stdout    # 2 runs x (8 all-to-alls + the replicate in two phases) x 8 ranks
+    if world == 8 and case[2] == "hmult" and case[8] == 0 and case[7] == 1:
         # per-digit pipelined exchanges (default when sharded): 2 runs x (2 beta + 2 = 8 all-to-alls + 1 replicate) x 8 ranks = 144
         # groups; every rank enters every one, also the ranks that own nothing of a list
         assert "groups 144 " in r.stdout, r.stdout

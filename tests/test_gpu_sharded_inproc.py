@@ -38,10 +38,18 @@ def assemble(ops, name, n_limbs, N, copy=0):
     (8, "config_4.cfg", "hrotate", 45, 35, 15, 16, 1, 1, 2),
     (4, "config_4.cfg", "hmult", 45, 35, 15, 16, 2, 1, 0),       # ... and where it is the automatic choice, batched
     (4, "config_4_N15.cfg", "hmult", 6, 5, 2, 15, 1, 1, 2),      # ranks that own no limb of a gathered list
+    (8, "config_4.cfg", "hmult", 45, 35, 15, 16, 2, 1, 0),       # two ops' residues = 2 MiB from one owner: replicated as scatter + exchange of chunks
+    (4, "config_4_N15.cfg", "hmult", 16, 10, 4, 15, 3, 1, -2),   # (plan < 0: that plan with HOMULATOR_REPLICATE_SPLIT=1) ... in the gather plan, uneven chunks
+    (16, "config_4_N15.cfg", "hmult", 6, 5, 2, 15, 1, 1, -2),    # ... 15 peers, 128 blocks: a short last chunk
 ])
-def test_sharded_in_process(world, cfg, opname, L, ell, alpha, logN, batch, fused, plan):
+def test_sharded_in_process(world, cfg, opname, L, ell, alpha, logN, batch, fused, plan, monkeypatch):
     from homulator_amd import host
     from homulator_amd.dist import run_in_process
+
+    split = plan < 0 or (batch > 1 and logN == 16)
+    if plan < 0:
+        monkeypatch.setenv("HOMULATOR_REPLICATE_SPLIT", "1")
+        plan = -plan
 
     def make(r):
         ov = {**({"batch": batch} if batch > 1 else {}), **({} if fused else {"shard_fused": 0}), **({"shard_plan": plan} if plan else {})}
@@ -58,10 +66,13 @@ def test_sharded_in_process(world, cfg, opname, L, ell, alpha, logN, batch, fuse
     gather = plan == 2 or (plan == 0 and world <= 4)
     if gather:
         assert "BCONV_COL" not in kinds and "NTT_IP" in kinds and not any(k.startswith("EXCH") for k in kinds)
-        assert grp.calls[0] // 2 == (3 if opname == "hmult" else 2), grp.calls
+        assert grp.calls[0] // 2 == (3 if opname == "hmult" else 2) + (1 if split and world >= 4 else 0), grp.calls
     else:
         assert ("BCONV_COL" in kinds and "NTT_IP" in kinds and "NTT" not in kinds) if fused else ("BCONV_COL" not in kinds and "NTT" in kinds)
     assert len(set(grp.calls)) == 1 and grp.calls[0] > 0, grp.calls          # every rank entered every exchange
+    if not gather and fused:
+        beta = -(-ell // alpha)
+        assert grp.calls[0] // 2 == 2 * beta + 2 + (opname == "hmult") + (1 if split else 0), grp.calls
     N = 1 << logN
     n_out = ell - 1 if opname == "hmult" else ell
     o = Oracle(logN, L, alpha)
