@@ -326,24 +326,30 @@ void hm_graph_destroy(hm_graph *graph);
 /* Execution options of a context (A/B measurements, tests; every option has a working default):
  *   "ntt_fused_small"  transform launches of at most this many limb-poly entries (default 96, N = 2^16) run both passes in
  *                ONE launch: the workgroups of a limb-poly meet at a counter in their XCD's L2 between the passes
- *                (k_ntt_fused8; 2-5 us faster than two kernels up to ~100 limb-polys); 0 switches it off.
- *                Env HOMULATOR_NTT_FUSED_SMALL.
+ *                (k_ntt_fused8; 2-5 us faster than two kernels up to ~100 limb-polys); 0 switches it off.  hm_create switches it off
+ *                by itself when an XCD cannot hold the 16 workgroups of a limb-poly at once (counter "ntt_fused_slots_per_xcd"),
+ *                and a rendezvous that times out switches it off for the rest of the context's life (HM_ERR_DEVICE on the next
+ *                synchronising call; graphs that hold such launches are refused from then on).  Env HOMULATOR_NTT_FUSED_SMALL.
  *   "ntt_fused_test_spread"  test hook: one-launch transforms take the agent-scope path of their rendezvous, as if the
  *                dispatcher had spread every limb-poly over two XCDs (slow; results unchanged; counted by "ntt_cross_xcd").
- *   "ntt_fused"  0 (default); 1: EVERY transform as one launch, in the wide geometry (slower than two kernels for launches
- *                that fill the chip more than once).  Env HOMULATOR_NTT_FUSED sets the default.
+ *   "ntt_fused_test_timeout"  test hook: tile 0 of every limb-poly withholds its arrival and the waiters spin briefly: every
+ *                one-launch transform times out (the error path above, on the GPU).
  *   "ntt_small_limbs"  two-kernel transform launches (single passes; "ntt_fused_small" 0) of at most this many limb-poly entries
  *                (default 64, N = 2^16) use the small-launch geometry (512-thread workgroups, 8 coefficients per thread);
  *                0 switches it off.  Env HOMULATOR_NTT_SMALL_LIMBS.
  *   "ntt_small_mode"   which passes of such a launch use it: bit 0 = COL, bit 1 = ROW (default 3; the hand-off is the same).
- *   "side_launches"    0 (default); 1: independent small kernels of one call (the conversion sizes of a ModUp inside
- *                hm_ntt_inner_product) run side by side, the later ones on a side stream between a fork and a join event;
- *                (measured slower on MI355X: the two cross-stream dependencies cost ~20 us); a value > 1 also sets the size limit in
- *                workgroups (4096).
- *                Env HOMULATOR_SIDE_LAUNCHES sets the default.
+ *   "nip_small_limbs"  hm_ntt_inner_product launches of at most this many limb records (default 64, N = 2^16) run in the same
+ *                small-launch geometry (k_ntt_row_ip8); 0 switches it off.  Env HOMULATOR_NIP_SMALL.
+ *   "bconv_col_outs"   output limbs per workgroup of the fused conversion + first pass: 0 = by launch size (default), 1, 2.
+ *                Env HOMULATOR_BCOL_OUTS.
+ *   "replicate_split_bytes"  hm_replicate_limbs of a list with ONE owner and at least this many bytes, on >= 4 ranks, runs as
+ *                scatter + exchange of chunks (every link carries 2 / (W - 1) of the list); default 2 MiB, 0 = never.  Every
+ *                rank of a communicator must use the same value.  Env HOMULATOR_REPLICATE_SPLIT.
  * Counters:
+ *   "arith"          the arithmetic back-end serving this context: 0 = word-wise Montgomery (q = h 2^32 + 1), 1 = generic (Shoup / Barrett).
  *   "ntt_cross_xcd"  limb-polys of one-launch transforms whose workgroups were NOT all placed on one XCD and took the
  *                    agent-scope hand-off (slow, still correct); expected 0 under the dispatcher's observed round-robin placement.
+ *   "ntt_fused_small", "ntt_fused_slots_per_xcd"  the threshold in force (0 = the one-launch form is off) and the guard's figure.
  * No reference counterpart: the reference's Arch has no tunables besides the .cfg keys (src/Arch.cpp:8-168). */
 hm_status hm_set_option(hm_ctx *ctx, const char *name, uint64_t value);
 hm_status hm_get_counter(hm_ctx *ctx, const char *name, uint64_t *value); /* synchronises */
