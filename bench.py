@@ -401,6 +401,8 @@ def main():
     single = None
     if world == 1 and (streams > 1 or batch > 1):   # latency mode beside it: one op at a time
         lat_op = tail_op if tail_op is not None else op
+        lat_op.enqueue(max(2, args.warmup))   # untimed: this instance's key and tables back into the caches the batched instances have just swept
+        lat_op.sync()
         barrier()
         t1 = time.perf_counter()
         lat_op.enqueue(args.steps)

@@ -4,9 +4,11 @@
 // INVOUT (round 5): 0 = no limb of the launch hands its outputs over as the first pass of their inverse transform (HM_NIP_INV_OUT), 1 = all of
 // them do, 2 = per limb (the record says).  mont32 runs a mixed launch as ONE kernel (2: 155 VGPRs); in the generic build that form spills
 // (the Shoup twiddles take twice the registers), so there the two kinds of limbs are two launches (0 and 1).
-template <int OUTS, int INVOUT>
+// TLR: log2 of the ROW tile a workgroup owns (HM_TL_ROW = 4096 coefficients = 16 rows; 11 = 8 rows: twice the workgroups of half the work,
+// for launches that would otherwise leave the chip unevenly loaded: 50 limb records x 16 tiles on 256 CUs is 3.1 per CU, i.e. 4 for some)
+template <int OUTS, int INVOUT, int TLR = HM_TL_ROW>
 __device__ __forceinline__ void hm_nip_body(const HmNipArgs &a) {
-  constexpr int TL = HM_TL_ROW, LOGR = HM_ROW_LOG, R2 = HmRounds<LOGR>::n - 1;
+  constexpr int TL = TLR, LOGR = HM_ROW_LOG, R2 = HmRounds<LOGR>::n - 1;
   __shared__ __attribute__((aligned(16))) uint64_t lds[HmLds<TL, LOGR, false>::WORDS];
   uint32_t entry, tile;
   if (!hm_block_map(1u << (a.logN - TL), a.n_limbs, a.logG, entry, tile)) return;
@@ -36,7 +38,7 @@ __device__ __forceinline__ void hm_nip_body(const HmNipArgs &a) {
     // loop as loop invariants and live (spilled) beside the accumulators
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
-    __builtin_assume(tid >= 0 && tid < (1 << HM_TL_ROW) / HM_EPT);
+    __builtin_assume(tid >= 0 && tid < (1 << TL) / HM_EPT);
     const uint32_t xl = rec->x[j];
     const uint64_t *y[OUTS];
 #pragma unroll
@@ -94,7 +96,7 @@ __device__ __forceinline__ void hm_nip_body(const HmNipArgs &a) {
       for (int i = 0; i < HM_EPT; ++i) st.v[i] = hm_mac_final(acc[k][i], m);
       int tid = threadIdx.x;
       asm volatile("" : "+v"(tid));   // (lane offsets recomputed per pass, as in the digit loop)
-      __builtin_assume(tid >= 0 && tid < (1 << HM_TL_ROW) / HM_EPT);
+      __builtin_assume(tid >= 0 && tid < (1 << TL) / HM_EPT);
       __syncthreads();   // the previous pass's last round has read the tile
       const HmTw sc = {0, 0};
       const HmEpi ep = hm_epi_none();
