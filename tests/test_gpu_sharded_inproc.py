@@ -91,6 +91,13 @@ def test_sharded_in_process(world, cfg, opname, L, ell, alpha, logN, batch, fuse
         assert grp.calls[0] % runs == 0 and grp.calls[0] // runs == 9, grp.calls  # per-digit pipelined: 2 beta + 2 = 8 all-to-alls + 1 replicate per hmult
         per_op = grp.bytes_recv[0] / runs
         assert 0 < per_op < 20 * 2 ** 20, per_op
+    if cfg == "config_4.cfg" and opname == "hmult" and batch == 1 and fused:
+        # the per-collective budget of DESIGN.md section 7 (tools/shard_budget.py derives it from the plans) against the bytes the transport moved
+        import os
+        import sys
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+        from shard_budget import received_per_rank
+        assert [b // 2 for b in grp.bytes_recv] == received_per_rank(world, 2 if gather else 1), (grp.bytes_recv, world, gather)
     for op in ops:
         op.close()
 

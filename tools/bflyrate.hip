@@ -84,6 +84,58 @@ __global__ void __launch_bounds__(512) k3(uint64_t *out, const uint64_t *in, uin
   uint64_t s = 0; for (int i = 0; i < 8; ++i) s ^= v[i] % q;
   out[tid] = s;
 }
+
+// ---- V4 (round 5 experiment): the two carry-word additions (mov + 64-bit add each) as multiply-adds by an opaque 1
+__device__ __forceinline__ uint64_t mont_acc_mad1(uint64_t c, uint64_t x, uint64_t wt, const HmBflyMod &m, uint32_t one) {
+  const uint32_t b0 = (uint32_t)x, b1 = (uint32_t)(x >> 32), w0 = (uint32_t)wt, w1 = (uint32_t)(wt >> 32);
+  const uint64_t P = (uint64_t)b0 * w0 + m.z;
+  uint32_t n0 = ~(uint32_t)P;
+  uint64_t A = (uint64_t)b0 * w1 + m.cc;
+  HM_PIN(n0); HM_PIN64(A);
+  A = (uint64_t)b1 * w0 + A;
+  A = (uint64_t)n0 * m.h + A;
+  uint32_t ph = (uint32_t)(P >> 32);
+  HM_PIN(ph);
+  const uint64_t S = (uint64_t)ph * one + A;
+  uint32_t n1 = ~(uint32_t)S;
+  HM_PIN(n1);
+  uint64_t B = (uint64_t)b1 * w1 + c;
+  B = (uint64_t)n1 * m.h + B;
+  uint32_t sh = (uint32_t)(S >> 32);
+  HM_PIN(sh);
+  return (uint64_t)sh * one + B;
+}
+template <int KIND>
+__device__ __forceinline__ void bfly_fwd_mad1(uint64_t &X, uint64_t &Y, uint64_t w, const HmBflyMod &m, uint32_t one) {
+  uint64_t x = X;
+  if (KIND >= 1) x = hm_csub_neg(x, m.nq4);
+  const uint64_t xn = mont_acc_mad1(x, Y, w, m, one);
+  Y = ((x << 1) + m.q2) - xn;
+  X = xn;
+}
+__global__ void __launch_bounds__(512) k4(uint64_t *out, const uint64_t *in, uint64_t q) {
+  uint64_t v[8]; uint64_t tw[7];
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  for (int i = 0; i < 8; ++i) v[i] = in[tid * 8 + i] % (2 * q);
+  for (int i = 0; i < 7; ++i) tw[i] = in[tid + i] % q;
+  const HmBflyMod m = hm_bfly_mod(q);
+  uint32_t one;
+  asm volatile("s_mov_b32 %0, 1" : "=s"(one));
+  for (int it = 0; it < ITERS / 2; ++it) {
+#pragma unroll
+    for (int jj = 0; jj < 6; ++jj) {
+      const int j = jj % 3, pb = 2 - j;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        if (e & (1 << pb)) continue;
+        if (jj & 1) bfly_fwd_mad1<1>(v[e], v[e | (1 << pb)], tw[(1 << j) - 1 + (e >> (3 - j))], m, one);
+        else        bfly_fwd_mad1<0>(v[e], v[e | (1 << pb)], tw[(1 << j) - 1 + (e >> (3 - j))], m, one);
+      }
+    }
+  }
+  uint64_t s = 0; for (int i = 0; i < 8; ++i) s ^= v[i] % q;
+  out[tid] = s;
+}
 // ---- V2s: round 3's shipped form for comparison (Shoup product with the approximate quotient, 9 multiplies, subtraction of 8q every other stage)
 template <int KIND>
 __device__ __forceinline__ void shoup_bfly_fwd_k(uint64_t &X, uint64_t &Y, const HmTw &t, const HmBflyMod &m) {
@@ -169,5 +221,6 @@ int main() {
   run<V2<2>>("V2 chain, csub every other stage", &s);
   run3(k2s, "V2s round 3: Shoup, csub every other stage", "shoup_wave_butterfly_ns");
   run3(k3, "V3 shipped: Montgomery, q = h 2^32 + 1", "wave_butterfly_ns");
+  run3(k4, "V4 experiment: carry words added by multiply-add x 1", "mad1_wave_butterfly_ns");
   return 0;
 }

@@ -46,15 +46,28 @@ def received(kind, owners, world, me):
     return sum(per_peer), max(per_peer)
 
 
+def collectives(pls):
+    """(kind, name, owners of the limb list) of every collective of rank 0's plan (the lists are identical on every rank: tests/test_dist_cpu.py)"""
+    out = []
+    for ln in [l for l in pls[0] if l.split()[0] in XK]:
+        owners = [int(x.split(":")[1]) for x in re.search(r"limbs=(\S+)", ln).group(1).strip(",").split(",")]
+        out.append((ln.split()[0], ln.split()[1], owners))
+    return out
+
+
 def budget(world, plan):
     pls = plans(world, plan)
     rows = []
-    for i, ln in enumerate([l for l in pls[0] if l.split()[0] in XK]):
-        kind, name = ln.split()[0], ln.split()[1]
-        owners = [int(x.split(":")[1]) for x in re.search(r"limbs=(\S+)", ln).group(1).strip(",").split(",")]
+    for kind, name, owners in collectives(pls):
         rec = [received(kind, owners, world, me) for me in range(world)]
         rows.append((kind, name, len(owners), max(r[0] for r in rec), max(r[1] for r in rec)))
     return pls, rows
+
+
+def received_per_rank(world, plan):
+    """bytes every rank receives per hmult (one-phase replicate): what tests/test_gpu_sharded_inproc.py compares with the bytes its transport moved"""
+    cs = collectives(plans(world, plan))
+    return [sum(received(kind, owners, world, me)[0] for kind, _, owners in cs) for me in range(world)]
 
 
 def model(world, plan, rows, pls, batch):
