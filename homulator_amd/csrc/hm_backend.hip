@@ -631,6 +631,10 @@ struct hm_ctx {
   // hm_replicate_limbs of a list with ONE owner (the rescale residues of a batch) and at least this many bytes, on >= 4 ranks: the owner scatters
   // one chunk to every peer and the peers exchange their chunks (each link carries 2 / (W - 1) of the list instead of all of it); 0 = never
   uint64_t replicate_split_bytes = 2u << 20;
+  // limb-polys per launch pair of a two-kernel transform (at most HM_NTT_MAX_ENTRIES): the hand-off between the passes of a launch pair is
+  // ntt_launch_entries x N x 8 bytes; what is written and read between a hand-off line's store and its load decides whether the load is
+  // served by the Infinity Cache (256 MiB) or by HBM
+  uint32_t ntt_launch_entries = HM_NTT_MAX_ENTRIES;
   bool nip_half = true;     // ... on half tiles (k_ntt_row_ip8h)
   uint32_t nip_small = 64;  // transform x key launches of at most this many limb records (N = 2^16) run in the small-launch geometry (k_ntt_row_ip8); 0 = off
   int n_cu = 256;
@@ -781,6 +785,7 @@ extern "C" hm_status hm_create(hm_ctx **out, const hm_params *p) {
     if (slots < (cc->P.N >> HM_TL_ROW)) cc->fused_small = 0;
   }
   if (const char *e = getenv("HOMULATOR_REPLICATE_SPLIT")) cc->replicate_split_bytes = strtoull(e, nullptr, 10);
+  if (const char *e = getenv("HOMULATOR_NTT_LAUNCH_ENTRIES")) cc->ntt_launch_entries = (uint32_t)std::max(8, atoi(e));
   if (const char *e = getenv("HOMULATOR_NIP_HALF")) cc->nip_half = atoi(e) != 0;
   if (const char *e = getenv("HOMULATOR_NIP_SMALL")) cc->nip_small = (uint32_t)std::max(0, atoi(e));
   if (const char *e = getenv("HOMULATOR_BCOL_OUTS")) cc->bcol_outs = (uint32_t)std::min(2, std::max(0, atoi(e)));
@@ -943,6 +948,7 @@ extern "C" hm_status hm_set_option(hm_ctx *c, const char *name, uint64_t value) 
   }
   if (!strcmp(name, "bconv_col_outs")) { if (value > 2) return fail(c, HM_ERR_ARG, "hm_set_option: bconv_col_outs is 0 (by launch size), 1 or 2"); c->bcol_outs = (uint32_t)value; return HM_OK; }
   if (!strcmp(name, "replicate_split_bytes")) { c->replicate_split_bytes = value; return HM_OK; }
+  if (!strcmp(name, "ntt_launch_entries")) { c->ntt_launch_entries = (uint32_t)std::max<uint64_t>(8, value); return HM_OK; }
   if (!strcmp(name, "nip_half_tiles")) { c->nip_half = value != 0; return HM_OK; }
   if (!strcmp(name, "nip_small_limbs")) { c->nip_small = (uint32_t)value; return HM_OK; }
   if (!strcmp(name, "ntt_small_mode")) { c->small_mode = (uint32_t)value & 3u; return HM_OK; }
@@ -1219,10 +1225,7 @@ static hm_status ntt_common(hm_ctx *c, const char *what, const uint64_t *in, con
   }
   // As few launches as the kernel-argument segment allows (HM_NTT_MAX_ENTRIES records), of equal size; the constants
   // of a launch live in a device table cached by content (plans repeat their launches)
-#ifndef HM_NTT_LAUNCH_ENTRIES
-#define HM_NTT_LAUNCH_ENTRIES HM_NTT_MAX_ENTRIES
-#endif
-  const uint32_t maxGroups = HM_NTT_LAUNCH_ENTRIES / G / 8 * 8;   // whole blocks of 8 groups (one per XCD)
+  const uint32_t maxGroups = std::max(8u, std::min<uint32_t>(HM_NTT_MAX_ENTRIES, c->ntt_launch_entries) / G / 8 * 8);   // whole blocks of 8 groups (one per XCD)
   const uint32_t nLaunch = ((uint32_t)groups.size() + maxGroups - 1) / maxGroups;
   const uint32_t perLaunch = nLaunch ? (((uint32_t)groups.size() + nLaunch - 1) / nLaunch + 7) / 8 * 8 : 0;
   for (uint32_t base = 0; base < groups.size(); base += perLaunch) {
