@@ -418,13 +418,8 @@ template <int OUTS, int INVOUT>
 __global__ void __launch_bounds__((1 << HM_TL_ROW) / 8) k_ntt_row_ip8(HmNipArgs a) {
   hm8::hm_nip_body<OUTS, INVOUT>(a);
 }
-// ... and on half tiles (8 rows of 256, 256-thread workgroups): the same per-thread code, twice the workgroups.  One op at a time
-// the launch is then 1 600 equal pieces of work on 256 CUs instead of 800: no CU is left with a fourth piece while others have three.
-#define HM_TL_ROW_HALF (HM_TL_ROW - 1)
-template <int OUTS, int INVOUT>
-__global__ void __launch_bounds__((1 << HM_TL_ROW_HALF) / 8) k_ntt_row_ip8h(HmNipArgs a) {
-  hm8::hm_nip_body<OUTS, INVOUT, HM_TL_ROW_HALF>(a);
-}
+// (The same on HALF tiles — hm_nip_body's TLR = 11: 1 792 equal pieces of work for one op instead of 896 — was built and measured level
+// within the noise, +0.5 % / +1.2 % / -1.7 % one op at a time on three boxes, and is not instantiated: profiles/r05_late_ab.txt.)
 
 #include "hm_bcol.h"
 __global__ void __launch_bounds__(256) k_tensor(HmTensorArgs a) {
@@ -635,7 +630,6 @@ struct hm_ctx {
   // ntt_launch_entries x N x 8 bytes; what is written and read between a hand-off line's store and its load decides whether the load is
   // served by the Infinity Cache (256 MiB) or by HBM
   uint32_t ntt_launch_entries = HM_NTT_MAX_ENTRIES;
-  bool nip_half = true;     // ... on half tiles (k_ntt_row_ip8h)
   uint32_t nip_small = 64;  // transform x key launches of at most this many limb records (N = 2^16) run in the small-launch geometry (k_ntt_row_ip8); 0 = off
   int n_cu = 256;
   // multi-GPU
@@ -786,7 +780,6 @@ extern "C" hm_status hm_create(hm_ctx **out, const hm_params *p) {
   }
   if (const char *e = getenv("HOMULATOR_REPLICATE_SPLIT")) cc->replicate_split_bytes = strtoull(e, nullptr, 10);
   if (const char *e = getenv("HOMULATOR_NTT_LAUNCH_ENTRIES")) cc->ntt_launch_entries = (uint32_t)std::max(8, atoi(e));
-  if (const char *e = getenv("HOMULATOR_NIP_HALF")) cc->nip_half = atoi(e) != 0;
   if (const char *e = getenv("HOMULATOR_NIP_SMALL")) cc->nip_small = (uint32_t)std::max(0, atoi(e));
   if (const char *e = getenv("HOMULATOR_BCOL_OUTS")) cc->bcol_outs = (uint32_t)std::min(2, std::max(0, atoi(e)));
   HM_HIP(nullptr, hipHostMalloc(reinterpret_cast<void **>(&cc->err_host), 64, hipHostMallocMapped));
@@ -949,7 +942,6 @@ extern "C" hm_status hm_set_option(hm_ctx *c, const char *name, uint64_t value) 
   if (!strcmp(name, "bconv_col_outs")) { if (value > 2) return fail(c, HM_ERR_ARG, "hm_set_option: bconv_col_outs is 0 (by launch size), 1 or 2"); c->bcol_outs = (uint32_t)value; return HM_OK; }
   if (!strcmp(name, "replicate_split_bytes")) { c->replicate_split_bytes = value; return HM_OK; }
   if (!strcmp(name, "ntt_launch_entries")) { c->ntt_launch_entries = (uint32_t)std::max<uint64_t>(8, value); return HM_OK; }
-  if (!strcmp(name, "nip_half_tiles")) { c->nip_half = value != 0; return HM_OK; }
   if (!strcmp(name, "nip_small_limbs")) { c->nip_small = (uint32_t)value; return HM_OK; }
   if (!strcmp(name, "ntt_small_mode")) { c->small_mode = (uint32_t)value & 3u; return HM_OK; }
   if (!strcmp(name, "ntt_small_limbs")) { c->small_ept8 = value != 0; c->small_limbs = (uint32_t)value; return HM_OK; }
@@ -1683,16 +1675,12 @@ extern "C" hm_status hm_ntt_inner_product(hm_ctx *c, const hm_ntt_ip_desc *d) {
 #if HM_GENERIC
     static const nip_kernel kern[2][3] = {{k_ntt_row_ip<1, 0>, k_ntt_row_ip<1, 1>, nullptr}, {k_ntt_row_ip<2, 0>, k_ntt_row_ip<2, 1>, nullptr}};
     static const nip_kernel kern8[2][3] = {{k_ntt_row_ip8<1, 0>, k_ntt_row_ip8<1, 1>, nullptr}, {k_ntt_row_ip8<2, 0>, k_ntt_row_ip8<2, 1>, nullptr}};
-    static const nip_kernel kern8h[2][3] = {{k_ntt_row_ip8h<1, 0>, k_ntt_row_ip8h<1, 1>, nullptr}, {k_ntt_row_ip8h<2, 0>, k_ntt_row_ip8h<2, 1>, nullptr}};
 #else
     static const nip_kernel kern[2][3] = {{k_ntt_row_ip<1, 0>, nullptr, k_ntt_row_ip<1, 2>}, {k_ntt_row_ip<2, 0>, nullptr, k_ntt_row_ip<2, 2>}};
     static const nip_kernel kern8[2][3] = {{k_ntt_row_ip8<1, 0>, nullptr, k_ntt_row_ip8<1, 2>}, {k_ntt_row_ip8<2, 0>, nullptr, k_ntt_row_ip8<2, 2>}};
-    static const nip_kernel kern8h[2][3] = {{k_ntt_row_ip8h<1, 0>, nullptr, k_ntt_row_ip8h<1, 2>}, {k_ntt_row_ip8h<2, 0>, nullptr, k_ntt_row_ip8h<2, 2>}};
 #endif
     // small launches (one op at a time: 50 limb records = 800 workgroups on 768 slots of the wide form) take the small-launch geometry
-    if (c->P.logN == 16 && cnt <= c->nip_small && c->nip_half)
-      hipLaunchKernelGGL(kern8h[K - 1][invForm], dim3(cnt * (c->P.N >> HM_TL_ROW_HALF)), dim3((1 << HM_TL_ROW_HALF) / 8), 0, c->stream, a);
-    else if (c->P.logN == 16 && cnt <= c->nip_small) hipLaunchKernelGGL(kern8[K - 1][invForm], grid, dim3((1 << HM_TL_ROW) / 8), 0, c->stream, a);
+    if (c->P.logN == 16 && cnt <= c->nip_small) hipLaunchKernelGGL(kern8[K - 1][invForm], grid, dim3((1 << HM_TL_ROW) / 8), 0, c->stream, a);
     else hipLaunchKernelGGL(kern[K - 1][invForm], grid, block, 0, c->stream, a);
     HM_HIP(c, hipGetLastError());
   }

@@ -4,8 +4,8 @@
 // INVOUT (round 5): 0 = no limb of the launch hands its outputs over as the first pass of their inverse transform (HM_NIP_INV_OUT), 1 = all of
 // them do, 2 = per limb (the record says).  mont32 runs a mixed launch as ONE kernel (2: 155 VGPRs); in the generic build that form spills
 // (the Shoup twiddles take twice the registers), so there the two kinds of limbs are two launches (0 and 1).
-// TLR: log2 of the ROW tile a workgroup owns (HM_TL_ROW = 4096 coefficients = 16 rows; 11 = 8 rows: twice the workgroups of half the work,
-// for launches that would otherwise leave the chip unevenly loaded: 50 limb records x 16 tiles on 256 CUs is 3.1 per CU, i.e. 4 for some)
+// TLR: log2 of the ROW tile a workgroup owns (HM_TL_ROW = 4096 coefficients = 16 rows; 11 = 8 rows works too — twice the workgroups of
+// half the work — and measured level: not instantiated)
 template <int OUTS, int INVOUT, int TLR = HM_TL_ROW>
 __device__ __forceinline__ void hm_nip_body(const HmNipArgs &a) {
   constexpr int TL = TLR, LOGR = HM_ROW_LOG, R2 = HmRounds<LOGR>::n - 1;

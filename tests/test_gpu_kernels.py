@@ -381,11 +381,9 @@ def test_ntt_inner_product_with_conversion_inside(n_in, chain):
         ctx.ntt_inner_product(ownb, xl, flags, hand, hl, evkb, yl, out, ol, mods, beta, 2, conv=conv)
         wide = out.download()
         ctx.set_option("nip_small_limbs", 4096)
-        for half in (0, 1):   # ... on 4096-coefficient tiles, then on half tiles (k_ntt_row_ip8h: the default of small launches)
-            ctx.set_option("nip_half_tiles", half)
-            ctx.fill_uniform(out, [0] * (nops * 2 * E), 3)
-            ctx.ntt_inner_product(ownb, xl, flags, hand, hl, evkb, yl, out, ol, mods, beta, 2, conv=conv)
-            assert np.array_equal(out.download(), wide), f"k_ntt_row_ip8{'h' if half else ''} differs from k_ntt_row_ip"
+        ctx.fill_uniform(out, [0] * (nops * 2 * E), 3)
+        ctx.ntt_inner_product(ownb, xl, flags, hand, hl, evkb, yl, out, ol, mods, beta, 2, conv=conv)
+        assert np.array_equal(out.download(), wide), "k_ntt_row_ip8 differs from k_ntt_row_ip"
         ctx.set_option("nip_small_limbs", 64)
         got = out.download().reshape(nops, 2, E, -1)
         for b in range(nops):
@@ -484,9 +482,8 @@ def test_inner_product_hands_over_the_first_pass_of_the_inverse_transform(chain)
             ol = [k * n + i for i in range(n) for k in range(outs)]
             scale = [o.moduli[m] - 3 - i for i, m in enumerate(ids)]
             X0 = o.ntt(ids, xe[0])
-            for rep in range(3):
-                ctx.set_option("nip_small_limbs", 64 if rep < 2 else 0)   # the small-launch geometry on half tiles and on whole ones, then the wide one
-                ctx.set_option("nip_half_tiles", 1 if rep == 0 else 0)
+            for rep in range(2):
+                ctx.set_option("nip_small_limbs", 64 if rep == 0 else 0)   # the small-launch geometry, then the wide one
                 ctx.fill_uniform(out, ids * outs, 99)
                 ctx.ntt_inner_product(xb, xl, coeff, hand, hl, yb, yl, out, ol, ids, T, outs, out_inverse=flags)
                 fl = [k * n + i for k in range(outs) for i in range(n) if flags[i]]
