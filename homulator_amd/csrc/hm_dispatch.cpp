@@ -62,7 +62,8 @@ static const char *load_backend(int arith) {   // nullptr = loaded
   const std::string path = own_dir() + "/" + kLibName[arith];
   void *h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
   if (!h) {
-    msg = std::string("cannot load the ") + kArithName[arith] + " arithmetic back-end " + path + ": " + (dlerror() ? dlerror() : "?") +
+    const char *why = dlerror();   // (one call: dlerror() clears the message it returns)
+    msg = std::string("cannot load the ") + kArithName[arith] + " arithmetic back-end " + path + ": " + (why ? why : "?") +
           " (build it: make -C homulator_amd/csrc); there is no CPU fallback";
     return msg.c_str();
   }

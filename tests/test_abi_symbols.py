@@ -72,6 +72,28 @@ def test_create_picks_the_arithmetic_backend_from_the_chain(monkeypatch):
     assert r == 1 or (isinstance(r, str) and ("no HIP device" in r or "hip" in r.lower()))
 
 
+def test_missing_backend_library_is_an_error_of_create(tmp_path):
+    """the dispatcher alone (its two back-end libraries not beside it): hm_create fails with a message that names the missing file — no
+    crash, no CPU fallback (a second process: the dispatcher caches the handles it has loaded)"""
+    import shutil
+    import sys
+    from homulator_amd import hip
+    shutil.copy(hip.LIB_PATH, tmp_path / "libhomulator_hip.so")
+    script = f"""
+import sys
+sys.path.insert(0, {ROOT!r})
+from homulator_amd import hip
+try:
+    hip.Context(13, 2, 1)
+except hip.HmError as e:
+    print("ERR:", e)
+"""
+    env = dict(os.environ, HOMULATOR_HIP_LIB=str(tmp_path / "libhomulator_hip.so"))
+    out = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "ERR:" in out.stdout and "libhm_m32.so" in out.stdout and "no CPU fallback" in out.stdout, out.stdout
+
+
 def test_fat_binary_targets_gfx950():
     """The hipcc wrapper silently falls back to gfx906 under some flag combinations: check the embedded code object of both arithmetic
     back-ends (libhm_m32.so, libhm_gen.so)."""
