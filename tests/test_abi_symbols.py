@@ -72,6 +72,17 @@ def test_create_picks_the_arithmetic_backend_from_the_chain(monkeypatch):
     assert r == 1 or (isinstance(r, str) and ("no HIP device" in r or "hip" in r.lower()))
 
 
+def test_generated_dispatch_table_matches_the_header(tmp_path):
+    """homulator_amd/csrc/hm_dispatch_gen.inc (committed, generated) is what tools/gen_dispatch.py makes of the header as it stands"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_dispatch", os.path.join(ROOT, "tools", "gen_dispatch.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    out = tmp_path / "gen.inc"
+    gen.main(str(out))
+    assert out.read_text() == open(gen.OUT).read(), "run python3 tools/gen_dispatch.py after changing include/homulator_hip.h"
+
+
 def test_missing_backend_library_is_an_error_of_create(tmp_path):
     """the dispatcher alone (its two back-end libraries not beside it): hm_create fails with a message that names the missing file — no
     crash, no CPU fallback (a second process: the dispatcher caches the handles it has loaded)"""
