@@ -235,7 +235,7 @@ typedef const HmQn *HmConstQn;
 // CPT coefficients x, x+1, .. (CPT = 2: one 16-byte access per input / output limb) for outputs [t0, t1).  The inputs
 // stay in registers for all outputs of the chunk; a row feeds 4 * N_IN * CPT multiply-adds as scalar operands.
 // (Requesting the NEXT output's row ahead of the products changed nothing: hipcc sinks the loads to the end of the
-// iteration, and the kernel is bound by VALU issue — per output and coefficient 4 * N_IN multiply-adds plus ~50
+// iteration, and the kernel is bound by VALU issue — per output and coefficient 4 * N_IN multiply-adds plus ~30
 // instructions of column recombination and Montgomery reduction — not by the scalar-cache latency.)
 // PACKED: the inputs are stored in the split-30 packed form (hm_pack30): the halves are taken as they are (a template parameter: chosen per
 // value at run time the select costs what the packed form saves)
