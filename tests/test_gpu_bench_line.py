@@ -1,0 +1,42 @@
+"""The driver's command, `python bench.py --gpus 1 --steps 20 --warmup 5`, end to end on the GPU: ONE JSON line on stdout with the fields the
+contract names (metric / value / roofline / cpu_baseline ...) and the side figures this build adds (hrotate, the generic chain, the one-launch
+transform's placement counter)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_line_contract():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines            # one line, nothing else on stdout
+    d = json.loads(lines[0])
+    assert d["metric"] == "hmult+key-switch ops/sec" and d["unit"] == "ops/s" and d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5
+    assert d["higher_is_better"] is True and d["vs_baseline"] is None and d["dtype"] == "u64" and d["data"] == "synthetic"
+    assert d["value"] > 1000 and abs(d["value"] * d["ms_per_step"] * 1e-3 - 1.0) < 1e-6
+    cfg = d["config"]
+    assert "config_4.cfg hmult L=45 l=35 alpha=15" in cfg["workload"] and "model" not in cfg
+    assert cfg["batch"] * cfg["streams"] == 20 and cfg["moduli"].startswith("mont32")
+    assert set(os.path.basename(p) for p in d["hip_library"]) >= {"libhomulator_hip.so", "libhm_m32.so"}
+    r = d["roofline"]
+    assert r["contract_bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.05 < r["frac"] < 1.0
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["us_per_launch"] * 1e3)) < 1e-6 * r["achieved"]
+    assert r["algorithmic_bytes_per_launch"] == 50 * 1048576 and r["traffic"] and r["traffic"] > r["algorithmic_bytes_per_launch"]
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "ops/s" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    assert d["value"] / c["value"] > 50          # (a reported baseline, not the target)
+    assert d["ntt_cross_xcd"] == {"after_sweep": 0, "after_timed_region": 0, "ntt_fused_small": 96}
+    assert d["hrotate"]["ops_per_s"] > 1000 and d["hrotate"]["steps"] == 20
+    assert d["generic_chain_ops_per_s"] > 1000 and 0 < d["generic_chain_frac_evk_once"] < 1 and d["generic_chain"]["moduli"].startswith("generic")
+    assert d["single_stream_ops_per_s"] > 1000 and d["sustained_ops_per_s"] > 1000
+    assert d["measured_hbm"] and d["measured_hbm"]["batch"] == cfg["batch"] and d["measured_hbm"]["instances"] == cfg["streams"]
+    assert d["roofline_op"] and "r05" in json.dumps(d["roofline_op"])
+    assert len(d["stage_us"]) == cfg["launches_per_op"] == 6
