@@ -409,6 +409,47 @@ def main():
         lat_op.sync()
         barrier()
         single = args.steps / (time.perf_counter() - t1)
+    # N > 1, beside the sharded figure: what the same N GPUs do with INDEPENDENT ops (every rank runs its own two one-GPU instances of
+    # `rep_batch` hmults per launch, no exchange): the node's capacity for a stream of unrelated ops, where `value` is ONE op's limbs spread
+    # over the GPUs.  Information only; any failure here leaves the line without the field.
+    replicas = None
+    if world > 1:
+        rep_batch, rep_launches, reps, ok = 10, 4, [], 1.0
+        try:
+            reps = [host.Op(CFG, opn, L, ELL, ALPHA, device=local_rank, overrides={"seed": host.SEED + 31 * (i + 1), "batch": rep_batch, "graph": 1, "world": 1, "rank": 0}) for i in range(2)]
+            for _ in range(3):
+                for r_ in reps:
+                    r_.enqueue(1)
+            for r_ in reps:
+                r_.sync()
+        except Exception as e:  # noqa: BLE001
+            ok = 0.0
+            print("replicas leg skipped:", repr(e), file=sys.stderr, flush=True)
+        flag = torch.tensor([ok], dtype=torch.float64, device=red_dev)   # every rank takes the same branch: a rank that failed must not leave the others in a collective
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if float(flag.item()) == 1.0:
+            barrier()
+            t1 = time.perf_counter()
+            try:
+                for _ in range(rep_launches):
+                    for r_ in reps:
+                        r_.enqueue(1)
+                for r_ in reps:
+                    r_.sync()
+            except Exception as e:  # noqa: BLE001
+                ok = 0.0
+                print("replicas leg failed:", repr(e), file=sys.stderr, flush=True)
+            barrier()
+            res = torch.tensor([time.perf_counter() - t1, -ok], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(res, op=dist.ReduceOp.MAX)
+            if float(res[1].item()) == -1.0:
+                replicas = {"ops_per_s": world * 2 * rep_launches * rep_batch / float(res[0].item()), "instances_per_gpu": 2, "batch": rep_batch,
+                            "note": "independent one-GPU instances on every rank, no exchange (weak scaling of unrelated ops); `value` is one op sharded over the GPUs"}
+        for r_ in reps:
+            try:
+                r_.close()
+            except Exception:  # noqa: BLE001
+                pass
     # per-launch device time of one op, each launch bracketed by its own event pair (collective when sharded)
     stage_rows = (tail_op if tail_op is not None else op).stage_times(5)   # sharded: of one batch
     batched_rows = ops[0].stage_times(3) if world == 1 and batch > 1 else None   # per launch of `batch` ops
@@ -450,6 +491,7 @@ def main():
             # the sweep and in the op instances, and whether the form was in force (0 = off: the guard of hm_create or a time-out)
             "ntt_cross_xcd": {"after_sweep": sweep_cross, "after_timed_region": op_cross, "ntt_fused_small": sweep_one_launch},
             "single_stream_ops_per_s": single,
+            "independent_replicas": replicas,
             "sustained_ops_per_s": sustained,
             "launches_in_timed_region_per_instance": args.steps // (batch * streams),
             "stage_us": [[kind, name, round(ns * 1e-3, 2)] for kind, name, ns in stage_rows],

@@ -120,6 +120,8 @@ def test_bench_flow_rehearsal_four_ranks():
     d = json.loads(line)
     assert d["n_gpus"] == 4 and d["steps"] == 8 and d["value"] > 0
     assert d["config"]["transport"] == "gloo-rehearsal" and d["exchange_us_per_op"] > 0
+    rep = d["independent_replicas"]    # beside the sharded figure: the same ranks running unrelated one-GPU ops (here all four on the one GPU)
+    assert rep and rep["ops_per_s"] > 0 and rep["instances_per_gpu"] == 2
     ov = d["exchange_overlap"]   # over gloo the exchanges are host-synchronous: whatever the estimate calls hidden is noise, the sum is the exchange time
     assert "gather plan" in d["config"]["parallelism"] and ov["collectives_per_launch"] == 3     # 4 ranks: the automatic choice
     assert ov["instances_in_flight"] == 1 and not ov["pipelined_per_digit"] and ov["hidden_us_per_op"] >= 0.0
