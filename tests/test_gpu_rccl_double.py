@@ -126,7 +126,7 @@ from homulator_amd import host
 from oracle.homoracle import Oracle
 world, cfg, L, ell, alpha, logN = 4, "config_4_N15.cfg", 16, 10, 4, 15
 uids = [host.rccl_unique_id(), host.rccl_unique_id()]
-ops = [[host.Op(cfg, "hmult", L, ell, alpha, rank=r, world=world, overrides={"seed": host.SEED + 7 * i}) for i in range(2)] for r in range(world)]
+ops = [[host.Op(cfg, "hmult", L, ell, alpha, rank=r, world=world, overrides={"seed": host.SEED + 7 * i, "shard_plan": %(plan)d}) for i in range(2)] for r in range(world)]
 err = [None] * world
 def work(r):
     try:
@@ -154,10 +154,11 @@ print("two communicators per rank: ok")
 """
 
 
-def test_two_sharded_instances_per_rank_with_a_communicator_each():
+@pytest.mark.parametrize("plan", [1, 2], ids=["all-to-all", "gather"])
+def test_two_sharded_instances_per_rank_with_a_communicator_each(plan):
     """the opt-in overlap mode of the bench (--sharded-streams 2): every rank drives two sharded instances, each with its own RCCL
-    communicator and stream, enqueued alternately; through the double, 4 ranks, three passes each, both instances bit-exact"""
+    communicator and stream, enqueued alternately; through the double, 4 ranks, three passes each, both instances bit-exact; both sharded plans"""
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "mock_rccl")], stdout=subprocess.DEVNULL)
     lib = os.path.join(ROOT, "tests", "mock_rccl", "libmockrccl.so")
-    r = subprocess.run([sys.executable, "-c", TWO_COMMS % {"root": ROOT}], env=dict(os.environ, HOMULATOR_RCCL_LIB=lib), capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, "-c", TWO_COMMS % {"root": ROOT, "plan": plan}], env=dict(os.environ, HOMULATOR_RCCL_LIB=lib), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "two communicators per rank: ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
