@@ -98,12 +98,22 @@ def measure_ntt_sweep(n_limbs, iters=48, sets=6):
         a, b = bufs[i % sets]
         ctx.ntt(a, b, ids)
     ns = ctx.timer_stop() / iters
+    # the same sweep IN PLACE (hm_ntt allows in == out), rotating over the 12 buffers (315 MB): the hand-off stores land on lines the input
+    # loads have just brought into the L2, so its loads need no fill from memory (information beside the contract's out-of-place figure)
+    flat = [x for pair in bufs for x in pair]
+    for i, x in enumerate(flat):
+        ctx.fill_uniform(x, ids, 31 + i)
+    _warm(ctx, lambda i: ctx.ntt(flat[i % len(flat)], flat[i % len(flat)], ids))
+    ctx.timer_start()
+    for i in range(iters):
+        ctx.ntt(flat[i % len(flat)], flat[i % len(flat)], ids)
+    ns_inplace = ctx.timer_stop() / iters
     cross = ctx.counter("ntt_cross_xcd")   # limb-polys whose workgroups were spread over XCDs (agent-scope path of the rendezvous): 0 expected
     one_launch = ctx.counter("ntt_fused_small")
     for a, b in bufs:
         a.free(); b.free()
     ctx.close()
-    return ns, cross, one_launch
+    return ns, cross, one_launch, ns_inplace
 
 
 def measure_second_op(opn, streams, batch, steps, device, extra=None):
@@ -463,7 +473,7 @@ def main():
         ms = dt / args.steps * 1e3
         value = args.steps / dt   # whole-job rate: the N GPUs complete `steps` sharded hmults together
         sweep_limbs = ELL + ALPHA
-        ntt_ns, sweep_cross, sweep_one_launch = measure_ntt_sweep(sweep_limbs)
+        ntt_ns, sweep_cross, sweep_one_launch, ntt_ns_inplace = measure_ntt_sweep(sweep_limbs)
         # limb-polys of one-launch transforms that took the agent-scope path of the rendezvous in the op instances (timed region, warm-up, stage timings)
         op_cross = sum(o.backend_counter("ntt_cross_xcd") for o in ops + ([tail_op] if tail_op is not None else []))
         arith = op.backend_counter("arith")
@@ -527,6 +537,10 @@ def main():
                              "floor_us": valu_floor_ns * 1e-3, "frac": valu_floor_ns / ntt_ns, "unit": "wave-butterflies/ns",
                              "achieved": BFLY_PER_LIMB_NTT / 64 * sweep_limbs / ntt_ns, "peak": 1.0 / wb_ns,
                              "source": rin.get("wave_butterfly_source")},
+                         "in_place": {"us_per_launch": ntt_ns_inplace * 1e-3, "achieved": NTT_ALG_BYTES * sweep_limbs / ntt_ns_inplace,
+                                      "frac": NTT_ALG_BYTES * sweep_limbs / ntt_ns_inplace / HBM_PEAK_GBS,
+                                      "note": "the same 50-limb sweep with in == out (k_ntt_fused8<false, 0, 1, false>): the hand-off stays on L2 lines the input loads brought in; "
+                                              "the op's own transforms are out of place, which is what `achieved` / `frac` above describe"},
                          "in_op": None if not inop_ns else {
                              "kernel": "the ModUp forward transforms of one launch of the timed region (115 limb-polys per op x batch) as ONE hm_ntt call = k_ntt_col + k_ntt_row, timed alone with HIP events on the backend's stream",
                              "limbs_per_launch_group": inop_limbs, "us": inop_ns * 1e-3, "us_per_limb": inop_ns * 1e-3 / inop_limbs,

@@ -30,6 +30,8 @@ def test_bench_line_contract():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.05 < r["frac"] < 1.0
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["us_per_launch"] * 1e3)) < 1e-6 * r["achieved"]
     assert r["algorithmic_bytes_per_launch"] == 50 * 1048576 and r["traffic"] and r["traffic"] > r["algorithmic_bytes_per_launch"]
+    ip = r["in_place"]      # the same sweep with in == out, beside the contract's figure
+    assert 0.05 < ip["frac"] < 1.0 and abs(ip["achieved"] - r["algorithmic_bytes_per_launch"] / (ip["us_per_launch"] * 1e3)) < 1e-6 * ip["achieved"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "ops/s" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
     assert d["value"] / c["value"] > 50          # (a reported baseline, not the target)
