@@ -303,7 +303,15 @@ struct HmNttFusedArgs {
   uint32_t pretend_spread;   // test hook (hm_set_option "ntt_fused_test_spread"): take the agent-scope path as if the limb-poly were spread over XCDs
   uint32_t spin_limit;       // HM_SPIN_LIMIT; the time-out test hook passes a short one
   uint32_t withhold;         // test hook (hm_set_option "ntt_fused_test_timeout"): tile 0 of every limb-poly never arrives
+#if defined(HM_FUSED_TRACE)   // development builds only (tools/ablate.sh trace "-DHM_FUSED_TRACE"): 8 time stamps per workgroup, 100 MHz wall clock
+  unsigned long long *trace;
+#endif
 };
+#if defined(HM_FUSED_TRACE)
+#define HM_STAMP(i) do { if (f.trace && threadIdx.x == 0) f.trace[(size_t)blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define HM_STAMP(i) do { } while (0)
+#endif
 // MODE_A: first pass (0, or 4 = mix prologue); MODE_B: last pass (1 forward, 3 fused epilogue, 2 inverse)
 // IN_AUX: cache policy of the first pass's input loads.  Out of place they are read once and only crowd the L2 that should keep the
 // hand-off: non-temporal loads (2) take 2-4 us off a 50-64 limb-poly launch; in place the hand-off lands on the very lines the input
@@ -318,6 +326,10 @@ __device__ __forceinline__ void hm_ntt_fused_body(const HmNttArgs &a, const HmNt
   const uint32_t members = 1u << (a.logN - TL);
   if (!hm_block_map(members, a.n_limbs, a.logG, entry, tile)) return;
   if (a.limb[entry].mod == HM_NTT_NONE) return;
+  HM_STAMP(0);
+#if defined(HM_FUSED_TRACE)
+  if (f.trace && threadIdx.x == 0) { unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); f.trace[(size_t)blockIdx.x * 8 + 6] = ((unsigned long long)hm_xcc_id() << 32) | hw; f.trace[(size_t)blockIdx.x * 8 + 7] = ((unsigned long long)entry << 32) | tile; }
+#endif
   uint32_t *flag = reinterpret_cast<uint32_t *>(lds + (W1 > W2 ? W1 : W2));
   if (!INV) hm_ntt_pass_run<LOG1, true, false, MODE_A, IN_AUX, 0, HM_EPI_CHUNK, GEO>(a, lds, entry, tile, threadIdx.x);
   else hm_ntt_pass_run<HM_ROW_LOG, false, true, MODE_A, IN_AUX, 0, HM_EPI_CHUNK, GEO>(a, lds, entry, tile, threadIdx.x);
@@ -329,15 +341,20 @@ __device__ __forceinline__ void hm_ntt_fused_body(const HmNttArgs &a, const HmNt
   // the arrival is published as soon as the hand-off is stored; the wait sits INSIDE the second pass's first phase, behind the requests for
   // its first round's twiddles (they do not depend on the hand-off and arrive while the workgroup waits) and in front of everything that
   // touches LDS or the hand-off
+  HM_STAMP(1);   // first pass stored (this workgroup's last store issued)
   hm_limb_arrive(f.ws, entry, f.withhold && tile == 0);
+  HM_STAMP(2);   // stores in the L2, arrival published
   uint32_t fast = 0;
   auto meet = [&] {
+    HM_STAMP(3);   // second pass's first twiddle requests issued: starts to wait
     fast = hm_limb_wait(f.ws, f.err, entry, members, flag, f.spin_limit, f.pretend_spread, tile);
     if (!fast) hm_limb_publish_everywhere(f.ws, f.err, entry, members, f.spin_limit);
+    HM_STAMP(4);   // all siblings have arrived
   };
   if (!INV) hm_ntt_pass_run<HM_ROW_LOG, false, false, MODE_B, HM_FUSED_MID_AUX, HM_FUSED_OUT_AUX, 1, GEO>(a, lds, entry, tile, tid2, meet);
   else hm_ntt_pass_run<LOG1, true, true, MODE_B, HM_FUSED_MID_AUX, HM_FUSED_OUT_AUX, HM_EPI_CHUNK, GEO>(a, lds, entry, tile, tid2, meet);
   if (fast == 2) return;   // timed out: the host zeroes the words (check_device_error)
+  HM_STAMP(5);   // second pass stored
   hm_limb_leave(f.ws, entry, members, fast);
 }
 // the small-launch geometry (512-thread workgroups, 8 coefficients per thread; N = 2^16)
@@ -617,6 +634,9 @@ struct hm_ctx {
   uint32_t small_mode = 3;     // which passes of a small launch use it: bit 0 COL, bit 1 ROW
   uint32_t small_limbs = 64;   // measured (tools/ntt_small_ab.py): 2-3 us per launch faster up to ~64 entries, equal at 115, slower from 128
   uint32_t fused_test_spread = 0;   // test hook: one-launch transforms take the agent-scope path
+#if defined(HM_FUSED_TRACE)
+  unsigned long long *fused_trace = nullptr;   // option "ntt_fused_trace" = a device address (development builds)
+#endif
   uint32_t fused_test_timeout = 0;  // test hook: tile 0 of every limb-poly withholds its arrival and the spins are short: the rendezvous times out
   uint32_t fused_slots_per_xcd = 0;  // workgroups of the one-launch transform an XCD holds at once (hm_create: occupancy x CUs per XCD)
   bool fused_broken = false;        // a rendezvous timed out: no one-launch transforms any more, graphs that hold one refuse to replay
@@ -931,6 +951,9 @@ extern "C" hm_status hm_wait_for(hm_ctx *c, hm_ctx *producer) {
 extern "C" hm_status hm_set_option(hm_ctx *c, const char *name, uint64_t value) {
   if (!c || !name) return HM_ERR_ARG;
   if (!strcmp(name, "ntt_fused_test_spread")) { c->fused_test_spread = value != 0; return HM_OK; }
+#if defined(HM_FUSED_TRACE)
+  if (!strcmp(name, "ntt_fused_trace")) { c->fused_trace = reinterpret_cast<unsigned long long *>((uintptr_t)value); return HM_OK; }
+#endif
   if (!strcmp(name, "ntt_fused_test_timeout")) { c->fused_test_timeout = value != 0; return HM_OK; }
   if (!strcmp(name, "ntt_fused_small")) {
     if (value > HM_NTT_MAX_ENTRIES) return fail(c, HM_ERR_ARG, "hm_set_option: ntt_fused_small above %d", HM_NTT_MAX_ENTRIES);
@@ -1105,7 +1128,11 @@ static void launch_ntt(hm_ctx *c, const HmNttArgs &a, bool fusedEpilogue, bool m
   // finishes.  Up to eight such kernels in flight on one GPU (contexts, instances; HIP drives four hardware queues by default) cannot
   // starve one another; the spins are bounded all the same.
   if (K.one[0] && a.n_limbs <= c->fused_small && a.logG == 0) {
+#if defined(HM_FUSED_TRACE)
+    const HmNttFusedArgs f = {c->ntt_ws, c->err_dev, c->fused_test_spread, c->fused_test_timeout ? 1u << 10 : HM_SPIN_LIMIT, c->fused_test_timeout, c->fused_trace};
+#else
     const HmNttFusedArgs f = {c->ntt_ws, c->err_dev, c->fused_test_spread, c->fused_test_timeout ? 1u << 10 : HM_SPIN_LIMIT, c->fused_test_timeout};
+#endif
     if (c->capturing) c->capture_has_fused = true;
     bool inPlace = a.in == a.out;   // every limb-poly transformed onto itself: the input loads keep their lines for the hand-off
     for (uint32_t e = 0; inPlace && e < a.n_limbs; ++e) inPlace = a.limb[e].mod == HM_NTT_NONE || a.limb[e].in == a.limb[e].out;
