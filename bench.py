@@ -80,15 +80,18 @@ def measure_ntt_inop(batch, iters=12, sets=2):
     return ns, n
 
 
-def measure_ntt_sweep(n_limbs, iters=48, sets=6):
+def measure_ntt_sweep(n_limbs, iters=48, sets=6, device=0, which=None):
     """forward NTT sweep over the extended basis (l + alpha limbs): device time per sweep, HIP events on the
     backend stream.  One sweep = one hm_ntt call = ONE launch (k_ntt_fused8: both passes, the hand-off through the XCD's L2 behind a
     rendezvous on XCD-local atomics; launches above 96 limb-polys run the two pass kernels k_ntt_col + k_ntt_row).
     The sweeps rotate over `sets` input/output buffer pairs (6 x 2 x 26 MB = 315 MB > the 256 MiB Infinity Cache), so
-    that every sweep reads its input from HBM rather than from a cache the previous replay left warm."""
+    that every sweep reads its input from HBM rather than from a cache the previous replay left warm.
+    N > 1 (round 6): every rank sweeps the limbs of the extended basis it owns (limb e -> e % N), all ranks at once; `sets` grows so that a
+    rank's rotation still exceeds its Infinity Cache."""
     from homulator_amd import hip
-    ctx = hip.Context(LOGN, L, ALPHA)
-    ids = ctx.ext_ids(ELL)[:n_limbs]
+    ctx = hip.Context(LOGN, L, ALPHA, device=device)
+    ids = ctx.ext_ids(ELL)[:n_limbs] if which is None else [ctx.ext_ids(ELL)[e] for e in which]   # which: a rank's own limbs of the extended basis (N > 1)
+    n_limbs = len(ids)
     bufs = [(ctx.alloc(n_limbs), ctx.alloc(n_limbs)) for _ in range(sets)]
     for i, (a, _) in enumerate(bufs):
         ctx.fill_uniform(a, ids, 1 + i)
@@ -266,6 +269,46 @@ def loaded_hip_library():
     return [os.path.relpath(p, ROOT) if p.startswith(ROOT) else p for p in libs]
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: this process starts the N ranks itself — fresh child processes with RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, the same argv — relays rank 0's ONE JSON line and returns the worst exit code.  Decided
+    before anything touches the GPU: this parent never imports torch and never initialises HIP (a process that has must not start or become
+    another program on this pool).  Under torch.distributed.run (WORLD_SIZE set) nothing of this runs."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:   # a free rendezvous port on the loop-back interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0) or None))
+    import threading
+    import time as _t
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    # like torch.distributed.run: a rank that fails takes the job down (the others would wait for it in a collective for ever)
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs):
+            _t.sleep(2.0)   # let the failing rank's peers print what they know
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()   # exactly the processes started above
+            break
+        _t.sleep(0.05)
+    rcs = [p.wait() for p in procs]
+    reader.join(timeout=10)
+    sys.stdout.write("".join(c for c in chunks if c))
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc]
+    if bad:
+        print(f"[bench] ranks failed (rank, exit code): {bad}", file=sys.stderr)
+    return 1 if bad else 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -288,6 +331,8 @@ def main():
                          "timed region (one launch set per instance); the one-op-at-a-time instance always enqueues directly")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:   # started plainly (`python bench.py --gpus N`): be the launcher
+        raise SystemExit(self_launch(args.gpus))
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -468,12 +513,34 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # N > 1: the NTT sweep of the extended basis with its limbs sharded like the op's (limb e -> rank e % N), every rank on its own limbs at
+    # the same time (north_star: "HBM GB/s for the NTT sweep ... at 1/2/4/8 GPUs"); per-rank device times gathered on rank 0
+    sharded_sweep = None
+    if world > 1:
+        own = [e for e in range(ELL + ALPHA) if e % world == rank]
+        barrier()
+        ns_r, cross_r, one_r, ns_ip_r = measure_ntt_sweep(len(own), sets=max(6, 6 * world // 2), device=local_rank, which=own)
+        tt = torch.zeros(3 * world, dtype=torch.float64, device=red_dev)
+        tt[3 * rank], tt[3 * rank + 1], tt[3 * rank + 2] = ns_r, len(own), cross_r
+        dist.all_reduce(tt)
+        sharded_sweep = {"ns": [float(tt[3 * r].item()) for r in range(world)], "limbs": [int(tt[3 * r + 1].item()) for r in range(world)],
+                         "cross": int(sum(tt[3 * r + 2].item() for r in range(world))), "one_launch": one_r, "ns_inplace_rank0": ns_ip_r}
+    comm_seen = None
+    if world > 1:
+        try:
+            comm_seen = {"world": op.backend_counter("comm_world"), "ranks_seen": op.backend_counter("comm_ranks_seen"), "transport": ["none", "rccl", "external"][op.backend_counter("comm_transport")]}
+        except Exception as e:  # noqa: BLE001
+            comm_seen = {"error": str(e)[:200]}
     out = None
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = args.steps / dt   # whole-job rate: the N GPUs complete `steps` sharded hmults together
         sweep_limbs = ELL + ALPHA
-        ntt_ns, sweep_cross, sweep_one_launch, ntt_ns_inplace = measure_ntt_sweep(sweep_limbs)
+        if sharded_sweep is None:
+            ntt_ns, sweep_cross, sweep_one_launch, ntt_ns_inplace = measure_ntt_sweep(sweep_limbs)
+        else:   # this rank's own launch is the `roofline` kernel (per GPU); the aggregate over the ranks rides beside it
+            sweep_limbs = sharded_sweep["limbs"][0]
+            ntt_ns, sweep_cross, sweep_one_launch, ntt_ns_inplace = sharded_sweep["ns"][0], sharded_sweep["cross"], sharded_sweep["one_launch"], sharded_sweep["ns_inplace_rank0"]
         # limb-polys of one-launch transforms that took the agent-scope path of the rendezvous in the op instances (timed region, warm-up, stage timings)
         op_cross = sum(o.backend_counter("ntt_cross_xcd") for o in ops + ([tail_op] if tail_op is not None else []))
         arith = op.backend_counter("arith")
@@ -497,6 +564,8 @@ def main():
                        "evk_note": "the ops of a batch share ONE evaluation key: the 157 MB key stream that the algorithmic figure charges per op is read from HBM once per batch, the other readers hit cache",
                        "streams_note": "`streams` instances in flight (own HBM pool / HIP stream each), each carrying `batch` independent hmults per launch (own inputs, one evaluation key); a step is one hmult"},
             "hip_library": loaded_hip_library(),
+            # N > 1: what the communicator of the HIP library itself reports (hm_get_counter comm_*): ranks_seen = ncclCommCount over RCCL
+            "comm": comm_seen,
             # one-launch transforms: limb-polys whose workgroups were spread over XCDs (the rendezvous' slow agent-scope path; 0 expected) after
             # the sweep and in the op instances, and whether the form was in force (0 = off: the guard of hm_create or a time-out)
             "ntt_cross_xcd": {"after_sweep": sweep_cross, "after_timed_region": op_cross, "ntt_fused_small": sweep_one_launch},
@@ -527,9 +596,9 @@ def main():
             "roofline": {"bound": "valu" if valu_floor_ns and valu_floor_ns > hbm_floor_ns else "hbm",   # the ceiling with the larger floor for this launch, measured
                          "contract_bound": "hbm",   # ... `achieved` / `peak` / `frac` / `traffic` are the HBM figures the task's contract asks for, whatever binds
                          "binding_ceiling": "valu" if valu_floor_ns and valu_floor_ns > hbm_floor_ns else "hbm",
-                         "kernel": "forward NTT sweep, 50 limbs = ONE launch, k_ntt_fused8<false, 0, 1, true> (COL pass on non-temporal input loads, per-limb rendezvous on XCD-local atomics, ROW pass)",
+                         "kernel": f"forward NTT sweep, {sweep_limbs} limbs = ONE launch, k_ntt_fused8<8, false, 0, 1, true> (COL pass on non-temporal input loads, per-limb rendezvous on XCD-local atomics, ROW pass)" + ("" if world == 1 else f": this rank's limbs of the 50-limb extended basis (limb e -> rank e % {world}), all ranks sweeping at once"),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": rin.get("ntt_sweep50_traffic_bytes") if sweep_limbs == 50 else None, "us_per_launch": ntt_ns * 1e-3,
+                         "traffic": rin.get("ntt_sweep50_traffic_bytes") if sweep_limbs == 50 and world == 1 else None, "us_per_launch": ntt_ns * 1e-3,
                          "algorithmic_bytes_per_launch": NTT_ALG_BYTES * sweep_limbs,
                          "working_set": "6 rotating buffer pairs, 315 MB: past the 256 MiB Infinity Cache",
                          "hbm": {"floor_us": hbm_floor_ns * 1e-3, "frac": hbm_floor_ns / ntt_ns},
@@ -537,6 +606,12 @@ def main():
                              "floor_us": valu_floor_ns * 1e-3, "frac": valu_floor_ns / ntt_ns, "unit": "wave-butterflies/ns",
                              "achieved": BFLY_PER_LIMB_NTT / 64 * sweep_limbs / ntt_ns, "peak": 1.0 / wb_ns,
                              "source": rin.get("wave_butterfly_source")},
+                         # N > 1: the whole 50-limb sweep over the N GPUs = every rank's launch at once; the slowest rank's time counts
+                         "sharded": None if sharded_sweep is None else {
+                             "limbs_per_rank": sharded_sweep["limbs"], "us_per_rank": [round(x * 1e-3, 2) for x in sharded_sweep["ns"]],
+                             "aggregate_gbs": NTT_ALG_BYTES * (ELL + ALPHA) / max(sharded_sweep["ns"]),
+                             "frac_per_gpu": [NTT_ALG_BYTES * n / t / HBM_PEAK_GBS for n, t in zip(sharded_sweep["limbs"], sharded_sweep["ns"])],
+                             "frac_of_aggregate_peak": NTT_ALG_BYTES * (ELL + ALPHA) / max(sharded_sweep["ns"]) / (HBM_PEAK_GBS * world)},
                          "in_place": {"us_per_launch": ntt_ns_inplace * 1e-3, "achieved": NTT_ALG_BYTES * sweep_limbs / ntt_ns_inplace,
                                       "frac": NTT_ALG_BYTES * sweep_limbs / ntt_ns_inplace / HBM_PEAK_GBS,
                                       "note": "the same 50-limb sweep with in == out (k_ntt_fused8<false, 0, 1, false>): the hand-off stays on L2 lines the input loads brought in; "

@@ -20,6 +20,7 @@
 #include "hm_modarith.h"
 #include "hm_ntt_core.h"
 #include "hm_params.h"
+#include "hm_caps.h"
 
 // ------------------------------------------------------------------------------------------------
 // kernels
@@ -144,12 +145,12 @@ __global__ void __launch_bounds__((1 << HM_TL_ROW) / HM_EPT) __attribute__((amdg
   hm_ntt_pass_body<HM_ROW_LOG, false, INV, MODE>(a);
 }
 
-// The small-launch geometry: 512-thread workgroups, 8 coefficients per thread (hm8), N = 2^16.  A launch of up to ~128 limb-polys
-// is ONE round of workgroups, so its time is the latency of one workgroup's pass; here every wave does half the serial work and the
-// launch brings twice the waves (a single op's stages, the 50-limb sweep of the extended basis, a sharded run's per-rank launches).
-template <bool INV, int MODE>
+// The small-launch geometry: 512-thread workgroups, 8 coefficients per thread (hm8), N = 2^16 and (round 6) N = 2^15.  A launch of up to
+// ~128 limb-polys is ONE round of workgroups, so its time is the latency of one workgroup's pass; here every wave does half the serial work
+// and the launch brings twice the waves (a single op's stages, the 50-limb sweep of the extended basis, a sharded run's per-rank launches).
+template <int LOG1, bool INV, int MODE>
 __global__ void __launch_bounds__((1 << HM_TL_COL) / 8) k_ntt_col8(HmNttArgs a) {
-  hm_ntt_pass_body<8, true, INV, MODE, Geo8>(a);
+  hm_ntt_pass_body<LOG1, true, INV, MODE, Geo8>(a);
 }
 template <bool INV, int MODE>
 __global__ void __launch_bounds__((1 << HM_TL_ROW) / 8) k_ntt_row8(HmNttArgs a) {
@@ -357,10 +358,11 @@ __device__ __forceinline__ void hm_ntt_fused_body(const HmNttArgs &a, const HmNt
   HM_STAMP(5);   // second pass stored
   hm_limb_leave(f.ws, entry, members, fast);
 }
-// the small-launch geometry (512-thread workgroups, 8 coefficients per thread; N = 2^16)
-template <bool INV, int MODE_A, int MODE_B, bool NTIN>
+// the small-launch geometry (512-thread workgroups, 8 coefficients per thread; LOG1 = 8: N = 2^16, 16 workgroups per limb-poly; LOG1 = 7,
+// round 6: N = 2^15, 8 workgroups per limb-poly)
+template <int LOG1, bool INV, int MODE_A, int MODE_B, bool NTIN>
 __global__ void __launch_bounds__((1 << HM_TL_ROW) / 8) k_ntt_fused8(HmNttArgs a, HmNttFusedArgs f) {
-  hm_ntt_fused_body<8, INV, MODE_A, MODE_B, Geo8, NTIN ? 2 : 0>(a, f);
+  hm_ntt_fused_body<LOG1, INV, MODE_A, MODE_B, Geo8, NTIN ? 2 : 0>(a, f);
 }
 
 // (Rounds 4 / 5 also built both passes as ONE persistent launch fed from per-XCD work queues — k_ntt_queue8: items of a limb-poly on one XCD
@@ -683,6 +685,7 @@ struct RcclApi {
   ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;   // optional (counter "comm_ranks_seen"; a test double need not have it)
   ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
@@ -710,6 +713,7 @@ static const char *rccl_load() {
   HM_SYM(Send, "ncclSend") HM_SYM(Recv, "ncclRecv") HM_SYM(GroupStart, "ncclGroupStart") HM_SYM(GroupEnd, "ncclGroupEnd")
   HM_SYM(GetErrorString, "ncclGetErrorString")
 #undef HM_SYM
+  g_rccl.CommCount = reinterpret_cast<decltype(g_rccl.CommCount)>(dlsym(h, "ncclCommCount"));
   g_rccl.h = h;
   return nullptr;
 }
@@ -732,6 +736,10 @@ static hm_status fail(hm_ctx *c, hm_status st, const char *fmt, ...) {
   } while (0)
 
 extern "C" const char *hm_version(void) { return "homulator-hip 0.1 (gfx950)"; }
+extern "C" hm_status hm_capability(uint32_t logN, const char *name, uint64_t *value) {
+  if (!name || !value) return HM_ERR_ARG;
+  return hm_cap_by_name(logN, name, value) ? HM_ERR_ARG : HM_OK;
+}
 extern "C" const char *hm_last_error(const hm_ctx *c) { return c ? c->err.c_str() : g_create_err.c_str(); }
 
 extern "C" hm_status hm_create(hm_ctx **out, const hm_params *p) {
@@ -791,12 +799,16 @@ extern "C" hm_status hm_create(hm_ctx **out, const hm_params *p) {
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, (1 << HM_TL_ROW) / 8, 0) != hipSuccess) nb = 0;
       slots = std::min(slots, (uint32_t)std::max(nb, 0) * (uint32_t)std::max(1, cc->n_cu / 8));
     };
-    probe(k_ntt_fused8<false, 0, 1, true>); probe(k_ntt_fused8<false, 0, 1, false>);
-    probe(k_ntt_fused8<false, 0, 3, true>); probe(k_ntt_fused8<false, 0, 3, false>);
-    probe(k_ntt_fused8<false, 4, 3, true>); probe(k_ntt_fused8<false, 4, 3, false>);
-    probe(k_ntt_fused8<true, 0, 2, true>);  probe(k_ntt_fused8<true, 0, 2, false>);
+    auto probeAll = [&](auto L1) {
+      constexpr int LOG1 = decltype(L1)::value;
+      probe(k_ntt_fused8<LOG1, false, 0, 1, true>); probe(k_ntt_fused8<LOG1, false, 0, 1, false>);
+      probe(k_ntt_fused8<LOG1, false, 0, 3, true>); probe(k_ntt_fused8<LOG1, false, 0, 3, false>);
+      probe(k_ntt_fused8<LOG1, false, 4, 3, true>); probe(k_ntt_fused8<LOG1, false, 4, 3, false>);
+      probe(k_ntt_fused8<LOG1, true, 0, 2, true>);  probe(k_ntt_fused8<LOG1, true, 0, 2, false>);
+    };
+    if (cc->P.logN == 15) probeAll(std::integral_constant<int, 7>()); else probeAll(std::integral_constant<int, 8>());
     cc->fused_slots_per_xcd = slots;
-    if (slots < (cc->P.N >> HM_TL_ROW)) cc->fused_small = 0;
+    if (slots < (cc->P.N >> HM_TL_ROW) || !hm_caps(cc->P.logN).small_geometry) cc->fused_small = 0;
   }
   if (const char *e = getenv("HOMULATOR_REPLICATE_SPLIT")) cc->replicate_split_bytes = strtoull(e, nullptr, 10);
   if (const char *e = getenv("HOMULATOR_NTT_LAUNCH_ENTRIES")) cc->ntt_launch_entries = (uint32_t)std::max(8, atoi(e));
@@ -806,7 +818,7 @@ extern "C" hm_status hm_create(hm_ctx **out, const hm_params *p) {
   memset(cc->err_host, 0, 64);
   HM_HIP(nullptr, hipHostGetDevicePointer(reinterpret_cast<void **>(&cc->err_dev), cc->err_host, 0));
   if (const char *e = getenv("HOMULATOR_NTT_FUSED_SMALL")) cc->fused_small = (uint32_t)std::min(HM_NTT_MAX_ENTRIES, std::max(0, atoi(e)));
-  if (cc->fused_slots_per_xcd < (cc->P.N >> HM_TL_ROW)) cc->fused_small = 0;   // the guard above wins over the environment
+  if (cc->fused_slots_per_xcd < (cc->P.N >> HM_TL_ROW) || !hm_caps(cc->P.logN).small_geometry) cc->fused_small = 0;   // the guard above wins over the environment
   if (const char *e = getenv("HOMULATOR_NTT_SMALL_LIMBS")) { cc->small_limbs = (uint32_t)atoi(e); cc->small_ept8 = cc->small_limbs != 0; }
   *out = c.release();
   return HM_OK;
@@ -958,12 +970,20 @@ extern "C" hm_status hm_set_option(hm_ctx *c, const char *name, uint64_t value) 
   if (!strcmp(name, "ntt_fused_small")) {
     if (value > HM_NTT_MAX_ENTRIES) return fail(c, HM_ERR_ARG, "hm_set_option: ntt_fused_small above %d", HM_NTT_MAX_ENTRIES);
     if (value && c->fused_broken) return fail(c, HM_ERR_UNSUPPORTED, "hm_set_option: a rendezvous of this context has timed out: one-launch transforms stay off");
+    if (value && !hm_caps(c->P.logN).small_geometry) return fail(c, HM_ERR_UNSUPPORTED, "hm_set_option: no one-launch transform at N = 2^%u", c->P.logN);
     if (value && c->fused_slots_per_xcd < (c->P.N >> HM_TL_ROW)) return fail(c, HM_ERR_UNSUPPORTED, "hm_set_option: an XCD holds %u workgroups of the one-launch transform, a limb-poly needs %u", c->fused_slots_per_xcd, c->P.N >> HM_TL_ROW);
     c->fused_small = (uint32_t)value;
     return HM_OK;
   }
   if (!strcmp(name, "bconv_col_outs")) { if (value > 2) return fail(c, HM_ERR_ARG, "hm_set_option: bconv_col_outs is 0 (by launch size), 1 or 2"); c->bcol_outs = (uint32_t)value; return HM_OK; }
-  if (!strcmp(name, "replicate_split_bytes")) { c->replicate_split_bytes = value; return HM_OK; }
+  if (!strcmp(name, "replicate_split_bytes")) {
+    // the threshold decides the SHAPE of a collective (one exchange or scatter + exchange): every rank must hold the same value.  It is
+    // compared across the ranks once, when the communicator is made (verify_replicate_split); after that it is fixed.
+    if ((c->comm || c->ext_fn) && value != c->replicate_split_bytes)
+      return fail(c, HM_ERR_UNSUPPORTED, "hm_set_option: replicate_split_bytes is fixed once the communicator exists (set it, the same on every rank, before hm_comm_init_*)");
+    c->replicate_split_bytes = value;
+    return HM_OK;
+  }
   if (!strcmp(name, "ntt_launch_entries")) { c->ntt_launch_entries = (uint32_t)std::max<uint64_t>(8, value); return HM_OK; }
   if (!strcmp(name, "nip_small_limbs")) { c->nip_small = (uint32_t)value; return HM_OK; }
   if (!strcmp(name, "ntt_small_mode")) { c->small_mode = (uint32_t)value & 3u; return HM_OK; }
@@ -974,7 +994,17 @@ extern "C" hm_status hm_get_counter(hm_ctx *c, const char *name, uint64_t *value
   if (!c || !name || !value) return HM_ERR_ARG;
   if (!strcmp(name, "arith")) { *value = HM_GENERIC; return HM_OK; }   // arithmetic back-end of this context: 0 = mont32 (word-wise Montgomery on q = h 2^32 + 1), 1 = generic
   if (!strcmp(name, "ntt_fused_slots_per_xcd")) { *value = c->fused_slots_per_xcd; return HM_OK; }
+  if (!strncmp(name, "cap_", 4) && !hm_cap_by_name(c->P.logN, name, value)) return HM_OK;   // the capability table of this context's ring size (hm_caps.h): what the host layer plans its fusions from
   if (!strcmp(name, "ntt_fused_small")) { *value = c->fused_small; return HM_OK; }   // 0: the one-launch form is off (option, guard, or after a time-out)
+  // the communicator as the library sees it: ranks_seen = ncclCommCount over RCCL (what the wire was set up for), the caller's figure otherwise
+  if (!strcmp(name, "comm_world")) { *value = (uint64_t)c->world; return HM_OK; }
+  if (!strcmp(name, "comm_transport")) { *value = c->comm ? 1 : c->ext_fn ? 2 : 0; return HM_OK; }
+  if (!strcmp(name, "comm_ranks_seen")) {
+    int n = c->world;
+    if (c->comm && g_rccl.CommCount && g_rccl.CommCount(c->comm, &n) != ncclSuccess) return fail(c, HM_ERR_COMM, "ncclCommCount failed");
+    *value = (uint64_t)n;
+    return HM_OK;
+  }
   if (!strcmp(name, "ntt_cross_xcd")) {
     HM_HIP(c, hipStreamSynchronize(c->stream));
     unsigned v = 0;
@@ -1094,15 +1124,26 @@ static const HmNttKernels &ntt_kernels(int form) {
       {k_ntt_row<true, 0>, k_ntt_col<LOG1, true, 2>, nullptr, nullptr, {nullptr, nullptr}}};
   return wide[form];
 }
-template <>
-const HmNttKernels &ntt_kernels<8>(int form) {
+// the ring sizes of the reference's configurations (config/config_4.cfg: N = 2^16, config_4_N15.cfg: N = 2^15) have all three forms
+template <int LOG1>
+static const HmNttKernels &ntt_kernels_all(int form) {
   static const HmNttKernels both[4] = {
-      {k_ntt_col<8, false, 0>, k_ntt_row<false, 1>, k_ntt_col8<false, 0>, k_ntt_row8<false, 1>, {k_ntt_fused8<false, 0, 1, true>, k_ntt_fused8<false, 0, 1, false>}},
-      {k_ntt_col<8, false, 0>, k_ntt_row<false, 3>, k_ntt_col8<false, 0>, k_ntt_row8<false, 3>, {k_ntt_fused8<false, 0, 3, true>, k_ntt_fused8<false, 0, 3, false>}},
-      {k_ntt_col<8, false, 4>, k_ntt_row<false, 3>, k_ntt_col8<false, 4>, k_ntt_row8<false, 3>, {k_ntt_fused8<false, 4, 3, true>, k_ntt_fused8<false, 4, 3, false>}},
-      {k_ntt_row<true, 0>, k_ntt_col<8, true, 2>, k_ntt_row8<true, 0>, k_ntt_col8<true, 2>, {k_ntt_fused8<true, 0, 2, true>, k_ntt_fused8<true, 0, 2, false>}}};
+      {k_ntt_col<LOG1, false, 0>, k_ntt_row<false, 1>, k_ntt_col8<LOG1, false, 0>, k_ntt_row8<false, 1>, {k_ntt_fused8<LOG1, false, 0, 1, true>, k_ntt_fused8<LOG1, false, 0, 1, false>}},
+      {k_ntt_col<LOG1, false, 0>, k_ntt_row<false, 3>, k_ntt_col8<LOG1, false, 0>, k_ntt_row8<false, 3>, {k_ntt_fused8<LOG1, false, 0, 3, true>, k_ntt_fused8<LOG1, false, 0, 3, false>}},
+      {k_ntt_col<LOG1, false, 4>, k_ntt_row<false, 3>, k_ntt_col8<LOG1, false, 4>, k_ntt_row8<false, 3>, {k_ntt_fused8<LOG1, false, 4, 3, true>, k_ntt_fused8<LOG1, false, 4, 3, false>}},
+      {k_ntt_row<true, 0>, k_ntt_col<LOG1, true, 2>, k_ntt_row8<true, 0>, k_ntt_col8<LOG1, true, 2>, {k_ntt_fused8<LOG1, true, 0, 2, true>, k_ntt_fused8<LOG1, true, 0, 2, false>}}};
   return both[form];
 }
+template <> const HmNttKernels &ntt_kernels<8>(int form) { return ntt_kernels_all<8>(form); }
+template <> const HmNttKernels &ntt_kernels<7>(int form) { return ntt_kernels_all<7>(form); }
+
+// The launch-size thresholds of the small-launch forms are stated in limb-polys of N = 2^16 (16 workgroups each); what decides is the number
+// of workgroups a launch brings, so a smaller ring admits proportionally more limb-polys (N = 2^15: twice as many; at most one launch's records)
+static uint32_t small_entries(const hm_ctx *c, uint32_t limbs16) {
+  if (!hm_caps(c->P.logN).small_geometry) return 0;
+  return std::min<uint32_t>(HM_NTT_MAX_ENTRIES, limbs16 << (16 - std::min(16u, c->P.logN)));
+}
+static uint32_t fused_small_entries(const hm_ctx *c) { return small_entries(c, c->fused_small); }
 
 template <int LOG1>
 static void launch_ntt(hm_ctx *c, const HmNttArgs &a, bool fusedEpilogue, bool mixPrologue, bool inverse, bool firstPassOnly, bool secondPassOnly = false) {
@@ -1111,7 +1152,7 @@ static void launch_ntt(hm_ctx *c, const HmNttArgs &a, bool fusedEpilogue, bool m
   const dim3 grid(a.n_limbs * (c->P.N >> HM_TL_ROW)), block16((1 << HM_TL_ROW) / HM_EPT), block8((1 << HM_TL_ROW) / 8);
   // small launches (one round of workgroups on the chip): the 8-coefficient geometry halves the serial work per wave (small_mode:
   // bit 0 = the COL pass, bit 1 = the ROW pass; the hand-off between the passes is the same in both geometries)
-  const bool small = K.first8 && c->small_ept8 && a.n_limbs <= c->small_limbs;
+  const bool small = K.first8 && c->small_ept8 && a.n_limbs <= small_entries(c, c->small_limbs);
   const bool col8 = small && (c->small_mode & 1), row8 = small && (c->small_mode & 2);
   const bool first8 = inverse ? row8 : col8, second8 = inverse ? col8 : row8;
   if (secondPassOnly) {   // the hand-off was written by a fused conversion + first pass (bconv_col_launch)
@@ -1127,7 +1168,7 @@ static void launch_ntt(hm_ctx *c, const HmNttArgs &a, bool fusedEpilogue, bool m
   // XCD's slots; hm_create checked that an XCD holds at least 16); every other resident workgroup belongs to a complete limb-poly and
   // finishes.  Up to eight such kernels in flight on one GPU (contexts, instances; HIP drives four hardware queues by default) cannot
   // starve one another; the spins are bounded all the same.
-  if (K.one[0] && a.n_limbs <= c->fused_small && a.logG == 0) {
+  if (K.one[0] && a.n_limbs <= fused_small_entries(c) && a.logG == 0) {
 #if defined(HM_FUSED_TRACE)
     const HmNttFusedArgs f = {c->ntt_ws, c->err_dev, c->fused_test_spread, c->fused_test_timeout ? 1u << 10 : HM_SPIN_LIMIT, c->fused_test_timeout, c->fused_trace};
 #else
@@ -1216,8 +1257,7 @@ static hm_status ntt_common(hm_ctx *c, const char *what, const uint64_t *in, con
   uint32_t logG = 1;
   // a call that will run as ONE launch (k_ntt_fused8) takes single limb-polys as groups: a kernel then has at most 15 workgroups per XCD
   // waiting for siblings that have no slot yet (launch_ntt), and the 50-limb sweep 56 entries instead of 64
-  if (c->P.logN == 16 && c->fused_small && !f.firstPassOnly && !f.secondPassOnly &&
-      (n + 7) / 8 * 8 <= c->fused_small) logG = 0;
+  if (fused_small_entries(c) && !f.firstPassOnly && !f.secondPassOnly && (n + 7) / 8 * 8 <= fused_small_entries(c)) logG = 0;
 #ifndef HM_NTT_MAX_LOGG
 #define HM_NTT_MAX_LOGG 3
 #endif
@@ -1569,9 +1609,9 @@ extern "C" hm_status hm_ntt_inner_product(hm_ctx *c, const hm_ntt_ip_desc *d) {
   const uint32_t n = d->n, T = d->n_terms, K = d->n_out;
   if (T == 0 || T > HM_NIP_MAX_TERMS || K == 0 || K > HM_NIP_MAX_OUT)
     return fail(c, HM_ERR_ARG, "hm_ntt_inner_product: n_terms in [1,%d], n_out in [1,%d]", HM_NIP_MAX_TERMS, HM_NIP_MAX_OUT);
-  if (d->out_inverse && c->P.logN != HM_ROW_LOG + 8) {   // the epilogue is the inverse ROW pass over the workgroup's own rows: tiles of whole rows at any N, but built and tested for 2^16
+  if (d->out_inverse && !hm_caps(c->P.logN).ip_inverse_out) {   // the epilogue is the inverse ROW pass over the workgroup's own rows: tiles of whole rows at any N; tested at 2^15 and 2^16
     for (uint32_t i = 0; i < n; ++i)
-      if (d->out_inverse[i]) return fail(c, HM_ERR_UNSUPPORTED, "hm_ntt_inner_product: out_inverse needs N = 2^16");
+      if (d->out_inverse[i]) return fail(c, HM_ERR_UNSUPPORTED, "hm_ntt_inner_product: out_inverse needs N = 2^15 or 2^16");
   }
   hm_status st;
   if ((st = check_limbs(c, "hm_ntt_inner_product", d->x_limbs, n * T)) || (st = check_limbs(c, "hm_ntt_inner_product", d->y_limbs, n * T * K)) ||
@@ -1707,7 +1747,7 @@ extern "C" hm_status hm_ntt_inner_product(hm_ctx *c, const hm_ntt_ip_desc *d) {
     static const nip_kernel kern8[2][3] = {{k_ntt_row_ip8<1, 0>, nullptr, k_ntt_row_ip8<1, 2>}, {k_ntt_row_ip8<2, 0>, nullptr, k_ntt_row_ip8<2, 2>}};
 #endif
     // small launches (one op at a time: 50 limb records = 800 workgroups on 768 slots of the wide form) take the small-launch geometry
-    if (c->P.logN == 16 && cnt <= c->nip_small) hipLaunchKernelGGL(kern8[K - 1][invForm], grid, dim3((1 << HM_TL_ROW) / 8), 0, c->stream, a);
+    if (cnt <= small_entries(c, c->nip_small)) hipLaunchKernelGGL(kern8[K - 1][invForm], grid, dim3((1 << HM_TL_ROW) / 8), 0, c->stream, a);
     else hipLaunchKernelGGL(kern[K - 1][invForm], grid, block, 0, c->stream, a);
     HM_HIP(c, hipGetLastError());
   }
@@ -1860,7 +1900,7 @@ static hm_status bconv_col_launch(hm_ctx *c, const hm_bconv_desc *descs, uint32_
   const uint32_t allTiles = c->P.N >> HM_TL_COL;
   if (!n_tiles) { tile0 = 0; n_tiles = allTiles; }
   if ((n_tiles & (n_tiles - 1)) || tile0 % n_tiles || tile0 + n_tiles > allTiles) return fail(c, HM_ERR_ARG, "fused conversion: tile range [%u, %u) of %u", tile0, tile0 + n_tiles, allTiles);
-  if (c->P.logN != 16 && c->P.logN != 15) return fail(c, HM_ERR_UNSUPPORTED, "fused conversion: N = 2^15 or 2^16 only");
+  if (!hm_caps(c->P.logN).bcol_max_in) return fail(c, HM_ERR_UNSUPPORTED, "fused conversion: N = 2^15 or 2^16 only");
   HM_HIP(c, hipSetDevice(c->device));
   // output limbs per workgroup: two share the loaded and split inputs (+2 % hmult/s at batch 10), but halve the workgroups of a launch that
   // fills the chip only once or twice (one op at a time: -2 %): by launch size unless the option says otherwise
@@ -1874,7 +1914,8 @@ static hm_status bconv_col_launch(hm_ctx *c, const hm_bconv_desc *descs, uint32_
   for (uint32_t pi = 0; pi < n_desc; ++pi) {
     const hm_bconv_desc &d = descs[pi];
     if (!d.in || !d.out || !d.in_ids || !d.out_ids) return fail(c, HM_ERR_ARG, "fused conversion: null argument");
-    if (d.n_in == 0 || d.n_in > HM_BCOL_MAX_IN) return fail(c, HM_ERR_UNSUPPORTED, "fused conversion: n_in %u not in [1,%d]", d.n_in, HM_BCOL_MAX_IN);
+    const uint32_t maxIn = mix ? hm_caps(c->P.logN).bcol_max_in_mix : hm_caps(c->P.logN).bcol_max_in;
+    if (d.n_in == 0 || d.n_in > maxIn) return fail(c, HM_ERR_UNSUPPORTED, "fused conversion: n_in %u not in [1,%u]%s", d.n_in, maxIn, mix ? " (with the mix prologue)" : "");
     if (d.n_out == 0 || d.n_out > HM_BCONV_MAX_OUT) return fail(c, HM_ERR_ARG, "fused conversion: n_out %u not in [1,%d]", d.n_out, HM_BCONV_MAX_OUT);
     if (d.log_len && d.log_len != c->P.logN) return fail(c, HM_ERR_UNSUPPORTED, "fused conversion: whole limb-polys only");
     if (d.out != descs[0].out) return fail(c, HM_ERR_ARG, "fused conversion: one hand-off buffer per call");

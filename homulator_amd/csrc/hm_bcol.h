@@ -4,6 +4,7 @@
 #pragma once
 #include "hm_elem_core.h"
 #include "hm_ntt_core.h"
+#include "hm_caps.h"   // HM_BCOL_MAX_IN, HM_BCOL_MAX_IN_MIX
 #ifndef HM_NTT_MIN_WAVES
 #define HM_NTT_MIN_WAVES 4
 #endif
@@ -13,6 +14,7 @@
 // tiles (the workgroups of the same (p, t) for the other outputs sit in neighbouring dispatch slots of one XCD and find the inputs in
 // L2), then runs the COL pass on them: the converted limb-poly never exists in HBM, only the first pass's hand-off does.
 template <int V> struct HmIc { static constexpr int value = V; };
+#define HM_BCOL_ONE_GROUP 15    // up to here every input of an access unit is held at once (16: hipcc leaves the arrays in scratch, 1 KB per lane)
 struct HmBcolProb {
   const uint64_t *in;
   const uint64_t *table, *qn;
@@ -118,6 +120,73 @@ __device__ __forceinline__ void hm_bcol_units(const PROB &p, HmNttState &st0, Hm
     __builtin_amdgcn_sched_barrier(0);   // one unit's loads in flight at a time (N_IN x 16 bytes per lane)
   }
 }
+// ---- digits of 16 .. 32 limbs (round 6: parameter set A and the `motivation` sweep convert from up to 28 limbs, script/README.md:17-22,
+// src/Operation.cpp:137-188) ----------------------------------------------------------------------------------------------------------
+// The inputs of an access unit are taken in two groups, [0, 16) and [16, N_IN): a group is loaded, split, multiplied into the 128-bit sums
+// of the workgroup's NOUT outputs and dropped before the next one is requested, so that the live inputs never exceed what the 15-limb form
+// holds (16 x 2 coefficients x 2 halves = 64 VGPRs; all N_IN at once left the arrays in scratch: 1 KB per lane at 16).  A group's table
+// entries are whole 8-entry rows (the second group starts at entry 16), read through the scalar cache as before; one reduction per output
+// (hm_redc_wide<N_IN>: two conditional subtractions above 16 terms).
+template <int C0, int CN, int NOUT, bool PACKED, class G0, class PROB>
+__device__ __forceinline__ void hm_bcol_group(const PROB &p, uint32_t rowsPerOut, uint32_t o0, uint32_t o1, uint32_t tile, int tid, int u, size_t N,
+                                              hm_u128 (&acc)[2][2]) {
+  uint32_t yl[2][CN], yh[2][CN];
+#pragma unroll
+  for (int i = 0; i < CN; ++i) {
+    uint64_t v0, v1;
+    hm_gld2<G0>(p.in + (size_t)p.in_limb[C0 + i] * N, tile, tid, u, v0, v1);
+    if (PACKED) {
+      yl[0][i] = (uint32_t)v0; yh[0][i] = (uint32_t)(v0 >> 32);
+      yl[1][i] = (uint32_t)v1; yh[1][i] = (uint32_t)(v1 >> 32);
+    } else {
+      yl[0][i] = (uint32_t)v0 & 0x3FFFFFFFu; yh[0][i] = (uint32_t)(v0 >> 30);
+      yl[1][i] = (uint32_t)v1 & 0x3FFFFFFFu; yh[1][i] = (uint32_t)(v1 >> 30);
+    }
+  }
+  constexpr int NG = (CN + 7) / 8;
+#pragma unroll
+  for (int k = 0; k < NOUT; ++k) {
+    const uint32_t o = k ? o1 : o0;
+    HmRow8 row[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) row[g] = HM_CONST_ROWS(p.table)[o * rowsPerOut + C0 / 8 + g];
+    acc[k][0] += hm_bconv_cols<CN>(yl[0], yh[0], row);
+    acc[k][1] += hm_bconv_cols<CN>(yl[1], yh[1], row);
+  }
+}
+template <int N_IN, int NOUT, bool PACKED, class G0, class PROB>
+__device__ __forceinline__ void hm_bcol_units_wide(const PROB &p, HmNttState &st0, HmNttState &st1, uint32_t o0, uint32_t o1, uint32_t tile, int tid, size_t N) {
+  static_assert(N_IN >= 16 && N_IN <= 32, "two input groups");
+  constexpr uint32_t ROWS = (N_IN + 7) / 8;   // 8-entry table rows per output (HM_BCONV_ROW)
+#pragma unroll
+  for (int u = 0; u < HM_UNITS; ++u) {
+    int i0, i1, x, c;
+    G0::unit(tid, u, i0, i1, x, c);
+    hm_u128 acc[2][2] = {{0, 0}, {0, 0}};
+    hm_bcol_group<0, (N_IN < 16 ? N_IN : 16), NOUT, PACKED, G0>(p, ROWS, o0, o1, tile, tid, u, N, acc);
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]));   // the first group's sums are complete before the second group's inputs are requested
+    if (NOUT == 2) asm volatile("" : "+v"(acc[1][0]), "+v"(acc[1][1]));
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    if constexpr (N_IN > 16) hm_bcol_group<16, N_IN - 16, NOUT, PACKED, G0>(p, ROWS, o0, o1, tile, tid, u, N, acc);
+    HmMod m0;
+    { const HmQn m = HM_CONST_QN(p.qn)[o0]; m0.q = m.q; m0.nqinv = m.nqinv; }
+    st0.v[i0] = hm_redc_wide<N_IN>(acc[0][0], m0);
+    st0.v[i1] = hm_redc_wide<N_IN>(acc[0][1], m0);
+    if (NOUT == 2) {
+      HmMod m1;
+      { const HmQn m = HM_CONST_QN(p.qn)[o1]; m1.q = m.q; m1.nqinv = m.nqinv; }
+      st1.v[i0] = hm_redc_wide<N_IN>(acc[1][0], m1);
+      st1.v[i1] = hm_redc_wide<N_IN>(acc[1][1], m1);
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(st0.v[i0]), "+v"(st0.v[i1]));
+    if (NOUT == 2) asm volatile("" : "+v"(st1.v[i0]), "+v"(st1.v[i1]));
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+  }
+}
 template <int N_IN, int LOG1, int NOUT, bool MIX, bool PACKED>
 __device__ __forceinline__ void hm_bconv_col_body(const HmBcolArgs &a) {
   constexpr int TL = HM_TL_COL;
@@ -146,7 +215,10 @@ __device__ __forceinline__ void hm_bconv_col_body(const HmBcolArgs &a) {
   const uint64_t *mix0 = MIX ? a.mix + (size_t)p.mix_limb[o0] * N : nullptr, *mix1 = MIX ? a.mix + (size_t)p.mix_limb[o1] * N : nullptr;
   // (the inputs' form is a template parameter of the KERNEL: two copies of the unit loop in one kernel shared one scalar-register budget,
   // and the packed copy reloaded spilled table words 1 262 times per workgroup — measured +0 % instead of the -16 % of the form on its own)
-  hm_bcol_units<N_IN, NOUT, MIX, PACKED, G0>(p, st0, st1, mix0, mix1, o0, o1, tile, tid, N);
+  if constexpr (N_IN > HM_BCOL_ONE_GROUP) {
+    static_assert(N_IN <= HM_BCOL_ONE_GROUP || !MIX, "the mix prologue is built for digits of up to 15 limbs (the opt-in fused ModDown conversion)");
+    hm_bcol_units_wide<N_IN, NOUT, PACKED, G0>(p, st0, st1, o0, o1, tile, tid, N);
+  } else hm_bcol_units<N_IN, NOUT, MIX, PACKED, G0>(p, st0, st1, mix0, mix1, o0, o1, tile, tid, N);
   __syncthreads();
   hm_bcol_rounds<TL, LOG1>(st0, tid, lds, HM_CONST_QN(p.qn)[o0].q, a.tw + (size_t)p.out_mod[o0] * N, a.out + (size_t)p.out_limb[o0] * N, tile);
   if (NOUT == 2 && two) {
@@ -171,7 +243,6 @@ __global__ void __launch_bounds__((1 << HM_TL_COL) / HM_EPT) __attribute__((amdg
 }
 
 
-#define HM_BCOL_MAX_IN 15   // 16 inputs: hipcc leaves the input arrays in scratch (1 KB per lane)
 typedef void (*hm_bcol_kernel)(HmBcolArgs);
 // nullptr: no such kernel (ring sizes other than 2^15 and 2^16 convert with hm_bconv_batch first; packed inputs with the mix prologue:
 // the opt-in fused ModDown conversion takes plain inputs)

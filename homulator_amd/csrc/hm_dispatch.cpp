@@ -21,6 +21,7 @@
 
 #include "../../include/homulator_hip.h"
 #include "hm_params.h"
+#include "hm_caps.h"
 
 struct hm_ctx {
   int arith;        // 0 = mont32, 1 = generic
@@ -86,7 +87,8 @@ extern "C" const char *hm_last_error(const hm_ctx *c) {
 extern "C" hm_status hm_create(hm_ctx **out, const hm_params *p) {
   if (!out || !p) { g_create_err = "hm_create: null argument"; return HM_ERR_ARG; }
   *out = nullptr;
-  if ((p->q != nullptr) != (p->p != nullptr || p->K == 0)) { g_create_err = "hm_create: q and p go together"; return HM_ERR_ARG; }
+  // q and p go together; K == 0 needs no p (a default chain with no special moduli has neither)
+  if ((p->q == nullptr && p->p != nullptr) || (p->q != nullptr && p->p == nullptr && p->K != 0)) { g_create_err = "hm_create: q and p go together"; return HM_ERR_ARG; }
   // which back-end: every modulus h 2^32 + 1 (or the default chain) -> mont32; anything else the generic one.  The chain itself is
   // validated by the back-end (primality, 1 mod 2N, range, duplicates): here only the form of the words is looked at.
   int arith = 0;
@@ -163,6 +165,11 @@ static HmApi *any_backend() {
   for (int a = 0; a < 2; ++a)
     if (!load_backend(a)) return &g_api[a];
   return nullptr;
+}
+// the capability table is host-side data: no back-end is loaded for it
+extern "C" hm_status hm_capability(uint32_t logN, const char *name, uint64_t *value) {
+  if (!name || !value) return HM_ERR_ARG;
+  return hm_cap_by_name(logN, name, value) ? HM_ERR_ARG : HM_OK;
 }
 extern "C" hm_status hm_comm_unique_id(void *out128) {
   HmApi *a = any_backend();

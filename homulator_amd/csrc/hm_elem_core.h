@@ -220,6 +220,26 @@ HM_HD uint64_t hm_bconv_dot(const uint32_t (&yl)[N_IN], const uint32_t (&yh)[N_I
   return hm_redc_wide<N_IN>(acc, m);
 }
 
+// the same sum for up to 16 consecutive inputs, NOT reduced: the carry-free split-30 columns of one group, recombined into a 128-bit value
+// (round 6: the fused conversion + first pass takes digits of 16 .. 32 limbs in two such groups, each loaded, multiplied and dropped before
+// the next one, so that at most 16 inputs x 2 coefficients x 2 halves = 64 VGPRs of inputs are live; hm_redc_wide<N_IN> reduces the sum of
+// the groups).  row = the table entries of these inputs (a whole number of 8-entry groups: the chunk starts at a multiple of 8).
+template <int CN>
+HM_HD hm_u128 hm_bconv_cols(const uint32_t (&yl)[CN], const uint32_t (&yh)[CN], const HmRow8 (&row)[(CN + 7) / 8]) {
+  static_assert(CN >= 1 && CN <= 16, "one carry-free column group");
+  uint64_t s00 = 0, s01 = 0, s10 = 0, s11 = 0;
+#pragma unroll
+  for (int i = 0; i < CN; ++i) {
+    const uint64_t w = row[i >> 3].w[i & 7];
+    const uint32_t wl = (uint32_t)w, wh = (uint32_t)(w >> 32);
+    s00 += (uint64_t)yl[i] * wl;
+    s01 += (uint64_t)yl[i] * wh;
+    s10 += (uint64_t)yh[i] * wl;
+    s11 += (uint64_t)yh[i] * wh;
+  }
+  return (hm_u128)s00 + (((hm_u128)s01 + s10) << 30) + ((hm_u128)s11 << 60);
+}
+
 // per-output modulus constants, stored behind the table rows (HmBconvProb::qn): no load depends on another load
 struct HmQn {
   uint64_t q, nqinv;

@@ -12,6 +12,7 @@ extern "C" hm_status hm_comm_unique_id(void *out128) {
   memcpy(out128, &id, sizeof id);
   return HM_OK;
 }
+static hm_status verify_replicate_split(hm_ctx *c);
 extern "C" hm_status hm_comm_init_rccl(hm_ctx *c, int rank, int world, const void *id128) {
   if (!c || !id128 || world < 1 || rank < 0 || rank >= world) return HM_ERR_ARG;
   if (c->P.N % ((uint32_t)world * 512u)) return fail(c, HM_ERR_ARG, "hm_comm_init: world %d does not divide N / 512", world);
@@ -22,13 +23,13 @@ extern "C" hm_status hm_comm_init_rccl(hm_ctx *c, int rank, int world, const voi
   ncclResult_t r = g_rccl.CommInitRank(&c->comm, world, id, rank);
   if (r != ncclSuccess) return fail(c, HM_ERR_COMM, "ncclCommInitRank: %s", g_rccl.GetErrorString(r));
   c->rank = rank; c->world = world; c->ext_fn = nullptr;
-  return HM_OK;
+  return verify_replicate_split(c);
 }
 extern "C" hm_status hm_comm_init_external(hm_ctx *c, int rank, int world, hm_exchange_fn fn, void *user) {
   if (!c || !fn || world < 1 || rank < 0 || rank >= world) return HM_ERR_ARG;
   if (c->P.N % ((uint32_t)world * 512u)) return fail(c, HM_ERR_ARG, "hm_comm_init: world %d does not divide N / 512", world);
   c->rank = rank; c->world = world; c->ext_fn = fn; c->ext_user = user;
-  return HM_OK;
+  return verify_replicate_split(c);
 }
 extern "C" hm_status hm_comm_info(const hm_ctx *c, int *rank, int *world) {
   if (!c) return HM_ERR_ARG;
@@ -94,6 +95,33 @@ static hm_status all_to_all(hm_ctx *c, hipStream_t S, const uint64_t *send, std:
   ncclResult_t e = g_rccl.GroupEnd();
   if (r == ncclSuccess) r = e;
   if (r != ncclSuccess) return fail(c, HM_ERR_COMM, "RCCL exchange: %s", g_rccl.GetErrorString(r));
+  return HM_OK;
+}
+
+// hm_replicate_limbs chooses between one exchange and scatter + exchange of chunks from replicate_split_bytes, which every process reads
+// from ITS environment (HOMULATOR_REPLICATE_SPLIT) or option: ranks that disagree would enter collectives of different shape and hang.
+// So the first thing a new communicator carries is every rank's threshold to every other rank (8 bytes per pair, over the transport
+// itself); a mismatch fails hm_comm_init_* with HM_ERR_COMM on every rank, and hm_set_option refuses to change the value afterwards.
+static hm_status verify_replicate_split(hm_ctx *c) {
+  const uint32_t W = (uint32_t)c->world, me = (uint32_t)c->rank;
+  if (W < 2) return HM_OK;
+  hm_status st;
+  if ((st = ensure_stage(c, 512u * W))) return st;
+  std::vector<uint64_t> mine(512u * W, c->replicate_split_bytes), got(512u * W, 0);
+  HM_HIP(c, hipMemcpyAsync(c->stage_send, mine.data(), 8u * mine.size(), hipMemcpyHostToDevice, c->stream));
+  std::vector<size_t> so(W, 0), sb(W, 8), ro(W, 0), rb(W, 8);
+  for (uint32_t p = 0; p < W; ++p) { so[p] = ro[p] = (size_t)p * 4096; }
+  if ((st = all_to_all(c, c->stream, c->stage_send, so, sb, c->stage_recv, ro, rb))) return st;
+  HM_HIP(c, hipMemcpyAsync(got.data(), c->stage_recv, 8u * got.size(), hipMemcpyDeviceToHost, c->stream));
+  HM_HIP(c, hipStreamSynchronize(c->stream));
+  for (uint32_t p = 0; p < W; ++p)
+    if (p != me && got[(size_t)p * 512] != c->replicate_split_bytes) {
+      st = fail(c, HM_ERR_COMM, "hm_comm_init: rank %u holds replicate_split_bytes = %llu, rank %u holds %llu (HOMULATOR_REPLICATE_SPLIT / hm_set_option must agree on every rank)",
+                me, (unsigned long long)c->replicate_split_bytes, p, (unsigned long long)got[(size_t)p * 512]);
+      if (c->comm && g_rccl.CommDestroy) { (void)g_rccl.CommDestroy(c->comm); c->comm = nullptr; }
+      c->ext_fn = nullptr; c->world = 1; c->rank = 0;
+      return st;
+    }
   return HM_OK;
 }
 
@@ -349,6 +377,8 @@ extern "C" hm_status hm_replicate_limbs(hm_ctx *c, uint64_t *buf, const uint32_t
     }
     if (me != owner) { ro1[owner] = run_of(me); rb1[owner] = len_of(me); }
     if ((st = all_to_all(c, S, c->stage_send, so1, sb1, c->stage_recv, ro1, rb1))) return st;
+    // phase 2 sends FROM and receives INTO stage_recv inside one group: a rank sends the run it received in phase 1 (bytes [run_of(me),
+    // + len)) and receives the other peers' runs at THEIR offsets — disjoint ranges of the one buffer, ordered behind phase 1 on the stream
     if ((st = all_to_all(c, S, c->stage_recv, so2, sb2, c->stage_recv, ro2, rb2))) return st;
     if (me == owner) return HM_OK;
     so.clear(); dof.clear();

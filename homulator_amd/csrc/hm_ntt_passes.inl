@@ -33,7 +33,9 @@ template <> struct HmRounds<6> { static constexpr int n = 2; static constexpr in
 template <> struct HmRounds<7> { static constexpr int n = 3; static constexpr int nb[4] = {3, 2, 2, 0}; static constexpr int k[4] = {4, 2, 0, 0}; };
 template <> struct HmRounds<8> { static constexpr int n = 3; static constexpr int nb[4] = {3, 3, 2, 0}; static constexpr int k[4] = {5, 2, 0, 0}; };
 template <> struct HmRounds<9> { static constexpr int n = 3; static constexpr int nb[4] = {3, 3, 3, 0}; static constexpr int k[4] = {6, 3, 0, 0}; };
-#else   // 8 coefficients per thread: a pair of radix-4 groups per round, four rounds of a 256-point pass (N = 2^16 only)
+#else   // 8 coefficients per thread: a pair of radix-4 groups per round, four rounds of a 256-point pass; the 128-point COL pass of
+        // N = 2^15 (round 6) ends on a radix-2 round (four groups per thread)
+template <> struct HmRounds<7> { static constexpr int n = 4; static constexpr int nb[4] = {2, 2, 2, 1}; static constexpr int k[4] = {5, 3, 1, 0}; };
 template <> struct HmRounds<8> { static constexpr int n = 4; static constexpr int nb[4] = {2, 2, 2, 2}; static constexpr int k[4] = {6, 4, 2, 0}; };
 #endif
 

@@ -20,7 +20,7 @@ SYMBOLS = [
     "hm_bconv", "hm_bconv_batch", "hm_bconv_consts", "hm_fill_uniform", "hm_timer_start", "hm_timer_stop", "hm_comm_unique_id", "hm_comm_init_rccl", "hm_comm_init_external",
     "hm_capture_begin", "hm_capture_end", "hm_graph_launch", "hm_graph_destroy", "hm_comm_info", "hm_slice_rows", "hm_limbs_to_slices", "hm_slices_to_limbs", "hm_replicate_limbs",
     "hm_set_option", "hm_get_counter", "hm_ntt_inner_product", "hm_exchange_stream", "hm_exchange_mark", "hm_exchange_wait",
-    "hm_bconv_col", "hm_limbs_to_colslices", "hm_colslices_to_limbs", "hm_ntt_second_pass", "hm_ntt_ex",
+    "hm_bconv_col", "hm_limbs_to_colslices", "hm_colslices_to_limbs", "hm_ntt_second_pass", "hm_ntt_ex", "hm_capability",
 ]
 
 
@@ -100,6 +100,7 @@ def load():
     L.hm_ntt_inner_product.argtypes = [vp, C.POINTER(hm_ntt_ip_desc)]
     L.hm_set_option.argtypes = [vp, C.c_char_p, u64]
     L.hm_get_counter.argtypes = [vp, C.c_char_p, C.POINTER(u64)]
+    L.hm_capability.argtypes = [u32, C.c_char_p, C.POINTER(u64)]
     L.hm_timer_start.argtypes = [vp]
     L.hm_timer_stop.argtypes = [vp, C.POINTER(u64)]
     _lib = L
@@ -108,6 +109,14 @@ def load():
 
 class HmError(RuntimeError):
     pass
+
+
+def capability(logN, name):
+    """the back-end's capability table (homulator_amd/csrc/hm_caps.h) for ring size 2^logN: needs no context and no GPU"""
+    v = C.c_uint64()
+    if load().hm_capability(int(logN), name.encode(), C.byref(v)) != 0:
+        raise HmError(f"hm_capability: unknown capability {name}")
+    return v.value
 
 
 def _u32(a):

@@ -11,6 +11,13 @@
 #include "../../homulator_amd/csrc/hm_params.h"
 #include "../../include/homulator_hip.h"
 
+// the back-end's capability table for this ring size (hm_capability: host-side data, no GPU): which fused forms have kernels.  The fusion
+// passes below ask it instead of naming ring sizes or digit widths (round 6).
+static uint32_t cap(uint32_t logN, const char *name) {
+  uint64_t v = 0;
+  return hm_capability(logN, name, &v) == HM_OK ? (uint32_t)v : 0u;
+}
+
 // one C-ABI call, with its argument arrays prebuilt so that run() is a tight loop of calls
 struct Arch::Launch {
   enum Kind { L_NTT, L_INTT, L_EWE, L_BCONV, L_AUTO, L_NTT_SUBSCALE, L_TENSOR, L_EXCH_IN, L_EXCH_OUT, L_REPLICATE, L_IP, L_NTT_IP,
@@ -111,8 +118,8 @@ Arch::Arch(Config *cfg) : config(cfg) {
   if (const char *e = getenv("HOMULATOR_PIPELINE_DIGITS")) pipelineDigits = world_ > 1 && std::string(e) != "0";
   // round 4: the fused kernels serve the sharded plan too — the ModUp conversion AND the first pass of its transforms run on the slice
   // holder's COLUMN slice (exchange in the transposed domain), the limb owner runs the transform x key kernel's second pass (config key
-  // shard_fused, default 1; needs world <= N / 4096 and N = 2^15 | 2^16).  Otherwise the per-digit transforms stay launches of their own.
-  shardFused = world_ > 1 && cfg->getValueOr("shard_fused", 1) != 0 && fuseHpip && fuseBconv && (logN == 16 || logN == 15) && world_ <= (n >> 12);
+  // shard_fused, default 1; needs world <= the column tiles of a limb-poly the back-end deals out: cap_col_slices).  Otherwise the per-digit transforms stay launches of their own.
+  shardFused = world_ > 1 && cfg->getValueOr("shard_fused", 1) != 0 && fuseHpip && fuseBconv && world_ <= cap(logN, "cap_col_slices");
   if (const char *e = getenv("HOMULATOR_SHARD_FUSED")) shardFused = shardFused && std::string(e) != "0";
   // Round 5: a second sharded plan, chosen by the bytes it moves.  `gather`: the conversions' INPUT limbs (the l scaled
   // limbs of the ModUp, the 2 alpha of the ModDown) are replicated to every rank (hm_replicate_limbs: one collective each) and every rank
@@ -514,7 +521,10 @@ void Arch::fusePasses(std::vector<Stage> &st) {
         ip->ipSrc = ip->ipX;
         ip->ipCoeff.assign(ip->ipX.size(), 0);
         std::vector<Instruction *> conv(ip->ipX.size(), nullptr);
-        bool allConv = fuseBconv && (world_ == 1 || shardFused || shardGather) && (logN == 16 || logN == 15);
+        // widest digit the fused conversion + first pass takes (0: none at this ring size); config key fuse_bconv_max_in caps it below what the
+        // back-end offers (A/B runs: 15 = the plan of rounds 3-5, where wider digits kept a conversion launch of their own)
+        const uint32_t maxConvIn = std::min<uint32_t>(cap(logN, "cap_bconv_col_max_in"), config->getValueOr("fuse_bconv_max_in", ~0u));
+        bool allConv = fuseBconv && (world_ == 1 || shardFused || shardGather) && maxConvIn != 0;
         for (size_t j = 0; j < ip->ipX.size(); ++j) {
           auto p = producer.find(ip->ipX[j]);
           if (p == producer.end()) continue;
@@ -530,7 +540,7 @@ void Arch::fusePasses(std::vector<Stage> &st) {
           auto pb = producer.find(t->operandList[0]);
           auto &rb = readers[t->operandList[0]];
           if (pb != producer.end() && pb->second->ops == BCONV_STEP2 && !dead.count(pb->second) && rb.size() == 1 && rb[0] == t &&
-              pb->second->operandList.size() - 1 <= 15 && pb->second->mod_id == ip->mod_id)
+              pb->second->operandList.size() - 1 <= maxConvIn && pb->second->mod_id == ip->mod_id)
             conv[j] = pb->second;
           else allConv = false;
         }
@@ -553,7 +563,7 @@ void Arch::fusePasses(std::vector<Stage> &st) {
   //      ROW pass's last round and the inverse ROW pass's first are the same round, so the pass runs from the registers).  The kernel stores
   //      the pass's hand-off into the INTT's output limb, the INTT record keeps its COL pass (hm_ntt_second_pass, with its scale), and the
   //      evaluation-form sums of those limbs (InnerProduceOut_Key{k}[0 .. alpha)) are never written or read back.
-  if (fuseHpip && fuseIpInv && (world_ == 1 || shardGather) && logN == 16) {
+  if (fuseHpip && fuseIpInv && (world_ == 1 || shardGather) && cap(logN, "cap_ip_inverse_out")) {
     std::map<AddrType, std::vector<Instruction *>> readers;
     for (auto &s : st)
       for (Instruction *i : s.ins) {
@@ -591,7 +601,8 @@ void Arch::fusePasses(std::vector<Stage> &st) {
   // (9, round 4) the ModDown side of (8): a fused forward transform (ModDowNTT + ModDownSub [+ rescale]) whose input is a P -> Q conversion
   //     output that nobody else reads takes the conversion into its first pass (src/Operation.cpp:489-590): ModdownBConvOut_Key(k) is
   //     never written or read back.  The last limb of a key keeps its conversion: the rescale residue is formed from it element-wise (4c).
-  if (fuseBconv && fuseModDown && (world_ == 1 || shardGather) && (logN == 16 || logN == 15)) {
+  if (fuseBconv && fuseModDown && (world_ == 1 || shardGather) && cap(logN, "cap_bconv_col_max_in_mix")) {
+    const uint32_t maxMixIn = cap(logN, "cap_bconv_col_max_in_mix");
     std::map<AddrType, std::vector<Instruction *>> readers;
     for (auto &s : st)
       for (Instruction *i : s.ins) {
@@ -611,7 +622,7 @@ void Arch::fusePasses(std::vector<Stage> &st) {
         auto pb = producer.find(t->operandList[0]);
         if (pb == producer.end() || pb->second->ops != BCONV_STEP2 || dead.count(pb->second) || pb->second->mod_id != t->mod_id) continue;
         auto &rb = readers[t->operandList[0]];
-        if (rb.size() != 1 || rb[0] != t || pb->second->operandList.size() - 1 > 15) continue;
+        if (rb.size() != 1 || rb[0] != t || pb->second->operandList.size() - 1 > (t->fMix ? maxMixIn : cap(logN, "cap_bconv_col_max_in"))) continue;
         t->fConvIn.assign(pb->second->operandList.begin(), pb->second->operandList.end() - 1);
         t->fConvMods = pb->second->inMods;
         t->refInstructions += pb->second->refInstructions * (unsigned long long)config->getValueOr("bconv_num_high", 1) * config->getValueOr("bconv_num_width", 1);
@@ -679,6 +690,7 @@ void Arch::fusePasses(std::vector<Stage> &st) {
           for (auto &y : i->ipY) for (AddrType yy : y) otherReads[yy]++;
           continue;
         }
+        if (i->ops == INTT && i->secondOnly) continue;   // (7b) its one operand is its own output: the in-place second pass is no other reader of it
         if (i->ops == BCONV_STEP2) convs.push_back(Conv{std::vector<AddrType>(i->operandList.begin(), i->operandList.end() - 1), i, -1});
         else if (!i->fConvIn.empty()) {
           if (i->fMix) { for (AddrType a : i->fConvIn) otherReads[a]++; }   // (the fused conversion with the mix prologue takes plain inputs)
@@ -855,7 +867,7 @@ void Arch::buildLaunches() {
         const uint32_t per = (uint32_t)limbIndex.size();
         std::vector<Launch *> front, back;
         std::vector<int> outSlots;
-        const uint32_t nTiles = (n >> 12) / world_;
+        const uint32_t nTiles = cap(logN, "cap_col_slices") / world_;   // column tiles of a limb-poly per rank
         for (size_t dj = 0; dj < digs.size(); ++dj) {
           Dig &dg = digs[dj];
           Launch *XI = new Launch, *BC = new Launch, *XO = new Launch;
@@ -1382,6 +1394,11 @@ std::string Arch::planText() const {
     if (l->kind == Launch::L_BCONV || l->kind == Launch::L_BCONV_COL) { cnt = 0; for (auto &q : l->probs) cnt += q.out.size(); }
     if (l->kind == Launch::L_IP || l->kind == Launch::L_NTT_IP) cnt = l->mods.size();
     out += std::string(names[l->kind]) + " " + l->name + " n=" + std::to_string(cnt) + " ref=" + std::to_string(l->refInstructions);
+    // pass 11: limb-polys an inverse transform stores split-30 packed / conversions (separate or inside a transform's first pass) that read packed inputs
+    const size_t po = (size_t)std::count(l->outPacked.begin(), l->outPacked.end(), 1), pi = (size_t)std::count_if(l->probs.begin(), l->probs.end(), [](const Launch::Prob &q) { return q.inPacked; });
+    if (po) out += " packed_out=" + std::to_string(po);
+    if (pi) out += " packed_in=" + std::to_string(pi) + "/" + std::to_string(l->probs.size());
+    if (l->secondOnly) out += " second_pass_only";
     if (l->recordSlot >= 0) out += " mark=" + std::to_string(l->recordSlot);
     if (!l->waitSlots.empty()) { out += " wait="; for (int w : l->waitSlots) out += std::to_string(w) + ","; }
     if (!l->exLimbs.empty()) {

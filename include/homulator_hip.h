@@ -352,6 +352,16 @@ void hm_graph_destroy(hm_graph *graph);
  *   "ntt_fused_small", "ntt_fused_slots_per_xcd"  the threshold in force (0 = the one-launch form is off) and the guard's figure.
  * No reference counterpart: the reference's Arch has no tunables besides the .cfg keys (src/Arch.cpp:8-168). */
 hm_status hm_set_option(hm_ctx *ctx, const char *name, uint64_t value);
+/* What the back-end has kernels for at ring size N = 2^logN (round 6: one table, homulator_amd/csrc/hm_caps.h, instead of ring-size tests in
+ * the callers).  Needs no context and no GPU; the same names are served by hm_get_counter for a context's own ring size:
+ *   "cap_small_geometry"        1: the 8-coefficient passes, the one-launch transform and the small-launch transform x key kernel exist
+ *   "cap_bconv_col_max_in"      widest digit (input limbs) of the fused conversion + first pass (hm_bconv_col, the conv lists of
+ *                               hm_ntt_ip_desc / hm_ntt_fused_desc); 0: convert with hm_bconv_batch first
+ *   "cap_bconv_col_max_in_mix"  ... when the conversion carries the mix prologue (hm_ntt_fused_desc.conv with mix)
+ *   "cap_ip_inverse_out"        1: hm_ntt_ip_desc.out_inverse is served
+ *   "cap_col_slices"            ranks the column tiles of a limb-poly can be dealt to (hm_limbs_to_colslices / hm_bconv_col with a tile range)
+ * Replaces: nothing upstream — the reference sizes its units from the .cfg (src/Arch.cpp:8-168) and has one shape of each. */
+hm_status hm_capability(uint32_t logN, const char *name, uint64_t *value);
 hm_status hm_get_counter(hm_ctx *ctx, const char *name, uint64_t *value); /* synchronises */
 
 /* Timing on the context's stream (replaces Arch::getCycle include/Arch.h:271: elapsed device time in

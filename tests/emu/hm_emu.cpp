@@ -158,26 +158,28 @@ int emu_ntt_sub_scale(void *h, uint32_t mod, const uint64_t *in, const uint64_t 
   run_pass<G16, HM_ROW_LOG, false, false, 3>(e, mod, out, out, sc, ep);
   return 0;
 }
-// the 8-coefficient geometry (hm8: 512-thread workgroups, radix-4 rounds), N = 2^16 only
+// the 8-coefficient geometry (hm8: 512-thread workgroups, radix-4 rounds), N = 2^16 and (round 6) N = 2^15
 int emu_ntt8(void *h, uint32_t mod, const uint64_t *in, uint64_t *out, int inverse, uint64_t scale, int has_scale) {
   Emu &e = *(Emu *)h;
-  if (e.P.logN != 16) return 1;
+  if (e.P.logN != 16 && e.P.logN != 15) return 1;
   uint64_t q = e.P.mod[mod], k = e.P.modc[mod].ninv;
   if (has_scale) k = hm::mulmod(k, scale, q);
-  run_ntt<G8, 8>(e, mod, in, out, inverse, hm_kconst(k, q));
+  if (e.P.logN == 16) run_ntt<G8, 8>(e, mod, in, out, inverse, hm_kconst(k, q));
+  else run_ntt<G8, 7>(e, mod, in, out, inverse, hm_kconst(k, q));
   return 0;
 }
 int emu_ntt_sub_scale8(void *h, uint32_t mod, const uint64_t *in, const uint64_t *minuend, const uint64_t *addend, uint64_t *out,
                        uint64_t k, const uint64_t *mix, uint64_t mix_k, uint64_t addend_k) {
   Emu &e = *(Emu *)h;
-  if (e.P.logN != 16) return 1;
+  if (e.P.logN != 16 && e.P.logN != 15) return 1;
   const uint64_t q = e.P.mod[mod];
   HmTw sc = hm_kconst(k, q);
   HmEpi ep = hm_epi_none();
   ep.a = minuend; ep.d = addend;
   if (addend_k) ep.dk = hm_kconst(addend_k, q);
   if (mix) { ep.b = mix; ep.bk = hm_kconst(mix_k, q); }
-  if (mix) run_pass<G8, 8, true, false, 4>(e, mod, in, out, sc, ep); else run_pass<G8, 8, true, false, 0>(e, mod, in, out, sc);
+  if (e.P.logN == 16) { if (mix) run_pass<G8, 8, true, false, 4>(e, mod, in, out, sc, ep); else run_pass<G8, 8, true, false, 0>(e, mod, in, out, sc); }
+  else { if (mix) run_pass<G8, 7, true, false, 4>(e, mod, in, out, sc, ep); else run_pass<G8, 7, true, false, 0>(e, mod, in, out, sc); }
   run_pass<G8, HM_ROW_LOG, false, false, 3>(e, mod, out, out, sc, ep);
   return 0;
 }

@@ -242,13 +242,15 @@ def test_emu_bconv_widest_accumulator(emu):
         emu.emu_destroy(h)
 
 
-def test_emu_ntt_eight_coefficients_per_thread(emu):
+@pytest.mark.parametrize("logN", [16, 15])
+def test_emu_ntt_eight_coefficients_per_thread(emu, logN):
     """the small-launch geometry (hm8: 512-thread workgroups, 8 coefficients per thread, four radix-4 rounds per pass) on the
-    CPU emulator at N = 2^16: forward, inverse (in place, fused scale), the all-(q-1) worst case of the lazy ranges, and the
-    merged ModDown + rescale form (mix prologue + sub-scale-add epilogue)"""
+    CPU emulator at N = 2^16 and N = 2^15 (round 6: the 128-point COL pass as three radix-4 rounds and a radix-2 round): forward,
+    inverse (in place, fused scale), the all-(q-1) worst case of the lazy ranges, and the merged ModDown + rescale form (mix
+    prologue + sub-scale-add epilogue)"""
     emu.emu_ntt8.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_int]
     emu.emu_ntt_sub_scale8.argtypes = [C.c_void_p, C.c_uint32] + [C.c_void_p] * 4 + [C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64]
-    logN, L, K = 16, 3, 2
+    L, K = 3, 2
     o = emu.oracle(logN, L, K)
     h = emu.create(o)
     try:

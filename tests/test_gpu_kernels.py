@@ -614,3 +614,40 @@ def test_packed_conversion_inputs(chain):
             assert np.array_equal(out.download(), want3), flag
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("logN,chain", [(16, "mont32"), (15, "mont32"), (16, "survey"), (15, 36)])
+@pytest.mark.parametrize("n_in,outs_per_wg", [(16, 1), (16, 2), (17, 2), (20, 0), (24, 2), (28, 1), (28, 2), (31, 2), (32, 1), (32, 2)])
+def test_wide_digit_conversion_inside_the_first_pass(logN, chain, n_in, outs_per_wg):
+    """round 6 (parameter set A: N = 2^15, alpha = 28, beta = 1; `motivation`: N = 2^16, alpha = 28 — script/README.md:17-22,
+    src/Operation.cpp:137-188, 314-352): digits of 16 .. 32 limbs convert inside the first pass of the transform that consumes them, in
+    two input groups (k_bconv_col / k_bconv_col2 with N_IN > 15).  One digit of n_in limbs converted to 9 (an odd count: the last
+    workgroup of the two-output form has one output) other limbs, transformed and multiplied with a key limb in one hm_ntt_inner_product
+    call, from plain and from split-30 packed inputs, one and two outputs per workgroup; worst-case operands (every input at q_i - 1: the
+    128-bit sums of both groups at their largest) on the first coefficients.  Against the oracle's conversion, transform and product."""
+    n_out, N = 9, 1 << logN
+    L, K = n_in, n_out
+    ctx, o, _ = make_env(logN, L, K, chain)
+    try:
+        assert ctx.counter("cap_bconv_col_max_in") == 32
+        ins, outs = list(range(n_in)), list(range(n_in, n_in + n_out))
+        y = o.fill_uniform(ins, 31)
+        for r, m in enumerate(ins):
+            y[r, :6] = o.moduli[m] - 1
+            y[r, 6:8] = [0, 1]
+        evk = o.fill_uniform(outs, 77)
+        want = o.ewe(0, outs, o.ntt(outs, o.bconv_matmul(ins, outs, y)), evk)
+        pk = lambda a: (a & np.uint64(0x3FFFFFFF)) | ((a >> np.uint64(30)) << np.uint64(32))
+        plain, packed = ctx.from_host(y), ctx.from_host(pk(y))
+        evkb, hand, out = ctx.from_host(evk), ctx.alloc(n_out), ctx.alloc(n_out)
+        ctx.set_option("bconv_col_outs", outs_per_wg)
+        for srcbuf, flag in ((plain, 0), (packed, 1)):
+            for small in (0, 4096):   # both geometries of the transform x key kernel
+                ctx.set_option("nip_small_limbs", small)
+                ctx.fill_uniform(out, outs, 98)
+                ctx.fill_uniform(hand, outs, 97)
+                ctx.ntt_inner_product(srcbuf, [0] * n_out, [1] * n_out, hand, list(range(n_out)), evkb, list(range(n_out)), out, list(range(n_out)), outs, 1, 1,
+                                      conv=[(srcbuf, None, ins, list(range(n_out)), outs, flag)])
+                assert np.array_equal(out.download(), want), (flag, small)
+    finally:
+        ctx.close()

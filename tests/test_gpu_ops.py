@@ -92,9 +92,9 @@ def test_hmult_bit_exact(cfg, logN, L, ell, alpha, fuse, chain):
     ids = list(range(ell))
     hpip = fuse in (True, "no_bconv", "moddown", "no_ip_inv", "no_pack")   # "no_bconv": fused transform x key kernel fed by a separate conversion launch; "moddown": pass 9 on
     mode = fuse
-    # pass 7b (N = 2^16, fused transform x key kernel): the special limbs and the last Q limb of the key-switch sum leave as the first pass of
+    # pass 7b (fused transform x key kernel; N = 2^15 too since round 6): the special limbs and the last Q limb of the key-switch sum leave as the first pass of
     # their inverse transform; "no_ip_inv" keeps them in evaluation form (every row compared)
-    ip_rows = ell - 1 if (hpip and logN == 16 and fuse != "no_ip_inv") else None
+    ip_rows = ell - 1 if (hpip and fuse != "no_ip_inv") else None
     op = host.Op(cfg, "hmult", L, ell, alpha, fuse=bool(fuse),
                  overrides=chain_overrides(chain, {"fuse_hpip": 0} if fuse == "no_hpip" else {"fuse_bconv": 0} if fuse == "no_bconv" else {"fuse_moddown": 1} if fuse == "moddown" else {"fuse_ip_inv": 0} if fuse == "no_ip_inv" else {"pack_bconv_in": 0} if fuse == "no_pack" else None))
     fuse = bool(fuse)
@@ -125,16 +125,19 @@ def test_hmult_bit_exact(cfg, logN, L, ell, alpha, fuse, chain):
     op.close()
 
 
-@pytest.mark.parametrize("fuse", [True, "no_bconv"])
+@pytest.mark.parametrize("fuse", [True, "no_bconv", "wide"])
 def test_hmult_mixed_conversion_launch(fuse):
-    """N = 2^16, l = 20, alpha = 16: digits of 16 and 4 limbs.  The 16-limb digit is wider than the fused conversion admits, so ONE
-    transform x key launch mixes digits converted inside their first pass with digits that arrive converted (their
-    first pass was skipped and the result silently wrong)."""
+    """N = 2^16, l = 20, alpha = 16: digits of 16 and 4 limbs.  With the fused conversion capped at 15 input limbs (config key
+    fuse_bconv_max_in: the plan of rounds 3-5) the 16-limb digit keeps its own conversion, so ONE transform x key launch mixes digits
+    converted inside their first pass with digits that arrive converted (their first pass was skipped and the result
+    silently wrong).  "wide" (round 6, the default): both digits convert inside their first pass, the 16-limb one in two input groups."""
     from homulator_amd import host
     L, ell, alpha = 45, 20, 16
     o = oracle(16, L, alpha)
     ct1, ct2, evk = inputs(o, ell)
-    op = host.Op("config_4.cfg", "hmult", L, ell, alpha, overrides={"fuse_bconv": 0} if fuse == "no_bconv" else None)
+    op = host.Op("config_4.cfg", "hmult", L, ell, alpha, overrides={"fuse_bconv": 0} if fuse == "no_bconv" else None if fuse == "wide" else {"fuse_bconv_max_in": 15})
+    kinds = [ln.split()[0] + ":" + ln.split()[1] for ln in op.plan()]
+    assert any(k.startswith("BCONV:ModUp_BCONV") for k in kinds) == (fuse != "wide"), kinds
     op.execute(1)
     ids = list(range(ell))
     d2 = o.ewe(0, ids, ct1[1], ct2[1])
@@ -158,7 +161,7 @@ def test_hrotate_bit_exact(cfg, logN, L, ell, alpha, fuse, chain):
     r0, r1 = o.automorph_eval(ct1[0], 5), o.automorph_eval(ct1[1], 5)
     assert np.array_equal(op.read("AUTOOutput(0)"), r0) and np.array_equal(op.read("AUTOOutput(1)"), r1)
     k0, k1, dd = o.keyswitch(ell, r1, evk, dump=True)
-    check_keyswitch_buffers(op, dd, ell, alpha, o.beta(ell), fuse, ip_rows=ell if (fuse and logN == 16) else None)   # 7b: the special limbs
+    check_keyswitch_buffers(op, dd, ell, alpha, o.beta(ell), fuse, ip_rows=ell if fuse else None)   # 7b: the special limbs
     exp = o.hrotate(ell, ct1, 5, evk)
     assert np.array_equal(op.read("out.c0"), exp[0])
     assert np.array_equal(op.read("out.c1"), exp[1])

@@ -12,6 +12,7 @@ from oracle.homoracle import Oracle
 
 pytestmark = pytest.mark.gpu
 SEED = 0x484F4D55
+BATCH_SEED_STRIDE = 100000   # host/src/Arch.cpp kBatchSeedStride
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _or = {}
 
@@ -24,9 +25,14 @@ def oracle(logN, L, K):
 
 
 @pytest.mark.parametrize("cfg,logN,L,alpha,ell,op", [
-    ("config_4_N15.cfg", 15, 28, 28, 28, "hmult"),     # set A, top level: beta = 1, ModUp 28 -> 28, ModDown 28 -> 28
+    ("config_4_N15.cfg", 15, 28, 28, 28, "hmult"),     # set A, top level: beta = 1, ModUp 28 -> 28 inside the first pass (two input groups, round 6), ModDown 28 -> 28
+    ("config_4_N15.cfg", 15, 28, 28, 28, "hrotate"),
+    ("config_4_N15.cfg", 15, 28, 28, 20, "hmult"),     # set A, a 20-limb digit
     ("config_4_N15.cfg", 15, 28, 28, 17, "hmult"),     # set A, 17 > 16 inputs: two column groups in k_bconv
+    ("config_4_N15.cfg", 15, 28, 28, 16, "hrotate"),   # set A, exactly one full input group
     ("config_4_N15.cfg", 15, 28, 28, 1, "hrotate"),    # set A, lowest rotate level
+    ("config_4.cfg", 16, 28, 28, 28, "hmult"),         # the `motivation` sweep (script/motivation/micro24_motivation.sh): N = 2^16, alpha = 28
+    ("config_4.cfg", 16, 28, 28, 19, "hrotate"),
     ("config_4.cfg", 16, 24, 6, 24, "hmult"),          # set C, beta = 4
     ("config_4.cfg", 16, 24, 6, 19, "hrotate"),        # set C, beta = 4 with a 1-limb last digit
     ("config_4.cfg", 16, 26, 9, 26, "hmult"),          # set D, beta = 3, last digit 8
@@ -37,9 +43,50 @@ def test_parameter_set_op_bit_exact(cfg, logN, L, alpha, ell, op):
     o = oracle(logN, L, alpha)
     ct1, ct2, evk = o.synth_ct(ell, SEED), o.synth_ct(ell, SEED + 2000), o.synth_evk(ell, SEED + 10000)
     h = host.Op(cfg, op, L, ell, alpha)
+    assert not any(ln.startswith("BCONV") and "ModUp_BCONV" in ln for ln in h.plan()), "every parameter set converts its ModUp digits inside the first pass"
     h.execute(1)
     exp = o.hmult(ell, ct1, ct2, evk) if op == "hmult" else o.hrotate(ell, ct1, 5, evk)
     assert np.array_equal(h.read("out.c0"), exp[0]) and np.array_equal(h.read("out.c1"), exp[1])
+    h.close()
+
+
+@pytest.mark.parametrize("chain_bits", [60, 36])
+@pytest.mark.parametrize("cfg,logN,L,alpha,ell,op,mode", [
+    ("config_4_N15.cfg", 15, 28, 28, 28, "hmult", "batch"),      # set A on the generic back-end, three ops per launch (the two-output conversion kernels)
+    ("config_4_N15.cfg", 15, 28, 28, 23, "hrotate", "no_pack"),  # plain (not split-30 packed) inputs into the two-group conversion
+    ("config_4.cfg", 16, 28, 28, 28, "hmult", "no_ip_inv"),      # motivation without pass 7b
+    ("config_4_N15.cfg", 15, 28, 28, 28, "hmult", "cap15"),      # the plan of rounds 3-5: a conversion launch of its own for the wide digit
+])
+def test_wide_digit_sets_in_the_other_modes(cfg, logN, L, alpha, ell, op, mode, chain_bits):
+    """the parameter sets with digits of more than 15 limbs (A, motivation) in the other fusion modes and on the generic arithmetic back-end
+    (SURVEY.md 8(d)'s chain as written; 36-bit words as config_4.cfg:9 models, N = 2^15 only: a 2^16 ring has too few 36-bit primes for
+    L + alpha = 56), bit-exact"""
+    from homulator_amd import host
+    if chain_bits == 36 and logN != 15:
+        pytest.skip("36-bit chain: N = 2^15 cases")
+    key = (logN, L, alpha, chain_bits)
+    if key not in _or:
+        _or[key] = Oracle(logN, L, alpha, chain="survey" if chain_bits == 60 else chain_bits)
+        _or[key].set_threads(8)
+    o = _or[key]
+    ov = {"chain_bits": chain_bits}
+    nb = 1
+    if mode == "batch":
+        ov["batch"] = nb = 3
+    elif mode == "no_pack":
+        ov["pack_bconv_in"] = 0
+    elif mode == "no_ip_inv":
+        ov["fuse_ip_inv"] = 0
+    elif mode == "cap15":
+        ov["fuse_bconv_max_in"] = 15
+    h = host.Op(cfg, op, L, ell, alpha, overrides=ov)
+    assert h.backend_counter("arith") == 1
+    h.execute(1)
+    for b in range(nb):
+        s = SEED + b * BATCH_SEED_STRIDE   # op b of a batch: own inputs, ONE evaluation key
+        ct1, ct2, evk = o.synth_ct(ell, s), o.synth_ct(ell, s + 2000), o.synth_evk(ell, SEED + 10000)
+        exp = o.hmult(ell, ct1, ct2, evk) if op == "hmult" else o.hrotate(ell, ct1, 5, evk)
+        assert np.array_equal(h.read("out.c0", copy=b), exp[0]) and np.array_equal(h.read("out.c1", copy=b), exp[1]), (mode, b)
     h.close()
 
 

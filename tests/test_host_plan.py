@@ -49,7 +49,9 @@ def test_headline_plan_is_six_launches():
 
 @pytest.mark.parametrize("cfg,L,ell,alpha,conv_inside", [
     ("config_4_N15.cfg", 16, 10, 4, True),     # N = 2^15 (round 4: the fused conversion exists for N = 2^15 and 2^16)
-    ("config_4.cfg", 28, 28, 28, False),       # parameter set A: 28 input limbs per digit (> 15)
+    ("config_4.cfg", 28, 28, 28, True),        # the `motivation` sweep: 28 input limbs per digit (round 6: two input groups inside the first pass)
+    ("config_4_N15.cfg", 28, 28, 28, True),    # parameter set A at its top level (N = 2^15, beta = 1)
+    ("config_4_N15.cfg", 28, 17, 28, True),    # set A, a 17-limb digit
     ("config_4.cfg", 24, 24, 6, True),         # set C: beta = 4
     ("config_4.cfg", 26, 20, 9, True),         # set D: uneven last digit (9, 9, 2)
     ("config_4.cfg", 8, 8, 8, True),           # beta = 1: the digit's own limbs need no transform
@@ -65,12 +67,13 @@ def test_where_the_conversion_moves_into_the_transform(cfg, L, ell, alpha, conv_
 
 
 def test_mixed_launch_keeps_the_wide_digits_conversion():
-    """config_4.cfg hmult 45 20 16: digits of 16 and 4 limbs.  The 4-limb digit's conversion moves into the first pass of its transforms
-    (16 limbs: the ones whose only transformed digit it is); the 16-limb digit is wider than the fused conversion admits and keeps its own
-    BCONV launch.  ONE NTT_IP launch then mixes both kinds: the backend runs the first pass of every transformed (limb, digit) that no
-    conversion of the call covers (round 3 skipped it as soon as any conversion was fused: ADVICE round 3, tests/test_gpu_ops.py has
-    the parity case)."""
-    p, total, n = plan("config_4.cfg", "hmult", 45, 20, 16)
+    """config_4.cfg hmult 45 20 16 with the fused conversion capped at 15 input limbs (config key fuse_bconv_max_in: the plan of rounds 3-5,
+    kept for A/B runs): digits of 16 and 4 limbs.  The 4-limb digit's conversion moves into the first pass of its transforms (16 limbs: the
+    ones whose only transformed digit it is); the 16-limb digit is wider than the cap and keeps its own BCONV launch.  ONE NTT_IP launch then
+    mixes both kinds: the backend runs the first pass of every transformed (limb, digit) that no conversion of the call covers (round 3
+    skipped it as soon as any conversion was fused: ADVICE round 3, tests/test_gpu_ops.py has the parity case).  Without the cap (round 6)
+    both digits convert inside their first pass and no ModUp conversion launch is left."""
+    p, total, n = plan("config_4.cfg", "hmult", 45, 20, 16, fuse_bconv_max_in=15)
     modup_bconv = [ln for ln in p if ln.startswith("BCONV") and "ModUp_BCONV" in ln]
     nip = [ln for ln in p if ln.startswith("NTT_IP")]
     assert len(modup_bconv) == 1 and len(nip) == 1, p
@@ -80,3 +83,29 @@ def test_mixed_launch_keeps_the_wide_digits_conversion():
     assert int(re.search(r"n=(\d+)", nip[0]).group(1)) == 36
     p0, total0, _ = plan("config_4.cfg", "hmult", 45, 20, 16, fuse_hpip=0, fuse_bconv=0)
     assert total0 == total
+    pw, totalw, nw = plan("config_4.cfg", "hmult", 45, 20, 16)
+    assert not [ln for ln in pw if ln.startswith("BCONV") and "ModUp_BCONV" in ln] and totalw == total and nw == n - 1
+
+
+def test_no_ring_size_is_named_in_the_planner():
+    """round 6: the fusion passes ask the back-end's capability table (hm_capability, homulator_amd/csrc/hm_caps.h) — no ring size or digit
+    width is spelled out in host/src/Arch.cpp"""
+    import os
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "host", "src", "Arch.cpp")).read()
+    assert not re.search(r"logN\s*[=!<>]=\s*1[3-7]", src) and "<= 15" not in src and "> 15" not in src and "n >> 12" not in src
+
+
+def test_packed_conversion_inputs_in_the_default_plan():
+    """pass 11 (split-30 packed conversion inputs) in the default plan of the headline op: BOTH inverse-transform launches store packed
+    limb-polys and BOTH conversions read them — the ModUp conversions inside NTT_IP and the ModDown conversions (whose inputs' inverse
+    transform is the in-place second pass of pass 7b: its read of its own output is no other reader)"""
+    p, _, _ = plan("config_4.cfg", "hmult", 45, 35, 15)
+    by = {}
+    for ln in p:
+        by.setdefault(ln.split()[0], []).append(ln)
+    assert " packed_out=35" in by["INTT"][0], by["INTT"][0]               # ModUp_DecompOut: the 35 scaled input limbs
+    assert " packed_in=3/3" in by["NTT_IP"][0], by["NTT_IP"][0]           # the three digits' conversions
+    assert " packed_out=30" in by["INTT"][1] and " second_pass_only" in by["INTT"][1], by["INTT"][1]   # ModDownBConvStep1_Key(k): 2 x 15 special limbs
+    assert " packed_in=" in by["BCONV"][0], by["BCONV"][0]
+    pn, _, _ = plan("config_4.cfg", "hmult", 45, 35, 15, pack_bconv_in=0)
+    assert not any("packed" in ln for ln in pn)
