@@ -1911,6 +1911,7 @@ static hm_status bconv_col_launch(hm_ctx *c, const hm_bconv_desc *descs, uint32_
     NOUT = wgs > 4096 ? 2 : 1;
   }
   std::map<uint32_t, std::vector<HmBcolProb>> byIn;   // key: n_in, + 256 for conversions whose inputs are stored packed (kernels of their own)
+  bool farApart = false;
   for (uint32_t pi = 0; pi < n_desc; ++pi) {
     const hm_bconv_desc &d = descs[pi];
     if (!d.in || !d.out || !d.in_ids || !d.out_ids) return fail(c, HM_ERR_ARG, "fused conversion: null argument");
@@ -1949,6 +1950,13 @@ static hm_status bconv_col_launch(hm_ctx *c, const hm_bconv_desc *descs, uint32_
     p.in = d.in; p.table = it->second; p.qn = it->second + (size_t)HM_BCONV_ROW(d.n_in) * d.n_out; p.n_in = d.n_in; p.n_out = d.n_out;
     p.in_packed = d.in_packed ? 1u : 0u;
     for (uint32_t i = 0; i < d.n_in; ++i) p.in_limb[i] = limb_at(d.in_limbs, i);
+    {   // ONE buffer descriptor per conversion: the lowest input limb-poly is the base, the others are byte offsets from it (HmBcolProb::in_off)
+      uint32_t lo = p.in_limb[0], hi = p.in_limb[0];
+      for (uint32_t i = 1; i < d.n_in; ++i) { lo = std::min(lo, p.in_limb[i]); hi = std::max(hi, p.in_limb[i]); }
+      if (((uint64_t)(hi - lo) + 1) << (c->P.logN + 3) > (1ull << 32)) { farApart = true; break; }   // inputs more than 4 GiB apart: the fallback below
+      p.in_base = d.in + (size_t)lo * c->P.N;
+      for (uint32_t i = 0; i < d.n_in; ++i) p.in_off[i] = (p.in_limb[i] - lo) << (c->P.logN + 3);
+    }
     for (uint32_t t = 0; t < d.n_out; ++t) { p.out_limb[t] = limb_at(d.out_limbs, t); p.out_mod[t] = d.out_ids[t]; }
     if (mix) {   // x = conv + k * mix before the first butterfly: constants in Shoup form, a device table cached by content
       std::vector<HmTw> mk(d.n_out);
@@ -1968,6 +1976,26 @@ static hm_status bconv_col_launch(hm_ctx *c, const hm_bconv_desc *descs, uint32_
     // profiles/r05_late_ab.txt — so the 120 instantiations it needs are not shipped)
     if (mix && d.in_packed) return fail(c, HM_ERR_UNSUPPORTED, "fused conversion: packed inputs and the mix prologue do not combine (convert from plain inputs)");
     byIn[d.n_in + (d.in_packed ? 256u : 0u)].push_back(p);
+  }
+  if (farApart) {
+    // A conversion whose input limb-polys are spread over more than 4 GiB of the buffer cannot be addressed from one descriptor with 32-bit
+    // offsets.  The plans of the host layer never produce one (a digit's limbs are neighbours in the pool); a caller's list that does is
+    // served by the two steps the fused kernel stands for: the conversion into the hand-off limbs, then the first pass in place on them.
+    if (n_tiles != allTiles) return fail(c, HM_ERR_UNSUPPORTED, "fused conversion on a column slice: the inputs of a conversion must lie within 4 GiB of each other");
+    hm_status st = hm_bconv_batch(c, descs, n_desc);
+    if (st) return st;
+    std::vector<uint32_t> limbs, mods, ml;
+    std::vector<uint64_t> mk;
+    for (uint32_t pi = 0; pi < n_desc; ++pi)
+      for (uint32_t t = 0; t < descs[pi].n_out; ++t) {
+        limbs.push_back(limb_at(descs[pi].out_limbs, t)); mods.push_back(descs[pi].out_ids[t]);
+        if (mix) { ml.push_back(mix->mix_limbs[pi][t]); mk.push_back(mix->mix_k[pi][t]); }
+      }
+    NttFused f;
+    f.firstPassOnly = true;
+    if (mix) { f.mix = mix->mix; f.mix_limbs = ml.data(); f.mix_k = mk.data(); f.minuend = descs[0].out; /* (marks the fused form: the first pass only reads the mix operand) */ }
+    std::vector<uint64_t> ones(limbs.size(), 1);
+    return ntt_common(c, "fused conversion", descs[0].out, limbs.data(), descs[0].out, limbs.data(), mods.data(), (uint32_t)limbs.size(), 0, mix ? ones.data() : nullptr, f);
   }
   struct Lnch { uint32_t n_in; dim3 grid; HmBcolArgs a; };
   std::vector<Lnch> ls;

@@ -25,7 +25,45 @@ struct HmBcolProb {
   uint32_t mix_limb[HM_BCONV_MAX_OUT];   // MIX: the operand added to output o before the transform (limb of HmBcolArgs::mix), constant in mixk
   const HmTw *mixk;                      // MIX: device, [n_out]
   uint32_t in_packed;                    // the inputs are stored in the split-30 packed form (hm_pack30): no shift / mask per input and workgroup
+  // round 6 (scalar-register diet): ONE buffer descriptor for all inputs of a conversion — base = the lowest input limb-poly, input i at
+  // byte offset in_off[i] from it (a scalar operand of the load).  A descriptor per input (four scalar registers each: 60 for a 15-limb
+  // digit, 112 for 28) was hoisted out of the unit loop together with the table rows and spilled into vector-register lanes: 390
+  // v_readlane / v_writelane in 5 531 vector instructions of k_bconv_col2<15>, 1 444 in 9 045 of k_bconv_col2<28>.  The host checks that
+  // the inputs of a conversion lie within 4 GiB of each other (the digits of a plan are neighbours in the pool); a conversion whose inputs
+  // are further apart runs as conversion + first pass (bconv_col_launch).
+  const uint64_t *in_base;
+  uint32_t in_off[HM_BCONV_MAX_IN];
 };
+// the table pointer made opaque once per access unit: the rows of an output are then requested again for every unit (scalar loads that hit
+// the scalar cache, issued while the unit's vector loads are in flight) instead of being held — 64 scalar registers for two outputs of a
+// 15-limb digit — across the whole unit loop
+#ifndef HM_BCOL_ROWS_PER_UNIT
+#define HM_BCOL_ROWS_PER_UNIT 1
+#endif
+#ifndef HM_BCOL_ONE_DESC
+#define HM_BCOL_ONE_DESC 1
+#endif
+template <class PROB>
+__device__ __forceinline__ const uint64_t *hm_bcol_table(const PROB &p) {
+  const uint64_t *t = p.table;
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (HM_BCOL_ROWS_PER_UNIT) asm volatile("" : "+s"(t));
+#endif
+  return t;
+}
+// input i of access unit u: 16 bytes per lane
+template <class G0, class PROB>
+__device__ __forceinline__ void hm_bcol_load_in(const PROB &p, int i, uint32_t tile, int tid, int u, size_t N, uint64_t &v0, uint64_t &v1) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (HM_BCOL_ONE_DESC) {
+    const hm_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(hm_rsrc(p.in_base), G0::gthr(tid, u) << 3, (G0::guni(tile, u) << 3) + p.in_off[i], 0);
+    v0 = (uint64_t)t.x | ((uint64_t)t.y << 32);
+    v1 = (uint64_t)t.z | ((uint64_t)t.w << 32);
+    return;
+  }
+#endif
+  hm_gld2<G0>(p.in + (size_t)p.in_limb[i] * N, tile, tid, u, v0, v1);
+}
 struct HmBcolArgs {
   const HmBcolProb *prob;   // device
   uint64_t *out;
@@ -94,7 +132,7 @@ __device__ __forceinline__ void hm_bcol_units(const PROB &p, HmNttState &st0, Hm
 #pragma unroll
     for (int i = 0; i < N_IN; ++i) {
       uint64_t v0, v1;
-      hm_gld2<G0>(p.in + (size_t)p.in_limb[i] * N, tile, tid, u, v0, v1);
+      hm_bcol_load_in<G0>(p, i, tile, tid, u, N, v0, v1);
 #if defined(HM_ABL_BCOL_PACKED)   // timing-only ablation: inputs taken as if already stored split (no shift / mask per input and output)
       yl[0][i] = (uint32_t)v0; yh[0][i] = (uint32_t)(v0 >> 32);
       yl[1][i] = (uint32_t)v1; yh[1][i] = (uint32_t)(v1 >> 32);
@@ -108,9 +146,10 @@ __device__ __forceinline__ void hm_bcol_units(const PROB &p, HmNttState &st0, Hm
       }
 #endif
     }
-    hm_bcol_convert<N_IN, MIX, G0>(yl, yh, p.table, p.qn, p.mixk, mix0, o0, tile, tid, u, st0.v[i0], st0.v[i1]);
+    const uint64_t *table = hm_bcol_table(p);
+    hm_bcol_convert<N_IN, MIX, G0>(yl, yh, table, p.qn, p.mixk, mix0, o0, tile, tid, u, st0.v[i0], st0.v[i1]);
     // an odd basis' last group converts its one output twice (wave-uniform; the copy is never transformed or stored)
-    if (NOUT == 2) hm_bcol_convert<N_IN, MIX, G0>(yl, yh, p.table, p.qn, p.mixk, mix1, o1, tile, tid, u, st1.v[i0], st1.v[i1]);
+    if (NOUT == 2) hm_bcol_convert<N_IN, MIX, G0>(yl, yh, table, p.qn, p.mixk, mix1, o1, tile, tid, u, st1.v[i0], st1.v[i1]);
 #if defined(__HIP_DEVICE_COMPILE__)
     // the results are "used" here: otherwise the products are sunk below the barrier to their first real use and ALL units' inputs are
     // loaded (and spilled) up front
@@ -128,13 +167,13 @@ __device__ __forceinline__ void hm_bcol_units(const PROB &p, HmNttState &st0, Hm
 // entries are whole 8-entry rows (the second group starts at entry 16), read through the scalar cache as before; one reduction per output
 // (hm_redc_wide<N_IN>: two conditional subtractions above 16 terms).
 template <int C0, int CN, int NOUT, bool PACKED, class G0, class PROB>
-__device__ __forceinline__ void hm_bcol_group(const PROB &p, uint32_t rowsPerOut, uint32_t o0, uint32_t o1, uint32_t tile, int tid, int u, size_t N,
+__device__ __forceinline__ void hm_bcol_group(const PROB &p, const uint64_t *table, uint32_t rowsPerOut, uint32_t o0, uint32_t o1, uint32_t tile, int tid, int u, size_t N,
                                               hm_u128 (&acc)[2][2]) {
   uint32_t yl[2][CN], yh[2][CN];
 #pragma unroll
   for (int i = 0; i < CN; ++i) {
     uint64_t v0, v1;
-    hm_gld2<G0>(p.in + (size_t)p.in_limb[C0 + i] * N, tile, tid, u, v0, v1);
+    hm_bcol_load_in<G0>(p, C0 + i, tile, tid, u, N, v0, v1);
     if (PACKED) {
       yl[0][i] = (uint32_t)v0; yh[0][i] = (uint32_t)(v0 >> 32);
       yl[1][i] = (uint32_t)v1; yh[1][i] = (uint32_t)(v1 >> 32);
@@ -149,7 +188,7 @@ __device__ __forceinline__ void hm_bcol_group(const PROB &p, uint32_t rowsPerOut
     const uint32_t o = k ? o1 : o0;
     HmRow8 row[NG];
 #pragma unroll
-    for (int g = 0; g < NG; ++g) row[g] = HM_CONST_ROWS(p.table)[o * rowsPerOut + C0 / 8 + g];
+    for (int g = 0; g < NG; ++g) row[g] = HM_CONST_ROWS(table)[o * rowsPerOut + C0 / 8 + g];
     acc[k][0] += hm_bconv_cols<CN>(yl[0], yh[0], row);
     acc[k][1] += hm_bconv_cols<CN>(yl[1], yh[1], row);
   }
@@ -163,13 +202,13 @@ __device__ __forceinline__ void hm_bcol_units_wide(const PROB &p, HmNttState &st
     int i0, i1, x, c;
     G0::unit(tid, u, i0, i1, x, c);
     hm_u128 acc[2][2] = {{0, 0}, {0, 0}};
-    hm_bcol_group<0, (N_IN < 16 ? N_IN : 16), NOUT, PACKED, G0>(p, ROWS, o0, o1, tile, tid, u, N, acc);
+    hm_bcol_group<0, (N_IN < 16 ? N_IN : 16), NOUT, PACKED, G0>(p, hm_bcol_table(p), ROWS, o0, o1, tile, tid, u, N, acc);
 #if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]));   // the first group's sums are complete before the second group's inputs are requested
     if (NOUT == 2) asm volatile("" : "+v"(acc[1][0]), "+v"(acc[1][1]));
     __builtin_amdgcn_sched_barrier(0);
 #endif
-    if constexpr (N_IN > 16) hm_bcol_group<16, N_IN - 16, NOUT, PACKED, G0>(p, ROWS, o0, o1, tile, tid, u, N, acc);
+    if constexpr (N_IN > 16) hm_bcol_group<16, N_IN - 16, NOUT, PACKED, G0>(p, hm_bcol_table(p), ROWS, o0, o1, tile, tid, u, N, acc);
     HmMod m0;
     { const HmQn m = HM_CONST_QN(p.qn)[o0]; m0.q = m.q; m0.nqinv = m.nqinv; }
     st0.v[i0] = hm_redc_wide<N_IN>(acc[0][0], m0);

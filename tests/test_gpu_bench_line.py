@@ -40,5 +40,36 @@ def test_bench_line_contract():
     assert d["generic_chain_ops_per_s"] > 1000 and 0 < d["generic_chain_frac_evk_once"] < 1 and d["generic_chain"]["moduli"].startswith("generic")
     assert d["single_stream_ops_per_s"] > 1000 and d["sustained_ops_per_s"] > 1000
     assert d["measured_hbm"] and d["measured_hbm"]["batch"] == cfg["batch"] and d["measured_hbm"]["instances"] == cfg["streams"]
-    assert d["roofline_op"] and "r05" in json.dumps(d["roofline_op"])
+    assert d["roofline_op"] and d["roofline_op"]["frac"] > 0.1
     assert len(d["stage_us"]) == cfg["launches_per_op"] == 6
+    # round 6: the op-level fractions inside `roofline`, the spread of `value` over three regions, medians for the side legs, the port's note
+    assert abs(r["op_frac_evk_once"] - d["hmult_frac_evk_once"]) < 1e-12 and 0.3 < r["op_frac_evk_once"] < 1.0
+    assert r["op_measured_frac"] is None or abs(r["op_measured_frac"] - d["measured_hbm"]["frac_of_peak"]) < 1e-12
+    lo, med, hi = d["value_min_median_max"]
+    assert lo <= med <= hi and lo <= d["value"] <= hi
+    for leg in (d["hrotate"], d["generic_chain"]):
+        a, b_, c_ = leg["ops_per_s_min_median_max"]
+        assert a <= b_ <= c_ and leg["ops_per_s"] == b_ and leg["regions"] == 3
+    assert "__int128" in c["note"]
+
+
+def test_plain_multi_gpu_command_launches_its_own_ranks():
+    """`python3 bench.py --gpus 2 --steps 8 --warmup 2` started PLAINLY (no torch.distributed.run, WORLD_SIZE unset): bench.py spawns the two
+    ranks itself (fresh child processes; the parent never touches the GPU), relays rank 0's one JSON line and returns 0.  Rehearsed on the one
+    GPU over gloo (HOMULATOR_DIST_BACKEND=gloo puts both ranks on device 0; RCCL refuses two ranks per device).  The line carries the sharded
+    NTT sweep per rank and what the HIP library's communicator reports."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HOMULATOR_DIST_BACKEND"] = "gloo"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "2"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 8 and d["value"] > 0 and d["config"]["transport"] == "gloo-rehearsal"
+    sh = d["roofline"]["sharded"]
+    assert sh["limbs_per_rank"] == [25, 25] and len(sh["us_per_rank"]) == 2 and sh["aggregate_gbs"] > 0 and all(0 < f < 1 for f in sh["frac_per_gpu"])
+    assert d["roofline"]["algorithmic_bytes_per_launch"] == 25 * 1048576
+    assert d["comm"] == {"world": 2, "ranks_seen": 2, "transport": "external"}
+    # a rank that fails takes the job down with a non-zero exit code instead of leaving its peer in a collective
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "2", "--op", "nonsense"], env=env, capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0

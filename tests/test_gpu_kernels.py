@@ -651,3 +651,46 @@ def test_wide_digit_conversion_inside_the_first_pass(logN, chain, n_in, outs_per
                 assert np.array_equal(out.download(), want), (flag, small)
     finally:
         ctx.close()
+
+
+def test_conversion_inputs_more_than_4_gib_apart():
+    """round 6: the fused conversion + first pass addresses all inputs of a conversion from ONE buffer descriptor with 32-bit offsets (the
+    scalar-register diet of k_bconv_col).  A caller whose input limb-polys lie more than 4 GiB apart (never the host layer's plans: a
+    digit's limbs are neighbours in the pool) is served by conversion + first pass as two steps inside the same C-ABI call: same results,
+    through hm_ntt_inner_product's conv list and through hm_ntt_mix_sub_scale's (with and without the mix prologue)."""
+    logN, N = 16, 1 << 16
+    L, K = 4, 3
+    ctx, o, _ = make_env(logN, L, K, "mont32")
+    try:
+        far = (1 << 32) // (8 * N) + 5                       # 8 197 limb-polys = 4 GiB + 2.5 MiB
+        big = ctx.alloc(far + 1)                              # 4.3 GB of HBM
+        ps, qs = [L, L + 1, L + 2], list(range(L))
+        y = o.fill_uniform(ps, 41)
+        y[:, :4] = [[o.moduli[m] - 1] * 4 for m in ps]
+        spread = [0, far, 7]                                  # input limbs of the one conversion: 4 GiB apart
+        for r, limb in enumerate(spread):
+            big.upload(y[r:r + 1], limb0=limb)
+        conv_exp = o.bconv_matmul(ps, qs, y)
+        # 1. inside the transform x key call
+        evk = o.fill_uniform(qs, 77)
+        evkb, hand, out = ctx.from_host(evk), ctx.alloc(L), ctx.alloc(L)
+        ctx.ntt_inner_product(big, [0] * L, [1] * L, hand, list(range(L)), evkb, list(range(L)), out, list(range(L)), qs, 1, 1,
+                              conv=[(big, spread, ps, list(range(L)), qs, 0)])
+        assert np.array_equal(out.download(), o.ewe(0, qs, o.ntt(qs, conv_exp), evk))
+        # 2. inside the merged transform: without and with the mix prologue
+        mn, ad, mx = (o.fill_uniform(qs, s) for s in (23, 24, 25))
+        k = [o.moduli[m] - 2 - r for r, m in enumerate(qs)]
+        mk = [(kk * 3 + 1) % o.moduli[m] for kk, m in zip(k, qs)]
+        ak = [(kk * 5 + 1) % o.moduli[m] for kk, m in zip(k, qs)]
+        dmn, dad, dmx, a = ctx.from_host(mn), ctx.from_host(ad), ctx.from_host(mx), ctx.alloc(L)
+        want = o.ewe(3, qs, o.ewe(6, qs, mn, None, o.ntt(qs, conv_exp), k=k), None, o.ewe(5, qs, ad, k=ak))
+        ctx.ntt_mix_sub_scale(None, dmn, a, qs, k, addend=dad, addend_k=ak, conv=[(big, spread, ps, list(range(L)), qs, 0)])
+        assert np.array_equal(a.download(), want)
+        x = o.ewe(3, qs, conv_exp, None, o.ewe(5, qs, mx, k=mk))
+        want_mix = o.ewe(3, qs, o.ewe(6, qs, mn, None, o.ntt(qs, x), k=k), None, o.ewe(5, qs, ad, k=ak))
+        ctx.fill_uniform(a, qs, 9)
+        ctx.ntt_mix_sub_scale(None, dmn, a, qs, k, addend=dad, addend_k=ak, mix=dmx, mix_k=mk, conv=[(big, spread, ps, list(range(L)), qs, 0)])
+        assert np.array_equal(a.download(), want_mix)
+        big.free()
+    finally:
+        ctx.close()

@@ -13,6 +13,16 @@ def brev(x, bits):
     return int(format(x, "0%db" % bits)[::-1], 2)
 
 
+def check_minimal_primitive_root(psi, q, N):
+    assert pow(psi, N, q) == q - 1  # primitive 2N-th root
+    r, best = psi, psi              # minimal among all primitive 2N-th roots (the odd powers of any one of them)
+    r2 = psi * psi % q
+    for _ in range(N - 1):
+        r = r * r2 % q
+        best = min(best, r)
+    assert best == psi
+
+
 def test_prime_chain_and_roots():
     o = Oracle(10, 6, 2)
     N = o.N
@@ -26,21 +36,37 @@ def test_prime_chain_and_roots():
             found.append(cand)
     assert found == mods
     for q, psi in zip(mods, o.psis):
-        assert pow(psi, N, q) == q - 1  # primitive 2N-th root
-        # minimal among all primitive 2N-th roots
-        r, best = psi, psi
-        r2 = psi * psi % q
-        for _ in range(N - 1):
-            r = r * r2 % q
-            best = min(best, r)
-        assert best == psi
+        check_minimal_primitive_root(psi, q, N)
 
 
-def test_prime_chain_n16_matches_spec():
-    o = Oracle(16, 3, 1)
-    for q in o.moduli:
-        assert sympy.isprime(q) and q % (1 << 32) == 1 and q % (1 << 17) == 1 and (1 << 59) < q < (1 << 60)
-    assert o.moduli[0] == max(o.moduli)
+@pytest.mark.parametrize("logN,bits,count", [(10, 60, 8), (15, 60, 14), (16, 60, 60), (10, 36, 8), (15, 36, 56), (16, 36, 60), (13, 45, 20), (12, 31, 9)])
+def test_generated_chains_are_exactly_the_largest_primes_below_the_bound(logN, bits, count):
+    """the chains the GPU suite and bench.py's generic_chain leg stand on ("survey" = SURVEY.md 8(d) as written: bits = 60; 36-bit words;
+    the 45- and 31-bit chains of the kernel tests): the oracle's generator (ho_chain_below) against an independent sympy enumeration of the
+    candidates c = 1 mod 2N below 2^bits, descending — every prime, no composite, nothing skipped, in order"""
+    from oracle.homoracle import chain_below
+    got = chain_below(logN, bits, count)
+    step = 2 << logN
+    c, want = ((1 << bits) - 2) // step * step + 1, []
+    while len(want) < count:
+        if sympy.isprime(c):
+            want.append(c)
+        c -= step
+    assert got == want
+    assert all(q % step == 1 and q < (1 << bits) for q in got)
+
+
+@pytest.mark.parametrize("chain", ["survey", 36, "caller"])
+@pytest.mark.parametrize("logN", [10, 13])
+def test_roots_of_the_other_chains_are_minimal(chain, logN):
+    from conftest import make_oracle
+    o = make_oracle(logN, 4, 2, chain)
+    assert len(set(o.moduli)) == 6
+    if chain != "caller":
+        assert o.moduli == sorted(o.moduli, reverse=True)
+    for q, psi in zip(o.moduli, o.psis):
+        assert sympy.isprime(q) and q % (2 * o.N) == 1
+        check_minimal_primitive_root(psi, q, o.N)
 
 
 def test_scalar_mulmod_powmod():
@@ -60,7 +86,8 @@ def test_barrett_ewe_edges(oracle_small):
     N = o.N
     for m in (0, 5, 6, 7):
         q = o.moduli[m]
-        edge = [0, 1, 2, q - 1, q - 2, q // 2, q // 2 + 1, (1 << 59), (1 << 59) + 1]
+        top = 1 << (q.bit_length() - 1)   # the highest power of two below q (2^59 on the 60-bit chains)
+        edge = [0, 1, 2, q - 1, q - 2, q // 2, q // 2 + 1, top, top + 1]
         rng = np.random.default_rng(m)
         a = np.array((edge * (N // len(edge) + 1))[:N], dtype=np.uint64)
         b = np.array([int(x) for x in rng.integers(0, q, N, dtype=np.uint64)], dtype=np.uint64)
@@ -84,10 +111,12 @@ def test_barrett_ewe_edges(oracle_small):
             assert [int(x) for x in got] == e, f"ewe op {op} mod {m}"
 
 
+@pytest.mark.parametrize("chain", ["mont32", "survey", 36, "caller"])
 @pytest.mark.parametrize("logN", [3, 4, 6])
-def test_ntt_is_evaluation_at_odd_powers(logN):
+def test_ntt_is_evaluation_at_odd_powers(logN, chain):
     """forward NTT out[i] = a(psi^(2*brev(i)+1)) — fixes the ordering convention (Appendix A (1))."""
-    o = Oracle(logN, 2, 1)
+    from conftest import make_oracle
+    o = make_oracle(logN, 2, 1, chain)
     N = o.N
     rng = np.random.default_rng(logN)
     for m in range(3):
@@ -99,9 +128,11 @@ def test_ntt_is_evaluation_at_odd_powers(logN):
             assert int(got[i]) == sum(c * pow(x, k, q) for k, c in enumerate(a)) % q
 
 
+@pytest.mark.parametrize("chain", ["mont32", "survey", 36, "caller"])
 @pytest.mark.parametrize("logN", [3, 5, 8, 10])
-def test_ntt_roundtrip_and_convolution(logN):
-    o = Oracle(logN, 3, 2)
+def test_ntt_roundtrip_and_convolution(logN, chain):
+    from conftest import make_oracle
+    o = make_oracle(logN, 3, 2, chain)
     N = o.N
     ids = list(range(5))
     rng = np.random.default_rng(logN)
@@ -283,3 +314,18 @@ def test_fill_uniform_definition(oracle_small):
             z = mix(((0x484F4D55 + i) * 0xD1342543DE82EF95 + x * 0x9E3779B97F4A7C15 + 0x632BE59BD9B4E019) & M)
             assert int(out[i, x]) == (z * q) >> 64
     assert int(out.max()) < max(o.moduli)
+
+
+@pytest.mark.parametrize("chain", ["mont32", "survey", 36])
+@pytest.mark.parametrize("logN,L,ell,alpha", [(16, 45, 35, 15), (15, 16, 10, 4)])
+def test_full_size_known_answers(logN, L, ell, alpha, chain):
+    """one full-size known answer per chain (tests/golden/oracle_hashes.json, written by tests/golden/make_oracle_hashes.py): hmult and
+    hrotate at BASELINE configs[2] / [3] and configs[0] — an edit of the oracle cannot move a full-size result silently"""
+    import json
+    import os
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    import make_oracle_hashes as g
+    want = json.load(open(os.path.join(here, "golden", "oracle_hashes.json")))[f"N{logN}_L{L}_l{ell}_a{alpha}_{chain}"]
+    assert g.compute(logN, L, ell, alpha, chain) == want
