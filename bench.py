@@ -308,7 +308,8 @@ def self_launch(n):
         _t.sleep(0.05)
     rcs = [p.wait() for p in procs]
     reader.join(timeout=10)
-    sys.stdout.write("".join(c for c in chunks if c))
+    for ln in "".join(c for c in chunks if c).splitlines():   # ONE JSON line on stdout; what libraries print there (gloo's connection notice) goes to stderr
+        print(ln, file=sys.stdout if ln.startswith("{") else sys.stderr)
     sys.stdout.flush()
     bad = [(r, rc) for r, rc in enumerate(rcs) if rc]
     if bad:

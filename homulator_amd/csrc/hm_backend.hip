@@ -241,7 +241,8 @@ __device__ __forceinline__ void hm_limb_arrive(HmNttSync *ws, uint32_t entry, bo
   __syncthreads();
   if (threadIdx.x == 0 && !withhold) hm_l2_add_noret(&ws->fast[entry].w, 1ull);
 }
-__device__ __forceinline__ uint32_t hm_limb_wait(HmNttSync *ws, unsigned *err, uint32_t entry, uint32_t members, uint32_t *lds_flag, uint32_t spin_limit, uint32_t pretend_spread = 0, uint32_t tile = 0) {
+__device__ __forceinline__ uint32_t hm_limb_wait(HmNttSync *ws, unsigned *err, uint32_t entry, uint32_t members, uint32_t *lds_flag, uint32_t spin_limit,
+    uint32_t pretend_spread = 0, uint32_t tile = 0) {
   if (threadIdx.x == 0) {
     unsigned long long *w = &ws->fast[entry].w;
     uint32_t fast = 0;
@@ -250,13 +251,15 @@ __device__ __forceinline__ uint32_t hm_limb_wait(HmNttSync *ws, unsigned *err, u
       // (pretend_spread: test hook — the workgroups behave as if those of odd tiles ran on another XCD, whose copy of the counter this one
       // never sees complete: exercises the agent-scope path on hardware that never spreads a limb-poly)
       if ((uint32_t)hm_l2_add(w, 0ull) == members && !pretend_spread) { fast = 1; break; }
-      if (spins == 0) (void)__hip_atomic_fetch_or(&ws->xccmask[entry], pretend_spread ? 1u << (tile & 1u) : 1u << hm_xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (spins == 0) (void)__hip_atomic_fetch_or(&ws->xccmask[entry], pretend_spread ? 1u << (tile & 1u) : 1u << hm_xcc_id(), __ATOMIC_RELAXED,
+          __HIP_MEMORY_SCOPE_AGENT);
       else if ((spins & 15u) == 15u) {
         const unsigned m = __hip_atomic_load(&ws->xccmask[entry], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (m & (m - 1u)) break;   // two XCDs: everybody takes the agent-scope path
       }
       __builtin_amdgcn_s_sleep(1);
-      if (++spins > spin_limit) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); fast = 2; break; }   // 2: timed out, leave without a second wait
+      // 2: timed out, leave without a second wait
+      if (++spins > spin_limit) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); fast = 2; break; }
     }
     *lds_flag = fast;
   }
@@ -329,7 +332,8 @@ __device__ __forceinline__ void hm_ntt_fused_body(const HmNttArgs &a, const HmNt
   if (a.limb[entry].mod == HM_NTT_NONE) return;
   HM_STAMP(0);
 #if defined(HM_FUSED_TRACE)
-  if (f.trace && threadIdx.x == 0) { unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); f.trace[(size_t)blockIdx.x * 8 + 6] = ((unsigned long long)hm_xcc_id() << 32) | hw; f.trace[(size_t)blockIdx.x * 8 + 7] = ((unsigned long long)entry << 32) | tile; }
+  if (f.trace && threadIdx.x == 0) { unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); f.trace[(size_t)blockIdx.x * 8 + 6] =
+      ((unsigned long long)hm_xcc_id() << 32) | hw; f.trace[(size_t)blockIdx.x * 8 + 7] = ((unsigned long long)entry << 32) | tile; }
 #endif
   uint32_t *flag = reinterpret_cast<uint32_t *>(lds + (W1 > W2 ? W1 : W2));
   if (!INV) hm_ntt_pass_run<LOG1, true, false, MODE_A, IN_AUX, 0, HM_EPI_CHUNK, GEO>(a, lds, entry, tile, threadIdx.x);
@@ -559,7 +563,8 @@ struct HmColArgs {
   const uint64_t *src;
   uint64_t *dst;
   uint32_t rows, cw, src_stride, dst_stride, n_chunks;
-  uint32_t src_off[HM_MAX_CHUNKS / 2], dst_off[HM_MAX_CHUNKS / 2];   // offset of the block's first element in 16-byte units (limb 65535 of N = 2^16 is past 2^32 words)
+  // offset of the block's first element in 16-byte units (limb 65535 of N = 2^16 is past 2^32 words)
+  uint32_t src_off[HM_MAX_CHUNKS / 2], dst_off[HM_MAX_CHUNKS / 2];
 };
 __global__ void __launch_bounds__(256) k_col_copy(HmColArgs a) {
   const uint32_t per = (a.rows * a.cw / 2 + 255) / 256;   // blocks per chunk, two words per thread
@@ -626,7 +631,8 @@ struct hm_ctx {
   std::map<std::vector<uint32_t>, uint64_t *> bconv_tables;  // key: n_in, in_ids..., out_ids...
   std::map<std::string, void *> ntt_tables;                  // launch tables (device_table), key: their bytes
   int live_graphs = 0;                                        // captured graphs that reference the tables: no eviction while > 0
-  std::vector<struct hm_graph *> graphs;                      // ... the graphs themselves: hm_destroy detaches them (a late hm_graph_destroy must not touch a freed context)
+  // ... the graphs themselves: hm_destroy detaches them (a late hm_graph_destroy must not touch a freed context)
+  std::vector<struct hm_graph *> graphs;
   bool capturing = false;
   std::string err;
   // one-launch transforms (k_ntt_fused): rendezvous words in HBM, a host-visible error word, and the switch
@@ -643,7 +649,9 @@ struct hm_ctx {
   uint32_t fused_slots_per_xcd = 0;  // workgroups of the one-launch transform an XCD holds at once (hm_create: occupancy x CUs per XCD)
   bool fused_broken = false;        // a rendezvous timed out: no one-launch transforms any more, graphs that hold one refuse to replay
   bool capture_has_fused = false;   // the capture in progress recorded a one-launch transform
-  uint32_t fused_small = 96;  // launches of up to this many entries (N = 2^16) run as ONE launch in the small-launch geometry (k_ntt_fused8): 2-5 us faster than two kernels up to ~100 limb-polys, slower from 128 (tools/ntt_fused_small_ab.py); 0 = off
+  // launches of up to this many entries (N = 2^16) run as ONE launch in the small-launch geometry (k_ntt_fused8): 2-5 us faster than two kernels up to ~100
+  // limb-polys, slower from 128 (tools/ntt_fused_small_ab.py); 0 = off
+  uint32_t fused_small = 96;
   uint32_t bcol_outs = 0;   // output limbs per workgroup of the fused conversion + first pass (1 | 2; 0 = by launch size)
   // hm_replicate_limbs of a list with ONE owner (the rescale residues of a batch) and at least this many bytes, on >= 4 ranks: the owner scatters
   // one chunk to every peer and the peers exchange their chunks (each link carries 2 / (W - 1) of the list instead of all of it); 0 = never
@@ -818,7 +826,8 @@ extern "C" hm_status hm_create(hm_ctx **out, const hm_params *p) {
   memset(cc->err_host, 0, 64);
   HM_HIP(nullptr, hipHostGetDevicePointer(reinterpret_cast<void **>(&cc->err_dev), cc->err_host, 0));
   if (const char *e = getenv("HOMULATOR_NTT_FUSED_SMALL")) cc->fused_small = (uint32_t)std::min(HM_NTT_MAX_ENTRIES, std::max(0, atoi(e)));
-  if (cc->fused_slots_per_xcd < (cc->P.N >> HM_TL_ROW) || !hm_caps(cc->P.logN).small_geometry) cc->fused_small = 0;   // the guard above wins over the environment
+  // the guard above wins over the environment
+  if (cc->fused_slots_per_xcd < (cc->P.N >> HM_TL_ROW) || !hm_caps(cc->P.logN).small_geometry) cc->fused_small = 0;
   if (const char *e = getenv("HOMULATOR_NTT_SMALL_LIMBS")) { cc->small_limbs = (uint32_t)atoi(e); cc->small_ept8 = cc->small_limbs != 0; }
   *out = c.release();
   return HM_OK;
@@ -907,7 +916,9 @@ static hm_status check_device_error(hm_ctx *c) {
     const char *why = code == 1 ? "XCD-local rendezvous: the workgroups of a limb-poly were not co-resident"
                     : code == 2 ? "agent-scope rendezvous of a limb-poly spread over XCDs"
                                 : "unknown";
-    return fail(c, HM_ERR_HIP, "one-launch transform: wait %u timed out (%s); results of the last launches are invalid, the context now uses two-kernel transforms and refuses to replay graphs that hold one-launch transforms", code, why);
+    return fail(c, HM_ERR_HIP,
+        "one-launch transform: wait %u timed out (%s); results of the last launches are invalid, the context now uses two-kernel transforms "
+        "and refuses to replay graphs that hold one-launch transforms", code, why);
   }
   return HM_OK;
 }
@@ -969,18 +980,22 @@ extern "C" hm_status hm_set_option(hm_ctx *c, const char *name, uint64_t value) 
   if (!strcmp(name, "ntt_fused_test_timeout")) { c->fused_test_timeout = value != 0; return HM_OK; }
   if (!strcmp(name, "ntt_fused_small")) {
     if (value > HM_NTT_MAX_ENTRIES) return fail(c, HM_ERR_ARG, "hm_set_option: ntt_fused_small above %d", HM_NTT_MAX_ENTRIES);
-    if (value && c->fused_broken) return fail(c, HM_ERR_UNSUPPORTED, "hm_set_option: a rendezvous of this context has timed out: one-launch transforms stay off");
+    if (value && c->fused_broken) return fail(c, HM_ERR_UNSUPPORTED,
+        "hm_set_option: a rendezvous of this context has timed out: one-launch transforms stay off");
     if (value && !hm_caps(c->P.logN).small_geometry) return fail(c, HM_ERR_UNSUPPORTED, "hm_set_option: no one-launch transform at N = 2^%u", c->P.logN);
-    if (value && c->fused_slots_per_xcd < (c->P.N >> HM_TL_ROW)) return fail(c, HM_ERR_UNSUPPORTED, "hm_set_option: an XCD holds %u workgroups of the one-launch transform, a limb-poly needs %u", c->fused_slots_per_xcd, c->P.N >> HM_TL_ROW);
+    if (value && c->fused_slots_per_xcd < (c->P.N >> HM_TL_ROW)) return fail(c, HM_ERR_UNSUPPORTED,
+        "hm_set_option: an XCD holds %u workgroups of the one-launch transform, a limb-poly needs %u", c->fused_slots_per_xcd, c->P.N >> HM_TL_ROW);
     c->fused_small = (uint32_t)value;
     return HM_OK;
   }
-  if (!strcmp(name, "bconv_col_outs")) { if (value > 2) return fail(c, HM_ERR_ARG, "hm_set_option: bconv_col_outs is 0 (by launch size), 1 or 2"); c->bcol_outs = (uint32_t)value; return HM_OK; }
+  if (!strcmp(name, "bconv_col_outs")) { if (value > 2) return fail(c, HM_ERR_ARG, "hm_set_option: bconv_col_outs is 0 (by launch size), 1 or 2");
+      c->bcol_outs = (uint32_t)value; return HM_OK; }
   if (!strcmp(name, "replicate_split_bytes")) {
     // the threshold decides the SHAPE of a collective (one exchange or scatter + exchange): every rank must hold the same value.  It is
     // compared across the ranks once, when the communicator is made (verify_replicate_split); after that it is fixed.
     if ((c->comm || c->ext_fn) && value != c->replicate_split_bytes)
-      return fail(c, HM_ERR_UNSUPPORTED, "hm_set_option: replicate_split_bytes is fixed once the communicator exists (set it, the same on every rank, before hm_comm_init_*)");
+      return fail(c, HM_ERR_UNSUPPORTED,
+          "hm_set_option: replicate_split_bytes is fixed once the communicator exists (set it, the same on every rank, before hm_comm_init_*)");
     c->replicate_split_bytes = value;
     return HM_OK;
   }
@@ -992,9 +1007,11 @@ extern "C" hm_status hm_set_option(hm_ctx *c, const char *name, uint64_t value) 
 }
 extern "C" hm_status hm_get_counter(hm_ctx *c, const char *name, uint64_t *value) {
   if (!c || !name || !value) return HM_ERR_ARG;
-  if (!strcmp(name, "arith")) { *value = HM_GENERIC; return HM_OK; }   // arithmetic back-end of this context: 0 = mont32 (word-wise Montgomery on q = h 2^32 + 1), 1 = generic
+  // arithmetic back-end of this context: 0 = mont32 (word-wise Montgomery on q = h 2^32 + 1), 1 = generic
+  if (!strcmp(name, "arith")) { *value = HM_GENERIC; return HM_OK; }
   if (!strcmp(name, "ntt_fused_slots_per_xcd")) { *value = c->fused_slots_per_xcd; return HM_OK; }
-  if (!strncmp(name, "cap_", 4) && !hm_cap_by_name(c->P.logN, name, value)) return HM_OK;   // the capability table of this context's ring size (hm_caps.h): what the host layer plans its fusions from
+  // the capability table of this context's ring size (hm_caps.h): what the host layer plans its fusions from
+  if (!strncmp(name, "cap_", 4) && !hm_cap_by_name(c->P.logN, name, value)) return HM_OK;
   if (!strcmp(name, "ntt_fused_small")) { *value = c->fused_small; return HM_OK; }   // 0: the one-launch form is off (option, guard, or after a time-out)
   // the communicator as the library sees it: ranks_seen = ncclCommCount over RCCL (what the wire was set up for), the caller's figure otherwise
   if (!strcmp(name, "comm_world")) { *value = (uint64_t)c->world; return HM_OK; }
@@ -1056,7 +1073,9 @@ extern "C" hm_status hm_capture_end(hm_ctx *c, hm_graph **out) {
 extern "C" hm_status hm_graph_launch(hm_ctx *c, hm_graph *g) {
   if (!c || !g) return HM_ERR_ARG;
   if (g->owner != c) return fail(c, HM_ERR_ARG, "hm_graph_launch: the graph was captured from another (or a destroyed) context");
-  if (g->has_fused && c->fused_broken) return fail(c, HM_ERR_UNSUPPORTED, "hm_graph_launch: the graph holds one-launch transforms and a rendezvous of this context has timed out: capture the plan again (it now uses two-kernel transforms)");
+  if (g->has_fused && c->fused_broken) return fail(c, HM_ERR_UNSUPPORTED,
+      "hm_graph_launch: the graph holds one-launch transforms and a rendezvous of this context has timed out: capture the plan again "
+      "(it now uses two-kernel transforms)");
   HM_HIP(c, hipGraphLaunch(g->exec, c->stream));
   return HM_OK;
 }
@@ -1128,10 +1147,14 @@ static const HmNttKernels &ntt_kernels(int form) {
 template <int LOG1>
 static const HmNttKernels &ntt_kernels_all(int form) {
   static const HmNttKernels both[4] = {
-      {k_ntt_col<LOG1, false, 0>, k_ntt_row<false, 1>, k_ntt_col8<LOG1, false, 0>, k_ntt_row8<false, 1>, {k_ntt_fused8<LOG1, false, 0, 1, true>, k_ntt_fused8<LOG1, false, 0, 1, false>}},
-      {k_ntt_col<LOG1, false, 0>, k_ntt_row<false, 3>, k_ntt_col8<LOG1, false, 0>, k_ntt_row8<false, 3>, {k_ntt_fused8<LOG1, false, 0, 3, true>, k_ntt_fused8<LOG1, false, 0, 3, false>}},
-      {k_ntt_col<LOG1, false, 4>, k_ntt_row<false, 3>, k_ntt_col8<LOG1, false, 4>, k_ntt_row8<false, 3>, {k_ntt_fused8<LOG1, false, 4, 3, true>, k_ntt_fused8<LOG1, false, 4, 3, false>}},
-      {k_ntt_row<true, 0>, k_ntt_col<LOG1, true, 2>, k_ntt_row8<true, 0>, k_ntt_col8<LOG1, true, 2>, {k_ntt_fused8<LOG1, true, 0, 2, true>, k_ntt_fused8<LOG1, true, 0, 2, false>}}};
+      {k_ntt_col<LOG1, false, 0>, k_ntt_row<false, 1>, k_ntt_col8<LOG1, false, 0>, k_ntt_row8<false, 1>, {k_ntt_fused8<LOG1, false, 0, 1, true>,
+          k_ntt_fused8<LOG1, false, 0, 1, false>}},
+      {k_ntt_col<LOG1, false, 0>, k_ntt_row<false, 3>, k_ntt_col8<LOG1, false, 0>, k_ntt_row8<false, 3>, {k_ntt_fused8<LOG1, false, 0, 3, true>,
+          k_ntt_fused8<LOG1, false, 0, 3, false>}},
+      {k_ntt_col<LOG1, false, 4>, k_ntt_row<false, 3>, k_ntt_col8<LOG1, false, 4>, k_ntt_row8<false, 3>, {k_ntt_fused8<LOG1, false, 4, 3, true>,
+          k_ntt_fused8<LOG1, false, 4, 3, false>}},
+      {k_ntt_row<true, 0>, k_ntt_col<LOG1, true, 2>, k_ntt_row8<true, 0>, k_ntt_col8<LOG1, true, 2>, {k_ntt_fused8<LOG1, true, 0, 2, true>,
+          k_ntt_fused8<LOG1, true, 0, 2, false>}}};
   return both[form];
 }
 template <> const HmNttKernels &ntt_kernels<8>(int form) { return ntt_kernels_all<8>(form); }
@@ -1170,7 +1193,8 @@ static void launch_ntt(hm_ctx *c, const HmNttArgs &a, bool fusedEpilogue, bool m
   // starve one another; the spins are bounded all the same.
   if (K.one[0] && a.n_limbs <= fused_small_entries(c) && a.logG == 0) {
 #if defined(HM_FUSED_TRACE)
-    const HmNttFusedArgs f = {c->ntt_ws, c->err_dev, c->fused_test_spread, c->fused_test_timeout ? 1u << 10 : HM_SPIN_LIMIT, c->fused_test_timeout, c->fused_trace};
+    const HmNttFusedArgs f = {c->ntt_ws, c->err_dev, c->fused_test_spread, c->fused_test_timeout ? 1u << 10 : HM_SPIN_LIMIT, c->fused_test_timeout,
+        c->fused_trace};
 #else
     const HmNttFusedArgs f = {c->ntt_ws, c->err_dev, c->fused_test_spread, c->fused_test_timeout ? 1u << 10 : HM_SPIN_LIMIT, c->fused_test_timeout};
 #endif
@@ -1194,7 +1218,8 @@ static hm_status device_table(hm_ctx *c, const void *data, size_t bytes, const v
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(c->stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
       return fail(c, HM_ERR_UNSUPPORTED, "a launch table is missing while the stream is capturing: run the plan once before hm_capture_begin");
-    if (c->ntt_tables.size() >= 1024 && c->live_graphs == 0 && !c->capturing) {  // callers that never repeat a launch (tests): start over rather than grow without bound
+    // callers that never repeat a launch (tests): start over rather than grow without bound
+    if (c->ntt_tables.size() >= 1024 && c->live_graphs == 0 && !c->capturing) {
       HM_HIP(c, hipStreamSynchronize(c->stream));
       for (auto &kv : c->ntt_tables) (void)hipFree(kv.second);
       c->ntt_tables.clear();
@@ -1241,7 +1266,8 @@ static hm_status ntt_common(hm_ctx *c, const char *what, const uint64_t *in, con
       (st = check_limbs(c, what, f.mix_limbs, n)) || (st = check_mods(c, what, mod_ids, n)))
     return st;
   for (uint32_t g = 0; f.addend_limbs && g < n; ++g)
-    if (f.addend_limbs[g] != HM_NO_LIMB && f.addend_limbs[g] >= 0xFFFFu) return fail(c, HM_ERR_ARG, "%s: addend limb index %u exceeds 65534", what, f.addend_limbs[g]);
+    if (f.addend_limbs[g] != HM_NO_LIMB && f.addend_limbs[g] >= 0xFFFFu) return fail(c, HM_ERR_ARG, "%s: addend limb index %u exceeds 65534", what,
+        f.addend_limbs[g]);
   for (uint32_t g = 0; g < n; ++g) {
     const uint64_t q = c->P.mod[mod_ids[g]];
     if ((k && k[g] >= q) || (f.addend_k && f.addend_k[g] >= q) || (f.mix_k && f.mix_k[g] >= q))
@@ -1284,7 +1310,8 @@ static hm_status ntt_common(hm_ctx *c, const char *what, const uint64_t *in, con
   }
   // As few launches as the kernel-argument segment allows (HM_NTT_MAX_ENTRIES records), of equal size; the constants
   // of a launch live in a device table cached by content (plans repeat their launches)
-  const uint32_t maxGroups = std::max(8u, std::min<uint32_t>(HM_NTT_MAX_ENTRIES, c->ntt_launch_entries) / G / 8 * 8);   // whole blocks of 8 groups (one per XCD)
+  // whole blocks of 8 groups (one per XCD)
+  const uint32_t maxGroups = std::max(8u, std::min<uint32_t>(HM_NTT_MAX_ENTRIES, c->ntt_launch_entries) / G / 8 * 8);
   const uint32_t nLaunch = ((uint32_t)groups.size() + maxGroups - 1) / maxGroups;
   const uint32_t perLaunch = nLaunch ? (((uint32_t)groups.size() + nLaunch - 1) / nLaunch + 7) / 8 * 8 : 0;
   for (uint32_t base = 0; base < groups.size(); base += perLaunch) {
@@ -1406,7 +1433,8 @@ extern "C" hm_status hm_ntt_mix_sub_scale(hm_ctx *c, const hm_ntt_fused_desc *d)
   const uint32_t n = d->n;
   std::map<uint32_t, uint32_t> byOut;   // output limb -> limb-poly of the call
   for (uint32_t i = 0; i < n; ++i)
-    if (!byOut.emplace(limb_at(d->out_limbs, i), i).second) return fail(c, HM_ERR_ARG, "hm_ntt_mix_sub_scale: output limb %u appears twice", limb_at(d->out_limbs, i));
+    if (!byOut.emplace(limb_at(d->out_limbs, i), i).second) return fail(c, HM_ERR_ARG, "hm_ntt_mix_sub_scale: output limb %u appears twice",
+        limb_at(d->out_limbs, i));
   std::vector<char> covered(n, 0);
   std::vector<std::vector<uint32_t>> mixLimbs(d->n_conv);
   std::vector<std::vector<uint64_t>> mixK(d->n_conv);
@@ -1421,7 +1449,8 @@ extern "C" hm_status hm_ntt_mix_sub_scale(hm_ctx *c, const hm_ntt_fused_desc *d)
       if (it == byOut.end()) return fail(c, HM_ERR_ARG, "hm_ntt_mix_sub_scale: conv[%u] output %u feeds no limb-poly of the call", j, t);
       const uint32_t i = it->second;
       if (covered[i]) return fail(c, HM_ERR_ARG, "hm_ntt_mix_sub_scale: limb-poly %u is fed by two conversions", i);
-      if (cv.out_ids[t] != d->mod_ids[i]) return fail(c, HM_ERR_ARG, "hm_ntt_mix_sub_scale: conv[%u] output %u has another modulus than the limb-poly it feeds", j, t);
+      if (cv.out_ids[t] != d->mod_ids[i]) return fail(c, HM_ERR_ARG,
+          "hm_ntt_mix_sub_scale: conv[%u] output %u has another modulus than the limb-poly it feeds", j, t);
       covered[i] = 1;
       mixLimbs[j].push_back(d->mix ? limb_at(d->mix_limbs, i) : 0);
       mixK[j].push_back(d->mix ? d->mix_k[i] : 0);
@@ -1450,7 +1479,8 @@ extern "C" hm_status hm_ntt_mix_sub_scale(hm_ctx *c, const hm_ntt_fused_desc *d)
     g.mix_limbs = d->mix ? ml.data() : nullptr; g.mix_k = d->mix ? mk.data() : nullptr;
     g.secondPassOnly = second;
     if (second) { g.mix = nullptr; g.mix_limbs = nullptr; g.mix_k = nullptr; }   // the prologue ran inside the conversion kernel
-    return ntt_common(c, "hm_ntt_mix_sub_scale", second ? d->out : d->in, second ? ol.data() : il.data(), d->out, ol.data(), mods.data(), (uint32_t)mods.size(), 0, kk.data(), g);
+    return ntt_common(c, "hm_ntt_mix_sub_scale", second ? d->out : d->in, second ? ol.data() : il.data(), d->out, ol.data(), mods.data(),
+        (uint32_t)mods.size(), 0, kk.data(), g);
   };
   if ((st = sub(1, true))) return st;
   return sub(0, false);
@@ -1609,7 +1639,8 @@ extern "C" hm_status hm_ntt_inner_product(hm_ctx *c, const hm_ntt_ip_desc *d) {
   const uint32_t n = d->n, T = d->n_terms, K = d->n_out;
   if (T == 0 || T > HM_NIP_MAX_TERMS || K == 0 || K > HM_NIP_MAX_OUT)
     return fail(c, HM_ERR_ARG, "hm_ntt_inner_product: n_terms in [1,%d], n_out in [1,%d]", HM_NIP_MAX_TERMS, HM_NIP_MAX_OUT);
-  if (d->out_inverse && !hm_caps(c->P.logN).ip_inverse_out) {   // the epilogue is the inverse ROW pass over the workgroup's own rows: tiles of whole rows at any N; tested at 2^15 and 2^16
+  // the epilogue is the inverse ROW pass over the workgroup's own rows: tiles of whole rows at any N; tested at 2^15 and 2^16
+  if (d->out_inverse && !hm_caps(c->P.logN).ip_inverse_out) {
     for (uint32_t i = 0; i < n; ++i)
       if (d->out_inverse[i]) return fail(c, HM_ERR_UNSUPPORTED, "hm_ntt_inner_product: out_inverse needs N = 2^15 or 2^16");
   }
@@ -1899,7 +1930,8 @@ static hm_status bconv_col_launch(hm_ctx *c, const hm_bconv_desc *descs, uint32_
   if (!c || !descs || n_desc == 0) return HM_ERR_ARG;
   const uint32_t allTiles = c->P.N >> HM_TL_COL;
   if (!n_tiles) { tile0 = 0; n_tiles = allTiles; }
-  if ((n_tiles & (n_tiles - 1)) || tile0 % n_tiles || tile0 + n_tiles > allTiles) return fail(c, HM_ERR_ARG, "fused conversion: tile range [%u, %u) of %u", tile0, tile0 + n_tiles, allTiles);
+  if ((n_tiles & (n_tiles - 1)) || tile0 % n_tiles || tile0 + n_tiles > allTiles) return fail(c, HM_ERR_ARG, "fused conversion: tile range [%u, %u) of %u",
+      tile0, tile0 + n_tiles, allTiles);
   if (!hm_caps(c->P.logN).bcol_max_in) return fail(c, HM_ERR_UNSUPPORTED, "fused conversion: N = 2^15 or 2^16 only");
   HM_HIP(c, hipSetDevice(c->device));
   // output limbs per workgroup: two share the loaded and split inputs (+2 % hmult/s at batch 10), but halve the workgroups of a launch that
@@ -1916,7 +1948,8 @@ static hm_status bconv_col_launch(hm_ctx *c, const hm_bconv_desc *descs, uint32_
     const hm_bconv_desc &d = descs[pi];
     if (!d.in || !d.out || !d.in_ids || !d.out_ids) return fail(c, HM_ERR_ARG, "fused conversion: null argument");
     const uint32_t maxIn = mix ? hm_caps(c->P.logN).bcol_max_in_mix : hm_caps(c->P.logN).bcol_max_in;
-    if (d.n_in == 0 || d.n_in > maxIn) return fail(c, HM_ERR_UNSUPPORTED, "fused conversion: n_in %u not in [1,%u]%s", d.n_in, maxIn, mix ? " (with the mix prologue)" : "");
+    if (d.n_in == 0 || d.n_in > maxIn) return fail(c, HM_ERR_UNSUPPORTED, "fused conversion: n_in %u not in [1,%u]%s", d.n_in, maxIn, mix ?
+        " (with the mix prologue)" : "");
     if (d.n_out == 0 || d.n_out > HM_BCONV_MAX_OUT) return fail(c, HM_ERR_ARG, "fused conversion: n_out %u not in [1,%d]", d.n_out, HM_BCONV_MAX_OUT);
     if (d.log_len && d.log_len != c->P.logN) return fail(c, HM_ERR_UNSUPPORTED, "fused conversion: whole limb-polys only");
     if (d.out != descs[0].out) return fail(c, HM_ERR_ARG, "fused conversion: one hand-off buffer per call");
@@ -1974,14 +2007,16 @@ static hm_status bconv_col_launch(hm_ctx *c, const hm_bconv_desc *descs, uint32_
     }
     // (measured with the combination built: the fused ModDown conversion stays 2.5 % behind the separate one with packed inputs too —
     // profiles/r05_late_ab.txt — so the 120 instantiations it needs are not shipped)
-    if (mix && d.in_packed) return fail(c, HM_ERR_UNSUPPORTED, "fused conversion: packed inputs and the mix prologue do not combine (convert from plain inputs)");
+    if (mix && d.in_packed) return fail(c, HM_ERR_UNSUPPORTED,
+        "fused conversion: packed inputs and the mix prologue do not combine (convert from plain inputs)");
     byIn[d.n_in + (d.in_packed ? 256u : 0u)].push_back(p);
   }
   if (farApart) {
     // A conversion whose input limb-polys are spread over more than 4 GiB of the buffer cannot be addressed from one descriptor with 32-bit
     // offsets.  The plans of the host layer never produce one (a digit's limbs are neighbours in the pool); a caller's list that does is
     // served by the two steps the fused kernel stands for: the conversion into the hand-off limbs, then the first pass in place on them.
-    if (n_tiles != allTiles) return fail(c, HM_ERR_UNSUPPORTED, "fused conversion on a column slice: the inputs of a conversion must lie within 4 GiB of each other");
+    if (n_tiles != allTiles) return fail(c, HM_ERR_UNSUPPORTED,
+        "fused conversion on a column slice: the inputs of a conversion must lie within 4 GiB of each other");
     hm_status st = hm_bconv_batch(c, descs, n_desc);
     if (st) return st;
     std::vector<uint32_t> limbs, mods, ml;
@@ -1993,9 +2028,11 @@ static hm_status bconv_col_launch(hm_ctx *c, const hm_bconv_desc *descs, uint32_
       }
     NttFused f;
     f.firstPassOnly = true;
-    if (mix) { f.mix = mix->mix; f.mix_limbs = ml.data(); f.mix_k = mk.data(); f.minuend = descs[0].out; /* (marks the fused form: the first pass only reads the mix operand) */ }
+    if (mix) { f.mix = mix->mix; f.mix_limbs = ml.data(); f.mix_k = mk.data(); f.minuend = descs[0].out;
+        /* (marks the fused form: the first pass only reads the mix operand) */ }
     std::vector<uint64_t> ones(limbs.size(), 1);
-    return ntt_common(c, "fused conversion", descs[0].out, limbs.data(), descs[0].out, limbs.data(), mods.data(), (uint32_t)limbs.size(), 0, mix ? ones.data() : nullptr, f);
+    return ntt_common(c, "fused conversion", descs[0].out, limbs.data(), descs[0].out, limbs.data(), mods.data(), (uint32_t)limbs.size(), 0, mix ?
+        ones.data() : nullptr, f);
   }
   struct Lnch { uint32_t n_in; dim3 grid; HmBcolArgs a; };
   std::vector<Lnch> ls;
@@ -2010,7 +2047,8 @@ static hm_status bconv_col_launch(hm_ctx *c, const hm_bconv_desc *descs, uint32_
     if (st) return st;
     uint32_t logTiles = 0;
     while ((1u << logTiles) < n_tiles) ++logTiles;
-    HmBcolArgs a = {static_cast<const HmBcolProb *>(dtab), out, c->d_tw_fwd, c->P.logN, (uint32_t)grp.size(), groups, mix ? mix->mix : nullptr, tile0, logTiles};
+    HmBcolArgs a = {static_cast<const HmBcolProb *>(dtab), out, c->d_tw_fwd, c->P.logN, (uint32_t)grp.size(), groups, mix ? mix->mix : nullptr, tile0,
+        logTiles};
     const uint32_t pairs = ((uint32_t)grp.size() * n_tiles + 7) / 8 * 8;
     ls.push_back(Lnch{kv.first, dim3(pairs * groups), a});
   }

@@ -222,10 +222,17 @@ def run_in_process(world, make_op, body):
     ops, res, err = [None] * world, [None] * world, [None] * world
     for r in range(world):
         ops[r] = make_op(r)
-        ops[r].comm_init_external(grp.transport(r))
 
     def work(r):
         try:
+            # hm_comm_init_* is a collective since round 6 (every rank tells every peer its replicate threshold over the new
+            # communicator): each rank's thread makes its own
+            ops[r].comm_init_external(grp.transport(r))
+            grp.barrier.wait(timeout=120)
+            if r == 0:   # the counters describe the op's own exchanges, not the communicator's first word
+                grp.calls = [0] * world
+                grp.bytes_recv = [0] * world
+            grp.barrier.wait(timeout=120)
             res[r] = body(r, ops[r])
         except Exception as e:  # noqa: BLE001
             err[r] = e

@@ -101,6 +101,7 @@ def load():
     L.hm_set_option.argtypes = [vp, C.c_char_p, u64]
     L.hm_get_counter.argtypes = [vp, C.c_char_p, C.POINTER(u64)]
     L.hm_capability.argtypes = [u32, C.c_char_p, C.POINTER(u64)]
+    L.hm_comm_init_external.argtypes = [vp, i32, i32, vp, vp]
     L.hm_timer_start.argtypes = [vp]
     L.hm_timer_stop.argtypes = [vp, C.POINTER(u64)]
     _lib = L

@@ -263,6 +263,10 @@ typedef int (*hm_exchange_fn)(void *user, const void *send_dev, const size_t *se
                               void *recv_dev, const size_t *recv_off, const size_t *recv_bytes);
 /* ^ per peer p: send_bytes[p] bytes at send_dev + send_off[p] go to rank p; recv_bytes[p] bytes from rank p land at
  *   recv_dev + recv_off[p]; the entries of the calling rank itself are 0.  Returns 0 on success. */
+/* hm_comm_init_rccl and hm_comm_init_external are COLLECTIVE: every rank of the communicator calls them at the same time (ncclCommInitRank is
+ * collective anyway; since round 6 both also carry one word from every rank to every peer over the new communicator — the
+ * "replicate_split_bytes" option, which decides the shape of hm_replicate_limbs' collective and must agree on all ranks: a mismatch fails
+ * the call with HM_ERR_COMM on every rank instead of hanging the first replicate). */
 hm_status hm_comm_unique_id(void *out128);
 hm_status hm_comm_init_rccl(hm_ctx *ctx, int rank, int world, const void *unique_id128);
 hm_status hm_comm_init_external(hm_ctx *ctx, int rank, int world, hm_exchange_fn fn, void *user);

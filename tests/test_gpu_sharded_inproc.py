@@ -145,3 +145,48 @@ def test_bench_flow_rehearsal_two_sharded_instances():
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["streams"] == 2
     ov = d["exchange_overlap"]
     assert ov["instances_in_flight"] == 2 and ov["hidden_us_per_op"] >= 0 and abs(ov["hidden_us_per_op"] + ov["exposed_us_per_op"] - d["exchange_us_per_op"]) < 0.05
+
+
+def test_ranks_that_disagree_on_the_replicate_threshold_fail_at_init():
+    """hm_replicate_limbs takes one exchange or scatter + exchange of chunks from `replicate_split_bytes`, which every process
+    reads from ITS environment / option: ranks that disagree would enter collectives of different shape and hang in RCCL.  Round 6: the first
+    thing a new communicator carries is every rank's threshold to every peer; a mismatch fails hm_comm_init_* with HM_ERR_COMM on EVERY rank
+    (nobody is left inside a collective), and the option is fixed once the communicator exists."""
+    import ctypes as C
+    import threading
+    from homulator_amd import hip
+    from homulator_amd.dist import InProcessGroup
+    world = 4
+    grp = InProcessGroup(world)
+    ctxs = [hip.Context(13, 3, 2) for _ in range(world)]
+    ctxs[2].set_option("replicate_split_bytes", 12345)   # one rank with another threshold
+    errs = [None] * world
+
+    def work(r):
+        fn = grp.transport(r)
+        st = ctxs[r].L.hm_comm_init_external(ctxs[r].h, r, world, C.cast(fn, C.c_void_p), None)
+        errs[r] = (st, ctxs[r].L.hm_last_error(ctxs[r].h).decode())
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert all(st == 4 for st, _ in errs), errs                      # HM_ERR_COMM everywhere
+    assert all("replicate_split_bytes" in msg for _, msg in errs), errs
+    assert all(c.counter("comm_world") == 1 and c.counter("comm_transport") == 0 for c in ctxs)   # no communicator was kept
+    # agreeing ranks: the communicator is made, reports itself, and the option is fixed from then on
+    ctxs[2].set_option("replicate_split_bytes", 2 << 20)
+    grp2 = InProcessGroup(world)
+
+    def work2(r):
+        fn = grp2.transport(r)
+        errs[r] = ctxs[r].L.hm_comm_init_external(ctxs[r].h, r, world, C.cast(fn, C.c_void_p), None)
+        ctxs[r]._keep = fn
+    th = [threading.Thread(target=work2, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert errs == [0] * world
+    assert all(c.counter("comm_world") == world and c.counter("comm_ranks_seen") == world and c.counter("comm_transport") == 2 for c in ctxs)
+    with pytest.raises(hip.HmError, match="fixed once the communicator exists"):
+        ctxs[0].set_option("replicate_split_bytes", 1)
+    ctxs[0].set_option("replicate_split_bytes", 2 << 20)   # the value in force: accepted
+    for c in ctxs:
+        c.close()
