@@ -14,6 +14,7 @@
 struct HmCaps {
   uint32_t small_geometry;    // the 8-coefficient passes (k_ntt_col8 / k_ntt_row8), the one-launch transform (k_ntt_fused8), the small-launch transform x key kernel (k_ntt_row_ip8)
   uint32_t bcol_max_in;       // widest digit the fused conversion + first pass takes (k_bconv_col / k_bconv_col2); 0: no such kernel at this ring size
+  uint32_t bcol_pref_in;      // widest digit for which the fused form is the FASTER plan (measured: gpurun_out/r06_sweep, profiles/r06_sweep_sets.txt); wider digits keep a conversion launch of their own unless the caller says otherwise (config key fuse_bconv_max_in)
   uint32_t bcol_max_in_mix;   // ... with the mix prologue
   uint32_t ip_inverse_out;    // hm_ntt_ip_desc.out_inverse: the transform x key kernel hands its outputs over as the first pass of their inverse transform (pass 7b)
   uint32_t col_slices;        // the transposed-domain exchange + conversion on a rank's column slice (hm_bconv_col with a tile range): ranks a limb-poly's 4096-coefficient column tiles can be dealt to
@@ -22,9 +23,11 @@ static inline HmCaps hm_caps(uint32_t logN) {
   // rows: ring size -> capabilities.  The two ring sizes of the reference's configuration files carry every fused form; the other sizes the
   // transforms support (2^13, 2^14, 2^17: tests and small-ring sweeps) run the plain plan.
   switch (logN) {
-  case 16: return HmCaps{1, HM_BCOL_MAX_IN, HM_BCOL_MAX_IN_MIX, 1, 16};
-  case 15: return HmCaps{1, HM_BCOL_MAX_IN, HM_BCOL_MAX_IN_MIX, 1, 8};
-  default: return HmCaps{0, 0, 0, 0, 0};
+  // N = 2^16: from 21 limbs on the two-group conversion inside the first pass is 2-5 % SLOWER per op than k_bconv<n> + first pass (every pair of
+  // outputs re-reads the digit's tiles from L2: 14 readers per tile at 28 limbs), level at 16-20; N = 2^15: faster or level at every width
+  case 16: return HmCaps{1, HM_BCOL_MAX_IN, 20, HM_BCOL_MAX_IN_MIX, 1, 16};
+  case 15: return HmCaps{1, HM_BCOL_MAX_IN, HM_BCOL_MAX_IN, HM_BCOL_MAX_IN_MIX, 1, 8};
+  default: return HmCaps{0, 0, 0, 0, 0, 0};
   }
 }
 // 0 = found
@@ -33,6 +36,7 @@ static inline int hm_cap_by_name(uint32_t logN, const char *name, uint64_t *valu
   if (!strcmp(name, "cap_small_geometry")) { *value = c.small_geometry; return 0; }
   if (!strcmp(name, "cap_bconv_col_max_in")) { *value = c.bcol_max_in; return 0; }
   if (!strcmp(name, "cap_bconv_col_max_in_mix")) { *value = c.bcol_max_in_mix; return 0; }
+  if (!strcmp(name, "cap_bconv_col_pref_in")) { *value = c.bcol_pref_in; return 0; }
   if (!strcmp(name, "cap_ip_inverse_out")) { *value = c.ip_inverse_out; return 0; }
   if (!strcmp(name, "cap_col_slices")) { *value = c.col_slices; return 0; }
   return 1;

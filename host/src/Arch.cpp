@@ -523,7 +523,8 @@ void Arch::fusePasses(std::vector<Stage> &st) {
         std::vector<Instruction *> conv(ip->ipX.size(), nullptr);
         // widest digit the fused conversion + first pass takes (0: none at this ring size); config key fuse_bconv_max_in caps it below what the
         // back-end offers (A/B runs: 15 = the plan of rounds 3-5, where wider digits kept a conversion launch of their own)
-        const uint32_t maxConvIn = std::min<uint32_t>(cap(logN, "cap_bconv_col_max_in"), config->getValueOr("fuse_bconv_max_in", ~0u));
+        // (default: the widest digit for which the fused form measured faster at this ring size, cap_bconv_col_pref_in)
+        const uint32_t maxConvIn = std::min<uint32_t>(cap(logN, "cap_bconv_col_max_in"), config->getValueOr("fuse_bconv_max_in", cap(logN, "cap_bconv_col_pref_in")));
         bool allConv = fuseBconv && (world_ == 1 || shardFused || shardGather) && maxConvIn != 0;
         for (size_t j = 0; j < ip->ipX.size(); ++j) {
           auto p = producer.find(ip->ipX[j]);

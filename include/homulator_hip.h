@@ -361,6 +361,8 @@ hm_status hm_set_option(hm_ctx *ctx, const char *name, uint64_t value);
  *   "cap_small_geometry"        1: the 8-coefficient passes, the one-launch transform and the small-launch transform x key kernel exist
  *   "cap_bconv_col_max_in"      widest digit (input limbs) of the fused conversion + first pass (hm_bconv_col, the conv lists of
  *                               hm_ntt_ip_desc / hm_ntt_fused_desc); 0: convert with hm_bconv_batch first
+ *   "cap_bconv_col_pref_in"     widest digit for which that fused form is also the faster plan on MI355X (wider ones: hm_bconv_batch + the
+ *                               transform's first pass; a planner's default, not a limit of the entry points)
  *   "cap_bconv_col_max_in_mix"  ... when the conversion carries the mix prologue (hm_ntt_fused_desc.conv with mix)
  *   "cap_ip_inverse_out"        1: hm_ntt_ip_desc.out_inverse is served
  *   "cap_col_slices"            ranks the column tiles of a limb-poly can be dealt to (hm_limbs_to_colslices / hm_bconv_col with a tile range)

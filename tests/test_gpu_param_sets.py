@@ -43,7 +43,8 @@ def test_parameter_set_op_bit_exact(cfg, logN, L, alpha, ell, op):
     o = oracle(logN, L, alpha)
     ct1, ct2, evk = o.synth_ct(ell, SEED), o.synth_ct(ell, SEED + 2000), o.synth_evk(ell, SEED + 10000)
     h = host.Op(cfg, op, L, ell, alpha)
-    assert not any(ln.startswith("BCONV") and "ModUp_BCONV" in ln for ln in h.plan()), "every parameter set converts its ModUp digits inside the first pass"
+    wide16 = logN == 16 and min(ell, alpha) > 20   # N = 2^16: digits above cap_bconv_col_pref_in keep their conversion launch (measured faster)
+    assert any(ln.startswith("BCONV") and "ModUp_BCONV" in ln for ln in h.plan()) == wide16
     h.execute(1)
     exp = o.hmult(ell, ct1, ct2, evk) if op == "hmult" else o.hrotate(ell, ct1, 5, evk)
     assert np.array_equal(h.read("out.c0"), exp[0]) and np.array_equal(h.read("out.c1"), exp[1])
@@ -55,6 +56,7 @@ def test_parameter_set_op_bit_exact(cfg, logN, L, alpha, ell, op):
     ("config_4_N15.cfg", 15, 28, 28, 28, "hmult", "batch"),      # set A on the generic back-end, three ops per launch (the two-output conversion kernels)
     ("config_4_N15.cfg", 15, 28, 28, 23, "hrotate", "no_pack"),  # plain (not split-30 packed) inputs into the two-group conversion
     ("config_4.cfg", 16, 28, 28, 28, "hmult", "no_ip_inv"),      # motivation without pass 7b
+    ("config_4.cfg", 16, 28, 28, 28, "hrotate", "wide32"),       # motivation with the 28-limb digit forced inside the first pass (fuse_bconv_max_in = 32)
     ("config_4_N15.cfg", 15, 28, 28, 28, "hmult", "cap15"),      # the plan of rounds 3-5: a conversion launch of its own for the wide digit
 ])
 def test_wide_digit_sets_in_the_other_modes(cfg, logN, L, alpha, ell, op, mode, chain_bits):
@@ -79,6 +81,8 @@ def test_wide_digit_sets_in_the_other_modes(cfg, logN, L, alpha, ell, op, mode, 
         ov["fuse_ip_inv"] = 0
     elif mode == "cap15":
         ov["fuse_bconv_max_in"] = 15
+    elif mode == "wide32":
+        ov["fuse_bconv_max_in"] = 32
     h = host.Op(cfg, op, L, ell, alpha, overrides=ov)
     assert h.backend_counter("arith") == 1
     h.execute(1)
