@@ -653,6 +653,7 @@ struct hm_ctx {
   // limb-polys, slower from 128 (tools/ntt_fused_small_ab.py); 0 = off
   uint32_t fused_small = 96;
   uint32_t bcol_outs = 0;   // output limbs per workgroup of the fused conversion + first pass (1 | 2; 0 = by launch size)
+  uint32_t bcol_merge = 1;  // small launches: the digits of a call run ONE kernel, the widest digit's (bconv_col_launch)
   // hm_replicate_limbs of a list with ONE owner (the rescale residues of a batch) and at least this many bytes, on >= 4 ranks: the owner scatters
   // one chunk to every peer and the peers exchange their chunks (each link carries 2 / (W - 1) of the list instead of all of it); 0 = never
   uint64_t replicate_split_bytes = 2u << 20;
@@ -822,6 +823,7 @@ extern "C" hm_status hm_create(hm_ctx **out, const hm_params *p) {
   if (const char *e = getenv("HOMULATOR_NTT_LAUNCH_ENTRIES")) cc->ntt_launch_entries = (uint32_t)std::max(8, atoi(e));
   if (const char *e = getenv("HOMULATOR_NIP_SMALL")) cc->nip_small = (uint32_t)std::max(0, atoi(e));
   if (const char *e = getenv("HOMULATOR_BCOL_OUTS")) cc->bcol_outs = (uint32_t)std::min(2, std::max(0, atoi(e)));
+  if (const char *e = getenv("HOMULATOR_BCOL_MERGE")) cc->bcol_merge = atoi(e) != 0;
   HM_HIP(nullptr, hipHostMalloc(reinterpret_cast<void **>(&cc->err_host), 64, hipHostMallocMapped));
   memset(cc->err_host, 0, 64);
   HM_HIP(nullptr, hipHostGetDevicePointer(reinterpret_cast<void **>(&cc->err_dev), cc->err_host, 0));
@@ -988,6 +990,7 @@ extern "C" hm_status hm_set_option(hm_ctx *c, const char *name, uint64_t value) 
     c->fused_small = (uint32_t)value;
     return HM_OK;
   }
+  if (!strcmp(name, "bconv_col_merge")) { c->bcol_merge = value != 0; return HM_OK; }
   if (!strcmp(name, "bconv_col_outs")) { if (value > 2) return fail(c, HM_ERR_ARG, "hm_set_option: bconv_col_outs is 0 (by launch size), 1 or 2");
       c->bcol_outs = (uint32_t)value; return HM_OK; }
   if (!strcmp(name, "replicate_split_bytes")) {
@@ -1944,8 +1947,29 @@ static hm_status bconv_col_launch(hm_ctx *c, const hm_bconv_desc *descs, uint32_
   }
   std::map<uint32_t, std::vector<HmBcolProb>> byIn;   // key: n_in, + 256 for conversions whose inputs are stored packed (kernels of their own)
   bool farApart = false;
+  // Round 6, small launches (one op at a time, a rank's share of a sharded op): digits of different width are launches of different kernels, one
+  // behind the other, and each leaves the chip part empty — hmult 45/35/15: 1 120 workgroups of <15> on 1 024 slots (a second, nearly empty
+  // round: 40.7 us) and then 720 of <5> (19.5 us).  When the whole call is small, the narrower digits run the WIDEST digit's kernel with zero
+  // table columns for the inputs they do not have (the padded inputs re-read the digit's first limb: exact zeros are added): ONE launch of
+  // 1 840 workgroups.  More multiply-adds for the narrow digit, fewer rounds for the launch; option "bconv_col_merge" (default 1; 0 = off).
+  std::vector<uint32_t> kernelNin(n_desc);
+  {
+    uint32_t widest[2] = {0, 0};
+    size_t wgs = 0;
+    for (uint32_t pi = 0; pi < n_desc; ++pi) {
+      widest[descs[pi].in_packed ? 1 : 0] = std::max(widest[descs[pi].in_packed ? 1 : 0], descs[pi].n_in);
+      wgs += (size_t)descs[pi].n_out * n_tiles;
+    }
+    const bool merge = c->bcol_merge && NOUT == 1 && !mix && wgs <= 4096;
+    for (uint32_t pi = 0; pi < n_desc; ++pi) {
+      const uint32_t w = widest[descs[pi].in_packed ? 1 : 0];
+      // (a digit runs the widest digit's kernel only inside one family: up to 15 limbs, or two input groups; and not for more than four times its own work)
+      kernelNin[pi] = merge && (w <= HM_BCOL_ONE_GROUP || descs[pi].n_in > HM_BCOL_ONE_GROUP) && w <= 4 * descs[pi].n_in ? w : descs[pi].n_in;
+    }
+  }
   for (uint32_t pi = 0; pi < n_desc; ++pi) {
     const hm_bconv_desc &d = descs[pi];
+    const uint32_t kn = kernelNin[pi];   // the input-basis size of the kernel this conversion runs (>= d.n_in)
     if (!d.in || !d.out || !d.in_ids || !d.out_ids) return fail(c, HM_ERR_ARG, "fused conversion: null argument");
     const uint32_t maxIn = mix ? hm_caps(c->P.logN).bcol_max_in_mix : hm_caps(c->P.logN).bcol_max_in;
     if (d.n_in == 0 || d.n_in > maxIn) return fail(c, HM_ERR_UNSUPPORTED, "fused conversion: n_in %u not in [1,%u]%s", d.n_in, maxIn, mix ?
@@ -1961,14 +1985,14 @@ static hm_status bconv_col_launch(hm_ctx *c, const hm_bconv_desc *descs, uint32_
       for (uint32_t t = 0; t < d.n_out; ++t)
         if (d.in_ids[i] == d.out_ids[t]) return fail(c, HM_ERR_ARG, "fused conversion: modulus %u is in both bases", d.in_ids[i]);
     std::vector<uint32_t> key;
-    key.push_back(d.n_in);
+    key.push_back(d.n_in | (kn != d.n_in ? kn << 16 : 0u));   // (a table padded to a wider kernel's rows is a table of its own)
     key.insert(key.end(), d.in_ids, d.in_ids + d.n_in);
     key.insert(key.end(), d.out_ids, d.out_ids + d.n_out);
     auto it = c->bconv_tables.find(key);
     if (it == c->bconv_tables.end()) {
       std::vector<uint64_t> qh(d.n_in), tb((size_t)d.n_in * d.n_out);
       c->P.bconv_consts(d.in_ids, d.n_in, d.out_ids, d.n_out, qh.data(), tb.data());
-      const uint32_t row = HM_BCONV_ROW(d.n_in);
+      const uint32_t row = HM_BCONV_ROW(kn);
       std::vector<uint64_t> tt((size_t)row * d.n_out, 0);
       for (uint32_t i = 0; i < d.n_in; ++i)
         for (uint32_t t = 0; t < d.n_out; ++t) tt[(size_t)t * row + i] = hm_bconv_entry(tb[(size_t)i * d.n_out + t], c->P.modc[d.out_ids[t]]);
@@ -1980,7 +2004,7 @@ static hm_status bconv_col_launch(hm_ctx *c, const hm_bconv_desc *descs, uint32_
     }
     HmBcolProb p;
     memset(&p, 0, sizeof p);
-    p.in = d.in; p.table = it->second; p.qn = it->second + (size_t)HM_BCONV_ROW(d.n_in) * d.n_out; p.n_in = d.n_in; p.n_out = d.n_out;
+    p.in = d.in; p.table = it->second; p.qn = it->second + (size_t)HM_BCONV_ROW(kn) * d.n_out; p.n_in = d.n_in; p.n_out = d.n_out;
     p.in_packed = d.in_packed ? 1u : 0u;
     for (uint32_t i = 0; i < d.n_in; ++i) p.in_limb[i] = limb_at(d.in_limbs, i);
     {   // ONE buffer descriptor per conversion: the lowest input limb-poly is the base, the others are byte offsets from it (HmBcolProb::in_off)
@@ -1989,6 +2013,7 @@ static hm_status bconv_col_launch(hm_ctx *c, const hm_bconv_desc *descs, uint32_
       if (((uint64_t)(hi - lo) + 1) << (c->P.logN + 3) > (1ull << 32)) { farApart = true; break; }   // inputs more than 4 GiB apart: the fallback below
       p.in_base = d.in + (size_t)lo * c->P.N;
       for (uint32_t i = 0; i < d.n_in; ++i) p.in_off[i] = (p.in_limb[i] - lo) << (c->P.logN + 3);
+      for (uint32_t i = d.n_in; i < kn; ++i) { p.in_limb[i] = p.in_limb[0]; p.in_off[i] = p.in_off[0]; }   // padded inputs: a valid limb-poly, zero table columns
     }
     for (uint32_t t = 0; t < d.n_out; ++t) { p.out_limb[t] = limb_at(d.out_limbs, t); p.out_mod[t] = d.out_ids[t]; }
     if (mix) {   // x = conv + k * mix before the first butterfly: constants in Shoup form, a device table cached by content
@@ -2009,7 +2034,7 @@ static hm_status bconv_col_launch(hm_ctx *c, const hm_bconv_desc *descs, uint32_
     // profiles/r05_late_ab.txt — so the 120 instantiations it needs are not shipped)
     if (mix && d.in_packed) return fail(c, HM_ERR_UNSUPPORTED,
         "fused conversion: packed inputs and the mix prologue do not combine (convert from plain inputs)");
-    byIn[d.n_in + (d.in_packed ? 256u : 0u)].push_back(p);
+    byIn[kn + (d.in_packed ? 256u : 0u)].push_back(p);
   }
   if (farApart) {
     // A conversion whose input limb-polys are spread over more than 4 GiB of the buffer cannot be addressed from one descriptor with 32-bit

@@ -23,9 +23,9 @@ static inline HmCaps hm_caps(uint32_t logN) {
   // rows: ring size -> capabilities.  The two ring sizes of the reference's configuration files carry every fused form; the other sizes the
   // transforms support (2^13, 2^14, 2^17: tests and small-ring sweeps) run the plain plan.
   switch (logN) {
-  // N = 2^16: from 21 limbs on the two-group conversion inside the first pass is 2-5 % SLOWER per op than k_bconv<n> + first pass (every pair of
-  // outputs re-reads the digit's tiles from L2: 14 readers per tile at 28 limbs), level at 16-20; N = 2^15: faster or level at every width
-  case 16: return HmCaps{1, HM_BCOL_MAX_IN, 20, HM_BCOL_MAX_IN_MIX, 1, 16};
+  // N = 2^16: the two-group conversion inside the first pass is 1-2 % SLOWER per op than k_bconv<n> + first pass at 16-20 limbs and up to 5 % at 28
+  // (every pair of outputs re-reads the digit's tiles from L2: 14 readers per tile at 28 limbs; profiles/r06_sweep_sets.txt); N = 2^15: 1-5 % faster
+  case 16: return HmCaps{1, HM_BCOL_MAX_IN, 15, HM_BCOL_MAX_IN_MIX, 1, 16};
   case 15: return HmCaps{1, HM_BCOL_MAX_IN, HM_BCOL_MAX_IN, HM_BCOL_MAX_IN_MIX, 1, 8};
   default: return HmCaps{0, 0, 0, 0, 0, 0};
   }

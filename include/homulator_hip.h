@@ -346,6 +346,9 @@ void hm_graph_destroy(hm_graph *graph);
  *                small-launch geometry (k_ntt_row_ip8); 0 switches it off.  Env HOMULATOR_NIP_SMALL.
  *   "bconv_col_outs"   output limbs per workgroup of the fused conversion + first pass: 0 = by launch size (default), 1, 2.
  *                Env HOMULATOR_BCOL_OUTS.
+ *   "bconv_col_merge"  small calls of the fused conversion (at most 4 096 workgroups, one output per workgroup): digits of different width run
+ *                ONE launch of the widest digit's kernel, the narrower ones with zero table columns for the inputs they lack (default 1: two
+ *                launches that each leave the chip part empty become one; 0 = one launch per digit width).  Env HOMULATOR_BCOL_MERGE.
  *   "replicate_split_bytes"  hm_replicate_limbs of a list with ONE owner and at least this many bytes, on >= 4 ranks, runs as
  *                scatter + exchange of chunks (every link carries 2 / (W - 1) of the list); default 2 MiB, 0 = never.  Every
  *                rank of a communicator must use the same value.  Env HOMULATOR_REPLICATE_SPLIT.

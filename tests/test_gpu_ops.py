@@ -130,12 +130,13 @@ def test_hmult_mixed_conversion_launch(fuse):
     """N = 2^16, l = 20, alpha = 16: digits of 16 and 4 limbs.  With the fused conversion capped at 15 input limbs (config key
     fuse_bconv_max_in: the plan of rounds 3-5) the 16-limb digit keeps its own conversion, so ONE transform x key launch mixes digits
     converted inside their first pass with digits that arrive converted (their first pass was skipped and the result
-    silently wrong).  "wide" (round 6, the default): both digits convert inside their first pass, the 16-limb one in two input groups."""
+    silently wrong).  "wide" (round 6; fuse_bconv_max_in = 32): both digits convert inside their first pass, the 16-limb one in two input groups
+    (the planner's default at N = 2^16 stops at 15 limbs, where the fused form measured faster: cap_bconv_col_pref_in)."""
     from homulator_amd import host
     L, ell, alpha = 45, 20, 16
     o = oracle(16, L, alpha)
     ct1, ct2, evk = inputs(o, ell)
-    op = host.Op("config_4.cfg", "hmult", L, ell, alpha, overrides={"fuse_bconv": 0} if fuse == "no_bconv" else None if fuse == "wide" else {"fuse_bconv_max_in": 15})
+    op = host.Op("config_4.cfg", "hmult", L, ell, alpha, overrides={"fuse_bconv": 0} if fuse == "no_bconv" else {"fuse_bconv_max_in": 32 if fuse == "wide" else 15})
     kinds = [ln.split()[0] + ":" + ln.split()[1] for ln in op.plan()]
     assert any(k.startswith("BCONV:ModUp_BCONV") for k in kinds) == (fuse != "wide"), kinds
     op.execute(1)

@@ -43,7 +43,7 @@ def test_parameter_set_op_bit_exact(cfg, logN, L, alpha, ell, op):
     o = oracle(logN, L, alpha)
     ct1, ct2, evk = o.synth_ct(ell, SEED), o.synth_ct(ell, SEED + 2000), o.synth_evk(ell, SEED + 10000)
     h = host.Op(cfg, op, L, ell, alpha)
-    wide16 = logN == 16 and min(ell, alpha) > 20   # N = 2^16: digits above cap_bconv_col_pref_in keep their conversion launch (measured faster)
+    wide16 = logN == 16 and min(ell, alpha) > 15   # N = 2^16: digits above cap_bconv_col_pref_in keep their conversion launch (measured faster)
     assert any(ln.startswith("BCONV") and "ModUp_BCONV" in ln for ln in h.plan()) == wide16
     h.execute(1)
     exp = o.hmult(ell, ct1, ct2, evk) if op == "hmult" else o.hrotate(ell, ct1, 5, evk)

@@ -50,8 +50,8 @@ def test_headline_plan_is_six_launches():
 @pytest.mark.parametrize("cfg,L,ell,alpha,conv_inside", [
     ("config_4_N15.cfg", 16, 10, 4, True),     # N = 2^15 (round 4: the fused conversion exists for N = 2^15 and 2^16)
     ("config_4.cfg", 28, 28, 28, False),       # the `motivation` sweep at N = 2^16: 28 input limbs per digit — the two-group fused form exists (round 6) but measured
-                                               # 2-5 % slower from 21 limbs on (cap_bconv_col_pref_in = 20): the planner keeps the conversion launch
-    ("config_4.cfg", 28, 20, 28, True),        # ... and fuses up to 20
+                                               # 1-5 % slower than conversion + first pass there (cap_bconv_col_pref_in = 15): the planner keeps the conversion launch
+    ("config_4.cfg", 28, 15, 28, True),        # ... and fuses up to 15
     ("config_4_N15.cfg", 28, 28, 28, True),    # parameter set A at its top level (N = 2^15, beta = 1)
     ("config_4_N15.cfg", 28, 17, 28, True),    # set A, a 17-limb digit
     ("config_4.cfg", 24, 24, 6, True),         # set C: beta = 4
@@ -74,7 +74,8 @@ def test_mixed_launch_keeps_the_wide_digits_conversion():
     ones whose only transformed digit it is); the 16-limb digit is wider than the cap and keeps its own BCONV launch.  ONE NTT_IP launch then
     mixes both kinds: the backend runs the first pass of every transformed (limb, digit) that no conversion of the call covers (round 3
     skipped it as soon as any conversion was fused: ADVICE round 3, tests/test_gpu_ops.py has the parity case).  Without the cap (round 6)
-    both digits convert inside their first pass and no ModUp conversion launch is left."""
+    both digits convert inside their first pass and no ModUp conversion launch is left once the cap is lifted (fuse_bconv_max_in = 32; the
+    planner's own default at N = 2^16 is the measured crossover, cap_bconv_col_pref_in = 15)."""
     p, total, n = plan("config_4.cfg", "hmult", 45, 20, 16, fuse_bconv_max_in=15)
     modup_bconv = [ln for ln in p if ln.startswith("BCONV") and "ModUp_BCONV" in ln]
     nip = [ln for ln in p if ln.startswith("NTT_IP")]
@@ -85,7 +86,7 @@ def test_mixed_launch_keeps_the_wide_digits_conversion():
     assert int(re.search(r"n=(\d+)", nip[0]).group(1)) == 36
     p0, total0, _ = plan("config_4.cfg", "hmult", 45, 20, 16, fuse_hpip=0, fuse_bconv=0)
     assert total0 == total
-    pw, totalw, nw = plan("config_4.cfg", "hmult", 45, 20, 16)   # (16 <= the preferred width at N = 2^16)
+    pw, totalw, nw = plan("config_4.cfg", "hmult", 45, 20, 16, fuse_bconv_max_in=32)   # every width the kernels take
     assert not [ln for ln in pw if ln.startswith("BCONV") and "ModUp_BCONV" in ln] and totalw == total and nw == n - 1
 
 
