@@ -162,6 +162,11 @@ def measure_second_op(opn, streams, batch, steps, device, extra=None):
     if tail is not None:
         tail.close()
     ms = dt / steps * 1e3
+    if opn in ELEMENTWISE_LP:   # the single-stage element-wise ops: operands + results, no key
+        alg = ELEMENTWISE_LP[opn] * ELL * LP
+        return {"workload": f"{CFG} {opn} L={L} l={ELL}", "ops_per_s": steps / dt, "ops_per_s_min_median_max": [steps / max(dts), steps / dt, steps / min(dts)], "regions": 3,
+                "us_per_op": ms * 1e3, "steps": steps, "streams": streams, "batch": batch, "launches_per_op": launches, "algorithmic_bytes": alg,
+                "achieved_gbs": alg / (ms * 1e-3) / 1e9, "frac_of_hbm_peak": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
     alg = HMULT_ALG_BYTES if opn == "hmult" else HROTATE_ALG_BYTES
     evk_once = alg - EVK_BYTES * (1 - 1 / batch)
     return {"workload": f"{CFG} {opn} L={L} l={ELL} alpha={ALPHA}" + (" (BASELINE configs[3]: automorphism + full hybrid key switch)" if opn == "hrotate" else ""),
@@ -252,9 +257,13 @@ def roofline_op(batched_rows, batch, rin):
             "frac": alg / (us[0] * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": pmc,
             "traffic_frac_of_peak": None if not pmc else pmc / (us[0] * 1e-6) / 1e9 / HBM_PEAK_GBS,
             "valu_wave_instructions_per_op": rin.get("ntt_ip_valu_per_op"), "source": rin.get("whole_op_source"),
-            "note": "timed alone on the chip (stage_us_per_op_batched); `bound`: VALU issue — per-kernel SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES, wait and LDS counters of the batched op at this round's HEAD: profiles/r05_pmc_kernels_batch10.txt"}
+            "note": "timed alone on the chip (stage_us_per_op_batched); `bound`: VALU issue — per-kernel SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES, wait and LDS counters of the batched op at this round's HEAD: profiles/r06_pmc_kernels_batch10.txt"}
 
 
+# limb-polys per level of the reference's single-stage ops (src/Operation.cpp:1114-1176 HADD, :1455-1523 PMULT, :1618-1680 PADD): every operand read
+# once, every result written once — hadd: two ciphertexts in, one out; pmult: a ciphertext and a plaintext in, a ciphertext out; padd: the
+# plaintext joins c0, c1 is carried over
+ELEMENTWISE_LP = {"hadd": 6, "pmult": 5, "padd": 5}
 DEFAULT_BATCH = 10
 # which arithmetic back-end the context chose for the chain it was given (hm_get_counter "arith")
 MODULI_NOTE = {
@@ -670,6 +679,9 @@ def main():
                 out["generic_chain"] = g
                 out["generic_chain_ops_per_s"] = g["ops_per_s"]
                 out["generic_chain_frac_evk_once"] = g["frac_evk_once"]
+        if world == 1 and opn == "hmult":   # the reference's other three ops (one element-wise stage each): rate and fraction of the HBM peak, same launch shape
+            # (50 launches per instance: a launch of ten element-wise ops is ~15 us)
+            out["elementwise"] = {o_: measure_second_op(o_, streams, batch, 50 * streams * batch, local_rank) for o_ in ("hadd", "pmult", "padd")}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(opn)
         try:  # the reference's own answer for the same command line, from the build's cycle model (backend = sim): host only

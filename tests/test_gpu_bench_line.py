@@ -23,8 +23,9 @@ def test_bench_line_contract():
     assert d["value"] > 1000 and abs(d["value"] * d["ms_per_step"] * 1e-3 - 1.0) < 1e-6
     cfg = d["config"]
     assert "config_4.cfg hmult L=45 l=35 alpha=15" in cfg["workload"] and "model" not in cfg
-    assert cfg["batch"] * cfg["streams"] == 20 and cfg["moduli"].startswith("mont32")
-    assert set(os.path.basename(p) for p in d["hip_library"]) >= {"libhomulator_hip.so", "libhm_m32.so"}
+    forced_generic = os.environ.get("HOMULATOR_ARITH") == "generic"   # (the suite also runs with every context forced onto the generic back-end)
+    assert cfg["batch"] * cfg["streams"] == 20 and cfg["moduli"].startswith("generic" if forced_generic else "mont32")
+    assert set(os.path.basename(p) for p in d["hip_library"]) >= {"libhomulator_hip.so", "libhm_gen.so" if forced_generic else "libhm_m32.so"}
     r = d["roofline"]
     assert r["contract_bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.05 < r["frac"] < 1.0
@@ -37,7 +38,8 @@ def test_bench_line_contract():
     assert d["value"] / c["value"] > 50          # (a reported baseline, not the target)
     assert d["ntt_cross_xcd"] == {"after_sweep": 0, "after_timed_region": 0, "ntt_fused_small": 96}
     assert d["hrotate"]["ops_per_s"] > 1000 and d["hrotate"]["steps"] == 20
-    assert d["generic_chain_ops_per_s"] > 1000 and 0 < d["generic_chain_frac_evk_once"] < 1 and d["generic_chain"]["moduli"].startswith("generic")
+    if not forced_generic:   # (the leg exists beside a headline on the default back-end)
+        assert d["generic_chain_ops_per_s"] > 1000 and 0 < d["generic_chain_frac_evk_once"] < 1 and d["generic_chain"]["moduli"].startswith("generic")
     assert d["single_stream_ops_per_s"] > 1000 and d["sustained_ops_per_s"] > 1000
     assert d["measured_hbm"] and d["measured_hbm"]["batch"] == cfg["batch"] and d["measured_hbm"]["instances"] == cfg["streams"]
     assert d["roofline_op"] and d["roofline_op"]["frac"] > 0.1
@@ -47,10 +49,13 @@ def test_bench_line_contract():
     assert r["op_measured_frac"] is None or abs(r["op_measured_frac"] - d["measured_hbm"]["frac_of_peak"]) < 1e-12
     lo, med, hi = d["value_min_median_max"]
     assert lo <= med <= hi and lo <= d["value"] <= hi
-    for leg in (d["hrotate"], d["generic_chain"]):
+    for leg in (d["hrotate"],) if forced_generic else (d["hrotate"], d["generic_chain"]):
         a, b_, c_ = leg["ops_per_s_min_median_max"]
         assert a <= b_ <= c_ and leg["ops_per_s"] == b_ and leg["regions"] == 3
     assert "__int128" in c["note"]
+    for o_ in ("hadd", "pmult", "padd"):   # the reference's single-stage ops: timed in the driver's line too (streaming kernels: a good part of the HBM peak)
+        e = d["elementwise"][o_]
+        assert e["ops_per_s"] > 10000 and 0.2 < e["frac_of_hbm_peak"] < 1.0 and e["launches_per_op"] >= 1
 
 
 def test_plain_multi_gpu_command_launches_its_own_ranks():
