@@ -273,11 +273,24 @@ template <int N_IN, int LOG1, bool MIX, bool PACKED>
 __global__ void __launch_bounds__((1 << HM_TL_COL) / HM_EPT) __attribute__((amdgpu_waves_per_eu(HM_NTT_MIN_WAVES))) k_bconv_col(HmBcolArgs a) {
   hm_bconv_col_body<N_IN, LOG1, 1, MIX, PACKED>(a);
 }
+// Two outputs wait in registers beside the split inputs.  Round 6: without the spilled scalar registers (which lived in vector-register lanes) the
+// 15-limb form needs 136 VGPRs; held to 128 (8 of them in scratch: four 8-byte loads and stores per thread) it runs four workgroups per CU instead
+// of three: +0.4 % on the op, +0.7 % one at a time (gpurun_out/r06_bcol4_ab: three interleaved rounds, every round ahead).  The two-group form
+// (16 .. 32 limbs: 149 VGPRs) keeps three — the launch bound cannot depend on a template parameter, hence a kernel template of its own.
 #ifndef HM_BCOL2_WAVES
-#define HM_BCOL2_WAVES 3   // two outputs wait in registers beside the split inputs: 168 VGPRs, three workgroups per CU
+#define HM_BCOL2_WAVES 4
+#endif
+#ifndef HM_BCOL2_WAVES_WIDE
+#define HM_BCOL2_WAVES_WIDE 3
 #endif
 template <int N_IN, int LOG1, bool MIX, bool PACKED>
 __global__ void __launch_bounds__((1 << HM_TL_COL) / HM_EPT) __attribute__((amdgpu_waves_per_eu(HM_BCOL2_WAVES))) k_bconv_col2(HmBcolArgs a) {
+  static_assert(N_IN <= HM_BCOL_ONE_GROUP, "digits of 16 .. 32 limbs: k_bconv_col2w");
+  hm_bconv_col_body<N_IN, LOG1, 2, MIX, PACKED>(a);
+}
+template <int N_IN, int LOG1, bool MIX, bool PACKED>
+__global__ void __launch_bounds__((1 << HM_TL_COL) / HM_EPT) __attribute__((amdgpu_waves_per_eu(HM_BCOL2_WAVES_WIDE))) k_bconv_col2w(HmBcolArgs a) {
+  static_assert(N_IN > HM_BCOL_ONE_GROUP, "digits of up to 15 limbs: k_bconv_col2");
   hm_bconv_col_body<N_IN, LOG1, 2, MIX, PACKED>(a);
 }
 

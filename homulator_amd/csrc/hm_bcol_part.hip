@@ -13,7 +13,11 @@
 #define HM_PASTE2(a, b) a##b
 #define HM_PASTE(a, b) HM_PASTE2(a, b)
 #define HM_K(n) k_bconv_col<n, HM_PART_LOG1, HM_PART_MIX, HM_PART_PACKED>,
+#if HM_PART_WIDE
+#define HM_K2(n) k_bconv_col2w<n, HM_PART_LOG1, HM_PART_MIX, HM_PART_PACKED>,
+#else
 #define HM_K2(n) k_bconv_col2<n, HM_PART_LOG1, HM_PART_MIX, HM_PART_PACKED>,
+#endif
 #if HM_PART_WIDE
 #define HM_ALL(K) K(16) K(17) K(18) K(19) K(20) K(21) K(22) K(23) K(24) K(25) K(26) K(27) K(28) K(29) K(30) K(31) K(32)
 #define HM_FIRST 16

@@ -58,23 +58,27 @@ def test_bench_line_contract():
         assert e["ops_per_s"] > 10000 and 0.2 < e["frac_of_hbm_peak"] < 1.0 and e["launches_per_op"] >= 1
 
 
-def test_plain_multi_gpu_command_launches_its_own_ranks():
+@pytest.mark.parametrize("n", [2, 4])
+def test_plain_multi_gpu_command_launches_its_own_ranks(n):
     """`python3 bench.py --gpus 2 --steps 8 --warmup 2` started PLAINLY (no torch.distributed.run, WORLD_SIZE unset): bench.py spawns the two
     ranks itself (fresh child processes; the parent never touches the GPU), relays rank 0's one JSON line and returns 0.  Rehearsed on the one
     GPU over gloo (HOMULATOR_DIST_BACKEND=gloo puts both ranks on device 0; RCCL refuses two ranks per device).  The line carries the sharded
     NTT sweep per rank and what the HIP library's communicator reports."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["HOMULATOR_DIST_BACKEND"] = "gloo"
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "2"], env=env, capture_output=True, text=True, timeout=900)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "8", "--warmup", "2"], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, lines
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 8 and d["value"] > 0 and d["config"]["transport"] == "gloo-rehearsal"
+    assert d["n_gpus"] == n and d["steps"] == 8 and d["value"] > 0 and d["config"]["transport"] == "gloo-rehearsal"
     sh = d["roofline"]["sharded"]
-    assert sh["limbs_per_rank"] == [25, 25] and len(sh["us_per_rank"]) == 2 and sh["aggregate_gbs"] > 0 and all(0 < f < 1 for f in sh["frac_per_gpu"])
-    assert d["roofline"]["algorithmic_bytes_per_launch"] == 25 * 1048576
-    assert d["comm"] == {"world": 2, "ranks_seen": 2, "transport": "external"}
+    own = [len([e for e in range(50) if e % n == r]) for r in range(n)]   # limb e of the extended basis -> rank e % n
+    assert sh["limbs_per_rank"] == own and len(sh["us_per_rank"]) == n and sh["aggregate_gbs"] > 0 and all(0 < f < 1 for f in sh["frac_per_gpu"])
+    assert d["roofline"]["algorithmic_bytes_per_launch"] == own[0] * 1048576
+    assert d["comm"] == {"world": n, "ranks_seen": n, "transport": "external"}
+    if n > 2:
+        return
     # a rank that fails takes the job down with a non-zero exit code instead of leaving its peer in a collective
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "2", "--op", "nonsense"], env=env, capture_output=True, text=True, timeout=300)
     assert bad.returncode != 0
