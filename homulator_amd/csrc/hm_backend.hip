@@ -653,6 +653,7 @@ struct hm_ctx {
   // limb-polys, slower from 128 (tools/ntt_fused_small_ab.py); 0 = off
   uint32_t fused_small = 96;
   uint32_t bcol_outs = 0;   // output limbs per workgroup of the fused conversion + first pass (1 | 2; 0 = by launch size)
+  uint32_t bconv_blocks = 3072;   // k_bconv: blocks a launch should have at least before its outputs are cut into fewer, larger chunks (a block re-reads its inputs per chunk)
   uint32_t bcol_merge = 1;  // small launches: the digits of a call run ONE kernel, the widest digit's (bconv_col_launch)
   // hm_replicate_limbs of a list with ONE owner (the rescale residues of a batch) and at least this many bytes, on >= 4 ranks: the owner scatters
   // one chunk to every peer and the peers exchange their chunks (each link carries 2 / (W - 1) of the list instead of all of it); 0 = never
@@ -824,6 +825,7 @@ extern "C" hm_status hm_create(hm_ctx **out, const hm_params *p) {
   if (const char *e = getenv("HOMULATOR_NIP_SMALL")) cc->nip_small = (uint32_t)std::max(0, atoi(e));
   if (const char *e = getenv("HOMULATOR_BCOL_OUTS")) cc->bcol_outs = (uint32_t)std::min(2, std::max(0, atoi(e)));
   if (const char *e = getenv("HOMULATOR_BCOL_MERGE")) cc->bcol_merge = atoi(e) != 0;
+  if (const char *e = getenv("HOMULATOR_BCONV_BLOCKS")) cc->bconv_blocks = (uint32_t)std::max(1, atoi(e));
   HM_HIP(nullptr, hipHostMalloc(reinterpret_cast<void **>(&cc->err_host), 64, hipHostMallocMapped));
   memset(cc->err_host, 0, 64);
   HM_HIP(nullptr, hipHostGetDevicePointer(reinterpret_cast<void **>(&cc->err_dev), cc->err_host, 0));
@@ -991,6 +993,7 @@ extern "C" hm_status hm_set_option(hm_ctx *c, const char *name, uint64_t value) 
     return HM_OK;
   }
   if (!strcmp(name, "bconv_col_merge")) { c->bcol_merge = value != 0; return HM_OK; }
+  if (!strcmp(name, "bconv_blocks")) { c->bconv_blocks = (uint32_t)std::max<uint64_t>(1, value); return HM_OK; }
   if (!strcmp(name, "bconv_col_outs")) { if (value > 2) return fail(c, HM_ERR_ARG, "hm_set_option: bconv_col_outs is 0 (by launch size), 1 or 2");
       c->bcol_outs = (uint32_t)value; return HM_OK; }
   if (!strcmp(name, "replicate_split_bytes")) {
@@ -1902,7 +1905,7 @@ extern "C" hm_status hm_bconv_batch(hm_ctx *c, const hm_bconv_desc *descs, uint3
       // output limbs per block: a block re-reads its N_IN input limbs for every chunk, so the chunk should be as large
       // as the launch allows while leaving >= ~4 rounds of blocks for the chip (3 blocks of 256 threads per CU)
       const uint32_t xb = std::max(1u, (1u << logN) / (HM_BCONV_THREADS * HM_BCONV_CPT));
-      const uint32_t want = 3072;
+      const uint32_t want = c->bconv_blocks;
       uint32_t nchunk = std::max<uint32_t>(1, (want + xb * a.n_prob - 1) / (xb * a.n_prob));
       nchunk = std::min(nchunk, (max_out + HM_BCONV_CHUNK / 2 - 1) / std::max(1, HM_BCONV_CHUNK / 2));  // chunks of >= 4 outputs
       nchunk = std::max<uint32_t>(1, nchunk);
