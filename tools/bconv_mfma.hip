@@ -120,12 +120,22 @@ __global__ void __launch_bounds__(64 * WAVES) k_bconv_mfma(const MfmaProb *probs
 #pragma unroll
       for (int s = 0; s < STEPS; ++s) {
         const v4i af = lds_a[(pr * STEPS + s) * 64 + lane];
+#if defined(ABL_NO_MFMA)   // timing-only ablations (wrong results): where the time goes
+        acc0[s] += af[0] ^ bf0[s][1]; acc1[s] += af[1] ^ bf1[s][2];
+#else
         acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bf0[s], acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bf1[s], acc1, 0, 0, 0);
+#endif
       }
       const uint32_t t = 2 * pr + kh;
       const uint64_t q = lds_q[2 * t], ol = lds_q[2 * t + 1];
+#if defined(ABL_NO_RECOMB)
+      uint64_t r0 = 0, r1 = 0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { r0 ^= (uint32_t)acc0[r]; r1 += (uint32_t)acc1[r]; }
+#else
       const uint64_t r0 = recombine(acc0, klo, khi, q), r1 = recombine(acc1, klo, khi, q);
+#endif
       if (ol != 0xFFFFFFFFu) {   // (an odd basis: the last pair's second output does not exist)
         ulonglong2 r = {r0, r1};
         *(GlobalV2)(uintptr_t)(p.out + (size_t)ol * N + x0) = r;
