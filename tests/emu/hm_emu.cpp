@@ -91,6 +91,37 @@ static void emu_bconv_n(Emu &e, HmBconvProb &p, const std::vector<uint64_t> &tb,
   }
 }
 
+// round 6: the arithmetic of the two-group conversion of k_bconv_col (digits of 16 .. 32 limbs, hm_bcol_units_wide): per output and coefficient the
+// 128-bit sums of the group [0, 16) and of the group [16, n_in) (hm_bconv_cols: carry-free split-30 columns, recombined per group), added, ONE
+// Montgomery reduction for all n_in terms (hm_redc_wide<N_IN>).  Same table format as the kernel (rows of 8-entry groups, Montgomery form,
+// split-30 packed); packed != 0: the inputs arrive in the split-30 packed form.
+template <int N_IN>
+static void emu_bconv_wide_n(Emu &e, const uint32_t *out_ids, uint32_t n_out, const std::vector<uint64_t> &tb, const uint64_t *in, uint64_t *out, int packed) {
+  constexpr int ROWS = (N_IN + 7) / 8, C1 = N_IN - 16;
+  const uint32_t N = e.P.N;
+  std::vector<HmRow8> rows((size_t)n_out * ROWS);
+  for (auto &r : rows) for (auto &w : r.w) w = 0;
+  for (uint32_t t = 0; t < n_out; ++t)
+    for (int i = 0; i < N_IN; ++i) rows[(size_t)t * ROWS + i / 8].w[i % 8] = hm_bconv_entry(tb[(size_t)i * n_out + t], e.P.modc[out_ids[t]]);
+  for (uint32_t t = 0; t < n_out; ++t) {
+    const HmMod &m = e.P.modc[out_ids[t]];
+    HmRow8 r0[2], r1[(C1 > 0 ? C1 + 7 : 8) / 8];
+    r0[0] = rows[(size_t)t * ROWS]; r0[1] = rows[(size_t)t * ROWS + 1];
+    for (int g = 0; g < (C1 + 7) / 8; ++g) r1[g] = rows[(size_t)t * ROWS + 2 + g];
+    for (uint32_t x = 0; x < N; ++x) {
+      uint32_t yl[16], yh[16], zl[C1 > 0 ? C1 : 1] = {0}, zh[C1 > 0 ? C1 : 1] = {0};
+      for (int i = 0; i < N_IN; ++i) {
+        const uint64_t v = in[(size_t)i * N + x];
+        const uint32_t lo = packed ? (uint32_t)v : (uint32_t)v & 0x3FFFFFFFu, hi = packed ? (uint32_t)(v >> 32) : (uint32_t)(v >> 30);
+        if (i < 16) { yl[i] = lo; yh[i] = hi; } else { zl[i - 16] = lo; zh[i - 16] = hi; }
+      }
+      hm_u128 acc = hm_bconv_cols<16>(yl, yh, r0);
+      if constexpr (C1 > 0) acc += hm_bconv_cols<C1>(zl, zh, r1);
+      out[(size_t)t * N + x] = hm_redc_wide<N_IN>(acc, m);
+    }
+  }
+}
+
 extern "C" {
 // q == nullptr: the default chain; otherwise a caller-chosen one (q: L moduli, p: K special moduli; primes = 1 mod 2N below 2^60).
 // Returns nullptr if the chain does not fit this build's arithmetic.
@@ -240,6 +271,19 @@ void emu_bconv_form(void *h, const uint32_t *in_ids, uint32_t n_in, const uint32
     HM_CASE(25) HM_CASE(26) HM_CASE(27) HM_CASE(28) HM_CASE(29) HM_CASE(30) HM_CASE(31) HM_CASE(32)
 #undef HM_CASE
   }
+}
+int emu_bconv_two_groups(void *h, const uint32_t *in_ids, uint32_t n_in, const uint32_t *out_ids, uint32_t n_out, const uint64_t *in, uint64_t *out, int packed) {
+  Emu &e = *(Emu *)h;
+  std::vector<uint64_t> qh(n_in), tb((size_t)n_in * n_out);
+  e.P.bconv_consts(in_ids, n_in, out_ids, n_out, qh.data(), tb.data());
+  switch (n_in) {
+#define HM_CASE(n) case n: emu_bconv_wide_n<n>(e, out_ids, n_out, tb, in, out, packed); break;
+    HM_CASE(16) HM_CASE(17) HM_CASE(18) HM_CASE(19) HM_CASE(20) HM_CASE(21) HM_CASE(22) HM_CASE(23) HM_CASE(24)
+    HM_CASE(25) HM_CASE(26) HM_CASE(27) HM_CASE(28) HM_CASE(29) HM_CASE(30) HM_CASE(31) HM_CASE(32)
+#undef HM_CASE
+  default: return 1;
+  }
+  return 0;
 }
 void emu_bconv_consts(void *h, const uint32_t *in_ids, uint32_t n_in, const uint32_t *out_ids, uint32_t n_out,
                       uint64_t *qh, uint64_t *tb) {

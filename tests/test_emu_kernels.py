@@ -478,3 +478,32 @@ def test_emu_generic_butterfly_and_reduction_ranges(emu_gen):
                         else:
                             assert a % q == (x + y) % q and b % q == (x - y) * w % q, (mod, kind, x, y, w)
         emu.emu_destroy(h)
+
+
+@pytest.mark.parametrize("n_in", [16, 17, 24, 28, 32])
+def test_emu_two_group_conversion_of_wide_digits(emu, n_in):
+    """round 6: the arithmetic of the conversion inside the first pass for digits of 16 .. 32 limbs (k_bconv_col's two input groups: hm_bconv_cols
+    per group, one hm_redc_wide over all terms) on the CPU emulator, on both arithmetic builds: random inputs, every input at q_i - 1 (the 128-bit
+    sums at their largest: two conditional subtractions above 16 terms), zeros and ones; plain and split-30 packed inputs; against the oracle's
+    conversion"""
+    emu.emu_bconv_two_groups.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int]
+    emu.emu_bconv_two_groups.restype = C.c_int
+    logN, n_out = 13, 5
+    o = emu.oracle(logN, n_in, n_out)
+    h = emu.create(o)
+    try:
+        in_ids, out_ids = list(range(n_in)), list(range(n_in, n_in + n_out))
+        x = o.fill_uniform(in_ids, 9)
+        for r, m in enumerate(in_ids):
+            x[r, :8] = o.moduli[m] - 1
+            x[r, 8:10] = [0, 1]
+        x[n_in - 1, 10] = o.moduli[in_ids[-1]] - 1
+        want = o.bconv_matmul(in_ids, out_ids, x)
+        ii, oi = np.array(in_ids, dtype=np.uint32), np.array(out_ids, dtype=np.uint32)
+        pk = (x & np.uint64(0x3FFFFFFF)) | ((x >> np.uint64(30)) << np.uint64(32))
+        for src, packed in ((x, 0), (pk, 1)):
+            out = np.zeros((n_out, o.N), dtype=np.uint64)
+            assert emu.emu_bconv_two_groups(h, p(ii), n_in, p(oi), n_out, p(np.ascontiguousarray(src)), p(out), packed) == 0
+            assert np.array_equal(out, want), packed
+    finally:
+        emu.emu_destroy(h)
