@@ -653,7 +653,8 @@ struct hm_ctx {
   // limb-polys, slower from 128 (tools/ntt_fused_small_ab.py); 0 = off
   uint32_t fused_small = 96;
   uint32_t bcol_outs = 0;   // output limbs per workgroup of the fused conversion + first pass (1 | 2; 0 = by launch size)
-  uint32_t bconv_blocks = 3072;   // k_bconv: blocks a launch should have at least before its outputs are cut into fewer, larger chunks (a block re-reads its inputs per chunk)
+  // k_bconv: blocks a launch should have at least before its outputs are cut into fewer, larger chunks (a block re-reads its inputs per chunk)
+  uint32_t bconv_blocks = 3072;
   uint32_t bcol_merge = 1;  // small launches: the digits of a call run ONE kernel, the widest digit's (bconv_col_launch)
   // hm_replicate_limbs of a list with ONE owner (the rescale residues of a batch) and at least this many bytes, on >= 4 ranks: the owner scatters
   // one chunk to every peer and the peers exchange their chunks (each link carries 2 / (W - 1) of the list instead of all of it); 0 = never
@@ -1942,28 +1943,34 @@ static hm_status bconv_col_launch(hm_ctx *c, const hm_bconv_desc *descs, uint32_
   HM_HIP(c, hipSetDevice(c->device));
   // output limbs per workgroup: two share the loaded and split inputs (+2 % hmult/s at batch 10), but halve the workgroups of a launch that
   // fills the chip only once or twice (one op at a time: -2 %): by launch size unless the option says otherwise
+  // Small calls whose digits differ in width run as ONE launch of the widest digit's kernel (below) — and then with two outputs per workgroup: 920
+  // workgroups on the chip's 1 024 slots (one round) where one output per workgroup made 1 840 (1.8 rounds): one op at a time +1.3 % on top of
+  // the merge (gpurun_out: tools/r06_nout_ab.sh).  A small call of ONE width keeps one output per workgroup (level since the four-wave kernels).
   uint32_t NOUT = c->bcol_outs;
-  if (!NOUT) {
-    size_t wgs = 0;
-    for (uint32_t pi = 0; pi < n_desc; ++pi) wgs += (size_t)descs[pi].n_out * n_tiles;
-    NOUT = wgs > 4096 ? 2 : 1;
+  size_t wgsAll = 0;
+  bool widths[2][HM_BCONV_MAX_IN + 1] = {};
+  uint32_t nWidths = 0;
+  for (uint32_t pi = 0; pi < n_desc; ++pi) {
+    wgsAll += (size_t)descs[pi].n_out * n_tiles;
+    bool &w = widths[descs[pi].in_packed ? 1 : 0][std::min<uint32_t>(descs[pi].n_in, HM_BCONV_MAX_IN)];
+    nWidths += !w;
+    w = true;
   }
+  const bool mayMerge = c->bcol_merge && !mix && wgsAll <= 4096 && nWidths > 1;
+  if (!NOUT) NOUT = wgsAll > 4096 || mayMerge ? 2 : 1;
   std::map<uint32_t, std::vector<HmBcolProb>> byIn;   // key: n_in, + 256 for conversions whose inputs are stored packed (kernels of their own)
   bool farApart = false;
   // Round 6, small launches (one op at a time, a rank's share of a sharded op): digits of different width are launches of different kernels, one
   // behind the other, and each leaves the chip part empty — hmult 45/35/15: 1 120 workgroups of <15> on 1 024 slots (a second, nearly empty
   // round: 40.7 us) and then 720 of <5> (19.5 us).  When the whole call is small, the narrower digits run the WIDEST digit's kernel with zero
   // table columns for the inputs they do not have (the padded inputs re-read the digit's first limb: exact zeros are added): ONE launch of
-  // 1 840 workgroups.  More multiply-adds for the narrow digit, fewer rounds for the launch; option "bconv_col_merge" (default 1; 0 = off).
+  // 1 840 workgroups (920 with two outputs each).  More multiply-adds for the narrow digit, fewer rounds for the launch; option "bconv_col_merge"
+  // (default 1; 0 = off).
   std::vector<uint32_t> kernelNin(n_desc);
   {
     uint32_t widest[2] = {0, 0};
-    size_t wgs = 0;
-    for (uint32_t pi = 0; pi < n_desc; ++pi) {
-      widest[descs[pi].in_packed ? 1 : 0] = std::max(widest[descs[pi].in_packed ? 1 : 0], descs[pi].n_in);
-      wgs += (size_t)descs[pi].n_out * n_tiles;
-    }
-    const bool merge = c->bcol_merge && NOUT == 1 && !mix && wgs <= 4096;
+    for (uint32_t pi = 0; pi < n_desc; ++pi) widest[descs[pi].in_packed ? 1 : 0] = std::max(widest[descs[pi].in_packed ? 1 : 0], descs[pi].n_in);
+    const bool merge = mayMerge;
     for (uint32_t pi = 0; pi < n_desc; ++pi) {
       const uint32_t w = widest[descs[pi].in_packed ? 1 : 0];
       // (a digit runs the widest digit's kernel only inside one family: up to 15 limbs, or two input groups; and not for more than four times its own work)
@@ -2016,7 +2023,8 @@ static hm_status bconv_col_launch(hm_ctx *c, const hm_bconv_desc *descs, uint32_
       if (((uint64_t)(hi - lo) + 1) << (c->P.logN + 3) > (1ull << 32)) { farApart = true; break; }   // inputs more than 4 GiB apart: the fallback below
       p.in_base = d.in + (size_t)lo * c->P.N;
       for (uint32_t i = 0; i < d.n_in; ++i) p.in_off[i] = (p.in_limb[i] - lo) << (c->P.logN + 3);
-      for (uint32_t i = d.n_in; i < kn; ++i) { p.in_limb[i] = p.in_limb[0]; p.in_off[i] = p.in_off[0]; }   // padded inputs: a valid limb-poly, zero table columns
+      // padded inputs: a valid limb-poly, zero table columns
+      for (uint32_t i = d.n_in; i < kn; ++i) { p.in_limb[i] = p.in_limb[0]; p.in_off[i] = p.in_off[0]; }
     }
     for (uint32_t t = 0; t < d.n_out; ++t) { p.out_limb[t] = limb_at(d.out_limbs, t); p.out_mod[t] = d.out_ids[t]; }
     if (mix) {   // x = conv + k * mix before the first butterfly: constants in Shoup form, a device table cached by content
