@@ -694,3 +694,58 @@ def test_conversion_inputs_more_than_4_gib_apart():
         big.free()
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("logN,chain", [(16, "mont32"), (15, "survey")])
+@pytest.mark.parametrize("widths", [(15, 5), (9, 3), (4, 4, 2), (28, 17), (20, 6)])
+def test_digits_of_a_small_call_merged_into_one_launch(logN, chain, widths):
+    """round 6: a SMALL fused-conversion call whose digits differ in width runs ONE launch of the widest digit's kernel (the narrower digits
+    with zero table columns for the inputs they lack; two outputs per workgroup) instead of one launch per width (option bconv_col_merge).
+    Both forms, packed and plain inputs mixed, against each other and against the oracle: hm_ntt_inner_product with one conversion per
+    digit, every digit converted to the limbs outside itself.  (28, 17): the two-group family merges among itself; (20, 6): a wide and a
+    narrow digit stay two launches (one family per kernel)."""
+    ell = sum(widths)
+    L, K, N = ell, 3, 1 << logN
+    ctx, o, _ = make_env(logN, L, K, chain)
+    try:
+        ext = o.ext_ids(ell); E = len(ext); T = len(widths)
+        digits, lo = [], 0
+        for w in widths:
+            digits.append(list(range(lo, lo + w))); lo += w
+        own = o.fill_uniform(list(range(ell)), 5)
+        scaled = o.fill_uniform(list(range(ell)), 6)
+        scaled[0, :4] = o.moduli[0] - 1
+        pk = (scaled & np.uint64(0x3FFFFFFF)) | ((scaled >> np.uint64(30)) << np.uint64(32))
+        evk = np.stack([o.fill_uniform(ext, 100 + j) for j in range(T)])
+        plain, packed, ownb, evkb = ctx.from_host(scaled), ctx.from_host(pk), ctx.from_host(own), ctx.from_host(evk.reshape(-1, N))
+        hand, out = ctx.alloc(T * E), ctx.alloc(E)
+        xl, flags, hl, yl, mods = [], [], [], [], []
+        for t in range(E):
+            for j, dj in enumerate(digits):
+                isown = t in dj
+                xl.append(t if isown else 0); hl.append(j * E + t); flags.append(0 if isown else 1)
+            yl += [j * E + t for j in range(T)]
+            mods.append(ext[t])
+        X = []
+        for j, dj in enumerate(digits):
+            outs = [t for t in range(E) if t not in dj]
+            full = np.zeros((E, N), dtype=np.uint64)
+            full[outs] = o.ntt([ext[t] for t in outs], o.bconv_matmul(dj, [ext[t] for t in outs], scaled[dj]))
+            full[dj] = own[dj]
+            X.append(full)
+        want = np.zeros((E, N), dtype=np.uint64)
+        for j in range(T):
+            want = o.ewe(3, ext, want, None, o.ewe(0, ext, X[j], evk[j]))
+        got = {}
+        for merge in (0, 1):
+            for use_packed in (0, 1):
+                src = packed if use_packed else plain
+                conv = [(src, dj, dj, [j * E + t for t in range(E) if t not in dj], [ext[t] for t in range(E) if t not in dj], use_packed) for j, dj in enumerate(digits)]
+                ctx.set_option("bconv_col_merge", merge)
+                ctx.fill_uniform(out, ext, 3)
+                ctx.fill_uniform(hand, ext * T, 4)
+                ctx.ntt_inner_product(ownb, xl, flags, hand, hl, evkb, yl, out, list(range(E)), mods, T, 1, conv=conv)
+                got[merge, use_packed] = out.download()
+                assert np.array_equal(got[merge, use_packed], want), (merge, use_packed)
+    finally:
+        ctx.close()
