@@ -200,12 +200,24 @@ HM_HD void hm_gst2(uint64_t *g, uint32_t tile, int tid, int a, uint64_t v0, uint
 
 // LDS image of a tile: word index of coefficient (x, c), x = position inside the sub-transform, c = which sub-transform.
 // STRIDED: [x][c] with the C columns contiguous; CONTIG: [c][x].  Swizzles (bijections that keep word pairs together):
-//   CONTIG (256-point rows): bits 2..4 ^= x[7:5], bit 1 ^= x[5] — the middle round reads 16-byte units at a 256-byte
-//     stride (x = hi*32 + e*4 + ..) and the last one 32 contiguous bytes per lane: both become conflict-free;
+//   CONTIG (256-point rows): XORs of bits of x into bits 1..4 of the word index, every source bit above its target (so the map
+//     inverts).  An image lives inside one pass, so each pass takes the set that suits its accesses (SWZ):
+//       0  forward pass, 16 coefficients per thread: bits 2..4 ^= x[7:5], bit 1 ^= x[5] — the middle round reads 16-byte units at a
+//          256-byte stride (x = hi*32 + e*4 + ..) and the last one 32 contiguous bytes per lane: both conflict-free;
+//       1  inverse pass, 16 per thread: bit 1 ^= x[2], bit 2 ^= x[4] ^ x[5], bits 3, 4 ^= x[6], x[7].  The inverse pass WRITES the
+//          32-bytes-per-lane round first, and 16-byte writes are banked differently from reads (8 groups of 8 lanes over 32
+//          banks, against 4 groups of 16 over 64): under set 0 those writes were 2-way, 25 % of the pass's LDS cycles
+//          (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE of k_ntt_row<true, 0> in profiles/r05_pmc_*, r06_pmc_*);
+//       2  8 per thread (four radix-4 rounds), both directions: bit 1 ^= x[2], bits 2, 3 ^= x[4], x[5], bit 4 ^= x[5] ^ x[7]; set 0
+//          cost it 25 % (forward) and 36 % (inverse) extra LDS cycles.
+//     Sets 1 and 2 come from an exhaustive search over such XOR sets against the chip's banking rules (tools/lds_banks.py, which
+//     also reproduces the counters above): every read and write of every round is conflict-free.  (Set 1 serves the forward pass
+//     as well, but costs it two more registers: the generic transform x key kernel then spills.)
 //   STRIDED with 16 columns: row x swaps with its neighbour when x[2] is set (8 columns: two bits, 4 columns: three) —
 //     the last round's rows are 4 apart (x = 4 xr + e), i.e. 512 bytes with 16 columns: without the swizzle two lanes
 //     of a 16-lane group share a bank.
-template <int TL, int LOGR, bool STRIDED>
+// The index is XOR-linear in x: idx(a | b, c) = idx(a, c) ^ idx(b, 0) for a & b == 0 (hm_lds_at relies on it).
+template <int TL, int LOGR, bool STRIDED, int SWZ>
 HM_HD int hm_lds_idx(int x, int c) {
   if (STRIDED) {
     constexpr int LOGC = TL - LOGR;
@@ -214,7 +226,16 @@ HM_HD int hm_lds_idx(int x, int c) {
     return w;
   }
   int w = (c << LOGR) | x;
-  if (LOGR == 8) w ^= (((x >> 5) & 7) << 2) ^ (((x >> 5) & 1) << 1);
+  if (LOGR == 8) {
+#if defined(HM_ABL_OLD_SWIZZLE)
+    constexpr int S = 0;
+#else
+    constexpr int S = SWZ;
+#endif
+    if (S == 0) w ^= (((x >> 5) & 7) << 2) ^ (((x >> 5) & 1) << 1);
+    if (S == 1) w ^= ((x >> 1) & 2) ^ ((((x >> 4) ^ (x >> 5)) & 1) << 2) ^ (((x >> 6) & 3) << 3);
+    if (S == 2) w ^= ((x >> 1) & 2) ^ (((x >> 4) & 3) << 2) ^ ((((x >> 5) ^ (x >> 7)) & 1) << 4);
+  }
   return w;
 }
 

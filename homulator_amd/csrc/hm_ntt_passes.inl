@@ -95,6 +95,24 @@ struct HmRound {
       x = xb | (2 * h);
     }
   }
+  // the same, x split into the thread's part xb and the unit's part d (a constant after unrolling; xb & d == 0): the LDS index is
+  // XOR-linear in x, so hm_lds_at takes idx(xb, c) ^ idx(d, 0) — one index per group and thread, one XOR with a constant per unit
+  static HM_HD void unit_split(int tid, int a, int &i0, int &i1, int &xb, int &d, int &c) {
+    int hi;
+    if (PAIRED) {
+      const int v = a / E, e = a % E;
+      i0 = (2 * v) * E + e;
+      i1 = (2 * v + 1) * E + e;
+      coords(tid, 2 * v, c, hi, xb);
+      d = e << K;
+    } else {
+      const int u = a / (E / 2), h = a % (E / 2);
+      i0 = u * E + 2 * h;
+      i1 = i0 + 1;
+      coords(tid, 0, c, hi, xb);   // group u of a thread is XR / NG groups after its group 0: bits above the lane's
+      d = ((XR / NG * u) << NB) | 2 * h;
+    }
+  }
   static HM_HD uint32_t gidx(uint32_t tile, int x, int c) {
     if (STRIDED) return ((uint32_t)x << HM_ROW_LOG) + (tile << LOGC) + (uint32_t)c;
     return (tile << TL) + ((uint32_t)c << LOGR) + (uint32_t)x;
@@ -293,39 +311,45 @@ HM_HD void hm_ph_store_global(const HmNttState &st, int tid, uint64_t *g, uint32
   }
 }
 
-template <int TL, int LOGR, bool STRIDED, int R>
+// LDS word index of access unit (xb | d, c): see HmRound::unit_split.  INV: the pass's direction picks the swizzle (hm_lds_idx)
+template <int TL, int LOGR, bool STRIDED, bool INV>
+HM_HD int hm_lds_at(int xb, int d, int c) {
+  constexpr int SWZ = HM_EPT == 8 ? 2 : INV ? 1 : 0;
+  return hm_lds_idx<TL, LOGR, STRIDED, SWZ>(xb, c) ^ hm_lds_idx<TL, LOGR, STRIDED, SWZ>(d, 0);
+}
+template <int TL, int LOGR, bool STRIDED, int R, bool INV = false>
 HM_HD void hm_ph_load_lds(HmNttState &st, int tid, const uint64_t *lds) {
   using G = HmRound<TL, LOGR, STRIDED, R>;
 #pragma unroll
   for (int a = 0; a < HM_UNITS; ++a) {
-    int i0, i1, x, c;
-    G::unit(tid, a, i0, i1, x, c);
-    hm_ld2(lds + hm_lds_idx<TL, LOGR, STRIDED>(x, c), st.v[i0], st.v[i1]);
+    int i0, i1, xb, d, c;
+    G::unit_split(tid, a, i0, i1, xb, d, c);
+    hm_ld2(lds + hm_lds_at<TL, LOGR, STRIDED, INV>(xb, d, c), st.v[i0], st.v[i1]);
   }
 }
 // MODE 4 with the tile in LDS: x = tile + k * mix, the mix operand straight from global memory
-template <int TL, int LOGR, bool STRIDED, int R, int AUX = 0>
+template <int TL, int LOGR, bool STRIDED, int R, int AUX = 0, bool INV = false>
 HM_HD void hm_ph_load_lds_mix(HmNttState &st, int tid, const uint64_t *lds, uint32_t tile, uint64_t q, HmEpi ep) {
   using G = HmRound<TL, LOGR, STRIDED, R>;
 #pragma unroll
   for (int a = 0; a < HM_UNITS; ++a) {
-    int i0, i1, x, c;
-    G::unit(tid, a, i0, i1, x, c);
+    int i0, i1, xb, d, c;
+    G::unit_split(tid, a, i0, i1, xb, d, c);
     uint64_t p0, p1, b0, b1;
     hm_gld2<G, AUX>(ep.b, tile, tid, a, b0, b1);
-    hm_ld2(lds + hm_lds_idx<TL, LOGR, STRIDED>(x, c), p0, p1);
+    hm_ld2(lds + hm_lds_at<TL, LOGR, STRIDED, INV>(xb, d, c), p0, p1);
     st.v[i0] = hm_addmod(p0, hm_kmul(b0, ep.bk, q), q);
     st.v[i1] = hm_addmod(p1, hm_kmul(b1, ep.bk, q), q);
   }
 }
-template <int TL, int LOGR, bool STRIDED, int R>
+template <int TL, int LOGR, bool STRIDED, int R, bool INV = false>
 HM_HD void hm_ph_store_lds(const HmNttState &st, int tid, uint64_t *lds) {
   using G = HmRound<TL, LOGR, STRIDED, R>;
 #pragma unroll
   for (int a = 0; a < HM_UNITS; ++a) {
-    int i0, i1, x, c;
-    G::unit(tid, a, i0, i1, x, c);
-    hm_st2(lds + hm_lds_idx<TL, LOGR, STRIDED>(x, c), st.v[i0], st.v[i1]);
+    int i0, i1, xb, d, c;
+    G::unit_split(tid, a, i0, i1, xb, d, c);
+    hm_st2(lds + hm_lds_at<TL, LOGR, STRIDED, INV>(xb, d, c), st.v[i0], st.v[i1]);
   }
 }
 
@@ -422,22 +446,22 @@ HM_HD void hm_ntt_phase(HmNttState &st, int tid, uint64_t *lds, const uint64_t *
 #endif
       hm_ph_load_tw<TL, LOGR, STRIDED, r1, PS::shared(r1)>(st, tid, twl, s0, prefix0);
     }
-    hm_ph_store_lds<TL, LOGR, STRIDED, r0>(st, tid, lds);
+    hm_ph_store_lds<TL, LOGR, STRIDED, r0, INV>(st, tid, lds);
   } else if constexpr (PHASE < n) {   // a middle round
     constexpr int i = PHASE - 1, ri = PS::exec(i), rn = PS::exec(i + 1);
     if (!PS::fromLds(rn)) hm_ph_load_tw<TL, LOGR, STRIDED, rn, PS::shared(rn)>(st, tid, twl, s0, prefix0);   // next round's, a round ahead
     if (iTW == i + 1 && iTW >= 2) hm_ph_load_twist<TL, LOGR, STRIDED, (TWR >= 0 ? TWR : 0)>(st, tid, twist_tile);  // used in the next phase
     if (PS::fromLds(ri)) hm_ph_load_tw<TL, LOGR, STRIDED, ri, PS::shared(ri)>(st, tid, ltw, s0, prefix0);
-    hm_ph_load_lds<TL, LOGR, STRIDED, ri>(st, tid, lds);
+    hm_ph_load_lds<TL, LOGR, STRIDED, ri, INV>(st, tid, lds);
     hm_ph_compute<TL, LOGR, STRIDED, ri, INV>(st, q);
-    hm_ph_store_lds<TL, LOGR, STRIDED, ri>(st, tid, lds);
+    hm_ph_store_lds<TL, LOGR, STRIDED, ri, INV>(st, tid, lds);
   } else {                            // the last round
     constexpr int rl = PS::exec(n - 1);
     // fused epilogue (MODE 3) / register hand-over (MODE 5): the twist constants are dead before the last round's twiddles are
     // read from LDS (the other order keeps 12 more registers alive and spilled inside the one-launch transform)
     constexpr bool TWIST_FIRST = (MODE == 3 || MODE == 5) && !INV && rl == TWR && PS::fromLds(rl);
     if (PS::fromLds(rl) && !TWIST_FIRST) hm_ph_load_tw<TL, LOGR, STRIDED, rl, PS::shared(rl)>(st, tid, ltw, s0, prefix0);
-    hm_ph_load_lds<TL, LOGR, STRIDED, rl>(st, tid, lds);
+    hm_ph_load_lds<TL, LOGR, STRIDED, rl, INV>(st, tid, lds);
     if (!INV && rl == TWR) hm_ph_twist(st, q);
     if (TWIST_FIRST) {
 #if defined(__HIP_DEVICE_COMPILE__)
