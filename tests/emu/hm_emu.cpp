@@ -122,6 +122,18 @@ static void emu_bconv_wide_n(Emu &e, const uint32_t *out_ids, uint32_t n_out, co
   }
 }
 
+// the 256-point ROW pass's LDS image as the kernels index it, for tools/lds_banks.py's bank model (tests/test_emu_kernels.py pins the
+// model to these): the LDS word of access unit a of thread tid in round R (ept = 16 / 8: geometry; inverse: the pass's direction)
+template <int R> static int row_unit16(int tid, int a, bool inv) {
+  int i0, i1, xb, d, c;
+  hm16::HmRound<12, 8, false, R>::unit_split(tid, a, i0, i1, xb, d, c);
+  return inv ? hm16::hm_lds_at<12, 8, false, true>(xb, d, c) : hm16::hm_lds_at<12, 8, false, false>(xb, d, c);
+}
+template <int R> static int row_unit8(int tid, int a, bool inv) {
+  int i0, i1, xb, d, c;
+  hm8::HmRound<12, 8, false, R>::unit_split(tid, a, i0, i1, xb, d, c);
+  return inv ? hm8::hm_lds_at<12, 8, false, true>(xb, d, c) : hm8::hm_lds_at<12, 8, false, false>(xb, d, c);
+}
 extern "C" {
 // q == nullptr: the default chain; otherwise a caller-chosen one (q: L moduli, p: K special moduli; primes = 1 mod 2N below 2^60).
 // Returns nullptr if the chain does not fit this build's arithmetic.
@@ -333,5 +345,9 @@ void emu_bfly(void *h, uint32_t mod, int kind, uint64_t *X, uint64_t *Y, uint64_
   else if (kind == 1) hm_bfly_fwd_k<1>(*X, *Y, wt, m);
   else if (kind == 2) hm_bfly_fwd_k<2>(*X, *Y, wt, m);
   else hm_bfly_inv(*X, *Y, wt, m);
+}
+int emu_row_lds_word(int ept, int R, int tid, int a, int inverse) {
+  if (ept == 16) return R == 0 ? row_unit16<0>(tid, a, inverse) : R == 1 ? row_unit16<1>(tid, a, inverse) : row_unit16<2>(tid, a, inverse);
+  return R == 0 ? row_unit8<0>(tid, a, inverse) : R == 1 ? row_unit8<1>(tid, a, inverse) : R == 2 ? row_unit8<2>(tid, a, inverse) : row_unit8<3>(tid, a, inverse);
 }
 }

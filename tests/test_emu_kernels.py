@@ -507,3 +507,30 @@ def test_emu_two_group_conversion_of_wide_digits(emu, n_in):
             assert np.array_equal(out, want), packed
     finally:
         emu.emu_destroy(h)
+
+
+@pytest.mark.parametrize("ept", [16, 8])
+def test_lds_bank_model_follows_the_kernels_and_finds_no_conflict(ept):
+    """tools/lds_banks.py restates the ROW pass's geometry and swizzles to count LDS bank conflicts by the chip's banking rules.  Pinned here to the
+    headers the kernels compile (every LDS word of every thread, round and access unit, both directions, through the emulator build), and the
+    claim itself: under the sets the passes use, no read or write of any round shares a bank inside a lane group — and the image is a bijection"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("lds_banks", os.path.join(HERE, "..", "tools", "lds_banks.py"))
+    lb = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lb)
+    emu = _load("libhm_emu.so")
+    emu.emu_row_lds_word.argtypes = [C.c_int] * 5
+    X, Cc = lb.coords(ept)
+    n, threads, units = X.shape
+    for inverse in (0, 1):
+        k = 2 if ept == 8 else inverse
+        swz = lb.xor_swizzle(lb.SETS[k])
+        for R in range(n):
+            W = swz((Cc[R] << lb.LOGR) | X[R], X[R])
+            got = np.array([[emu.emu_row_lds_word(ept, R, t, a, inverse) for a in range(units)] for t in range(threads)])
+            assert np.array_equal(W, got), (ept, R, inverse)
+        fwd, inv = lb.evaluate(ept, X, Cc, swz)
+        assert (inv if inverse else fwd)[0] == 0
+    # and the set the passes used up to round 5 costs what the counters of profiles/r06_pmc_kernels_batch10.txt say (inverse hm16: 25 %)
+    fwd, inv = lb.evaluate(ept, X, Cc, lb.xor_swizzle(lb.SETS[0]))
+    assert (fwd, inv) == (((0, 768), (256, 1024)) if ept == 16 else ((384, 1536), (640, 1792)))
