@@ -1134,7 +1134,8 @@ static hm_status check_mods(hm_ctx *c, const char *what, const uint32_t *m, uint
 // The kernels of a transform, by form: 0 = forward, 1 = forward with the fused epilogue (MODE 3), 2 = forward with the mix prologue and
 // the epilogue (MODE 4 + 3), 3 = inverse.  `first` / `second` = the two pass kernels in the order they run (forward: COL then ROW,
 // inverse: ROW then COL) in the 16-coefficient geometry; `first8` / `second8` = the same in the small-launch geometry and `one` = both
-// passes in one launch ([0] out of place: non-temporal input loads, [1] in place), N = 2^16 only.
+// passes in one launch ([0] out of place: non-temporal input loads, [1] in place); the small-launch forms exist where hm_caps says so
+// (N = 2^15 and 2^16).
 typedef void (*hm_ntt_kernel)(HmNttArgs);
 typedef void (*hm_ntt_one_kernel)(HmNttArgs, HmNttFusedArgs);
 struct HmNttKernels {

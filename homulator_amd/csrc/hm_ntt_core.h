@@ -246,7 +246,8 @@ HM_HD int hm_lds_idx(int x, int c) {
 //   hm8:   8 coefficients per thread, 512-thread workgroups on the same 4096-coefficient tiles, radix-4 rounds — twice the waves,
 //         half the serial work per wave: for launches of up to ~128 limb-polys (a single op's stages, the 50-limb sweep of the
 //         extended basis, the per-rank launches of a sharded run), which do not fill the chip with the wide geometry and are
-//         bound by the latency of ONE workgroup's pass.  N = 2^16 only (both passes of length 256).
+//         bound by the latency of ONE workgroup's pass.  N = 2^16 (both passes of length 256) and, since round 6, N = 2^15 (a 128-point
+//         COL pass: three radix-4 rounds + a radix-2 round).
 // ---------------------------------------------------------------------------------------------------
 #define HM_EPT 16                      // coefficients per thread
 #define HM_UNITS (HM_EPT / 2)          // 16-byte access units per thread

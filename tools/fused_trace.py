@@ -57,3 +57,20 @@ v = np.array(list(occ.values()))
 print(f"  placement: {len(occ)} (xcc, se, cu) slots used; workgroups per CU min {v.min()} median {int(np.median(v))} max {v.max()}")
 for r, tt in enumerate(rows):
     print(f"  rep {r}: span {us(tt[:, 5].max() - tt[:, 0].min()):6.2f}  wait median {np.median(us(tt[:, 4] - tt[:, 3])):5.2f}  first pass median {np.median(us(tt[:, 1] - tt[:, 0])):5.2f}  second {np.median(us(tt[:, 5] - tt[:, 4])):5.2f}")
+# where the slow first passes are: by XCD, by the workgroups sharing the CU, by tile (column slice) and by dispatch order
+fp = us(t[:, 1] - t[:, 0])
+tile = t[:, 7] & 0xFFFFFFFF
+print("  first pass by XCD (workgroups, median, p90, last end):  " + "  ".join(
+    f"x{x}: {int((xcc == x).sum())} {np.median(fp[xcc == x]):.1f} {np.percentile(fp[xcc == x], 90):.1f} {us(t[xcc == x, 5].max() - t0):.1f}" for x in range(8) if (xcc == x).any()))
+per_cu = np.array([occ[(x, s_, c)] for x, s_, c in zip(xcc, se, cu)])
+print("  first pass by workgroups on the CU:  " + "  ".join(f"{k}: n={int((per_cu == k).sum())} median {np.median(fp[per_cu == k]):.1f} p90 {np.percentile(fp[per_cu == k], 90):.1f}"
+      for k in np.unique(per_cu)))
+print("  first pass by tile (median):  " + " ".join(f"{np.median(fp[tile == k]):.1f}" for k in range(16)))
+order = np.argsort(t[:, 0])
+q = np.array_split(order, 8)
+print("  first pass by start order (eighths, median / p90):  " + "  ".join(f"{np.median(fp[i]):.1f}/{np.percentile(fp[i], 90):.1f}" for i in q))
+ents = np.unique(ent)
+lim = np.array([np.median(fp[ent == e]) for e in ents])
+print("  first pass by limb-poly (median of its 16 workgroups), in entry order:  " + " ".join(f"{x:.0f}" for x in lim))
+if os.environ.get("FUSED_TRACE_DUMP"):
+    np.save(os.environ["FUSED_TRACE_DUMP"], t)
