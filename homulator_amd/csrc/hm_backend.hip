@@ -94,13 +94,15 @@ __device__ __forceinline__ void hm_ntt_pass_run(const HmNttArgs &a, uint64_t *ld
   typedef const HmNttEntry __attribute__((address_space(4))) *ConstEntry;
   const ConstEntry entries = (ConstEntry)(uintptr_t)a.entry;
   if constexpr (MODE == 2) { sc.w = entries[entry].sc.w; sc.ws = entries[entry].sc.ws; ep.pack = entries[entry].pack; }
-  if constexpr (MODE == 3) {
+  if constexpr (MODE == 3 || MODE == 7) {
     const auto &en = entries[entry];
     sc.w = en.sc.w; sc.ws = en.sc.ws;
     ep.a = a.minuend + (size_t)lb.aux * N;
     ep.d = a.addend && en.alimb != HM_NTT_NONE ? a.addend + (size_t)en.alimb * N : nullptr;  // per limb-poly
     ep.dk.w = en.ak.w; ep.dk.ws = en.ak.ws;
+    if constexpr (MODE == 7) { ep.g = en.galois; ep.logN = a.logN; }
   }
+  if constexpr (MODE == 6) { ep.g = entries[entry].galois; ep.logN = a.logN; }
   if constexpr (MODE == 4) {
     const auto &en = entries[entry];
     ep.b = a.mix + (size_t)en.mixlimb * N;
@@ -135,7 +137,8 @@ __device__ __forceinline__ void hm_ntt_pass_body(const HmNttArgs &a) {
 #define HM_NTT_MIN_WAVES_COL HM_NTT_MIN_WAVES
 #endif
 // MODE 0: first pass / plain hand-off; 1: forward final; 2: inverse final (x scale); 3: forward final with the fused
-// epilogue; 4: forward first pass with the mix prologue
+// epilogue; 4: forward first pass with the mix prologue; 6: inverse first pass whose input is read through an automorphism; 7: MODE 3 with the
+// addend read through an automorphism (round 6: hrotate's automorphism launch folded into the ModUp INTT and the final add)
 template <int LOGR, bool INV, int MODE>
 __global__ void __launch_bounds__((1 << HM_TL_COL) / HM_EPT) __attribute__((amdgpu_waves_per_eu(HM_NTT_MIN_WAVES_COL))) k_ntt_col(HmNttArgs a) {
   hm_ntt_pass_body<LOGR, true, INV, MODE>(a);
@@ -336,7 +339,7 @@ __device__ __forceinline__ void hm_ntt_fused_body(const HmNttArgs &a, const HmNt
       ((unsigned long long)hm_xcc_id() << 32) | hw; f.trace[(size_t)blockIdx.x * 8 + 7] = ((unsigned long long)entry << 32) | tile; }
 #endif
   uint32_t *flag = reinterpret_cast<uint32_t *>(lds + (W1 > W2 ? W1 : W2));
-  if (!INV) hm_ntt_pass_run<LOG1, true, false, MODE_A, IN_AUX, 0, HM_EPI_CHUNK, GEO>(a, lds, entry, tile, threadIdx.x);
+  if constexpr (!INV) hm_ntt_pass_run<LOG1, true, false, MODE_A, IN_AUX, 0, HM_EPI_CHUNK, GEO>(a, lds, entry, tile, threadIdx.x);
   else hm_ntt_pass_run<HM_ROW_LOG, false, true, MODE_A, IN_AUX, 0, HM_EPI_CHUNK, GEO>(a, lds, entry, tile, threadIdx.x);
   // a thread id the compiler cannot connect with the first pass's: otherwise lane offsets of the second pass are computed
   // up front and kept (spilled) through the first
@@ -356,7 +359,7 @@ __device__ __forceinline__ void hm_ntt_fused_body(const HmNttArgs &a, const HmNt
     if (!fast) hm_limb_publish_everywhere(f.ws, f.err, entry, members, f.spin_limit);
     HM_STAMP(4);   // all siblings have arrived
   };
-  if (!INV) hm_ntt_pass_run<HM_ROW_LOG, false, false, MODE_B, HM_FUSED_MID_AUX, HM_FUSED_OUT_AUX, 1, GEO>(a, lds, entry, tile, tid2, meet);
+  if constexpr (!INV) hm_ntt_pass_run<HM_ROW_LOG, false, false, MODE_B, HM_FUSED_MID_AUX, HM_FUSED_OUT_AUX, 1, GEO>(a, lds, entry, tile, tid2, meet);
   else hm_ntt_pass_run<LOG1, true, true, MODE_B, HM_FUSED_MID_AUX, HM_FUSED_OUT_AUX, HM_EPI_CHUNK, GEO>(a, lds, entry, tile, tid2, meet);
   if (fast == 2) return;   // timed out: the host zeroes the words (check_device_error)
   HM_STAMP(5);   // second pass stored
@@ -816,6 +819,7 @@ extern "C" hm_status hm_create(hm_ctx **out, const hm_params *p) {
       probe(k_ntt_fused8<LOG1, false, 0, 3, true>); probe(k_ntt_fused8<LOG1, false, 0, 3, false>);
       probe(k_ntt_fused8<LOG1, false, 4, 3, true>); probe(k_ntt_fused8<LOG1, false, 4, 3, false>);
       probe(k_ntt_fused8<LOG1, true, 0, 2, true>);  probe(k_ntt_fused8<LOG1, true, 0, 2, false>);
+      probe(k_ntt_fused8<LOG1, true, 6, 2, true>);  probe(k_ntt_fused8<LOG1, false, 0, 7, true>); probe(k_ntt_fused8<LOG1, false, 0, 7, false>);
     };
     if (cc->P.logN == 15) probeAll(std::integral_constant<int, 7>()); else probeAll(std::integral_constant<int, 8>());
     cc->fused_slots_per_xcd = slots;
@@ -1132,7 +1136,8 @@ static hm_status check_mods(hm_ctx *c, const char *what, const uint32_t *m, uint
 }
 
 // The kernels of a transform, by form: 0 = forward, 1 = forward with the fused epilogue (MODE 3), 2 = forward with the mix prologue and
-// the epilogue (MODE 4 + 3), 3 = inverse.  `first` / `second` = the two pass kernels in the order they run (forward: COL then ROW,
+// the epilogue (MODE 4 + 3), 3 = inverse, 4 = inverse with the input read through an automorphism (MODE 6), 5 = form 1 with the addend read
+// through an automorphism (MODE 7).  `first` / `second` = the two pass kernels in the order they run (forward: COL then ROW,
 // inverse: ROW then COL) in the 16-coefficient geometry; `first8` / `second8` = the same in the small-launch geometry and `one` = both
 // passes in one launch ([0] out of place: non-temporal input loads, [1] in place); the small-launch forms exist where hm_caps says so
 // (N = 2^15 and 2^16).
@@ -1142,19 +1147,22 @@ struct HmNttKernels {
   hm_ntt_kernel first, second, first8, second8;
   hm_ntt_one_kernel one[2];
 };
+#define HM_NTT_FORMS 6
 template <int LOG1>
 static const HmNttKernels &ntt_kernels(int form) {
-  static const HmNttKernels wide[4] = {
+  static const HmNttKernels wide[HM_NTT_FORMS] = {
       {k_ntt_col<LOG1, false, 0>, k_ntt_row<false, 1>, nullptr, nullptr, {nullptr, nullptr}},
       {k_ntt_col<LOG1, false, 0>, k_ntt_row<false, 3>, nullptr, nullptr, {nullptr, nullptr}},
       {k_ntt_col<LOG1, false, 4>, k_ntt_row<false, 3>, nullptr, nullptr, {nullptr, nullptr}},
-      {k_ntt_row<true, 0>, k_ntt_col<LOG1, true, 2>, nullptr, nullptr, {nullptr, nullptr}}};
+      {k_ntt_row<true, 0>, k_ntt_col<LOG1, true, 2>, nullptr, nullptr, {nullptr, nullptr}},
+      {k_ntt_row<true, 6>, k_ntt_col<LOG1, true, 2>, nullptr, nullptr, {nullptr, nullptr}},
+      {k_ntt_col<LOG1, false, 0>, k_ntt_row<false, 7>, nullptr, nullptr, {nullptr, nullptr}}};
   return wide[form];
 }
 // the ring sizes of the reference's configurations (config/config_4.cfg: N = 2^16, config_4_N15.cfg: N = 2^15) have all three forms
 template <int LOG1>
 static const HmNttKernels &ntt_kernels_all(int form) {
-  static const HmNttKernels both[4] = {
+  static const HmNttKernels both[HM_NTT_FORMS] = {
       {k_ntt_col<LOG1, false, 0>, k_ntt_row<false, 1>, k_ntt_col8<LOG1, false, 0>, k_ntt_row8<false, 1>, {k_ntt_fused8<LOG1, false, 0, 1, true>,
           k_ntt_fused8<LOG1, false, 0, 1, false>}},
       {k_ntt_col<LOG1, false, 0>, k_ntt_row<false, 3>, k_ntt_col8<LOG1, false, 0>, k_ntt_row8<false, 3>, {k_ntt_fused8<LOG1, false, 0, 3, true>,
@@ -1162,7 +1170,12 @@ static const HmNttKernels &ntt_kernels_all(int form) {
       {k_ntt_col<LOG1, false, 4>, k_ntt_row<false, 3>, k_ntt_col8<LOG1, false, 4>, k_ntt_row8<false, 3>, {k_ntt_fused8<LOG1, false, 4, 3, true>,
           k_ntt_fused8<LOG1, false, 4, 3, false>}},
       {k_ntt_row<true, 0>, k_ntt_col<LOG1, true, 2>, k_ntt_row8<true, 0>, k_ntt_col8<LOG1, true, 2>, {k_ntt_fused8<LOG1, true, 0, 2, true>,
-          k_ntt_fused8<LOG1, true, 0, 2, false>}}};
+          k_ntt_fused8<LOG1, true, 0, 2, false>}},
+      // (a gathered input is never read in place: one variant of the one-launch form serves)
+      {k_ntt_row<true, 6>, k_ntt_col<LOG1, true, 2>, k_ntt_row8<true, 6>, k_ntt_col8<LOG1, true, 2>, {k_ntt_fused8<LOG1, true, 6, 2, true>,
+          k_ntt_fused8<LOG1, true, 6, 2, true>}},
+      {k_ntt_col<LOG1, false, 0>, k_ntt_row<false, 7>, k_ntt_col8<LOG1, false, 0>, k_ntt_row8<false, 7>, {k_ntt_fused8<LOG1, false, 0, 7, true>,
+          k_ntt_fused8<LOG1, false, 0, 7, false>}}};
   return both[form];
 }
 template <> const HmNttKernels &ntt_kernels<8>(int form) { return ntt_kernels_all<8>(form); }
@@ -1177,9 +1190,10 @@ static uint32_t small_entries(const hm_ctx *c, uint32_t limbs16) {
 static uint32_t fused_small_entries(const hm_ctx *c) { return small_entries(c, c->fused_small); }
 
 template <int LOG1>
-static void launch_ntt(hm_ctx *c, const HmNttArgs &a, bool fusedEpilogue, bool mixPrologue, bool inverse, bool firstPassOnly, bool secondPassOnly = false) {
+static void launch_ntt(hm_ctx *c, const HmNttArgs &a, int form, bool firstPassOnly, bool secondPassOnly = false) {
   // n_limbs = entries, a multiple of 8 (one group per XCD); one workgroup per 4096-coefficient tile of each pass (HM_TL_COL == HM_TL_ROW)
-  const HmNttKernels &K = ntt_kernels<LOG1>(inverse ? 3 : mixPrologue ? 2 : fusedEpilogue ? 1 : 0);
+  const HmNttKernels &K = ntt_kernels<LOG1>(form);
+  const bool inverse = form == 3 || form == 4;
   const dim3 grid(a.n_limbs * (c->P.N >> HM_TL_ROW)), block16((1 << HM_TL_ROW) / HM_EPT), block8((1 << HM_TL_ROW) / 8);
   // small launches (one round of workgroups on the chip): the 8-coefficient geometry halves the serial work per wave (small_mode:
   // bit 0 = the COL pass, bit 1 = the ROW pass; the hand-off between the passes is the same in both geometries)
@@ -1258,6 +1272,8 @@ struct NttFused {
   const uint32_t *mix_limbs = nullptr;
   const uint64_t *mix_k = nullptr;
   const uint8_t *outPacked = nullptr;   // inverse: per limb-poly, store the split-30 packed form (hm_pack30)
+  const uint32_t *inGalois = nullptr;   // inverse (round 6): per limb-poly, the input is read through X -> X^g (0 / 1: as stored)
+  const uint32_t *addGalois = nullptr;  // fused forward (round 6): per limb-poly, the addend is read through X -> X^g (0 / 1: as stored)
   bool firstPassOnly = false;   // forward transform: run the COL pass only (the hand-off stays in `out`)
   bool secondPassOnly = false;  // forward transform: the hand-off is already in `out` (a fused conversion wrote it): run the ROW pass only
 };
@@ -1282,6 +1298,20 @@ static hm_status ntt_common(hm_ctx *c, const char *what, const uint64_t *in, con
       return fail(c, HM_ERR_ARG, "%s: constant [%u] is not reduced", what, g);
     if (f.addend_k && f.addend_k[g] == 0) return fail(c, HM_ERR_ARG, "%s: addend_k[%u] is zero (pass addend = NULL instead)", what, g);
   }
+  // operands read through an automorphism (round 6): odd Galois elements below 2N; 0 and 1 mean "as stored"
+  bool anyInGalois = false, anyAddGalois = false;
+  for (uint32_t g = 0; g < n; ++g) {
+    const uint32_t gi = f.inGalois ? f.inGalois[g] : 0, ga = f.addGalois ? f.addGalois[g] : 0;
+    if ((gi && (!(gi & 1) || gi >= 2 * c->P.N)) || (ga && (!(ga & 1) || ga >= 2 * c->P.N)))
+      return fail(c, HM_ERR_ARG, "%s: Galois element [%u] is not an odd number below 2N", what, g);
+    anyInGalois |= gi > 1; anyAddGalois |= ga > 1;
+    // a gathered input is read from OTHER tiles than the one a workgroup writes: never in place
+    if (gi > 1 && in == out && limb_at(in_limbs, g) == limb_at(out_limbs, g)) return fail(c, HM_ERR_ARG,
+        "%s: limb-poly [%u] is read through an automorphism and cannot be transformed in place", what, g);
+  }
+  if (anyInGalois && (!inverse || f.secondPassOnly)) return fail(c, HM_ERR_ARG, "%s: only the inverse transform reads its input through an automorphism", what);
+  if (anyAddGalois && (!fused || f.mix || !f.addend)) return fail(c, HM_ERR_UNSUPPORTED,
+      "%s: the addend is read through an automorphism by the fused forward transform without the mix prologue only", what);
   HM_HIP(c, hipSetDevice(c->device));
   // group limb-polys that share a modulus (see hm_block_map): G = the largest of 8, 4, 2 for which at least 7 of 8 limb-polys
   // of the call fall into full same-modulus groups (a batch of 10 ops x 2 keys has 20 limb-polys per modulus, a 50-limb sweep
@@ -1342,7 +1372,9 @@ static hm_status ntt_common(hm_ctx *c, const char *what, const uint64_t *in, con
           if (k) v = hm::mulmod(v, k[g], q);
           t.sc = hm_kconst(v, q);
           t.pack = f.outPacked && f.outPacked[g] ? 1 : 0;
+          if (anyInGalois) t.galois = f.inGalois[g] ? f.inGalois[g] : 1u;
         } else if (fused) {
+          if (anyAddGalois) t.galois = f.addGalois[g] ? f.addGalois[g] : 1u;
           t.sc = hm_kconst(k[g], q);
           a.limb[e].aux = (uint16_t)limb_at(f.minuend_limbs, g);
           t.alimb = f.addend_limbs && f.addend_limbs[g] == HM_NO_LIMB ? (uint16_t)HM_NTT_NONE : (uint16_t)limb_at(f.addend_limbs, g);
@@ -1365,13 +1397,13 @@ static hm_status ntt_common(hm_ctx *c, const char *what, const uint64_t *in, con
     a.entry = dtab;
     a.minuend = f.minuend; a.addend = f.addend; a.mix = f.mix;
     a.logN = c->P.logN; a.n_limbs = cnt; a.logG = logG;
-    const bool mixPro = fused && f.mix;
+    const int form = inverse ? (anyInGalois ? 4 : 3) : fused ? (f.mix ? 2 : anyAddGalois ? 5 : 1) : 0;
     switch (c->P.logN - HM_ROW_LOG) {
-    case 5: launch_ntt<5>(c, a, fused, mixPro, inverse, f.firstPassOnly, f.secondPassOnly); break;
-    case 6: launch_ntt<6>(c, a, fused, mixPro, inverse, f.firstPassOnly, f.secondPassOnly); break;
-    case 7: launch_ntt<7>(c, a, fused, mixPro, inverse, f.firstPassOnly, f.secondPassOnly); break;
-    case 8: launch_ntt<8>(c, a, fused, mixPro, inverse, f.firstPassOnly, f.secondPassOnly); break;
-    case 9: launch_ntt<9>(c, a, fused, mixPro, inverse, f.firstPassOnly, f.secondPassOnly); break;
+    case 5: launch_ntt<5>(c, a, form, f.firstPassOnly, f.secondPassOnly); break;
+    case 6: launch_ntt<6>(c, a, form, f.firstPassOnly, f.secondPassOnly); break;
+    case 7: launch_ntt<7>(c, a, form, f.firstPassOnly, f.secondPassOnly); break;
+    case 8: launch_ntt<8>(c, a, form, f.firstPassOnly, f.secondPassOnly); break;
+    case 9: launch_ntt<9>(c, a, form, f.firstPassOnly, f.secondPassOnly); break;
     default: return fail(c, HM_ERR_UNSUPPORTED, "%s: logN %u", what, c->P.logN);
     }
     HM_HIP(c, hipGetLastError());
@@ -1406,6 +1438,8 @@ extern "C" hm_status hm_ntt_ex(hm_ctx *c, const hm_ntt_desc *d) {
   NttFused f;
   f.secondPassOnly = d->second_pass_only != 0;
   f.outPacked = d->out_packed;
+  f.inGalois = d->in_galois;
+  if (d->in_galois && !d->inverse) return fail(c, HM_ERR_ARG, "hm_ntt_ex: in_galois is only defined for the inverse transform");
   if (f.secondPassOnly) return ntt_common(c, "hm_ntt_ex", d->out, d->out_limbs, d->out, d->out_limbs, d->mod_ids, d->n, d->inverse, d->scale, f);
   return ntt_common(c, "hm_ntt_ex", d->in, d->in_limbs, d->out, d->out_limbs, d->mod_ids, d->n, d->inverse, d->scale, f);
 }
@@ -1435,6 +1469,9 @@ extern "C" hm_status hm_ntt_mix_sub_scale(hm_ctx *c, const hm_ntt_fused_desc *d)
   NttFused f;
   f.minuend = d->minuend; f.minuend_limbs = d->minuend_limbs; f.addend = d->addend; f.addend_limbs = d->addend_limbs;
   f.addend_k = d->addend_k; f.mix = d->mix; f.mix_limbs = d->mix_limbs; f.mix_k = d->mix_k;
+  f.addGalois = d->addend_galois;
+  if (d->addend_galois && (d->n_conv || d->mix || !d->addend)) return fail(c, HM_ERR_UNSUPPORTED,
+      "hm_ntt_mix_sub_scale: addend_galois needs an addend and combines with neither the mix prologue nor conversions inside the transform");
   if (!d->n_conv) return ntt_common(c, "hm_ntt_mix_sub_scale", d->in, d->in_limbs, d->out, d->out_limbs, d->mod_ids, d->n, 0, d->k, f);
   // ---- some or all inputs are conversions that run inside their transform's first pass (round 4: the ModDown side)
   if (!d->conv) return fail(c, HM_ERR_ARG, "hm_ntt_mix_sub_scale: n_conv without descriptors");

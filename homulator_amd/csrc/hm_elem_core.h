@@ -318,21 +318,7 @@ HM_HD void hm_bconv_thread(const PROB &p, uint32_t logN, uint32_t x, uint32_t t0
   }
 }
 
-// ---- K2 automorphism in evaluation form: out[i] = in[pi_g(i)] (bit-reversed NTT layout)
-HM_HD uint32_t hm_brev(uint32_t x, uint32_t bits) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  return __brev(x) >> (32 - bits);
-#else
-  uint32_t r = 0;
-  for (uint32_t i = 0; i < bits; ++i) { r = (r << 1) | (x & 1); x >>= 1; }
-  return r;
-#endif
-}
-HM_HD uint32_t hm_auto_src(uint32_t i, uint32_t g, uint32_t logN) {
-  uint32_t mask = (2u << logN) - 1;
-  uint32_t e = (g * (2 * hm_brev(i, logN) + 1)) & mask;
-  return hm_brev((e - 1) >> 1, logN);
-}
+// (K2, the automorphism's index map hm_auto_src: hm_ntt_core.h — the transforms gather through it as well)
 
 // ---- deterministic synthetic data (same definition as oracle/homoracle.c ho_fill_uniform)
 HM_HD uint64_t hm_mix64(uint64_t z) {

@@ -85,7 +85,8 @@ struct HmNttEntry {                  // the part of a record that is not needed 
   uint16_t alimb, mixlimb;           // MODE 3 addend limb (HM_NTT_NONE: no addend), MODE 4 operand limb
   uint16_t pack;                     // MODE 2 (round 5): the output is stored in the split-30 packed form of the base conversions' inputs
   uint16_t pad;
-  uint64_t pad1;
+  uint32_t galois;                   // MODE 6: the input, MODE 7: the addend is read through the automorphism X -> X^galois (1 = as stored)
+  uint32_t pad1;
   HmTw sc;                           // inverse: N^-1 * extra scale; fused forward: the epilogue constant k
   HmTw ak;                           // fused forward: addend constant (w == 0: none)
   HmTw mixk;                         // MODE 4 prologue constant
@@ -115,14 +116,36 @@ struct HmEpi {  // the prologue / epilogue operands of one limb-poly, resolved b
   const uint64_t *b;         // mix operand (MODE 4)
   HmTw bk;
   uint32_t pack;             // MODE 2: store hm_pack30(value) (wave-uniform)
+  uint32_t g, logN;          // MODE 6 / 7: the Galois element the input / the addend is gathered through, and the ring size its index map needs
 };
-HM_HD HmEpi hm_epi_none() { return HmEpi{nullptr, nullptr, HmTw{0, 0}, nullptr, HmTw{0, 0}, 0}; }
+HM_HD HmEpi hm_epi_none() { return HmEpi{nullptr, nullptr, HmTw{0, 0}, nullptr, HmTw{0, 0}, 0, 0, 0}; }
 // Split-30 packed form (round 5): x < 2^60 stored as (x mod 2^30) | ((x >> 30) << 32) — the two 30-bit halves a base conversion multiplies
 // with, one per dword.  The inverse transforms that feed ONLY base conversions (ModUp_DecompOut, ModDownBConvStep1: src/Operation.cpp:
 // 104-135, 447-487) store this form (two instructions per value, once), and every conversion workgroup that reads the value (one per pair
 // of output limbs: 18 readers per value in a 35-output ModUp digit) takes the halves as they are instead of shifting and masking again.
 HM_HD uint64_t hm_pack30(uint64_t x) { return (x & 0x3FFFFFFFull) | ((x >> 30) << 32); }
 HM_HD uint64_t hm_unpack30(uint64_t p) { return (p & 0x3FFFFFFFull) | ((p >> 32) << 30); }
+
+// ---- K2 automorphism in evaluation form: out[i] = in[pi_g(i)] (bit-reversed NTT layout)
+HM_HD uint32_t hm_brev(uint32_t x, uint32_t bits) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __brev(x) >> (32 - bits);
+#else
+  uint32_t r = 0;
+  for (uint32_t i = 0; i < bits; ++i) { r = (r << 1) | (x & 1); x >>= 1; }
+  return r;
+#endif
+}
+HM_HD uint32_t hm_auto_src(uint32_t i, uint32_t g, uint32_t logN) {
+  uint32_t mask = (2u << logN) - 1;
+  uint32_t e = (g * (2 * hm_brev(i, logN) + 1)) & mask;
+  return hm_brev((e - 1) >> 1, logN);
+}
+// The map is affine in the natural index and both sides are stored bit-reversed, so every aligned block of 2^k outputs comes from ONE aligned
+// block of 2^k inputs, for every k: a 4096-coefficient tile from one tile, a 16-byte access unit (outputs 2m, 2m + 1) from one aligned pair
+// of inputs — in order, or swapped (hm_auto_src(2m + 1) = hm_auto_src(2m) ^ 1).  A transform can therefore read its input (MODE 6), or its
+// epilogue's addend (MODE 7), THROUGH the automorphism with the same 16-byte loads it uses anyway: hrotate's automorphism launch
+// (InsGen::GenAUTO, src/InsGen.cpp:46-71) folds into the ModUp INTT and the final add (round 6).
 
 // 16-byte accesses (two adjacent words; p is 16-byte aligned)
 HM_HD void hm_ld2(const uint64_t *p, uint64_t &a, uint64_t &b) {
@@ -196,6 +219,24 @@ HM_HD void hm_gst2(uint64_t *g, uint32_t tile, int tid, int a, uint64_t v0, uint
 #else
   hm_st2(g + G::guni(tile, a) + G::gthr(tid, a), v0, v1);
 #endif
+}
+
+// the access unit whose first word is coefficient i (even) of limb-poly `g`, read through the automorphism X -> X^galois: one 16-byte load from
+// the aligned pair that holds both sources, the words swapped when the pair arrives in the other order (hm_auto_src above)
+template <int AUX = 0>
+HM_HD void hm_gld2_auto(const uint64_t *g, uint32_t i, uint32_t galois, uint32_t logN, uint64_t &v0, uint64_t &v1) {
+  const uint32_t s = hm_auto_src(i, galois, logN);
+  uint64_t a, b;
+#if defined(__HIP_DEVICE_COMPILE__)
+  const hm_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(hm_rsrc(g), (int)((s & ~1u) << 3), 0, AUX);
+  a = (uint64_t)t.x | ((uint64_t)t.y << 32);
+  b = (uint64_t)t.z | ((uint64_t)t.w << 32);
+#else
+  hm_ld2(g + (s & ~1u), a, b);
+#endif
+  const bool swap = s & 1u;
+  v0 = swap ? b : a;
+  v1 = swap ? a : b;
 }
 
 // LDS image of a tile: word index of coefficient (x, c), x = position inside the sub-transform, c = which sub-transform.

@@ -239,6 +239,18 @@ HM_HD void hm_ph_load_global(HmNttState &st, int tid, const uint64_t *g, uint32_
 #endif
   }
 }
+// MODE 6 (round 6): the input is read through an automorphism (ep.g; hm_gld2_auto): INTT(auto(x)) without auto(x) in memory
+template <int TL, int LOGR, bool STRIDED, int R, int AUX = 0>
+HM_HD void hm_ph_load_global_auto(HmNttState &st, int tid, const uint64_t *g, uint32_t tile, const HmEpi &ep) {
+  using G = HmRound<TL, LOGR, STRIDED, R>;
+  static_assert(!STRIDED, "units of the COL pass are pairs of columns, not of neighbours in memory");
+#pragma unroll
+  for (int a = 0; a < HM_UNITS; ++a) {
+    int i0, i1, x, c;
+    G::unit(tid, a, i0, i1, x, c);
+    hm_gld2_auto<AUX>(g, G::gidx(tile, x, c), ep.g, ep.logN, st.v[i0], st.v[i1]);
+  }
+}
 // MODE 4: the same with the linear prologue x = in + k * mix (both reduced; x reduced)
 template <int TL, int LOGR, bool STRIDED, int R, int AUX = 0>
 HM_HD void hm_ph_load_global_mix(HmNttState &st, int tid, const uint64_t *g, uint32_t tile, uint64_t q, HmEpi ep) {
@@ -265,7 +277,7 @@ template <int MODE>
 HM_HD uint64_t hm_epilogue(uint64_t a, uint64_t va, uint64_t vd, uint64_t q, HmTw sc, const HmEpi &ep) {
   if (MODE == 1) return hm_reduce_fwd(a, q);
   if (MODE == 2) { a = hm_kmul(a, sc, q); return ep.pack ? hm_pack30(a) : a; }
-  if (MODE == 3) {  // a in [0, 2 HM_LAZY_Q q): minuend - a + 2 HM_LAZY_Q q stays positive and below 9q < 2^64 (mont32: 5q < 2^63); the product reduces it
+  if (MODE == 3 || MODE == 7) {  // a in [0, 2 HM_LAZY_Q q): minuend - a + 2 HM_LAZY_Q q stays positive and below 9q < 2^64 (mont32: 5q < 2^63); the product reduces it
     a = hm_kmul(va + 2 * HM_LAZY_Q * q - a, sc, q);
     if (ep.d) a = hm_addmod(a, ep.dk.w ? hm_kmul(vd, ep.dk, q) : vd, q);
   }
@@ -282,7 +294,7 @@ HM_HD void hm_ph_store_global(const HmNttState &st, int tid, uint64_t *g, uint32
     uint64_t ea[2 * CH], ed[2 * CH];
 #pragma unroll
     for (int k = 0; k < 2 * CH; ++k) ea[k] = ed[k] = 0;
-    if (MODE == 3) {
+    if (MODE == 3 || MODE == 7) {
 #pragma unroll
       for (int k = 0; k < CH && a2 + k < HM_UNITS; ++k) {
         int i0, i1, x, c;
@@ -291,7 +303,9 @@ HM_HD void hm_ph_store_global(const HmNttState &st, int tid, uint64_t *g, uint32
         hm_gld2<G>(ep.a, tile, tid, a2 + k, ea[2 * k], ea[2 * k + 1]);
 #endif
 #if !defined(HM_ABL_EPI_NOD)
-        if (ep.d) hm_gld2<G>(ep.d, tile, tid, a2 + k, ed[2 * k], ed[2 * k + 1]);
+        if constexpr (MODE == 7) {   // the addend through an automorphism (ep.g; 1 = as stored)
+          if (ep.d) hm_gld2_auto<0>(ep.d, G::gidx(tile, x, c), ep.g, ep.logN, ed[2 * k], ed[2 * k + 1]);
+        } else if (ep.d) hm_gld2<G>(ep.d, tile, tid, a2 + k, ed[2 * k], ed[2 * k + 1]);
 #endif
       }
     }
@@ -306,7 +320,7 @@ HM_HD void hm_ph_store_global(const HmNttState &st, int tid, uint64_t *g, uint32
                  hm_epilogue<MODE>(st.v[i1], ea[2 * k + 1], ed[2 * k + 1], q, sc, ep));
     }
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (MODE == 3) __builtin_amdgcn_sched_barrier(0);
+    if (MODE == 3 || MODE == 7) __builtin_amdgcn_sched_barrier(0);
 #endif
   }
 }
@@ -432,6 +446,7 @@ HM_HD void hm_ntt_phase(HmNttState &st, int tid, uint64_t *lds, const uint64_t *
     if (PS::anyLds()) hm_ph_stage_tw<TL, LOGR, STRIDED>(tid, lds, twl);
     if (FROMREG) { static_assert(!FROMREG || MODE != 4, "the mix prologue reads its operands from memory"); }
     else if (MODE == 4) hm_ph_load_global_mix<TL, LOGR, STRIDED, r0, LDAUX>(st, tid, src, tile, q, ep);
+    else if constexpr (MODE == 6) hm_ph_load_global_auto<TL, LOGR, STRIDED, r0, LDAUX>(st, tid, src, tile, ep);
     else hm_ph_load_global<TL, LOGR, STRIDED, r0, LDAUX>(st, tid, src, tile);
     // the twist constants are requested one phase ahead of the twisted round (phase iTW + 1)
     if (iTW >= 0 && iTW <= 1) hm_ph_load_twist<TL, LOGR, STRIDED, (TWR >= 0 ? TWR : 0)>(st, tid, twist_tile);
@@ -459,7 +474,7 @@ HM_HD void hm_ntt_phase(HmNttState &st, int tid, uint64_t *lds, const uint64_t *
     constexpr int rl = PS::exec(n - 1);
     // fused epilogue (MODE 3) / register hand-over (MODE 5): the twist constants are dead before the last round's twiddles are
     // read from LDS (the other order keeps 12 more registers alive and spilled inside the one-launch transform)
-    constexpr bool TWIST_FIRST = (MODE == 3 || MODE == 5) && !INV && rl == TWR && PS::fromLds(rl);
+    constexpr bool TWIST_FIRST = (MODE == 3 || MODE == 5 || MODE == 7) && !INV && rl == TWR && PS::fromLds(rl);
     if (PS::fromLds(rl) && !TWIST_FIRST) hm_ph_load_tw<TL, LOGR, STRIDED, rl, PS::shared(rl)>(st, tid, ltw, s0, prefix0);
     hm_ph_load_lds<TL, LOGR, STRIDED, rl, INV>(st, tid, lds);
     if (!INV && rl == TWR) hm_ph_twist(st, q);

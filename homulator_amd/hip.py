@@ -28,7 +28,7 @@ class hm_ntt_fused_desc(C.Structure):
     _fields_ = [("in_", C.c_void_p), ("in_limbs", C.c_void_p), ("mix", C.c_void_p), ("mix_limbs", C.c_void_p), ("mix_k", C.c_void_p),
                 ("minuend", C.c_void_p), ("minuend_limbs", C.c_void_p), ("addend", C.c_void_p), ("addend_limbs", C.c_void_p),
                 ("addend_k", C.c_void_p), ("out", C.c_void_p), ("out_limbs", C.c_void_p), ("mod_ids", C.c_void_p), ("n", C.c_uint32),
-                ("k", C.c_void_p), ("conv", C.c_void_p), ("n_conv", C.c_uint32)]
+                ("k", C.c_void_p), ("conv", C.c_void_p), ("n_conv", C.c_uint32), ("addend_galois", C.c_void_p)]
 
 
 class hm_ntt_ip_desc(C.Structure):
@@ -47,7 +47,8 @@ class hm_bconv_desc(C.Structure):
 
 class hm_ntt_desc(C.Structure):
     _fields_ = [("in_", C.c_void_p), ("in_limbs", C.c_void_p), ("out", C.c_void_p), ("out_limbs", C.c_void_p), ("mod_ids", C.c_void_p), ("n", C.c_uint32),
-                ("inverse", C.c_int), ("scale", C.c_void_p), ("second_pass_only", C.c_int), ("out_packed", C.c_void_p)]
+                ("inverse", C.c_int), ("scale", C.c_void_p), ("second_pass_only", C.c_int), ("out_packed", C.c_void_p),
+                ("in_galois", C.c_void_p)]
 
 
 class hm_params(C.Structure):
@@ -217,18 +218,20 @@ class Context:
         return list(range(ell)) + [self.nQ + i for i in range(self.K)]
 
     # ---- compute calls (device pointers + limb lists)
-    def ntt(self, src, dst, mod_ids, inverse=False, in_limbs=None, out_limbs=None, scale=None, out_packed=None):
-        """out_packed (inverse only): per limb, store the split-30 packed form the base conversions take with in_packed (hm_ntt_ex)"""
+    def ntt(self, src, dst, mod_ids, inverse=False, in_limbs=None, out_limbs=None, scale=None, out_packed=None, in_galois=None):
+        """out_packed (inverse only): per limb, store the split-30 packed form the base conversions take with in_packed (hm_ntt_ex);
+        in_galois (inverse only): per limb, read the input through the automorphism X -> X^g (hm_ntt_ex)"""
         n = len(mod_ids)
         k1, pi = _u32(in_limbs)
         k2, po = _u32(out_limbs)
         k3, pm = _u32(mod_ids)
         k4, ps = _u64(scale)
-        if out_packed is None:
+        if out_packed is None and in_galois is None:
             self._ck(self.L.hm_ntt(self.h, src.ptr, pi, dst.ptr, po, pm, n, 1 if inverse else 0, ps))
             return
-        pk = np.ascontiguousarray(np.asarray(out_packed, dtype=np.uint8))
-        d = hm_ntt_desc(src.ptr, pi, dst.ptr, po, pm, n, 1 if inverse else 0, ps, 0, pk.ctypes.data_as(C.c_void_p))
+        pk = None if out_packed is None else np.ascontiguousarray(np.asarray(out_packed, dtype=np.uint8))
+        k5, pg = _u32(in_galois)
+        d = hm_ntt_desc(src.ptr, pi, dst.ptr, po, pm, n, 1 if inverse else 0, ps, 0, None if pk is None else pk.ctypes.data_as(C.c_void_p), pg)
         self._ck(self.L.hm_ntt_ex(self.h, C.byref(d)))
 
     def ntt_sub_scale(self, src, minuend, out, mod_ids, k, addend=None, in_limbs=None, minuend_limbs=None, addend_limbs=None,
@@ -239,12 +242,13 @@ class Context:
                                          keep[2][1], out.ptr, keep[3][1], keep[4][1], len(mod_ids), pk))
 
     def ntt_mix_sub_scale(self, src, minuend, out, mod_ids, k, mix=None, mix_k=None, addend=None, addend_k=None, in_limbs=None,
-                          mix_limbs=None, minuend_limbs=None, addend_limbs=None, out_limbs=None, conv=None):
+                          mix_limbs=None, minuend_limbs=None, addend_limbs=None, out_limbs=None, conv=None, addend_galois=None):
         """out = (minuend - NTT(src + mix_k * mix)) * k + addend * addend_k (merged ModDown + rescale of one limb).
         conv = [(src, in_limbs, in_ids, out_limbs_of_the_fed_limb_polys, out_ids), ...]: `src` of those limb-polys is this base conversion,
         computed inside the transform's first pass (src may then be None)"""
         keep = [_u32(x) for x in (in_limbs, mix_limbs, minuend_limbs, addend_limbs, out_limbs, mod_ids)]
         ks = [_u64(x) for x in (mix_k, addend_k, k)]
+        kg = _u32(addend_galois)   # per limb: read the addend through the automorphism X -> X^g
         ptr = lambda v: None if v is None else v.ptr
         descs, keep2 = None, []
         if conv:
@@ -256,7 +260,8 @@ class Context:
                 dd.in_, dd.in_limbs, dd.in_ids, dd.n_in = csrc.ptr, arrs[0][1], arrs[1][1], len(in_ids)
                 dd.out, dd.out_limbs, dd.out_ids, dd.n_out, dd.log_len = out.ptr, arrs[2][1], arrs[3][1], len(out_ids), 0
         d = hm_ntt_fused_desc(ptr(src) if src is not None else out.ptr, keep[0][1], ptr(mix), keep[1][1], ks[0][1], minuend.ptr, keep[2][1], ptr(addend), keep[3][1], ks[1][1],
-                              out.ptr, keep[4][1], keep[5][1], len(mod_ids), ks[2][1], C.cast(descs, C.c_void_p) if conv else None, len(conv) if conv else 0)
+                              out.ptr, keep[4][1], keep[5][1], len(mod_ids), ks[2][1], C.cast(descs, C.c_void_p) if conv else None, len(conv) if conv else 0,
+                              kg[1])
         self._ck(self.L.hm_ntt_mix_sub_scale(self.h, C.byref(d)))
 
     def tensor(self, a, b, c, d, o0, o1, o2, mod_ids, limbs=None):

@@ -108,6 +108,11 @@ typedef struct hm_ntt_fused_desc {
    * limb-polys are ignored, the others are transformed as usual.  N = 2^15 or 2^16 and n_in <= 15 (HM_ERR_UNSUPPORTED otherwise).
    * Bit-identical to hm_bconv_batch + the call without conv. */
   const struct hm_bconv_desc *conv; uint32_t n_conv;
+  /* optional (NULL: none; round 6): addend_galois[i] = g > 1 reads the addend of limb-poly i through the automorphism X -> X^g (evaluation form, as
+   * hm_automorph): out = (minuend - NTT(in)) * k + automorph_g(addend) [* addend_k] — hrotate's final add takes AUTOOutput(0) this way and
+   * AUTO_Key(0) (src/Operation.cpp hrotate, InsGen::GenAUTO src/InsGen.cpp:46-71) is never written; 0 / 1 = the addend as stored.  g odd, below 2N.
+   * Needs an addend; not with mix or conv (HM_ERR_UNSUPPORTED).  Bit-identical to hm_automorph + the call without it. */
+  const uint32_t *addend_galois;
 } hm_ntt_fused_desc;
 hm_status hm_ntt_mix_sub_scale(hm_ctx *ctx, const hm_ntt_fused_desc *desc);
 
@@ -209,6 +214,10 @@ typedef struct hm_ntt_desc {
   int inverse;         const uint64_t *scale;
   int second_pass_only;
   const uint8_t *out_packed;
+  /* optional (NULL: none; round 6; inverse only, not with second_pass_only): in_galois[i] = g > 1 reads limb-poly i of `in` through the automorphism
+   * X -> X^g: out_i = INTT(automorph_g(in_i)) — AUTO_Key(1) + ModUp_INTT of hrotate in one pass over HBM (the index map takes aligned blocks to
+   * aligned blocks, so the transform's own 16-byte loads serve).  0 / 1 = as stored.  Such a limb-poly cannot be transformed in place. */
+  const uint32_t *in_galois;
 } hm_ntt_desc;
 hm_status hm_ntt_ex(hm_ctx *ctx, const hm_ntt_desc *desc);
 

@@ -134,6 +134,15 @@ template <int R> static int row_unit8(int tid, int a, bool inv) {
   hm8::HmRound<12, 8, false, R>::unit_split(tid, a, i0, i1, xb, d, c);
   return inv ? hm8::hm_lds_at<12, 8, false, true>(xb, d, c) : hm8::hm_lds_at<12, 8, false, false>(xb, d, c);
 }
+// round 6: the transforms that read an operand through an automorphism (MODE 6: the inverse transform's input; MODE 7: the fused epilogue's addend),
+// both geometries (ept = 16 / 8)
+template <class G, int LOG1>
+static void run_intt_auto(const Emu &e, uint32_t mod, const uint64_t *in, uint64_t *out, HmTw sc, uint32_t g) {
+  HmEpi ep = hm_epi_none();
+  ep.g = g; ep.logN = e.P.logN;
+  run_pass<G, HM_ROW_LOG, false, true, 6>(e, mod, in, out, sc, ep);
+  run_pass<G, LOG1, true, true, 2>(e, mod, out, out, sc);
+}
 extern "C" {
 // q == nullptr: the default chain; otherwise a caller-chosen one (q: L moduli, p: K special moduli; primes = 1 mod 2N below 2^60).
 // Returns nullptr if the chain does not fit this build's arithmetic.
@@ -224,6 +233,45 @@ int emu_ntt_sub_scale8(void *h, uint32_t mod, const uint64_t *in, const uint64_t
   if (e.P.logN == 16) { if (mix) run_pass<G8, 8, true, false, 4>(e, mod, in, out, sc, ep); else run_pass<G8, 8, true, false, 0>(e, mod, in, out, sc); }
   else { if (mix) run_pass<G8, 7, true, false, 4>(e, mod, in, out, sc, ep); else run_pass<G8, 7, true, false, 0>(e, mod, in, out, sc); }
   run_pass<G8, HM_ROW_LOG, false, false, 3>(e, mod, out, out, sc, ep);
+  return 0;
+}
+int emu_intt_auto(void *h, uint32_t mod, const uint64_t *in, uint64_t *out, uint32_t galois, int ept) {
+  Emu &e = *(Emu *)h;
+  if (in == out || (ept == 8 && e.P.logN != 16 && e.P.logN != 15)) return 1;
+  const uint64_t q = e.P.mod[mod];
+  const HmTw sc = hm_kconst(e.P.modc[mod].ninv, q);
+  if (ept == 8) { if (e.P.logN == 16) run_intt_auto<G8, 8>(e, mod, in, out, sc, galois); else run_intt_auto<G8, 7>(e, mod, in, out, sc, galois); return 0; }
+  switch (e.P.logN - HM_ROW_LOG) {
+  case 5: run_intt_auto<G16, 5>(e, mod, in, out, sc, galois); break;
+  case 6: run_intt_auto<G16, 6>(e, mod, in, out, sc, galois); break;
+  case 7: run_intt_auto<G16, 7>(e, mod, in, out, sc, galois); break;
+  case 8: run_intt_auto<G16, 8>(e, mod, in, out, sc, galois); break;
+  case 9: run_intt_auto<G16, 9>(e, mod, in, out, sc, galois); break;
+  default: return 1;
+  }
+  return 0;
+}
+int emu_ntt_sub_scale_auto(void *h, uint32_t mod, const uint64_t *in, const uint64_t *minuend, const uint64_t *addend, uint64_t *out, uint64_t k,
+                           uint64_t addend_k, uint32_t galois, int ept) {
+  Emu &e = *(Emu *)h;
+  if (ept == 8 && e.P.logN != 16 && e.P.logN != 15) return 1;
+  const uint64_t q = e.P.mod[mod];
+  const HmTw sc = hm_kconst(k, q);
+  HmEpi ep = hm_epi_none();
+  ep.a = minuend; ep.d = addend; ep.g = galois; ep.logN = e.P.logN;
+  if (addend_k) ep.dk = hm_kconst(addend_k, q);
+  if (ept == 8) {
+    if (e.P.logN == 16) run_pass<G8, 8, true, false, 0>(e, mod, in, out, sc); else run_pass<G8, 7, true, false, 0>(e, mod, in, out, sc);
+    run_pass<G8, HM_ROW_LOG, false, false, 7>(e, mod, out, out, sc, ep);
+    return 0;
+  }
+  switch (e.P.logN - HM_ROW_LOG) {
+#define HM_CASE(n) case n: run_pass<G16, n, true, false, 0>(e, mod, in, out, sc); break;
+    HM_CASE(5) HM_CASE(6) HM_CASE(7) HM_CASE(8) HM_CASE(9)
+#undef HM_CASE
+  default: return 1;
+  }
+  run_pass<G16, HM_ROW_LOG, false, false, 7>(e, mod, out, out, sc, ep);
   return 0;
 }
 void emu_tensor(void *h, uint32_t mod, const uint64_t *a, const uint64_t *b, const uint64_t *c, const uint64_t *d, uint64_t *o0,

@@ -534,3 +534,36 @@ def test_lds_bank_model_follows_the_kernels_and_finds_no_conflict(ept):
     # and the set the passes used up to round 5 costs what the counters of profiles/r06_pmc_kernels_batch10.txt say (inverse hm16: 25 %)
     fwd, inv = lb.evaluate(ept, X, Cc, lb.xor_swizzle(lb.SETS[0]))
     assert (fwd, inv) == (((0, 768), (256, 1024)) if ept == 16 else ((384, 1536), (640, 1792)))
+
+
+@pytest.mark.parametrize("logN,ept", [(13, 16), (15, 16), (16, 16), (15, 8), (16, 8)])
+def test_emu_transforms_that_read_through_an_automorphism(emu, logN, ept):
+    """round 6: hrotate's automorphism launch folded into its consumers.  MODE 6: the inverse transform reads its input through X -> X^g
+    (INTT(automorph_g(x)) with automorph_g(x) never in memory); MODE 7: the fused forward transform's epilogue reads the ADDEND through it
+    (out = (minuend - NTT(x)) * k + automorph_g(addend) [* addend_k]).  The index map takes aligned pairs to aligned pairs (in order or swapped),
+    so the passes' own 16-byte units serve; here every unit of every thread of both geometries against the oracle's automorphism + transform,
+    with Galois elements that swap pairs (5: rotation by one slot), that do not (2N - 1: conjugation), 25, 3 and the identity"""
+    emu.emu_intt_auto.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]
+    emu.emu_ntt_sub_scale_auto.argtypes = [C.c_void_p, C.c_uint32] + [C.c_void_p] * 4 + [C.c_uint64, C.c_uint64, C.c_uint32, C.c_int]
+    L, K = 2, 1
+    o = emu.oracle(logN, L, K)
+    h = emu.create(o)
+    N = 1 << logN
+    try:
+        for m in (0, L):
+            q = o.moduli[m]
+            x, mn, ad = (o.fill_uniform([m], s + 10 * m)[0] for s in (1, 2, 3))
+            x[:2] = [q - 1, 0]
+            ad[:2] = [0, q - 1]
+            for g in (5, 2 * N - 1, 25, 3, 1):
+                out = np.empty_like(x)
+                assert emu.emu_intt_auto(h, m, p(x), p(out), g, ept) == 0
+                assert np.array_equal(out, o.ntt([m], o.automorph_eval(x[None], g), inverse=True)[0]), (m, g)
+                k, ak = q - 2, q - 5
+                assert emu.emu_ntt_sub_scale_auto(h, m, p(x), p(mn), p(ad), p(out), k, 0, g, ept) == 0
+                base = o.ewe(6, [m], mn[None], None, o.ntt([m], x[None]), k=[k])
+                assert np.array_equal(out, o.ewe(3, [m], base, None, o.automorph_eval(ad[None], g))[0]), (m, g)
+                assert emu.emu_ntt_sub_scale_auto(h, m, p(x), p(mn), p(ad), p(out), k, ak, g, ept) == 0
+                assert np.array_equal(out, o.ewe(3, [m], base, None, o.ewe(5, [m], o.automorph_eval(ad[None], g), k=[ak]))[0]), (m, g)
+    finally:
+        emu.emu_destroy(h)

@@ -194,6 +194,63 @@ def test_automorph_eval(env, rot):
     d.free(); out.free()
 
 
+@pytest.mark.parametrize("n,opts", [(7, {}), (7, {"ntt_fused_small": 0}), (130, {})], ids=["one-launch", "small-two-kernels", "wide"])
+def test_transforms_that_read_through_an_automorphism(env, n, opts):
+    """round 6: hrotate's AUTO launch folded into its consumers (hm_ntt_desc.in_galois, hm_ntt_fused_desc.addend_galois).  INTT(automorph_g(x)) and
+    (minuend - NTT(x)) * k + automorph_g(addend) [* addend_k] in one call each, against the oracle's automorphism + transform: per-limb Galois
+    elements (rotations, the conjugation, 1 / 0 = as stored), limb-polys without addend beside gathered ones, in every kernel form a launch
+    size selects (both passes in one launch, the small-launch pair of kernels, the wide geometry); and what the call refuses"""
+    ctx, o, hip = env
+    before = {name: ctx.counter(name) for name in opts}
+    for name, v in opts.items():
+        ctx.set_option(name, v)
+    try:
+        N2 = 2 * o.N
+        ids = [i % (o.L + o.K) for i in range(n)]
+        gs = [[5, N2 - 1, 25, 1, 0, pow(5, 7, N2), 3][i % 7] for i in range(n)]
+        x, mn, ad = (o.fill_uniform(ids, s) for s in (11, 12, 13))
+        dx, dmn, dad = (ctx.from_host(v) for v in (x, mn, ad))
+        out = ctx.alloc(n)
+        auto = lambda v: np.stack([o.automorph_eval(v[r][None], g if g else 1)[0] for r, g in enumerate(gs)])
+        sel = list(range(n)) if n <= 16 else [0, 1, 2, 3, 4, 5, 6, 63, 64, 127, 128, 129]
+        pick = lambda a: a[sel]
+        sids = [ids[i] for i in sel]
+        ctx.ntt(dx, out, ids, inverse=True, in_galois=gs)
+        assert np.array_equal(pick(out.download()), o.ntt(sids, pick(auto(x)), inverse=True))
+        scale = [o.moduli[m] - 7 - (r % 5) for r, m in enumerate(ids)]
+        ctx.ntt(dx, out, ids, inverse=True, in_galois=gs, scale=scale, out_packed=[r % 2 for r in range(n)])
+        got, exp = pick(out.download()), o.ewe(5, sids, o.ntt(sids, pick(auto(x)), inverse=True), k=[scale[i] for i in sel])
+        for j, r in enumerate(sel):
+            e = exp[j]
+            assert np.array_equal(got[j], (e & np.uint64(0x3FFFFFFF)) | ((e >> np.uint64(30)) << np.uint64(32)) if r % 2 else e), r
+        k = [o.moduli[m] - 3 - (r % 9) for r, m in enumerate(ids)]
+        ak = [(kk * 11 + 5) % o.moduli[m] for kk, m in zip(k, ids)]
+        NO = 0xFFFFFFFF
+        al = [NO if r % 3 == 2 else r for r in range(n)]
+        base = o.ewe(6, sids, pick(mn), None, o.ntt(sids, pick(x)), k=[k[i] for i in sel])
+        ctx.ntt_mix_sub_scale(dx, dmn, out, ids, k, addend=dad, addend_limbs=al, addend_galois=gs)
+        got, with_add = pick(out.download()), o.ewe(3, sids, base, None, pick(auto(ad)))
+        for j, r in enumerate(sel):
+            assert np.array_equal(got[j], base[j] if r % 3 == 2 else with_add[j]), r
+        ctx.ntt_mix_sub_scale(dx, dmn, out, ids, k, addend=dad, addend_k=ak, addend_galois=gs)
+        assert np.array_equal(pick(out.download()), o.ewe(3, sids, base, None, o.ewe(5, sids, pick(auto(ad)), k=[ak[i] for i in sel])))
+        with pytest.raises(hip.HmError):
+            ctx.ntt(dx, dx, ids, inverse=True, in_galois=gs)                                  # gathered input, in place
+        with pytest.raises(hip.HmError):
+            ctx.ntt(dx, out, ids, inverse=False, in_galois=gs)                                # forward transform
+        with pytest.raises(hip.HmError):
+            ctx.ntt(dx, out, ids, inverse=True, in_galois=[4] * n)                            # even Galois element
+        with pytest.raises(hip.HmError):
+            ctx.ntt_mix_sub_scale(dx, dmn, out, ids, k, addend_galois=gs)                     # no addend
+        with pytest.raises(hip.HmError):
+            ctx.ntt_mix_sub_scale(dx, dmn, out, ids, k, mix=dad, mix_k=ak, addend=dad, addend_galois=gs)   # with the mix prologue
+        for b_ in (dx, dmn, dad, out):
+            b_.free()
+    finally:
+        for name, v in before.items():
+            ctx.set_option(name, v)
+
+
 def test_errors_are_loud(env):
     ctx, o, hip = env
     d = ctx.alloc(2)
