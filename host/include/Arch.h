@@ -116,6 +116,7 @@ private:
   bool fuseBconv = true;  // config key fuse_bconv: the ModUp conversion runs inside the first pass of the fused transform x key kernel   // config key fuse_hpip: the ModUp transforms' last pass runs inside the inner-product kernel
   bool fuseIpInv = true;     // pass (7b): the inner product's special limbs leave as the first pass of the ModDown's inverse transform
   bool packBconvIn = true;   // pass (11): inverse transforms that feed only base conversions store the split-30 packed form
+  bool fuseAuto = true;      // pass (12): an automorphism read only as a transform's input / a fused transform's addend is gathered by that transform
   bool fuseModDown = true;   // pass (9): the ModDown conversion inside the merged transform's first pass (default: by batch size)
   uint32_t n = 0, logN = 0, clusterCount = 1;
   uint32_t maxLevel_ = 0, curLevel_ = 0, world_ = 1, rank_ = 0;

@@ -47,6 +47,8 @@ public:
   bool packedOut = false;    // INTT record (11, round 5): the output is stored in the split-30 packed form (only base conversions read it)
   bool inPacked = false;     // BCONV record / fused transform with fConvIn (11): the conversion's inputs are stored packed
   std::vector<uint8_t> ipConvPacked;   // IP record (11): per digit, the inputs of the digit's fused conversion are stored packed
+  // (12, round 6) an AUTO record folded into its readers: an INTT record reads its input, a fused forward transform its addend, through X -> X^g
+  uint32_t inGalois = 0, fAddendGalois = 0;   // 0: as stored
   bool fusedEpi = false;
   AddrType fSubFrom = 0, fAdd = 0;
   bool fusedTensor = false;            // MAC2 record that also produces d0 -> extraOutputs[0] and d2 -> extraOutputs[1]

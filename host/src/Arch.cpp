@@ -29,6 +29,7 @@ struct Arch::Launch {
   std::vector<uint8_t> ipInv;     // L_NTT_IP (7b): per limb, 1 = the outputs leave as the first pass of their inverse transform
   bool secondOnly = false;        // L_INTT (7b): hm_ntt_second_pass — the first pass was run by the inner-product kernel
   std::vector<uint8_t> outPacked; // L_INTT (11): per limb-poly, 1 = stored in the split-30 packed form of the conversions' inputs
+  std::vector<uint32_t> inGalois, addGalois;   // (12) L_INTT: per limb-poly, the input / L_NTT_SUBSCALE: the addend is read through X -> X^g (0: as stored); empty: none
   uint32_t ipTerms = 0, ipOuts = 0;
   std::string name;
   std::string statKey;
@@ -109,6 +110,10 @@ Arch::Arch(Config *cfg) : config(cfg) {
   // workgroup (18 per value in a 35-output ModUp digit).  Config key pack_bconv_in (default 1).
   packBconvIn = cfg->getValueOr("pack_bconv_in", 1) != 0;
   if (const char *e = getenv("HOMULATOR_PACK_BCONV_IN")) packBconvIn = std::string(e) != "0";
+  // (12, round 6) an automorphism whose output only feeds inverse transforms' inputs / fused forward transforms' addends is read through by them
+  // (hrotate: AUTO_Key(0) -> the final add).  Config key fuse_auto (default 1).
+  fuseAuto = cfg->getValueOr("fuse_auto", 1) != 0;
+  if (const char *e = getenv("HOMULATOR_FUSE_AUTO")) fuseAuto = std::string(e) != "0";
   fuseModDown = cfg->getValueOr("fuse_moddown", 0) != 0;
   if (const char *e = getenv("HOMULATOR_FUSE_MODDOWN")) fuseModDown = std::string(e) != "0";
   // sharded runs: the exchanges of digit j+1 run on the context's exchange stream while digit j converts and transforms (SURVEY.md 7:
@@ -724,6 +729,48 @@ void Arch::fusePasses(std::vector<Stage> &st) {
       for (Instruction *x : s.ins)
         if (x->ops == INTT && !dead.count(x) && read.count(x->OutputOperand)) x->packedOut = true;
   }
+  // (12) round 6: an automorphism whose output is read ONLY as the input of inverse transforms and / or as the addend of fused forward transforms
+  //      folds into those readers (hm_ntt_desc.in_galois, hm_ntt_fused_desc.addend_galois): the index map takes aligned blocks to aligned blocks, so
+  //      a transform gathers through it with its own 16-byte loads, and AUTOOutput is never written or read back.  hrotate: AUTO_Key(1) -> ModUp_INTT,
+  //      AUTO_Key(0) -> the final add inside ModDowNTT's epilogue: 6 -> 5 launches, 140 limb-polys less traffic.  Config key fuse_auto (default 1).
+  if (fuseAuto) {
+    struct Reader { Instruction *ins; int role; };   // role 0: INTT input, 1: fused forward transform's addend, -1: anything else
+    std::map<AddrType, std::vector<Reader>> readers;
+    for (auto &s : st)
+      for (Instruction *i : s.ins) {
+        if (dead.count(i)) continue;
+        if (i->ops == IP && !i->ipX.empty()) {
+          for (AddrType a : (i->ipSrc.empty() ? i->ipX : i->ipSrc)) readers[a].push_back({i, -1});
+          for (auto &v : i->ipConvIn) for (AddrType a : v) readers[a].push_back({i, -1});
+          for (auto &y : i->ipY) for (AddrType a : y) readers[a].push_back({i, -1});
+          continue;
+        }
+        const bool plainIntt = i->ops == INTT && !i->secondOnly && i->fConvIn.empty() && !i->inGalois;
+        for (AddrType a : operands(i)) readers[a].push_back({i, plainIntt && a == i->operandList[0] ? 0 : -1});
+        for (AddrType a : i->fConvIn) readers[a].push_back({i, -1});
+        if (i->fusedSubScale) {
+          readers[i->fMinuend].push_back({i, -1});
+          if (i->fAddend) readers[i->fAddend].push_back({i, i->ops == NTT && !i->fMix && i->fConvIn.empty() && !i->fAddendGalois ? 1 : -1});
+          if (i->fMix) readers[i->fMix].push_back({i, -1});
+        }
+        if (i->fusedEpi) { readers[i->fSubFrom].push_back({i, -1}); if (i->fAdd) readers[i->fAdd].push_back({i, -1}); }
+      }
+    for (auto &s : st)
+      for (Instruction *A : s.ins) {
+        if (A->ops != AUTO || dead.count(A) || A->galois <= 1) continue;
+        auto r = readers.find(A->OutputOperand);
+        if (r == readers.end() || r->second.empty()) continue;   // nobody reads it inside the op: a result
+        bool ok = true;
+        for (const Reader &x : r->second) ok &= x.role >= 0 && x.ins->mod_id == A->mod_id && x.ins->OutputOperand != A->operandList[0];
+        if (!ok) continue;
+        for (const Reader &x : r->second) {
+          if (x.role == 0) { x.ins->operandList[0] = A->operandList[0]; x.ins->inGalois = A->galois; }
+          else { x.ins->fAddend = A->operandList[0]; x.ins->fAddendGalois = A->galois; }
+        }
+        r->second.front().ins->refInstructions += A->refInstructions;
+        dead.insert(A);
+      }
+  }
   // drop dead instructions and empty stages; upstream instructions of eliminated pass-through records are
   // accounted on the first surviving instruction so that the retired total still matches getTotalIns()
   unsigned long long orphan = 0;
@@ -1065,12 +1112,14 @@ void Arch::buildLaunches() {
       } else if (f->fusedSubScale) {
         L->kind = Launch::L_NTT_SUBSCALE; L->statKey = "NTT";
         bool anyAddend = false;   // the addend is per limb-poly (hrotate: key 0 adds the rotated c0, key 1 nothing)
+        bool anyAddGalois = false;   // (12) ... and key 0's addend through the automorphism
         for (const Part *g : group)
-          for (Instruction *i : g->ins) anyAddend |= i->fAddend != 0;
+          for (Instruction *i : g->ins) { anyAddend |= i->fAddend != 0; anyAddGalois |= i->fAddendGalois != 0; }
         for (const Part *g : group)
           for (Instruction *i : g->ins) {
             L->a.push_back(limbOf(i->operandList[0])); L->b.push_back(limbOf(i->fMinuend));
             if (anyAddend) L->c.push_back(i->fAddend ? limbOf(i->fAddend) : HM_NO_LIMB);
+            if (anyAddGalois) L->addGalois.push_back(i->fAddendGalois);
             L->out.push_back(limbOf(i->OutputOperand)); L->mods.push_back(i->mod_id); L->k.push_back(i->constant);
             if (f->fMix) {  // the part key keeps merged and plain records apart
               L->d.push_back(limbOf(i->fMix)); L->mixK.push_back(i->fMixConst);
@@ -1099,8 +1148,12 @@ void Arch::buildLaunches() {
       } else if (f->ops == NTT || f->ops == INTT) {
         L->kind = f->ops == NTT ? Launch::L_NTT : Launch::L_INTT; L->statKey = "NTT";
         L->secondOnly = f->secondOnly;
+        bool anyInGalois = false;
+        for (const Part *g : group)
+          for (Instruction *i : g->ins) anyInGalois |= i->inGalois != 0;
         for (const Part *g : group)
           for (Instruction *i : g->ins) {
+            if (anyInGalois) L->inGalois.push_back(i->inGalois);
             L->a.push_back(limbOf(i->operandList[0])); L->out.push_back(limbOf(i->OutputOperand)); L->mods.push_back(i->mod_id);
             L->k.push_back(i->hasConstant ? i->constant : 1);
             L->hasK |= i->hasConstant;
@@ -1279,6 +1332,7 @@ void Arch::replicateForBatch() {
       }
       rep(l->a, true); rep(l->b, true); rep(l->c, true); rep(l->d, true);
       rep(l->out, true); rep(l->out1, true); rep(l->out2, true); rep(l->mods, false);
+      rep(l->inGalois, false); rep(l->addGalois, false);
       for (std::vector<uint64_t> *kv : {&l->k, &l->mixK, &l->addK}) {
         const size_t k0 = kv->size();
         for (uint32_t c = 1; c < batch_; ++c)
@@ -1400,6 +1454,12 @@ std::string Arch::planText() const {
     if (po) out += " packed_out=" + std::to_string(po);
     if (pi) out += " packed_in=" + std::to_string(pi) + "/" + std::to_string(l->probs.size());
     if (l->secondOnly) out += " second_pass_only";
+    // pass 12: limb-polys whose input (INTT) / addend (fused forward transform) is read through an automorphism
+    for (const auto *gv : {&l->inGalois, &l->addGalois}) {
+      uint32_t cnt = 0, g = 0;
+      for (uint32_t x : *gv) if (x > 1) { ++cnt; g = x; }
+      if (cnt) out += std::string(gv == &l->inGalois ? " auto_in=" : " auto_addend=") + std::to_string(cnt) + "/g" + std::to_string(g);
+    }
     if (l->recordSlot >= 0) out += " mark=" + std::to_string(l->recordSlot);
     if (!l->waitSlots.empty()) { out += " wait="; for (int w : l->waitSlots) out += std::to_string(w) + ","; }
     if (!l->exLimbs.empty()) {
@@ -1424,18 +1484,18 @@ void Arch::enqueue(Launch &l) {
   case Launch::L_INTT: {
     const bool anyPacked = std::find(l.outPacked.begin(), l.outPacked.end(), 1) != l.outPacked.end();
     hm_ntt_desc d = {pool, l.a.data(), pool, l.out.data(), l.mods.data(), cnt, 1, l.hasK ? l.k.data() : nullptr, l.secondOnly ? 1 : 0,
-                     anyPacked ? l.outPacked.data() : nullptr};
+                     anyPacked ? l.outPacked.data() : nullptr, l.inGalois.empty() ? nullptr : l.inGalois.data()};
     st = hm_ntt_ex(ctx, &d);
     break;
   }
   case Launch::L_NTT_SUBSCALE:
-    if (!l.mixK.empty() || !l.probs.empty()) {
+    if (!l.mixK.empty() || !l.probs.empty() || !l.addGalois.empty()) {
       for (auto &q : l.probs)
         descs.push_back(hm_bconv_desc{pool, q.in.data(), q.inMods.data(), (uint32_t)q.in.size(), pool, q.out.data(), q.outMods.data(), (uint32_t)q.out.size(), 0,
                                     nullptr, nullptr, nullptr, nullptr, nullptr, q.inPacked ? 1u : 0u});
       hm_ntt_fused_desc d = {pool, l.a.data(), l.mixK.empty() ? nullptr : pool, l.mixK.empty() ? nullptr : l.d.data(), l.mixK.empty() ? nullptr : l.mixK.data(), pool, l.b.data(),
                              l.c.empty() ? nullptr : pool, l.c.empty() ? nullptr : l.c.data(), l.addK.empty() ? nullptr : l.addK.data(), pool, l.out.data(), l.mods.data(), cnt,
-                             l.k.data(), descs.empty() ? nullptr : descs.data(), (uint32_t)descs.size()};
+                             l.k.data(), descs.empty() ? nullptr : descs.data(), (uint32_t)descs.size(), l.addGalois.empty() ? nullptr : l.addGalois.data()};
       st = hm_ntt_mix_sub_scale(ctx, &d);
     } else {
       st = hm_ntt_sub_scale(ctx, pool, l.a.data(), pool, l.b.data(), l.c.empty() ? nullptr : pool, l.c.empty() ? nullptr : l.c.data(), pool,

@@ -151,16 +151,25 @@ def test_hmult_mixed_conversion_launch(fuse):
 
 
 @pytest.mark.parametrize("cfg,logN,L,ell,alpha", CASES)
-@pytest.mark.parametrize("fuse", [False, True])
+@pytest.mark.parametrize("fuse", [False, True, "auto-launch"])
 @pytest.mark.parametrize("chain", ["mont32", "survey"])
 def test_hrotate_bit_exact(cfg, logN, L, ell, alpha, fuse, chain):
+    """fuse = True: the default plan — since round 6 (pass 12) the final add reads c0 THROUGH the automorphism and AUTOOutput(0) is never written;
+    "auto-launch": the same plan with both automorphisms as a launch (fuse_auto = 0)"""
     from homulator_amd import host
     o = oracle(logN, L, alpha, chain)
     ct1, _, evk = inputs(o, ell)
-    op = host.Op(cfg, "hrotate", L, ell, alpha, fuse=fuse, overrides=chain_overrides(chain))
+    ov = dict(chain_overrides(chain) or {})
+    if fuse == "auto-launch":
+        ov["fuse_auto"] = 0
+    op = host.Op(cfg, "hrotate", L, ell, alpha, fuse=bool(fuse), overrides=ov or None)
+    folded = any(" auto_addend=" in ln for ln in op.plan())
+    assert folded == (fuse is True)
     op.execute(1)
     r0, r1 = o.automorph_eval(ct1[0], 5), o.automorph_eval(ct1[1], 5)
-    assert np.array_equal(op.read("AUTOOutput(0)"), r0) and np.array_equal(op.read("AUTOOutput(1)"), r1)
+    assert np.array_equal(op.read("AUTOOutput(1)"), r1)
+    if not folded:
+        assert np.array_equal(op.read("AUTOOutput(0)"), r0)
     k0, k1, dd = o.keyswitch(ell, r1, evk, dump=True)
     check_keyswitch_buffers(op, dd, ell, alpha, o.beta(ell), fuse, ip_rows=ell if fuse else None)   # 7b: the special limbs
     exp = o.hrotate(ell, ct1, 5, evk)

@@ -112,3 +112,16 @@ def test_packed_conversion_inputs_in_the_default_plan():
     assert " packed_in=" in by["BCONV"][0], by["BCONV"][0]
     pn, _, _ = plan("config_4.cfg", "hmult", 45, 35, 15, pack_bconv_in=0)
     assert not any("packed" in ln for ln in pn)
+
+
+def test_the_automorphism_of_c0_folds_into_the_final_add():
+    """pass 12 (round 6): an automorphism read only as the addend of a fused forward transform (hrotate: AUTO_Key(0) -> the final add inside
+    ModDowNTT's epilogue) is gathered by that transform; AUTO_Key(1) stays a launch (the inner product reads the rotated c1's own limbs in
+    evaluation form).  The instruction total stays upstream's; fuse_auto = 0 restores the launch of both"""
+    p, total, n = plan("config_4.cfg", "hrotate", 45, 35, 15)
+    assert n == 6 and kinds(p)[0] == "AUTO" and " n=35 " in p[0] + " " and "AUTO_Key(0)" not in p[0]
+    assert p[-1].startswith("NTT_SUBSCALE") and " auto_addend=35/g5" in p[-1]
+    p0, total0, n0 = plan("config_4.cfg", "hrotate", 45, 35, 15, fuse_auto=0)
+    assert n0 == 6 and total0 == total and " n=70 " in p0[0] + " " and "auto_addend" not in p0[-1]
+    pg, _, _ = plan("config_4_N15.cfg", "hrotate", 16, 10, 4, galois=25)
+    assert " auto_addend=10/g25" in pg[-1]
