@@ -400,6 +400,7 @@ struct HmNipArgs {
   const HmMod *mods;
   uint32_t logN, n_limbs, logG, n_terms;
   const HmNipLimb *limb;  // device, [n_limbs]
+  uint32_t x_galois;      // the XG kernels: evaluation-form operands are read through X -> X^x_galois
 };
 typedef const HmNipLimb __attribute__((address_space(4))) *HmConstNipLimb;
 #ifndef HM_NIP_WAVES
@@ -433,16 +434,16 @@ namespace hm8 {
 }
 #undef HM_EPT
 #define HM_EPT 16
-template <int OUTS, int INVOUT>
+template <int OUTS, int INVOUT, bool XG = false>
 __global__ void __launch_bounds__((1 << HM_TL_ROW) / HM_EPT) __attribute__((amdgpu_waves_per_eu(HM_NIP_WAVES))) k_ntt_row_ip(HmNipArgs a) {
-  hm16::hm_nip_body<OUTS, INVOUT>(a);
+  hm16::hm_nip_body<OUTS, INVOUT, HM_TL_ROW, XG>(a);
 }
 // The same in the small-launch geometry (round 5): one op at a time the launch is 800 workgroups on 768 slots (155 VGPRs: three 256-thread
 // workgroups per CU) and pays a second, nearly empty round.  512-thread workgroups with 8 coefficients per thread halve the serial work of
 // a workgroup and the accumulator registers per thread: the last round's idle time halves with them.  N = 2^16.
-template <int OUTS, int INVOUT>
+template <int OUTS, int INVOUT, bool XG = false>
 __global__ void __launch_bounds__((1 << HM_TL_ROW) / 8) k_ntt_row_ip8(HmNipArgs a) {
-  hm8::hm_nip_body<OUTS, INVOUT>(a);
+  hm8::hm_nip_body<OUTS, INVOUT, HM_TL_ROW, XG>(a);
 }
 // (The same on HALF tiles — hm_nip_body's TLR = 11: 1 792 equal pieces of work for one op instead of 896 — was built and measured level
 // within the noise, +0.5 % / +1.2 % / -1.7 % one op at a time on three boxes, and is not instantiated: profiles/r05_late_ab.txt.)
@@ -1689,6 +1690,7 @@ extern "C" hm_status hm_ntt_inner_product(hm_ctx *c, const hm_ntt_ip_desc *d) {
     for (uint32_t i = 0; i < n; ++i)
       if (d->out_inverse[i]) return fail(c, HM_ERR_UNSUPPORTED, "hm_ntt_inner_product: out_inverse needs N = 2^15 or 2^16");
   }
+  if (d->x_galois && (!(d->x_galois & 1) || d->x_galois >= 2 * c->P.N)) return fail(c, HM_ERR_ARG, "hm_ntt_inner_product: x_galois is not an odd number below 2N");
   hm_status st;
   if ((st = check_limbs(c, "hm_ntt_inner_product", d->x_limbs, n * T)) || (st = check_limbs(c, "hm_ntt_inner_product", d->y_limbs, n * T * K)) ||
       (st = check_limbs(c, "hm_ntt_inner_product", d->out_limbs, n * K)) || (st = check_mods(c, "hm_ntt_inner_product", d->mod_ids, n)))
@@ -1822,9 +1824,19 @@ extern "C" hm_status hm_ntt_inner_product(hm_ctx *c, const hm_ntt_ip_desc *d) {
     static const nip_kernel kern[2][3] = {{k_ntt_row_ip<1, 0>, nullptr, k_ntt_row_ip<1, 2>}, {k_ntt_row_ip<2, 0>, nullptr, k_ntt_row_ip<2, 2>}};
     static const nip_kernel kern8[2][3] = {{k_ntt_row_ip8<1, 0>, nullptr, k_ntt_row_ip8<1, 2>}, {k_ntt_row_ip8<2, 0>, nullptr, k_ntt_row_ip8<2, 2>}};
 #endif
+    // (round 6) the same with the evaluation-form operands read through an automorphism (hm_ntt_ip_desc.x_galois)
+#if HM_GENERIC
+    static const nip_kernel kernG[2][3] = {{k_ntt_row_ip<1, 0, true>, k_ntt_row_ip<1, 1, true>, nullptr}, {k_ntt_row_ip<2, 0, true>, k_ntt_row_ip<2, 1, true>, nullptr}};
+    static const nip_kernel kern8G[2][3] = {{k_ntt_row_ip8<1, 0, true>, k_ntt_row_ip8<1, 1, true>, nullptr}, {k_ntt_row_ip8<2, 0, true>, k_ntt_row_ip8<2, 1, true>, nullptr}};
+#else
+    static const nip_kernel kernG[2][3] = {{k_ntt_row_ip<1, 0, true>, nullptr, k_ntt_row_ip<1, 2, true>}, {k_ntt_row_ip<2, 0, true>, nullptr, k_ntt_row_ip<2, 2, true>}};
+    static const nip_kernel kern8G[2][3] = {{k_ntt_row_ip8<1, 0, true>, nullptr, k_ntt_row_ip8<1, 2, true>}, {k_ntt_row_ip8<2, 0, true>, nullptr, k_ntt_row_ip8<2, 2, true>}};
+#endif
+    const bool xg = d->x_galois > 1;
+    a.x_galois = d->x_galois;
     // small launches (one op at a time: 50 limb records = 800 workgroups on 768 slots of the wide form) take the small-launch geometry
-    if (cnt <= small_entries(c, c->nip_small)) hipLaunchKernelGGL(kern8[K - 1][invForm], grid, dim3((1 << HM_TL_ROW) / 8), 0, c->stream, a);
-    else hipLaunchKernelGGL(kern[K - 1][invForm], grid, block, 0, c->stream, a);
+    if (cnt <= small_entries(c, c->nip_small)) hipLaunchKernelGGL((xg ? kern8G : kern8)[K - 1][invForm], grid, dim3((1 << HM_TL_ROW) / 8), 0, c->stream, a);
+    else hipLaunchKernelGGL((xg ? kernG : kern)[K - 1][invForm], grid, block, 0, c->stream, a);
     HM_HIP(c, hipGetLastError());
   }
   }   // sets

@@ -6,7 +6,9 @@
 // (the Shoup twiddles take twice the registers), so there the two kinds of limbs are two launches (0 and 1).
 // TLR: log2 of the ROW tile a workgroup owns (HM_TL_ROW = 4096 coefficients = 16 rows; 11 = 8 rows works too — twice the workgroups of
 // half the work — and measured level: not instantiated)
-template <int OUTS, int INVOUT, int TLR = HM_TL_ROW>
+// XG (round 6): the digits that arrive in evaluation form (a limb's own digit) are read through the automorphism X -> X^a.x_galois — hrotate's
+// rotated c1 is then never written (AUTO_Key(1) folds into the ModUp INTT and into this kernel); instantiations of their own
+template <int OUTS, int INVOUT, int TLR = HM_TL_ROW, bool XG = false>
 __device__ __forceinline__ void hm_nip_body(const HmNipArgs &a) {
   constexpr int TL = TLR, LOGR = HM_ROW_LOG, R2 = HmRounds<LOGR>::n - 1;
   __shared__ __attribute__((aligned(16))) uint64_t lds[HmLds<TL, LOGR, false>::WORDS];
@@ -62,7 +64,11 @@ __device__ __forceinline__ void hm_nip_body(const HmNipArgs &a) {
       hm_ph_below_2q(st, m.q);
 #endif
     } else {
-      hm_ph_load_global<TL, LOGR, false, R2, HM_NIP_LD_AUX>(st, tid, a.x + (size_t)xl * N, tile);
+      if constexpr (XG) {
+        HmEpi ep = hm_epi_none();
+        ep.g = a.x_galois; ep.logN = a.logN;
+        hm_ph_load_global_auto<TL, LOGR, false, R2, HM_NIP_LD_AUX>(st, tid, a.x + (size_t)xl * N, tile, ep);
+      } else hm_ph_load_global<TL, LOGR, false, R2, HM_NIP_LD_AUX>(st, tid, a.x + (size_t)xl * N, tile);
     }
 #if HM_NIP_PREFETCH
     hm_ph_mac_regs<OUTS, Acc>(st, acc, e, m, j);

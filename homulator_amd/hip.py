@@ -35,7 +35,7 @@ class hm_ntt_ip_desc(C.Structure):
     _fields_ = [("x", C.c_void_p), ("x_limbs", C.c_void_p), ("x_is_coeff", C.c_void_p), ("hand", C.c_void_p), ("hand_limbs", C.c_void_p),
                 ("y", C.c_void_p), ("y_limbs", C.c_void_p), ("out", C.c_void_p), ("out_limbs", C.c_void_p), ("mod_ids", C.c_void_p),
                 ("n", C.c_uint32), ("n_terms", C.c_uint32), ("n_out", C.c_uint32), ("conv", C.c_void_p), ("n_conv", C.c_uint32),
-                ("out_inverse", C.c_void_p)]
+                ("out_inverse", C.c_void_p), ("x_galois", C.c_uint32)]
 
 
 class hm_bconv_desc(C.Structure):
@@ -282,10 +282,11 @@ class Context:
         k3, ps = _u64(scale)
         self._ck(self.L.hm_ntt_second_pass(self.h, buf.ptr, pl, pm, len(mod_ids), 1 if inverse else 0, ps))
 
-    def ntt_inner_product(self, x, x_limbs, x_is_coeff, hand, hand_limbs, y, y_limbs, out, out_limbs, mod_ids, n_terms, n_out, conv=None, out_inverse=None):
+    def ntt_inner_product(self, x, x_limbs, x_is_coeff, hand, hand_limbs, y, y_limbs, out, out_limbs, mod_ids, n_terms, n_out, conv=None, out_inverse=None,
+                          x_galois=0):
         """out[i][k] = sum_j (NTT(x[i][j]) if x_is_coeff[i][j] else x[i][j]) * y[i][k][j]: the HPIP unit as a fused NTT-epilogue x key MAC.
         conv = [(src, in_limbs, in_ids, hand_out_limbs, out_ids), ...]: the transformed digits are these base conversions, computed inside
-        the transforms' first pass (their outputs are hand-off limbs of `hand`)"""
+        the transforms' first pass (their outputs are hand-off limbs of `hand`); x_galois = g: the evaluation-form digits are read through X -> X^g"""
         keep = [_u32(v) for v in (x_limbs, hand_limbs, y_limbs, out_limbs, mod_ids)]
         flags = np.ascontiguousarray(np.asarray(x_is_coeff, dtype=np.uint8))
         descs, keep2 = None, []
@@ -301,7 +302,7 @@ class Context:
         d = hm_ntt_ip_desc(x.ptr, keep[0][1], flags.ctypes.data_as(C.c_void_p), None if hand is None else hand.ptr, keep[1][1], y.ptr, keep[2][1],
                            out.ptr, keep[3][1], keep[4][1], len(mod_ids), n_terms, n_out,
                            C.cast(descs, C.c_void_p) if conv else None, len(conv) if conv else 0,
-                           None if inv is None else inv.ctypes.data_as(C.c_void_p))
+                           None if inv is None else inv.ctypes.data_as(C.c_void_p), int(x_galois))
         self._ck(self.L.hm_ntt_inner_product(self.h, C.byref(d)))
 
     def automorph(self, src, dst, n, galois, in_limbs=None, out_limbs=None):

@@ -194,6 +194,10 @@ typedef struct hm_ntt_ip_desc {
    * finishes the transform.  The sums themselves never reach HBM.  N = 2^16 (HM_ERR_UNSUPPORTED otherwise).  Bit-identical to the call
    * without it followed by hm_ntt(.., inverse = 1, ..). */
   const uint8_t *out_inverse;
+  /* optional (0: none; round 6): x_galois = g > 1 reads the digits that arrive in EVALUATION form (x_is_coeff == 0: a limb's own digit) through the
+   * automorphism X -> X^g, as hm_automorph would have stored them: with hm_ntt_desc.in_galois on the ModUp INTT, hrotate's rotated c1 (AUTO_Key(1),
+   * InsGen::GenAUTO src/InsGen.cpp:46-71) is never written.  g odd, below 2N.  Bit-identical to hm_automorph + the call without it. */
+  uint32_t x_galois;
 } hm_ntt_ip_desc;
 hm_status hm_ntt_inner_product(hm_ctx *ctx, const hm_ntt_ip_desc *desc);
 /* K1, second half: the last pass of a transform whose first pass has already been run into `buf` by another call — the inverse ROW pass of

@@ -405,6 +405,43 @@ def test_ntt_inner_product_fused(env, terms, outs):
         b_.free()
 
 
+@pytest.mark.parametrize("n,inv", [(70, False), (70, True), (9, True), (9, False)], ids=["wide", "wide-inverse-out", "small-inverse-out", "small"])
+@pytest.mark.parametrize("outs", [2, 1])
+def test_ntt_inner_product_reads_own_digits_through_an_automorphism(env, n, inv, outs):
+    """round 6 (hm_ntt_ip_desc.x_galois): the digits that arrive in evaluation form are read through X -> X^g — the same result as the call on
+    operands hm_automorph has rotated first, bit for bit, in the wide and the small-launch geometry, with and without the inverse first pass on
+    the outputs, for a rotation that swaps the words of a 16-byte unit (5) and the conjugation that does not; transformed digits are untouched"""
+    ctx, o, hip = env
+    M, terms = o.L + o.K, 3
+    ids = [(i * 5 + 1) % M for i in range(n)]
+    X = [o.fill_uniform(ids, 10 + j) for j in range(terms)]
+    Y = [[o.fill_uniform(ids, 100 + 10 * k + j) for j in range(terms)] for k in range(outs)]
+    coeff = [[(i + j) % 3 != 0 for j in range(terms)] for i in range(n)]
+    xb = ctx.from_host(np.concatenate(X))
+    yb = ctx.from_host(np.concatenate([Y[k][j] for k in range(outs) for j in range(terms)]))
+    hand, out, ref, rot = ctx.alloc(n * terms), ctx.alloc(n * outs), ctx.alloc(n * outs), ctx.alloc(n * terms)
+    xl = [j * n + i for i in range(n) for j in range(terms)]
+    yl = [(k * terms + j) * n + i for i in range(n) for k in range(outs) for j in range(terms)]
+    ol = [k * n + i for i in range(n) for k in range(outs)]
+    flags = [c for row in coeff for c in row]
+    oi = [1 if inv and i % 2 else 0 for i in range(n)] if inv else None
+    for g in (5, 2 * o.N - 1):
+        # reference: rotate the evaluation-form operands first (the transformed digits stay as they are), then the plain call
+        Xr = [X[j].copy() for j in range(terms)]
+        for j in range(terms):
+            for i in range(n):
+                if not coeff[i][j]:
+                    Xr[j][i] = o.automorph_eval(X[j][i][None], g)[0]
+        rot.upload(np.concatenate(Xr))
+        ctx.ntt_inner_product(rot, xl, flags, hand, xl, yb, yl, ref, ol, ids, terms, outs, out_inverse=oi)
+        ctx.ntt_inner_product(xb, xl, flags, hand, xl, yb, yl, out, ol, ids, terms, outs, out_inverse=oi, x_galois=g)
+        assert np.array_equal(out.download(), ref.download()), g
+    with pytest.raises(hip.HmError):
+        ctx.ntt_inner_product(xb, xl, flags, hand, xl, yb, yl, out, ol, ids, terms, outs, x_galois=6)
+    for b_ in (xb, yb, out, ref, hand, rot):
+        b_.free()
+
+
 @pytest.mark.parametrize("chain", ["mont32", "survey"])
 @pytest.mark.parametrize("n_in", [1, 2, 5, 9, 15])
 def test_ntt_inner_product_with_conversion_inside(n_in, chain):
