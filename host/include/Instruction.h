@@ -49,6 +49,7 @@ public:
   std::vector<uint8_t> ipConvPacked;   // IP record (11): per digit, the inputs of the digit's fused conversion are stored packed
   // (12, round 6) an AUTO record folded into its readers: an INTT record reads its input, a fused forward transform its addend, through X -> X^g
   uint32_t inGalois = 0, fAddendGalois = 0;   // 0: as stored
+  uint32_t ipXGalois = 0;                     // ... and a transform x key record its evaluation-form digits (hm_ntt_ip_desc.x_galois)
   bool fusedEpi = false;
   AddrType fSubFrom = 0, fAdd = 0;
   bool fusedTensor = false;            // MAC2 record that also produces d0 -> extraOutputs[0] and d2 -> extraOutputs[1]

@@ -30,6 +30,7 @@ struct Arch::Launch {
   bool secondOnly = false;        // L_INTT (7b): hm_ntt_second_pass — the first pass was run by the inner-product kernel
   std::vector<uint8_t> outPacked; // L_INTT (11): per limb-poly, 1 = stored in the split-30 packed form of the conversions' inputs
   std::vector<uint32_t> inGalois, addGalois;   // (12) L_INTT: per limb-poly, the input / L_NTT_SUBSCALE: the addend is read through X -> X^g (0: as stored); empty: none
+  uint32_t xGalois = 0;                        // (12) L_NTT_IP: the evaluation-form digits are read through X -> X^g
   uint32_t ipTerms = 0, ipOuts = 0;
   std::string name;
   std::string statKey;
@@ -729,32 +730,44 @@ void Arch::fusePasses(std::vector<Stage> &st) {
       for (Instruction *x : s.ins)
         if (x->ops == INTT && !dead.count(x) && read.count(x->OutputOperand)) x->packedOut = true;
   }
-  // (12) round 6: an automorphism whose output is read ONLY as the input of inverse transforms and / or as the addend of fused forward transforms
-  //      folds into those readers (hm_ntt_desc.in_galois, hm_ntt_fused_desc.addend_galois): the index map takes aligned blocks to aligned blocks, so
-  //      a transform gathers through it with its own 16-byte loads, and AUTOOutput is never written or read back.  hrotate: AUTO_Key(1) -> ModUp_INTT,
-  //      AUTO_Key(0) -> the final add inside ModDowNTT's epilogue: 6 -> 5 launches, 140 limb-polys less traffic.  Config key fuse_auto (default 1).
+  // (12) round 6: an automorphism whose output is read ONLY as the input of inverse transforms, as the addend of fused forward transforms and / or as
+  //      the evaluation-form digits of transform x key records folds into those readers (hm_ntt_desc.in_galois, hm_ntt_fused_desc.addend_galois,
+  //      hm_ntt_ip_desc.x_galois): the index map takes aligned blocks to aligned blocks, so a kernel gathers through it with its own 16-byte loads,
+  //      and AUTOOutput is never written or read back.  hrotate: AUTO_Key(1) -> ModUp_INTT + the key product's own digits, AUTO_Key(0) -> the final
+  //      add inside ModDowNTT's epilogue: 6 -> 5 launches, 140 limb-polys less traffic.  Config key fuse_auto (default 1).
+  //      The key product takes ONE Galois element per launch: its records fold only if every evaluation-form digit of every such record of the op
+  //      is the output of a foldable automorphism by the same element (one GPU; the sharded plans keep the launch).
   if (fuseAuto) {
-    struct Reader { Instruction *ins; int role; };   // role 0: INTT input, 1: fused forward transform's addend, -1: anything else
-    std::map<AddrType, std::vector<Reader>> readers;
+    struct Reader { Instruction *ins; int role; size_t digit; };   // role 0: INTT input, 1: fused forward transform's addend, 2: evaluation-form digit of a
+    std::map<AddrType, std::vector<Reader>> readers;               // transform x key record, -1: anything else
+    std::vector<Reader> ownDigits;
     for (auto &s : st)
       for (Instruction *i : s.ins) {
         if (dead.count(i)) continue;
         if (i->ops == IP && !i->ipX.empty()) {
-          for (AddrType a : (i->ipSrc.empty() ? i->ipX : i->ipSrc)) readers[a].push_back({i, -1});
-          for (auto &v : i->ipConvIn) for (AddrType a : v) readers[a].push_back({i, -1});
-          for (auto &y : i->ipY) for (AddrType a : y) readers[a].push_back({i, -1});
+          const bool nip = std::find(i->ipCoeff.begin(), i->ipCoeff.end(), 1) != i->ipCoeff.end() && world_ == 1 && !i->ipXGalois;
+          const auto &src = i->ipSrc.empty() ? i->ipX : i->ipSrc;
+          for (size_t j = 0; j < src.size(); ++j) {
+            const bool own = nip && !i->ipCoeff[j] && !(j < i->ipConvIn.size() && !i->ipConvIn[j].empty());
+            readers[src[j]].push_back({i, own ? 2 : -1, j});
+            if (own) ownDigits.push_back({i, 2, j});
+          }
+          for (auto &v : i->ipConvIn) for (AddrType a : v) readers[a].push_back({i, -1, 0});
+          for (auto &y : i->ipY) for (AddrType a : y) readers[a].push_back({i, -1, 0});
           continue;
         }
         const bool plainIntt = i->ops == INTT && !i->secondOnly && i->fConvIn.empty() && !i->inGalois;
-        for (AddrType a : operands(i)) readers[a].push_back({i, plainIntt && a == i->operandList[0] ? 0 : -1});
-        for (AddrType a : i->fConvIn) readers[a].push_back({i, -1});
+        for (AddrType a : operands(i)) readers[a].push_back({i, plainIntt && a == i->operandList[0] ? 0 : -1, 0});
+        for (AddrType a : i->fConvIn) readers[a].push_back({i, -1, 0});
         if (i->fusedSubScale) {
-          readers[i->fMinuend].push_back({i, -1});
-          if (i->fAddend) readers[i->fAddend].push_back({i, i->ops == NTT && !i->fMix && i->fConvIn.empty() && !i->fAddendGalois ? 1 : -1});
-          if (i->fMix) readers[i->fMix].push_back({i, -1});
+          readers[i->fMinuend].push_back({i, -1, 0});
+          if (i->fAddend) readers[i->fAddend].push_back({i, i->ops == NTT && !i->fMix && i->fConvIn.empty() && !i->fAddendGalois ? 1 : -1, 0});
+          if (i->fMix) readers[i->fMix].push_back({i, -1, 0});
         }
-        if (i->fusedEpi) { readers[i->fSubFrom].push_back({i, -1}); if (i->fAdd) readers[i->fAdd].push_back({i, -1}); }
+        if (i->fusedEpi) { readers[i->fSubFrom].push_back({i, -1, 0}); if (i->fAdd) readers[i->fAdd].push_back({i, -1, 0}); }
       }
+    std::map<AddrType, Instruction *> cand;   // output address -> the automorphism that every reader can read through
+    bool anyOwn = false;
     for (auto &s : st)
       for (Instruction *A : s.ins) {
         if (A->ops != AUTO || dead.count(A) || A->galois <= 1) continue;
@@ -763,13 +776,35 @@ void Arch::fusePasses(std::vector<Stage> &st) {
         bool ok = true;
         for (const Reader &x : r->second) ok &= x.role >= 0 && x.ins->mod_id == A->mod_id && x.ins->OutputOperand != A->operandList[0];
         if (!ok) continue;
-        for (const Reader &x : r->second) {
-          if (x.role == 0) { x.ins->operandList[0] = A->operandList[0]; x.ins->inGalois = A->galois; }
-          else { x.ins->fAddend = A->operandList[0]; x.ins->fAddendGalois = A->galois; }
-        }
-        r->second.front().ins->refInstructions += A->refInstructions;
-        dead.insert(A);
+        cand[A->OutputOperand] = A;
+        for (const Reader &x : r->second) anyOwn |= x.role == 2;
       }
+    if (anyOwn) {   // one Galois element per key-product launch
+      uint32_t g0 = 0;
+      bool uniform = true;
+      for (const Reader &x : ownDigits) {
+        auto c = cand.find((x.ins->ipSrc.empty() ? x.ins->ipX : x.ins->ipSrc)[x.digit]);
+        if (c == cand.end() || (g0 && c->second->galois != g0)) { uniform = false; break; }
+        g0 = c->second->galois;
+      }
+      if (!uniform)
+        for (auto it = cand.begin(); it != cand.end();) {
+          bool own = false;
+          for (const Reader &x : readers[it->first]) own |= x.role == 2;
+          it = own ? cand.erase(it) : std::next(it);
+        }
+    }
+    for (auto &kv : cand) {
+      Instruction *A = kv.second;
+      auto &rd = readers[kv.first];
+      for (const Reader &x : rd) {
+        if (x.role == 0) { x.ins->operandList[0] = A->operandList[0]; x.ins->inGalois = A->galois; }
+        else if (x.role == 1) { x.ins->fAddend = A->operandList[0]; x.ins->fAddendGalois = A->galois; }
+        else { (x.ins->ipSrc.empty() ? x.ins->ipX : x.ins->ipSrc)[x.digit] = A->operandList[0]; x.ins->ipXGalois = A->galois; }
+      }
+      rd.front().ins->refInstructions += A->refInstructions;
+      dead.insert(A);
+    }
   }
   // drop dead instructions and empty stages; upstream instructions of eliminated pass-through records are
   // accounted on the first surviving instruction so that the retired total still matches getTotalIns()
@@ -1083,6 +1118,7 @@ void Arch::buildLaunches() {
             for (AddrType o : i->extraOutputs) L->out.push_back(limbOf(o));
             L->mods.push_back(i->mod_id);
             L->ipInv.push_back(i->ipInvOut ? 1 : 0);
+            if (i->ipXGalois) L->xGalois = i->ipXGalois;   // (12): uniform over the op's records by construction
             lp += (unsigned long long)L->ipTerms * L->ipOuts + L->ipOuts;
           }
         for (auto &q : L->probs) lp += q.in.size();
@@ -1460,6 +1496,7 @@ std::string Arch::planText() const {
       for (uint32_t x : *gv) if (x > 1) { ++cnt; g = x; }
       if (cnt) out += std::string(gv == &l->inGalois ? " auto_in=" : " auto_addend=") + std::to_string(cnt) + "/g" + std::to_string(g);
     }
+    if (l->xGalois) out += " auto_x=g" + std::to_string(l->xGalois);
     if (l->recordSlot >= 0) out += " mark=" + std::to_string(l->recordSlot);
     if (!l->waitSlots.empty()) { out += " wait="; for (int w : l->waitSlots) out += std::to_string(w) + ","; }
     if (!l->exLimbs.empty()) {
@@ -1511,7 +1548,7 @@ void Arch::enqueue(Launch &l) {
                                     nullptr, nullptr, nullptr, nullptr, nullptr, q.inPacked ? 1u : 0u});
     hm_ntt_ip_desc d = {pool, l.a.data(), l.ipCoeff.data(), pool, l.c.data(), pool, l.b.data(), pool, l.out.data(), l.mods.data(),
                         (uint32_t)l.mods.size(), l.ipTerms, l.ipOuts, descs.empty() ? nullptr : descs.data(), (uint32_t)descs.size(),
-                        std::find(l.ipInv.begin(), l.ipInv.end(), 1) != l.ipInv.end() ? l.ipInv.data() : nullptr};
+                        std::find(l.ipInv.begin(), l.ipInv.end(), 1) != l.ipInv.end() ? l.ipInv.data() : nullptr, l.xGalois};
     st = hm_ntt_inner_product(ctx, &d);
     break;
   }

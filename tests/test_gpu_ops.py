@@ -150,12 +150,16 @@ def test_hmult_mixed_conversion_launch(fuse):
     op.close()
 
 
+def beta_of(ell, alpha):
+    return (ell + alpha - 1) // alpha
+
+
 @pytest.mark.parametrize("cfg,logN,L,ell,alpha", CASES)
 @pytest.mark.parametrize("fuse", [False, True, "auto-launch"])
 @pytest.mark.parametrize("chain", ["mont32", "survey"])
 def test_hrotate_bit_exact(cfg, logN, L, ell, alpha, fuse, chain):
-    """fuse = True: the default plan — since round 6 (pass 12) the final add reads c0 THROUGH the automorphism and AUTOOutput(0) is never written;
-    "auto-launch": the same plan with both automorphisms as a launch (fuse_auto = 0)"""
+    """fuse = True: the default plan — since round 6 (pass 12) the ModUp INTT, the key product and the final add read the ciphertext THROUGH the
+    automorphism and neither AUTOOutput is ever written; "auto-launch": the same plan with both automorphisms as a launch (fuse_auto = 0)"""
     from homulator_amd import host
     o = oracle(logN, L, alpha, chain)
     ct1, _, evk = inputs(o, ell)
@@ -165,11 +169,15 @@ def test_hrotate_bit_exact(cfg, logN, L, ell, alpha, fuse, chain):
     op = host.Op(cfg, "hrotate", L, ell, alpha, fuse=bool(fuse), overrides=ov or None)
     folded = any(" auto_addend=" in ln for ln in op.plan())
     assert folded == (fuse is True)
+    launched = " ".join(ln for ln in op.plan() if ln.startswith("AUTO"))   # (a one-digit key switch keeps AUTO_Key(1): its Q limbs' key products are
+    if beta_of(ell, alpha) > 1:                                             # plain inner products, which read the rotated c1 from memory)
+        assert ("AUTO_Key(1)" in launched) == (fuse is not True)
     op.execute(1)
     r0, r1 = o.automorph_eval(ct1[0], 5), o.automorph_eval(ct1[1], 5)
-    assert np.array_equal(op.read("AUTOOutput(1)"), r1)
-    if not folded:
+    if "AUTO_Key(0)" in launched:
         assert np.array_equal(op.read("AUTOOutput(0)"), r0)
+    if "AUTO_Key(1)" in launched:
+        assert np.array_equal(op.read("AUTOOutput(1)"), r1)
     k0, k1, dd = o.keyswitch(ell, r1, evk, dump=True)
     check_keyswitch_buffers(op, dd, ell, alpha, o.beta(ell), fuse, ip_rows=ell if fuse else None)   # 7b: the special limbs
     exp = o.hrotate(ell, ct1, 5, evk)

@@ -42,7 +42,9 @@ def test_headline_plan_is_six_launches():
     p9, total9, n9 = plan("config_4.cfg", "hmult", 45, 35, 15, fuse_hpip=0)
     assert kinds(p9)[2:5] == ["BCONV", "NTT", "IP"] and total9 == total
     ph, totalh, nh = plan("config_4.cfg", "hrotate", 45, 35, 15)
-    assert nh == 6 and kinds(ph) == ["AUTO", "INTT", "NTT_IP", "INTT", "BCONV", "NTT_SUBSCALE"] and totalh == 7328000
+    assert nh == 5 and kinds(ph) == ["INTT", "NTT_IP", "INTT", "BCONV", "NTT_SUBSCALE"] and totalh == 7328000   # (pass 12: no automorphism launch)
+    pha, totalha, nha = plan("config_4.cfg", "hrotate", 45, 35, 15, fuse_auto=0)
+    assert nha == 6 and kinds(pha) == ["AUTO"] + kinds(ph) and totalha == totalh
     phm, _, nhm = plan("config_4.cfg", "hrotate", 45, 35, 15, fuse_moddown=1)
     assert nhm == 5 and kinds(phm) == ["AUTO", "INTT", "NTT_IP", "INTT", "NTT_SUBSCALE"]   # no conversion launch at all
 
@@ -114,14 +116,21 @@ def test_packed_conversion_inputs_in_the_default_plan():
     assert not any("packed" in ln for ln in pn)
 
 
-def test_the_automorphism_of_c0_folds_into_the_final_add():
-    """pass 12 (round 6): an automorphism read only as the addend of a fused forward transform (hrotate: AUTO_Key(0) -> the final add inside
-    ModDowNTT's epilogue) is gathered by that transform; AUTO_Key(1) stays a launch (the inner product reads the rotated c1's own limbs in
-    evaluation form).  The instruction total stays upstream's; fuse_auto = 0 restores the launch of both"""
+def test_the_automorphisms_of_hrotate_fold_into_their_readers():
+    """pass 12 (round 6): an automorphism whose output only feeds inverse transforms' inputs, fused forward transforms' addends and the
+    evaluation-form digits of transform x key records is read THROUGH by those kernels.  hrotate: AUTO_Key(1) -> ModUp_INTT + the key product's
+    own digits, AUTO_Key(0) -> the final add inside ModDowNTT's epilogue; no automorphism launch is left (6 -> 5), the instruction total stays
+    upstream's.  Where a reader cannot gather (the plain inner-product kernel of fuse_hpip = 0; the final transform with the conversion inside,
+    fuse_moddown = 1) that automorphism stays a launch of its 35 limb-polys; fuse_auto = 0 keeps both"""
     p, total, n = plan("config_4.cfg", "hrotate", 45, 35, 15)
-    assert n == 6 and kinds(p)[0] == "AUTO" and " n=35 " in p[0] + " " and "AUTO_Key(0)" not in p[0]
-    assert p[-1].startswith("NTT_SUBSCALE") and " auto_addend=35/g5" in p[-1]
+    assert n == 5 and "AUTO" not in kinds(p)
+    assert " auto_in=35/g5" in p[0] and " auto_x=g5" in p[1] and p[-1].startswith("NTT_SUBSCALE") and " auto_addend=35/g5" in p[-1]
     p0, total0, n0 = plan("config_4.cfg", "hrotate", 45, 35, 15, fuse_auto=0)
-    assert n0 == 6 and total0 == total and " n=70 " in p0[0] + " " and "auto_addend" not in p0[-1]
+    assert n0 == 6 and total0 == total and " n=70 " in p0[0] + " " and not any("auto_" in ln for ln in p0)
+    ph, totalh, _ = plan("config_4.cfg", "hrotate", 45, 35, 15, fuse_hpip=0)       # the plain inner product reads the rotated c1 from memory
+    assert kinds(ph)[0] == "AUTO" and "AUTO_Key(0)" not in ph[0] and " n=35 " in ph[0] + " " and " auto_addend=35/g5" in ph[-1] and totalh == total
+    assert not any("auto_in" in ln or "auto_x" in ln for ln in ph)
+    pm, totalm, _ = plan("config_4.cfg", "hrotate", 45, 35, 15, fuse_moddown=1)    # the final transform converts inside: it takes a plain addend
+    assert kinds(pm)[0] == "AUTO" and "AUTO_Key(1)" not in pm[0] and " auto_in=35/g5" in pm[1] and " auto_x=g5" in pm[2] and totalm == total
     pg, _, _ = plan("config_4_N15.cfg", "hrotate", 16, 10, 4, galois=25)
-    assert " auto_addend=10/g25" in pg[-1]
+    assert " auto_in=10/g25" in pg[0] and " auto_x=g25" in pg[1] and " auto_addend=10/g25" in pg[-1]

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 6: hrotate's automorphism of c0 folded into the final add (pass 12, fuse_auto) against the plan with both automorphisms as a launch:
+# round 6: hrotate's automorphisms folded into their readers (pass 12, fuse_auto: ModUp INTT + key product + final add gather) against the plan with the AUTO launch:
 # parity (every hrotate test of the suite + the new kernel test), then stage times and bench.py's hrotate leg, interleaved on ONE box
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/r06_auto_ab; mkdir -p $OUT
 export TMPDIR=/tmp
