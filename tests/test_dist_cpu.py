@@ -115,8 +115,14 @@ def test_sharded_plans_are_collectively_consistent(opname, world, batch, pipelin
         per_rank.append(sum(int(re.search(r" n=(\d+)", ln).group(1)) for ln in pl if kind(ln) in EW))
     # (against the one-GPU plan with the conversions as launches of their own, as in every sharded plan: with fuse_bconv the residue's
     # element-wise step is the ModDown conversion's epilogue and is not a limb-poly of an EWE launch)
+    # (... and with the automorphism launches the sharded plans keep: one GPU reads the rotated c1 through the automorphism in the key product too —
+    # pass 12 —, a sharded plan folds AUTO_Key(0) into the final add only: the same element-wise limb-polys once both count AUTO_Key(1))
     single_conv = host.Op("config_4.cfg", opname, L, ell, alpha, backend=host.BACKEND_COUNT, overrides={**ov, "fuse_bconv": 0})
     n_single = sum(int(re.search(r" n=(\d+)", ln).group(1)) for ln in single_conv.plan() if kind(ln) in EW)
+    if opname == "hrotate":
+        assert all(sum(1 for ln in pl if kind(ln) == "AUTO" and "AUTO_Key(0)" not in ln) == 1 and any(" auto_addend=" in ln for ln in pl) for pl in plans)
+        if not any(kind(ln) == "AUTO" for ln in single_conv.plan()):
+            n_single += ell * batch   # the l limb-polys of AUTO_Key(1) per op
     assert sum(per_rank) == n_single
     assert max(per_rank) - min(per_rank) <= 12 * batch   # balanced up to the remainder limbs of each stage
     # the instruction accounting of the sharded plans adds up to the one-GPU total
@@ -153,8 +159,11 @@ def test_gather_plan_is_collectively_consistent(opname, world, batch, plan):
         # the order on every rank: gather -> transform x key -> inverse -> gather -> conversion (-> gather) -> merged ModDown + rescale transform
         assert ks.index("REPLICATE") < ks.index("NTT_IP") < ks.index("BCONV") < ks.index("NTT_SUBSCALE")
     # the work of every launch kind is partitioned exactly (conversions included: each rank converts the output limbs it owns) ...
+    # (AUTO: a sharded plan keeps AUTO_Key(1) as a launch of the l rotated c1 limb-polys — one GPU reads them through the automorphism, pass 12 —
+    # and folds AUTO_Key(0) into the final add like one GPU does)
     for k in ("TENSOR", "AUTO", "INTT", "NTT_IP", "BCONV", "NTT_SUBSCALE"):
-        assert sum(num(ln, "n") for pl in plans for ln in pl if kind(ln) == k) == sum(num(ln, "n") for ln in single.plan() if kind(ln) == k), k
+        kept = ell * batch if k == "AUTO" and opname == "hrotate" and not any(kind(ln) == "AUTO" for ln in single.plan()) else 0
+        assert sum(num(ln, "n") for pl in plans for ln in pl if kind(ln) == k) == sum(num(ln, "n") for ln in single.plan() if kind(ln) == k) + kept, k
     per_rank = [sum(num(ln, "n") for ln in pl if kind(ln) != "REPLICATE") for pl in plans]
     assert max(per_rank) - min(per_rank) <= 12 * batch
     # ... and so is the instruction accounting
