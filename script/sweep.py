@@ -55,8 +55,8 @@ def alg_limb_polys(op, ell, alpha):
 assert alg_limb_polys("hmult", 35, 15) == (2103, 300) and alg_limb_polys("hrotate", 35, 15)[0] == 1685   # SURVEY.md 8(d)'s own figures
 
 
-R5_PLAN = {"fuse_bconv_max_in": 15}                         # rounds 3-5: digits of more than 15 limbs kept a conversion launch of their own
-R5_PLAN_N15 = {"fuse_bconv_max_in": 15, "fuse_ip_inv": 0}   # ... and N = 2^15 had no pass 7b
+R5_PLAN = {"fuse_bconv_max_in": 15, "fuse_auto": 0}         # rounds 3-5: digits of more than 15 limbs kept a conversion launch of their own; hrotate ran its AUTO launch
+R5_PLAN_N15 = {"fuse_bconv_max_in": 15, "fuse_ip_inv": 0, "fuse_auto": 0}   # ... and N = 2^15 had no pass 7b
 R5_ENV_N15 = {"HOMULATOR_NTT_FUSED_SMALL": "0", "HOMULATOR_NTT_SMALL_LIMBS": "0", "HOMULATOR_NIP_SMALL": "0"}   # ... nor the small-launch forms
 
 

@@ -36,7 +36,7 @@ for s in ("A", "B", "C", "D", "motivation"):
             out.append(f"{s:10s} {op:8s} {chain:7s} top level {x[0]['lv']:2d}: {x[0]['us']:7.1f} us/op {x[0]['ops']:6.0f} ops/s frac {x[0]['frac']:.3f} ({x[0]['once']:.3f} key once) | "
                        f"frac over the levels: max {max(fr):.3f} min {min(fr):.3f} (level {x[fr.index(min(fr))]['lv']}) | levels below 0.6 x their neighbours: {dips or 'none'}")
     out.append("")
-out.append("## same box, interleaved: HEAD against the launch plan of round 5 (--plan r5: fused conversion capped at 15 input limbs; at N = 2^15 also no pass 7b and no small-launch forms), mont32, us per op")
+out.append("## same box, interleaved: HEAD against the launch plan of round 5 (--plan r5: fused conversion capped at 15 input limbs, the automorphism as a launch; at N = 2^15 also no pass 7b and no small-launch forms), mont32, us per op")
 out.append("## (set A: the wide conversion inside the first pass + the small-launch forms at N = 2^15; motivation: the two plans coincide since the default at N = 2^16 stops at 15 limbs —")
 out.append("##  the run with the wide conversion forced inside, 1-5 % slower, is profiles/r06_wide_stage_times.txt and the first sweep of the round: gpurun_out/r06_sweep_ab)")
 for s in ("A", "motivation"):
