@@ -502,9 +502,17 @@ __global__ void __launch_bounds__(256) k_inner_product(HmIpArgs a) {
   const HmMod m = a.mods[lb.mod];
   const size_t off = (size_t)chunk * 512 + 2 * threadIdx.x;
   ulonglong2 vx[TERMS], vy[OUTS][TERMS];
+  // x through an automorphism (wave-uniform choice): the aligned pair that holds this unit's two sources, swapped when it arrives in the other order
+  size_t offx = off;
+  bool swap = false;
+  if (a.x_galois > 1) {
+    const uint32_t s = hm_auto_src((uint32_t)off, a.x_galois, a.logN);
+    offx = s & ~1u; swap = s & 1u;
+  }
 #pragma unroll
   for (int j = 0; j < TERMS; ++j) {
-    vx[j] = *reinterpret_cast<const ulonglong2 *>(a.x + (size_t)lb.x[j] * N + off);
+    vx[j] = *reinterpret_cast<const ulonglong2 *>(a.x + (size_t)lb.x[j] * N + offx);
+    if (swap) { const unsigned long long t = vx[j].x; vx[j].x = vx[j].y; vx[j].y = t; }
 #pragma unroll
     for (int k = 0; k < OUTS; ++k) vy[k][j] = *reinterpret_cast<const ulonglong2 *>(a.y + (size_t)lb.y[k][j] * N + off);
   }
@@ -1640,7 +1648,17 @@ static void launch_ip(hm_ctx *c, const HmIpArgs &a) {
 extern "C" hm_status hm_inner_product(hm_ctx *c, const uint64_t *x, const uint32_t *x_limbs, const uint64_t *y,
                                       const uint32_t *y_limbs, uint64_t *out, const uint32_t *out_limbs,
                                       const uint32_t *mod_ids, uint32_t n, uint32_t n_terms, uint32_t n_out) {
+  const hm_ip_desc d = {x, x_limbs, y, y_limbs, out, out_limbs, mod_ids, n, n_terms, n_out, 0};
+  return hm_inner_product_ex(c, &d);
+}
+extern "C" hm_status hm_inner_product_ex(hm_ctx *c, const hm_ip_desc *d) {
   if (!c) return HM_ERR_ARG;
+  if (!d) return fail(c, HM_ERR_ARG, "hm_inner_product: null argument");
+  const uint64_t *x = d->x, *y = d->y;
+  uint64_t *out = d->out;
+  const uint32_t *x_limbs = d->x_limbs, *y_limbs = d->y_limbs, *out_limbs = d->out_limbs, *mod_ids = d->mod_ids;
+  const uint32_t n = d->n, n_terms = d->n_terms, n_out = d->n_out;
+  if (d->x_galois && (!(d->x_galois & 1) || d->x_galois >= 2 * c->P.N)) return fail(c, HM_ERR_ARG, "hm_inner_product: x_galois is not an odd number below 2N");
   if (!x || !y || !out || !x_limbs || !y_limbs || !out_limbs) return fail(c, HM_ERR_ARG, "hm_inner_product: null argument");
   if (n_terms == 0 || n_terms > HM_IP_MAX_TERMS || n_out == 0 || n_out > HM_IP_MAX_OUT)
     return fail(c, HM_ERR_ARG, "hm_inner_product: n_terms in [1,%d], n_out in [1,%d]", HM_IP_MAX_TERMS, HM_IP_MAX_OUT);
@@ -1653,6 +1671,7 @@ extern "C" hm_status hm_inner_product(hm_ctx *c, const uint64_t *x, const uint32
     const uint32_t cnt = std::min<uint32_t>(HM_IP_MAX_LIMBS, n - base);
     HmIpArgs a;
     a.x = x; a.y = y; a.out = out; a.mods = c->d_mods; a.logN = c->P.logN; a.n_limbs = cnt; a.n_terms = n_terms; a.n_out = n_out;
+    a.x_galois = d->x_galois;
     for (uint32_t i = 0; i < cnt; ++i) {
       const uint32_t g = base + i;
       HmIpLimb &l = a.limb[i];

@@ -107,6 +107,7 @@ struct HmIpArgs {
   uint64_t *out;
   const HmMod *mods;
   uint32_t logN, n_limbs, n_terms, n_out;
+  uint32_t x_galois;   // > 1: the x operands are read through the automorphism X -> X^x_galois (round 6, hm_inner_product_ex)
   HmIpLimb limb[HM_IP_MAX_LIMBS];
 };
 

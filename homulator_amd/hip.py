@@ -20,7 +20,7 @@ SYMBOLS = [
     "hm_bconv", "hm_bconv_batch", "hm_bconv_consts", "hm_fill_uniform", "hm_timer_start", "hm_timer_stop", "hm_comm_unique_id", "hm_comm_init_rccl", "hm_comm_init_external",
     "hm_capture_begin", "hm_capture_end", "hm_graph_launch", "hm_graph_destroy", "hm_comm_info", "hm_slice_rows", "hm_limbs_to_slices", "hm_slices_to_limbs", "hm_replicate_limbs",
     "hm_set_option", "hm_get_counter", "hm_ntt_inner_product", "hm_exchange_stream", "hm_exchange_mark", "hm_exchange_wait",
-    "hm_bconv_col", "hm_limbs_to_colslices", "hm_colslices_to_limbs", "hm_ntt_second_pass", "hm_ntt_ex", "hm_capability",
+    "hm_bconv_col", "hm_limbs_to_colslices", "hm_colslices_to_limbs", "hm_ntt_second_pass", "hm_ntt_ex", "hm_capability", "hm_inner_product_ex",
 ]
 
 
@@ -29,6 +29,11 @@ class hm_ntt_fused_desc(C.Structure):
                 ("minuend", C.c_void_p), ("minuend_limbs", C.c_void_p), ("addend", C.c_void_p), ("addend_limbs", C.c_void_p),
                 ("addend_k", C.c_void_p), ("out", C.c_void_p), ("out_limbs", C.c_void_p), ("mod_ids", C.c_void_p), ("n", C.c_uint32),
                 ("k", C.c_void_p), ("conv", C.c_void_p), ("n_conv", C.c_uint32), ("addend_galois", C.c_void_p)]
+
+
+class hm_ip_desc(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("x_limbs", C.c_void_p), ("y", C.c_void_p), ("y_limbs", C.c_void_p), ("out", C.c_void_p), ("out_limbs", C.c_void_p),
+                ("mod_ids", C.c_void_p), ("n", C.c_uint32), ("n_terms", C.c_uint32), ("n_out", C.c_uint32), ("x_galois", C.c_uint32)]
 
 
 class hm_ntt_ip_desc(C.Structure):
@@ -88,6 +93,7 @@ def load():
     L.hm_ntt.argtypes = [vp, vp, vp, vp, vp, vp, u32, i32, vp]
     L.hm_ntt_second_pass.argtypes = [vp, vp, vp, vp, u32, i32, vp]
     L.hm_ntt_ex.argtypes = [vp, C.POINTER(hm_ntt_desc)]
+    L.hm_inner_product_ex.argtypes = [vp, C.POINTER(hm_ip_desc)]
     L.hm_ntt_sub_scale.argtypes = [vp] + [vp] * 9 + [u32, vp]
     L.hm_ntt_mix_sub_scale.argtypes = [vp, C.POINTER(hm_ntt_fused_desc)]
     L.hm_tensor.argtypes = [vp] + [vp] * 15 + [u32]
@@ -270,8 +276,12 @@ class Context:
         self._ck(self.L.hm_tensor(self.h, a.ptr, keep[0][1], b.ptr, keep[1][1], c.ptr, keep[2][1], d.ptr, keep[3][1], o0.ptr, keep[4][1],
                                   o1.ptr, keep[5][1], o2.ptr, keep[6][1], keep[7][1], len(mod_ids)))
 
-    def inner_product(self, x, x_limbs, y, y_limbs, out, out_limbs, mod_ids, n_terms, n_out):
+    def inner_product(self, x, x_limbs, y, y_limbs, out, out_limbs, mod_ids, n_terms, n_out, x_galois=0):
         keep = [_u32(v) for v in (x_limbs, y_limbs, out_limbs, mod_ids)]
+        if x_galois:   # the x operands through the automorphism X -> X^g (hm_inner_product_ex)
+            d = hm_ip_desc(x.ptr, keep[0][1], y.ptr, keep[1][1], out.ptr, keep[2][1], keep[3][1], len(mod_ids), n_terms, n_out, int(x_galois))
+            self._ck(self.L.hm_inner_product_ex(self.h, C.byref(d)))
+            return
         self._ck(self.L.hm_inner_product(self.h, x.ptr, keep[0][1], y.ptr, keep[1][1], out.ptr, keep[2][1], keep[3][1], len(mod_ids),
                                          n_terms, n_out))
 

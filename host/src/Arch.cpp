@@ -30,7 +30,7 @@ struct Arch::Launch {
   bool secondOnly = false;        // L_INTT (7b): hm_ntt_second_pass — the first pass was run by the inner-product kernel
   std::vector<uint8_t> outPacked; // L_INTT (11): per limb-poly, 1 = stored in the split-30 packed form of the conversions' inputs
   std::vector<uint32_t> inGalois, addGalois;   // (12) L_INTT: per limb-poly, the input / L_NTT_SUBSCALE: the addend is read through X -> X^g (0: as stored); empty: none
-  uint32_t xGalois = 0;                        // (12) L_NTT_IP: the evaluation-form digits are read through X -> X^g
+  uint32_t xGalois = 0;                        // (12) L_NTT_IP: the evaluation-form digits, L_IP: the x operands are read through X -> X^g
   uint32_t ipTerms = 0, ipOuts = 0;
   std::string name;
   std::string statKey;
@@ -745,10 +745,11 @@ void Arch::fusePasses(std::vector<Stage> &st) {
       for (Instruction *i : s.ins) {
         if (dead.count(i)) continue;
         if (i->ops == IP && !i->ipX.empty()) {
-          const bool nip = std::find(i->ipCoeff.begin(), i->ipCoeff.end(), 1) != i->ipCoeff.end() && world_ == 1 && !i->ipXGalois;
+          // a transform x key record reads its own digits in evaluation form, a plain inner-product record (no digit transformed inside) all of them
+          const bool anyT = std::find(i->ipCoeff.begin(), i->ipCoeff.end(), 1) != i->ipCoeff.end(), can = world_ == 1 && !i->ipXGalois;
           const auto &src = i->ipSrc.empty() ? i->ipX : i->ipSrc;
           for (size_t j = 0; j < src.size(); ++j) {
-            const bool own = nip && !i->ipCoeff[j] && !(j < i->ipConvIn.size() && !i->ipConvIn[j].empty());
+            const bool own = can && (!anyT || (!i->ipCoeff[j] && !(j < i->ipConvIn.size() && !i->ipConvIn[j].empty())));
             readers[src[j]].push_back({i, own ? 2 : -1, j});
             if (own) ownDigits.push_back({i, 2, j});
           }
@@ -800,7 +801,11 @@ void Arch::fusePasses(std::vector<Stage> &st) {
       for (const Reader &x : rd) {
         if (x.role == 0) { x.ins->operandList[0] = A->operandList[0]; x.ins->inGalois = A->galois; }
         else if (x.role == 1) { x.ins->fAddend = A->operandList[0]; x.ins->fAddendGalois = A->galois; }
-        else { (x.ins->ipSrc.empty() ? x.ins->ipX : x.ins->ipSrc)[x.digit] = A->operandList[0]; x.ins->ipXGalois = A->galois; }
+        else {
+          x.ins->ipX[x.digit] = A->operandList[0];
+          if (!x.ins->ipSrc.empty()) x.ins->ipSrc[x.digit] = A->operandList[0];
+          x.ins->ipXGalois = A->galois;
+        }
       }
       rd.front().ins->refInstructions += A->refInstructions;
       dead.insert(A);
@@ -1133,6 +1138,7 @@ void Arch::buildLaunches() {
             L->out.push_back(limbOf(i->OutputOperand));
             for (AddrType o : i->extraOutputs) L->out.push_back(limbOf(o));
             L->mods.push_back(i->mod_id);
+            if (i->ipXGalois) L->xGalois = i->ipXGalois;   // (12): uniform over the op's records by construction
           }
         L->bytes = (unsigned long long)(L->ipTerms * (1 + L->ipOuts) + L->ipOuts) * LP * count;
       } else if (f->fusedTensor) {
@@ -1540,6 +1546,10 @@ void Arch::enqueue(Launch &l) {
     }
     break;
   case Launch::L_IP:
+    if (l.xGalois) {
+      const hm_ip_desc d = {pool, l.a.data(), pool, l.b.data(), pool, l.out.data(), l.mods.data(), (uint32_t)l.mods.size(), l.ipTerms, l.ipOuts, l.xGalois};
+      st = hm_inner_product_ex(ctx, &d);
+    } else
     st = hm_inner_product(ctx, pool, l.a.data(), pool, l.b.data(), pool, l.out.data(), l.mods.data(), (uint32_t)l.mods.size(), l.ipTerms, l.ipOuts);
     break;
   case Launch::L_NTT_IP: {

@@ -155,6 +155,18 @@ hm_status hm_tensor(hm_ctx *ctx, const uint64_t *a, const uint32_t *a_limbs, con
 hm_status hm_inner_product(hm_ctx *ctx, const uint64_t *x, const uint32_t *x_limbs, const uint64_t *y,
                            const uint32_t *y_limbs, uint64_t *out, const uint32_t *out_limbs,
                            const uint32_t *mod_ids, uint32_t n, uint32_t n_terms, uint32_t n_out);
+/* The same with its arguments in one record (round 6) and x_galois = g > 1: the x operands are read through the automorphism X -> X^g (as
+ * hm_automorph would have stored them; 0 / 1: as stored) — a one-digit key switch of hrotate, whose Q limbs multiply the rotated c1 itself with the
+ * key, then needs no AUTO_Key(1) launch (InsGen::GenAUTO src/InsGen.cpp:46-71).  Same reference interface as hm_inner_product. */
+typedef struct hm_ip_desc {
+  const uint64_t *x;  const uint32_t *x_limbs;
+  const uint64_t *y;  const uint32_t *y_limbs;
+  uint64_t *out;      const uint32_t *out_limbs;
+  const uint32_t *mod_ids;
+  uint32_t n, n_terms, n_out;
+  uint32_t x_galois;
+} hm_ip_desc;
+hm_status hm_inner_product_ex(hm_ctx *ctx, const hm_ip_desc *desc);
 
 /* K1 x K5 — the HPIP unit as a fused NTT-epilogue x evaluation-key MAC: for extended limb i,
  *     out[i][k] = sum_{j < n_terms} X_j[i] * y[i][k][j],   X_j[i] = NTT(x[i][j]) if x_is_coeff[i][j] else x[i][j]

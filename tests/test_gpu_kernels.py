@@ -405,6 +405,37 @@ def test_ntt_inner_product_fused(env, terms, outs):
         b_.free()
 
 
+@pytest.mark.parametrize("terms,outs", [(1, 2), (3, 2), (2, 1)])
+def test_inner_product_reads_x_through_an_automorphism(env, terms, outs):
+    """round 6 (hm_inner_product_ex, x_galois): the plain inner product with its x operands read through X -> X^g, against the call on operands the
+    oracle has rotated: a one-digit key switch of hrotate multiplies the rotated c1 itself with the key"""
+    ctx, o, hip = env
+    M = o.L + o.K
+    ids = [(i * 5 + 1) % M for i in range(21)]
+    n = len(ids)
+    X = [o.fill_uniform(ids, 10 + j) for j in range(terms)]
+    Y = [[o.fill_uniform(ids, 100 + 10 * k + j) for j in range(terms)] for k in range(outs)]
+    xb = ctx.from_host(np.concatenate(X))
+    yb = ctx.from_host(np.concatenate([Y[k][j] for k in range(outs) for j in range(terms)]))
+    out = ctx.alloc(n * outs)
+    xl = [j * n + i for i in range(n) for j in range(terms)]
+    yl = [(k * terms + j) * n + i for i in range(n) for k in range(outs) for j in range(terms)]
+    ol = [k * n + i for i in range(n) for k in range(outs)]
+    for g in (5, 2 * o.N - 1, 25):
+        ctx.inner_product(xb, xl, yb, yl, out, ol, ids, terms, outs, x_galois=g)
+        got = out.download()
+        XR = [o.automorph_eval(X[j], g) for j in range(terms)]
+        for k in range(outs):
+            exp = o.ewe(0, ids, XR[0], Y[k][0])
+            for j in range(1, terms):
+                exp = o.ewe(2, ids, XR[j], Y[k][j], exp)
+            assert np.array_equal(got[k * n:(k + 1) * n], exp), (g, k)
+    with pytest.raises(hip.HmError):
+        ctx.inner_product(xb, xl, yb, yl, out, ol, ids, terms, outs, x_galois=2)
+    for b_ in (xb, yb, out):
+        b_.free()
+
+
 @pytest.mark.parametrize("n,inv", [(70, False), (70, True), (9, True), (9, False)], ids=["wide", "wide-inverse-out", "small-inverse-out", "small"])
 @pytest.mark.parametrize("outs", [2, 1])
 def test_ntt_inner_product_reads_own_digits_through_an_automorphism(env, n, inv, outs):

@@ -150,10 +150,6 @@ def test_hmult_mixed_conversion_launch(fuse):
     op.close()
 
 
-def beta_of(ell, alpha):
-    return (ell + alpha - 1) // alpha
-
-
 @pytest.mark.parametrize("cfg,logN,L,ell,alpha", CASES)
 @pytest.mark.parametrize("fuse", [False, True, "auto-launch"])
 @pytest.mark.parametrize("chain", ["mont32", "survey"])
@@ -169,9 +165,8 @@ def test_hrotate_bit_exact(cfg, logN, L, ell, alpha, fuse, chain):
     op = host.Op(cfg, "hrotate", L, ell, alpha, fuse=bool(fuse), overrides=ov or None)
     folded = any(" auto_addend=" in ln for ln in op.plan())
     assert folded == (fuse is True)
-    launched = " ".join(ln for ln in op.plan() if ln.startswith("AUTO"))   # (a one-digit key switch keeps AUTO_Key(1): its Q limbs' key products are
-    if beta_of(ell, alpha) > 1:                                             # plain inner products, which read the rotated c1 from memory)
-        assert ("AUTO_Key(1)" in launched) == (fuse is not True)
+    launched = " ".join(ln for ln in op.plan() if ln.startswith("AUTO"))
+    assert ("AUTO_Key(1)" in launched) == (fuse is not True)   # (a one-digit key switch too: its Q limbs' plain inner products gather as well)
     op.execute(1)
     r0, r1 = o.automorph_eval(ct1[0], 5), o.automorph_eval(ct1[1], 5)
     if "AUTO_Key(0)" in launched:

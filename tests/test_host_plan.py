@@ -134,3 +134,7 @@ def test_the_automorphisms_of_hrotate_fold_into_their_readers():
     assert kinds(pm)[0] == "AUTO" and "AUTO_Key(1)" not in pm[0] and " auto_in=35/g5" in pm[1] and " auto_x=g5" in pm[2] and totalm == total
     pg, _, _ = plan("config_4_N15.cfg", "hrotate", 16, 10, 4, galois=25)
     assert " auto_in=10/g25" in pg[0] and " auto_x=g25" in pg[1] and " auto_addend=10/g25" in pg[-1]
+    # a one-digit key switch (parameter sets A and `motivation`): the Q limbs multiply the rotated c1 itself with the key in a plain inner product,
+    # which gathers too (hm_inner_product_ex)
+    p1, _, _ = plan("config_4.cfg", "hrotate", 28, 28, 28)
+    assert "AUTO" not in kinds(p1) and p1[1].startswith("IP ") and " auto_x=g5" in p1[1] and " auto_in=28/g5" in p1[0] and " auto_addend=28/g5" in p1[-1]
