@@ -767,11 +767,21 @@ void Arch::fusePasses(std::vector<Stage> &st) {
         }
         if (i->fusedEpi) { readers[i->fSubFrom].push_back({i, -1, 0}); if (i->fAdd) readers[i->fAdd].push_back({i, -1, 0}); }
       }
+    // (the readers will read the automorphism's SOURCE, and later than the automorphism did: nothing may write that source from the automorphism's
+    // stage on — the reference's operations never write their inputs; a program that does keeps its launch)
+    std::map<AddrType, size_t> lastWrite;
+    for (size_t si = 0; si < st.size(); ++si)
+      for (Instruction *i : st[si].ins) {
+        if (dead.count(i)) continue;
+        lastWrite[i->OutputOperand] = si;
+        for (AddrType o : i->extraOutputs) lastWrite[o] = si;
+      }
     std::map<AddrType, Instruction *> cand;   // output address -> the automorphism that every reader can read through
     bool anyOwn = false;
-    for (auto &s : st)
-      for (Instruction *A : s.ins) {
+    for (size_t si = 0; si < st.size(); ++si)
+      for (Instruction *A : st[si].ins) {
         if (A->ops != AUTO || dead.count(A) || A->galois <= 1) continue;
+        { auto w = lastWrite.find(A->operandList[0]); if (w != lastWrite.end() && w->second >= si) continue; }
         auto r = readers.find(A->OutputOperand);
         if (r == readers.end() || r->second.empty()) continue;   // nobody reads it inside the op: a result
         bool ok = true;
