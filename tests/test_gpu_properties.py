@@ -6,6 +6,8 @@ correct implementation, bit for bit because everything is exact modular arithmet
   * the evaluation-form automorphism by g followed by the one by g^-1 mod 2N is the identity, and it commutes with the element-wise product;
   * base conversion is linear on inputs whose sum does not wrap: conv(a) + conv(b) = conv(a + b) mod q_t when a_i + b_i < q_i for every limb;
   * the ops of a batch are independent: op c of a batch equals the same op run alone.
+  * two launch plans of one op are one function: hrotate with its automorphisms read through by their consumers (pass 12) = hrotate with the
+    automorphism as a launch, at the sizes of parameter sets B and `motivation`.
 These complement the oracle comparisons (tests/test_gpu_ops.py, test_gpu_kernels.py), which pin the values; here nothing but the product path runs."""
 import numpy as np
 import pytest
@@ -107,3 +109,28 @@ def test_base_conversion_is_linear_without_wrap_at_full_size():
         assert np.array_equal(ca.download(), cs.download())
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("shape", [(45, 35, 15), (28, 28, 28)], ids=["three-digits", "one-digit"])
+@pytest.mark.parametrize("batch", [1, 3])
+def test_hrotate_reads_through_the_automorphism_or_launches_it_at_full_size(shape, batch):
+    """hrotate at the full sizes of parameter sets B (three digits) and `motivation` (one digit) with its automorphisms folded into their readers
+    (planner pass 12: the ModUp INTT, the key product — transform x key kernel or plain inner product — and the final add gather through X -> X^g)
+    against the same op with the automorphism as a launch of its own: two launch plans, one function — identical outputs, every limb, every op of a
+    batch.  And rotating by g, then by g^-1 with the SAME key material is not the identity (a key switch happens each time): the outputs differ
+    from the input, i.e. the comparison is not between two untouched buffers"""
+    from homulator_amd import host
+    Lq, ell, alpha = shape
+    ov = {"batch": batch} if batch > 1 else {}
+    folded = host.Op(CFG, "hrotate", Lq, ell, alpha, overrides=ov or None)
+    assert not any(ln.startswith("AUTO") for ln in folded.plan()) and any(" auto_in=" in ln for ln in folded.plan())
+    launched = host.Op(CFG, "hrotate", Lq, ell, alpha, overrides={**ov, "fuse_auto": 0})
+    assert sum(ln.startswith("AUTO") for ln in launched.plan()) == 1
+    folded.execute(1)
+    launched.execute(1)
+    for c in range(batch):
+        for name in ("out.c0", "out.c1"):
+            a, b = folded.read(name, copy=c), launched.read(name, copy=c)
+            assert np.array_equal(a, b), (name, c)
+        assert not np.array_equal(folded.read("out.c0", copy=c), folded.read("ct1.c0", copy=c))
+    folded.close(); launched.close()
