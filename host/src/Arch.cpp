@@ -736,7 +736,8 @@ void Arch::fusePasses(std::vector<Stage> &st) {
   //      and AUTOOutput is never written or read back.  hrotate: AUTO_Key(1) -> ModUp_INTT + the key product's own digits, AUTO_Key(0) -> the final
   //      add inside ModDowNTT's epilogue: 6 -> 5 launches, 140 limb-polys less traffic.  Config key fuse_auto (default 1).
   //      The key product takes ONE Galois element per launch: its records fold only if every evaluation-form digit of every such record of the op
-  //      is the output of a foldable automorphism by the same element (one GPU; the sharded plans keep the launch).
+  //      is the output of a foldable automorphism by the same element (one GPU and the gather plan, whose ranks run the one-GPU kernels on whole
+  //      limb-polys; the column-slice plan keeps AUTO_Key(1) as a launch).
   if (fuseAuto) {
     struct Reader { Instruction *ins; int role; size_t digit; };   // role 0: INTT input, 1: fused forward transform's addend, 2: evaluation-form digit of a
     std::map<AddrType, std::vector<Reader>> readers;               // transform x key record, -1: anything else
@@ -746,7 +747,7 @@ void Arch::fusePasses(std::vector<Stage> &st) {
         if (dead.count(i)) continue;
         if (i->ops == IP && !i->ipX.empty()) {
           // a transform x key record reads its own digits in evaluation form, a plain inner-product record (no digit transformed inside) all of them
-          const bool anyT = std::find(i->ipCoeff.begin(), i->ipCoeff.end(), 1) != i->ipCoeff.end(), can = world_ == 1 && !i->ipXGalois;
+          const bool anyT = std::find(i->ipCoeff.begin(), i->ipCoeff.end(), 1) != i->ipCoeff.end(), can = (world_ == 1 || shardGather) && !i->ipXGalois;   // (the gather plan's ranks run the one-GPU kernels on the limb-polys they own)
           const auto &src = i->ipSrc.empty() ? i->ipX : i->ipSrc;
           for (size_t j = 0; j < src.size(); ++j) {
             const bool own = can && (!anyT || (!i->ipCoeff[j] && !(j < i->ipConvIn.size() && !i->ipConvIn[j].empty())));

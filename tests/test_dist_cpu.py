@@ -159,11 +159,12 @@ def test_gather_plan_is_collectively_consistent(opname, world, batch, plan):
         # the order on every rank: gather -> transform x key -> inverse -> gather -> conversion (-> gather) -> merged ModDown + rescale transform
         assert ks.index("REPLICATE") < ks.index("NTT_IP") < ks.index("BCONV") < ks.index("NTT_SUBSCALE")
     # the work of every launch kind is partitioned exactly (conversions included: each rank converts the output limbs it owns) ...
-    # (AUTO: a sharded plan keeps AUTO_Key(1) as a launch of the l rotated c1 limb-polys — one GPU reads them through the automorphism, pass 12 —
-    # and folds AUTO_Key(0) into the final add like one GPU does)
+    # (hrotate: the gather plan's ranks run the one-GPU kernels on the limb-polys they own, so they read through the automorphism exactly as one
+    # GPU does — pass 12: no AUTO launch on any rank)
+    if opname == "hrotate":
+        assert not any(kind(ln) == "AUTO" for pl in plans for ln in pl) and all(any(" auto_x=" in ln for ln in pl) for pl in plans)
     for k in ("TENSOR", "AUTO", "INTT", "NTT_IP", "BCONV", "NTT_SUBSCALE"):
-        kept = ell * batch if k == "AUTO" and opname == "hrotate" and not any(kind(ln) == "AUTO" for ln in single.plan()) else 0
-        assert sum(num(ln, "n") for pl in plans for ln in pl if kind(ln) == k) == sum(num(ln, "n") for ln in single.plan() if kind(ln) == k) + kept, k
+        assert sum(num(ln, "n") for pl in plans for ln in pl if kind(ln) == k) == sum(num(ln, "n") for ln in single.plan() if kind(ln) == k), k
     per_rank = [sum(num(ln, "n") for ln in pl if kind(ln) != "REPLICATE") for pl in plans]
     assert max(per_rank) - min(per_rank) <= 12 * batch
     # ... and so is the instruction accounting
