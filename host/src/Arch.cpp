@@ -1223,14 +1223,18 @@ void Arch::buildLaunches() {
         const int m = useMask[f->opcode];
         int nops = 1;
         for (int b = 0; b < 4; ++b) nops += (m >> b) & 1;
-        for (const Part *g : group)
-          for (Instruction *i : g->ins) {
-            auto get = [&](int b) { return (m & (1 << b)) ? limbOf(i->operandList[b]) : 0u; };
-            L->a.push_back(get(0)); L->b.push_back(get(1)); L->c.push_back(get(2)); L->d.push_back(get(3));
-            L->out.push_back(limbOf(i->OutputOperand)); L->mods.push_back(i->mod_id);
-            L->k.push_back(i->hasConstant ? i->constant : 0);
-            L->hasK |= i->hasConstant;
-          }
+        // entries of one modulus side by side: records that share an operand (pmult: c0 x pt and c1 x pt of a limb) then sit 128 workgroups apart
+        // in dispatch order, on the same XCD, and the second reader finds the shared limb-poly in L2 instead of fetching it again
+        std::vector<Instruction *> recs;
+        for (const Part *g : group) recs.insert(recs.end(), g->ins.begin(), g->ins.end());
+        std::stable_sort(recs.begin(), recs.end(), [](const Instruction *x, const Instruction *y) { return x->mod_id < y->mod_id; });
+        for (Instruction *i : recs) {
+          auto get = [&](int b) { return (m & (1 << b)) ? limbOf(i->operandList[b]) : 0u; };
+          L->a.push_back(get(0)); L->b.push_back(get(1)); L->c.push_back(get(2)); L->d.push_back(get(3));
+          L->out.push_back(limbOf(i->OutputOperand)); L->mods.push_back(i->mod_id);
+          L->k.push_back(i->hasConstant ? i->constant : 0);
+          L->hasK |= i->hasConstant;
+        }
         L->bytes = (unsigned long long)nops * LP * count;
       } else if (f->ops == BCONV_STEP2) {
         L->kind = Launch::L_BCONV; L->statKey = "BCONV";
