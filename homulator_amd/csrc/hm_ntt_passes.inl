@@ -269,9 +269,10 @@ HM_HD void hm_ph_load_global_mix(HmNttState &st, int tid, const uint64_t *g, uin
 
 // MODE 5 (ROW pass of the fused transform x key inner product): the last pass keeps its results in registers (lazy, below
 // 2 HM_LAZY_Q q) and stores nothing; hm_ph_mac consumes them.
-// the epilogue of one coefficient.  MODE 0 / 4: store as is (lazy values, hand-off between the two passes; 4 = first
-// pass with the mix prologue); 1: forward final, reduce [0, 2 HM_LAZY_Q q) -> [0,q); 2: inverse final, multiply by the per-limb
-// constant and reduce to [0,q); 3: forward final fused with out = (minuend - x) * k [+ addend [* ak]]
+// the epilogue of one coefficient.  MODE 0 / 4 / 6: store as is (lazy values, hand-off between the two passes; 4 = first
+// pass with the mix prologue, 6 = inverse first pass whose input is read through an automorphism); 1: forward final, reduce [0, 2 HM_LAZY_Q q) -> [0,q); 2: inverse final, multiply by the per-limb
+// constant and reduce to [0,q); 3: forward final fused with out = (minuend - x) * k [+ addend [* ak]]; 7: the same with the addend read through an
+// automorphism (hm_ph_store_global gathers it)
 // (sc, ep.dk, ep.bk: constant records made by hm_kconst on the host; hm_kmul multiplies by them)
 template <int MODE>
 HM_HD uint64_t hm_epilogue(uint64_t a, uint64_t va, uint64_t vd, uint64_t q, HmTw sc, const HmEpi &ep) {
