@@ -157,6 +157,7 @@ def measure_second_op(opn, streams, batch, steps, device, extra=None):
     cross = sum(o.backend_counter("ntt_cross_xcd") for o in ops + ([tail] if tail is not None else []))
     arith = ops[0].backend_counter("arith")
     launches = ops[0].launch_count()
+    auto_launches = sum(1 for ln in ops[0].plan() if ln.startswith("AUTO"))
     for o in ops:
         o.close()
     if tail is not None:
@@ -172,6 +173,8 @@ def measure_second_op(opn, streams, batch, steps, device, extra=None):
     return {"workload": f"{CFG} {opn} L={L} l={ELL} alpha={ALPHA}" + (" (BASELINE configs[3]: automorphism + full hybrid key switch)" if opn == "hrotate" else ""),
             "moduli": MODULI_NOTE[arith], "ops_per_s": steps / dt, "ops_per_s_min_median_max": [steps / max(dts), steps / dt, steps / min(dts)], "regions": 3,
             "ms_per_step": ms, "steps": steps, "streams": streams, "batch": batch, "launches_per_op": launches,
+            **({"automorphism_launches": auto_launches, "automorphism_note": "the ModUp INTT, the key product and the final add read the ciphertext THROUGH the automorphism "
+                "(planner pass 12, config key fuse_auto): no AUTO launch on one GPU; the algorithmic bytes still charge SURVEY 8(d)'s automorphism stage"} if opn == "hrotate" else {}),
             "frac_of_hbm_peak": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "frac_evk_once": evk_once / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "ntt_cross_xcd": cross}
 

@@ -38,6 +38,7 @@ def test_bench_line_contract():
     assert d["value"] / c["value"] > 50          # (a reported baseline, not the target)
     assert d["ntt_cross_xcd"] == {"after_sweep": 0, "after_timed_region": 0, "ntt_fused_small": 96}
     assert d["hrotate"]["ops_per_s"] > 1000 and d["hrotate"]["steps"] == 20
+    assert d["hrotate"]["launches_per_op"] == 5 and d["hrotate"]["automorphism_launches"] == 0   # (pass 12: its readers gather through the automorphism)
     if not forced_generic:   # (the leg exists beside a headline on the default back-end)
         assert d["generic_chain_ops_per_s"] > 1000 and 0 < d["generic_chain_frac_evk_once"] < 1 and d["generic_chain"]["moduli"].startswith("generic")
     assert d["single_stream_ops_per_s"] > 1000 and d["sustained_ops_per_s"] > 1000
