@@ -470,26 +470,39 @@ __global__ void __launch_bounds__(256) k_tensor(HmTensorArgs a) {
   *reinterpret_cast<ulonglong2 *>(a.o2 + (size_t)lb.o2 * N + x) = r2;
 }
 
+// 16-byte units per thread of the element-wise kernel, 512 coefficients apart, all loads in flight before the first use.  1: 89 600 workgroups for a batch of
+// ten hadd; 2 / 4 measured padd +3 / +5 %, pmult +1 %, hadd within the noise (tools/r06_ewe_ab.sh): not worth a second shape of the kernel's launch
+#ifndef HM_EWE_UNITS
+#define HM_EWE_UNITS 1
+#endif
 template <int OP>
 __global__ void __launch_bounds__(256) k_ewe(HmEweArgs a) {
   const uint32_t N = 1u << a.logN;
-  const uint32_t per_limb = N / 512;  // blocks per limb: 256 threads x 2 coefficients
+  const uint32_t per_limb = N / (512 * HM_EWE_UNITS);  // blocks per limb: 256 threads x HM_EWE_UNITS 16-byte units, 512 coefficients apart
   uint32_t entry = blockIdx.x / per_limb, chunk = blockIdx.x % per_limb;
   if (entry >= a.n_limbs) return;
   const HmEweLimb lb = a.limb[entry];
   const HmMod m = a.mods[lb.mod];
   const HmTw k = a.k[entry];
-  const size_t x = (size_t)chunk * 512 + 2 * threadIdx.x;
+  const size_t x0 = (size_t)chunk * (512 * HM_EWE_UNITS) + 2 * threadIdx.x;
   constexpr int uses = hm_ewe_uses(OP);
-  ulonglong2 va = {0, 0}, vb = {0, 0}, vc = {0, 0}, vd = {0, 0};
-  if (uses & 1) va = *reinterpret_cast<const ulonglong2 *>(a.a + (size_t)lb.a * N + x);
-  if (uses & 2) vb = *reinterpret_cast<const ulonglong2 *>(a.b + (size_t)lb.b * N + x);
-  if (uses & 4) vc = *reinterpret_cast<const ulonglong2 *>(a.c + (size_t)lb.c * N + x);
-  if (uses & 8) vd = *reinterpret_cast<const ulonglong2 *>(a.d + (size_t)lb.d * N + x);
-  ulonglong2 r;
-  r.x = hm_ewe_one<OP>(va.x, vb.x, vc.x, vd.x, k, m);
-  r.y = hm_ewe_one<OP>(va.y, vb.y, vc.y, vd.y, k, m);
-  *reinterpret_cast<ulonglong2 *>(a.out + (size_t)lb.out * N + x) = r;
+  ulonglong2 va[HM_EWE_UNITS], vb[HM_EWE_UNITS], vc[HM_EWE_UNITS], vd[HM_EWE_UNITS];
+#pragma unroll
+  for (int u = 0; u < HM_EWE_UNITS; ++u) {   // every load of the thread in flight before the first use
+    const size_t x = x0 + 512 * u;
+    va[u] = vb[u] = vc[u] = vd[u] = ulonglong2{0, 0};
+    if (uses & 1) va[u] = *reinterpret_cast<const ulonglong2 *>(a.a + (size_t)lb.a * N + x);
+    if (uses & 2) vb[u] = *reinterpret_cast<const ulonglong2 *>(a.b + (size_t)lb.b * N + x);
+    if (uses & 4) vc[u] = *reinterpret_cast<const ulonglong2 *>(a.c + (size_t)lb.c * N + x);
+    if (uses & 8) vd[u] = *reinterpret_cast<const ulonglong2 *>(a.d + (size_t)lb.d * N + x);
+  }
+#pragma unroll
+  for (int u = 0; u < HM_EWE_UNITS; ++u) {
+    ulonglong2 r;
+    r.x = hm_ewe_one<OP>(va[u].x, vb[u].x, vc[u].x, vd[u].x, k, m);
+    r.y = hm_ewe_one<OP>(va[u].y, vb[u].y, vc[u].y, vd[u].y, k, m);
+    *reinterpret_cast<ulonglong2 *>(a.out + (size_t)lb.out * N + x0 + 512 * u) = r;
+  }
 }
 
 template <int TERMS, int OUTS>
@@ -1590,7 +1603,7 @@ extern "C" hm_status hm_automorph(hm_ctx *c, const uint64_t *in, const uint32_t 
 
 template <int OP>
 static void launch_ewe(hm_ctx *c, const HmEweArgs &a) {
-  hipLaunchKernelGGL((k_ewe<OP>), dim3(a.n_limbs * (c->P.N / 512)), dim3(256), 0, c->stream, a);
+  hipLaunchKernelGGL((k_ewe<OP>), dim3(a.n_limbs * (c->P.N / (512 * HM_EWE_UNITS))), dim3(256), 0, c->stream, a);
 }
 
 extern "C" hm_status hm_ewe(hm_ctx *c, int op, const uint64_t *pa, const uint32_t *la, const uint64_t *pb,
