@@ -736,8 +736,8 @@ void Arch::fusePasses(std::vector<Stage> &st) {
   //      and AUTOOutput is never written or read back.  hrotate: AUTO_Key(1) -> ModUp_INTT + the key product's own digits, AUTO_Key(0) -> the final
   //      add inside ModDowNTT's epilogue: 6 -> 5 launches, 140 limb-polys less traffic.  Config key fuse_auto (default 1).
   //      The key product takes ONE Galois element per launch: its records fold only if every evaluation-form digit of every such record of the op
-  //      is the output of a foldable automorphism by the same element (one GPU and the gather plan, whose ranks run the one-GPU kernels on whole
-  //      limb-polys; the column-slice plan keeps AUTO_Key(1) as a launch).
+  //      is the output of a foldable automorphism by the same element.  Sharded plans fold the same way: a limb-poly's transforms and key product run on
+  //      the rank that owns the limb, where the automorphism's source limb lives too.
   if (fuseAuto) {
     struct Reader { Instruction *ins; int role; size_t digit; };   // role 0: INTT input, 1: fused forward transform's addend, 2: evaluation-form digit of a
     std::map<AddrType, std::vector<Reader>> readers;               // transform x key record, -1: anything else
@@ -747,7 +747,7 @@ void Arch::fusePasses(std::vector<Stage> &st) {
         if (dead.count(i)) continue;
         if (i->ops == IP && !i->ipX.empty()) {
           // a transform x key record reads its own digits in evaluation form, a plain inner-product record (no digit transformed inside) all of them
-          const bool anyT = std::find(i->ipCoeff.begin(), i->ipCoeff.end(), 1) != i->ipCoeff.end(), can = (world_ == 1 || shardGather) && !i->ipXGalois;   // (the gather plan's ranks run the one-GPU kernels on the limb-polys they own)
+          const bool anyT = std::find(i->ipCoeff.begin(), i->ipCoeff.end(), 1) != i->ipCoeff.end(), can = !i->ipXGalois;   // (any plan: a limb-poly's key product runs on the rank that owns the limb, and so does the automorphism's source limb)
           const auto &src = i->ipSrc.empty() ? i->ipX : i->ipSrc;
           for (size_t j = 0; j < src.size(); ++j) {
             const bool own = can && (!anyT || (!i->ipCoeff[j] && !(j < i->ipConvIn.size() && !i->ipConvIn[j].empty())));
@@ -1026,6 +1026,7 @@ void Arch::buildLaunches() {
             L->out.push_back(limbOf(i->OutputOperand));
             for (AddrType o : i->extraOutputs) L->out.push_back(limbOf(o));
             L->mods.push_back(i->mod_id);
+            if (i->ipXGalois) L->xGalois = i->ipXGalois;   // (12)
             lp += (unsigned long long)L->ipTerms * L->ipOuts + L->ipOuts;
           }
           if (any) L->name += (L->name.empty() ? "" : "+") + g->name;

@@ -115,13 +115,13 @@ def test_sharded_plans_are_collectively_consistent(opname, world, batch, pipelin
         per_rank.append(sum(int(re.search(r" n=(\d+)", ln).group(1)) for ln in pl if kind(ln) in EW))
     # (against the one-GPU plan with the conversions as launches of their own, as in every sharded plan: with fuse_bconv the residue's
     # element-wise step is the ModDown conversion's epilogue and is not a limb-poly of an EWE launch)
-    # (... and with the automorphism launches the sharded plans keep: one GPU reads the rotated c1 through the automorphism in the key product too —
-    # pass 12 —, a sharded plan folds AUTO_Key(0) into the final add only: the same element-wise limb-polys once both count AUTO_Key(1))
     single_conv = host.Op("config_4.cfg", opname, L, ell, alpha, backend=host.BACKEND_COUNT, overrides={**ov, "fuse_bconv": 0})
     n_single = sum(int(re.search(r" n=(\d+)", ln).group(1)) for ln in single_conv.plan() if kind(ln) in EW)
-    if opname == "hrotate":
-        assert all(sum(1 for ln in pl if kind(ln) == "AUTO" and "AUTO_Key(0)" not in ln) == 1 and any(" auto_addend=" in ln for ln in pl) for pl in plans)
-        if not any(kind(ln) == "AUTO" for ln in single_conv.plan()):
+    if opname == "hrotate":   # pass 12: a sharded plan reads through the automorphism wherever one GPU does (the plain inner product of the unfused plan cannot)
+        keeps = ov.get("fuse_hpip") == 0
+        assert all(sum(1 for ln in pl if kind(ln) == "AUTO" and "AUTO_Key(0)" not in ln) == (1 if keeps else 0) and any(" auto_addend=" in ln for ln in pl)
+                   for pl in plans)
+        if keeps and not any(kind(ln) == "AUTO" for ln in single_conv.plan()):
             n_single += ell * batch   # the l limb-polys of AUTO_Key(1) per op
     assert sum(per_rank) == n_single
     assert max(per_rank) - min(per_rank) <= 12 * batch   # balanced up to the remainder limbs of each stage
