@@ -1327,13 +1327,28 @@ static hm_status ntt_common(hm_ctx *c, const char *what, const uint64_t *in, con
     if ((gi && (!(gi & 1) || gi >= 2 * c->P.N)) || (ga && (!(ga & 1) || ga >= 2 * c->P.N)))
       return fail(c, HM_ERR_ARG, "%s: Galois element [%u] is not an odd number below 2N", what, g);
     anyInGalois |= gi > 1; anyAddGalois |= ga > 1;
-    // a gathered input is read from OTHER tiles than the one a workgroup writes: never in place
-    if (gi > 1 && in == out && limb_at(in_limbs, g) == limb_at(out_limbs, g)) return fail(c, HM_ERR_ARG,
-        "%s: limb-poly [%u] is read through an automorphism and cannot be transformed in place", what, g);
+  }
+  if (anyInGalois && in == out) {   // a gathered input is read from OTHER tiles than the one a workgroup writes: no limb-poly the call writes may be one it gathers from
+    std::vector<char> written;
+    for (uint32_t g = 0; g < n; ++g) { const uint32_t l = limb_at(out_limbs, g); if (l >= written.size()) written.resize((size_t)l + 1, 0); written[l] = 1; }
+    for (uint32_t g = 0; g < n; ++g) {
+      const uint32_t l = limb_at(in_limbs, g);
+      if (f.inGalois[g] > 1 && l < written.size() && written[l]) return fail(c, HM_ERR_ARG,
+          "%s: limb-poly [%u] is read through an automorphism from a limb the call also writes (not in place, and not onto another entry's source)", what, g);
+    }
   }
   if (anyInGalois && (!inverse || f.secondPassOnly)) return fail(c, HM_ERR_ARG, "%s: only the inverse transform reads its input through an automorphism", what);
   if (anyAddGalois && (!fused || f.mix || !f.addend)) return fail(c, HM_ERR_UNSUPPORTED,
       "%s: the addend is read through an automorphism by the fused forward transform without the mix prologue only", what);
+  if (anyAddGalois && f.addend == out) {   // ... from other positions than the ones a workgroup writes: no output limb-poly may be a gathered addend
+    std::vector<char> written;
+    for (uint32_t g = 0; g < n; ++g) { const uint32_t l = limb_at(out_limbs, g); if (l >= written.size()) written.resize((size_t)l + 1, 0); written[l] = 1; }
+    for (uint32_t g = 0; g < n; ++g) {
+      if (f.addGalois[g] <= 1 || (f.addend_limbs && f.addend_limbs[g] == HM_NO_LIMB)) continue;
+      const uint32_t l = limb_at(f.addend_limbs, g);
+      if (l < written.size() && written[l]) return fail(c, HM_ERR_ARG, "%s: the addend of limb-poly [%u] is read through an automorphism from a limb the call writes", what, g);
+    }
+  }
   HM_HIP(c, hipSetDevice(c->device));
   // group limb-polys that share a modulus (see hm_block_map): G = the largest of 8, 4, 2 for which at least 7 of 8 limb-polys
   // of the call fall into full same-modulus groups (a batch of 10 ops x 2 keys has 20 limb-polys per modulus, a 50-limb sweep
@@ -1673,6 +1688,11 @@ extern "C" hm_status hm_inner_product_ex(hm_ctx *c, const hm_ip_desc *d) {
   const uint32_t n = d->n, n_terms = d->n_terms, n_out = d->n_out;
   if (d->x_galois && (!(d->x_galois & 1) || d->x_galois >= 2 * c->P.N)) return fail(c, HM_ERR_ARG, "hm_inner_product: x_galois is not an odd number below 2N");
   if (!x || !y || !out || !x_limbs || !y_limbs || !out_limbs) return fail(c, HM_ERR_ARG, "hm_inner_product: null argument");
+  if (d->x_galois > 1 && x == out) {   // gathered operands come from other positions than the ones a workgroup writes
+    for (uint32_t i = 0; i < n * n_terms; ++i)
+      for (uint32_t k = 0; k < n * n_out; ++k)
+        if (x_limbs[i] == out_limbs[k]) return fail(c, HM_ERR_ARG, "hm_inner_product: an operand read through the automorphism is a limb the call writes");
+  }
   if (n_terms == 0 || n_terms > HM_IP_MAX_TERMS || n_out == 0 || n_out > HM_IP_MAX_OUT)
     return fail(c, HM_ERR_ARG, "hm_inner_product: n_terms in [1,%d], n_out in [1,%d]", HM_IP_MAX_TERMS, HM_IP_MAX_OUT);
   hm_status st;
@@ -1723,6 +1743,13 @@ extern "C" hm_status hm_ntt_inner_product(hm_ctx *c, const hm_ntt_ip_desc *d) {
       if (d->out_inverse[i]) return fail(c, HM_ERR_UNSUPPORTED, "hm_ntt_inner_product: out_inverse needs N = 2^15 or 2^16");
   }
   if (d->x_galois && (!(d->x_galois & 1) || d->x_galois >= 2 * c->P.N)) return fail(c, HM_ERR_ARG, "hm_ntt_inner_product: x_galois is not an odd number below 2N");
+  if (d->x_galois > 1 && d->x == d->out) {   // gathered operands come from other positions than the ones a workgroup writes
+    std::vector<char> written;
+    for (uint32_t i = 0; i < n * K; ++i) { const uint32_t l = d->out_limbs[i]; if (l >= written.size()) written.resize((size_t)l + 1, 0); written[l] = 1; }
+    for (uint32_t i = 0; i < n * T; ++i)
+      if (!d->x_is_coeff[i] && d->x_limbs[i] < written.size() && written[d->x_limbs[i]]) return fail(c, HM_ERR_ARG,
+          "hm_ntt_inner_product: an operand read through the automorphism is a limb the call writes");
+  }
   hm_status st;
   if ((st = check_limbs(c, "hm_ntt_inner_product", d->x_limbs, n * T)) || (st = check_limbs(c, "hm_ntt_inner_product", d->y_limbs, n * T * K)) ||
       (st = check_limbs(c, "hm_ntt_inner_product", d->out_limbs, n * K)) || (st = check_mods(c, "hm_ntt_inner_product", d->mod_ids, n)))

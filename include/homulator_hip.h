@@ -232,7 +232,8 @@ typedef struct hm_ntt_desc {
   const uint8_t *out_packed;
   /* optional (NULL: none; round 6; inverse only, not with second_pass_only): in_galois[i] = g > 1 reads limb-poly i of `in` through the automorphism
    * X -> X^g: out_i = INTT(automorph_g(in_i)) — AUTO_Key(1) + ModUp_INTT of hrotate in one pass over HBM (the index map takes aligned blocks to
-   * aligned blocks, so the transform's own 16-byte loads serve).  0 / 1 = as stored.  Such a limb-poly cannot be transformed in place. */
+   * aligned blocks, so the transform's own 16-byte loads serve).  0 / 1 = as stored.  A limb-poly read this way must not be a limb-poly the same call writes
+   * (neither in place nor another entry's output: HM_ERR_ARG). */
   const uint32_t *in_galois;
 } hm_ntt_desc;
 hm_status hm_ntt_ex(hm_ctx *ctx, const hm_ntt_desc *desc);

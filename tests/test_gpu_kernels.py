@@ -236,6 +236,10 @@ def test_transforms_that_read_through_an_automorphism(env, n, opts):
         assert np.array_equal(pick(out.download()), o.ewe(3, sids, base, None, o.ewe(5, sids, pick(auto(ad)), k=[ak[i] for i in sel])))
         with pytest.raises(hip.HmError):
             ctx.ntt(dx, dx, ids, inverse=True, in_galois=gs)                                  # gathered input, in place
+        with pytest.raises(hip.HmError):                                                      # ... or onto another entry's source
+            ctx.ntt(dx, dx, ids, inverse=True, in_galois=gs, out_limbs=list(range(1, n)) + [0])
+        with pytest.raises(hip.HmError):                                                      # a gathered addend that the call writes
+            ctx.ntt_mix_sub_scale(dx, dmn, dad, ids, k, addend=dad, addend_galois=gs)
         with pytest.raises(hip.HmError):
             ctx.ntt(dx, out, ids, inverse=False, in_galois=gs)                                # forward transform
         with pytest.raises(hip.HmError):
@@ -432,6 +436,8 @@ def test_inner_product_reads_x_through_an_automorphism(env, terms, outs):
             assert np.array_equal(got[k * n:(k + 1) * n], exp), (g, k)
     with pytest.raises(hip.HmError):
         ctx.inner_product(xb, xl, yb, yl, out, ol, ids, terms, outs, x_galois=2)
+    with pytest.raises(hip.HmError):                                                          # gathered operands the call writes
+        ctx.inner_product(xb, xl, yb, yl, xb, ol, ids, terms, outs, x_galois=5)
     for b_ in (xb, yb, out):
         b_.free()
 
